@@ -1,0 +1,87 @@
+"""ctypes binding of oracle/liboracle.so -- the CPU oracle (test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(_ROOT, "oracle", "liboracle.so")
+
+BYTES_PER_BLOB, BYTES_PER_CELL, CELLS, BYTES_PER_G1 = 131072, 2048, 128, 48
+
+
+class OracleError(Exception):
+    def __init__(self, code):
+        super().__init__(f"oracle error {code}")
+        self.code = code
+
+
+def _lib():
+    if not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")])
+    lib = C.CDLL(_SO)
+    lib.oracle_ctx_new.restype = C.c_void_p
+    lib.oracle_ctx_new.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int]
+    lib.oracle_ctx_free.argtypes = [C.c_void_p]
+    return lib
+
+
+class Oracle:
+    def __init__(self, use_precomp=False, threads=1):
+        self.lib = _lib()
+        srs = open(os.path.join(_ROOT, "rust-eth-kzg_amd", "data", "trusted_setup_4096.bin"), "rb").read()
+        self.ctx = C.c_void_p(self.lib.oracle_ctx_new(srs, len(srs), int(use_precomp), threads))
+        assert self.ctx.value, "oracle_ctx_new failed"
+
+    def close(self):
+        if self.ctx:
+            self.lib.oracle_ctx_free(self.ctx)
+            self.ctx = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise OracleError(rc)
+
+    def blob_to_kzg_commitment(self, blob):
+        if len(blob) != BYTES_PER_BLOB:
+            raise OracleError(3)
+        out = C.create_string_buffer(48)
+        self._chk(self.lib.oracle_blob_to_kzg_commitment(self.ctx, blob, out))
+        return out.raw
+
+    def compute_cells_and_kzg_proofs(self, blob):
+        if len(blob) != BYTES_PER_BLOB:
+            raise OracleError(3)
+        cells = C.create_string_buffer(CELLS * BYTES_PER_CELL)
+        proofs = C.create_string_buffer(CELLS * 48)
+        self._chk(self.lib.oracle_compute_cells_and_kzg_proofs(self.ctx, blob, cells, proofs))
+        return ([cells.raw[i * 2048:(i + 1) * 2048] for i in range(CELLS)],
+                [proofs.raw[i * 48:(i + 1) * 48] for i in range(CELLS)])
+
+    def compute_cells(self, blob):
+        if len(blob) != BYTES_PER_BLOB:
+            raise OracleError(3)
+        cells = C.create_string_buffer(CELLS * BYTES_PER_CELL)
+        self._chk(self.lib.oracle_compute_cells(self.ctx, blob, cells))
+        return [cells.raw[i * 2048:(i + 1) * 2048] for i in range(CELLS)]
+
+    def verify_cell_kzg_proof_batch(self, commitments, cell_indices, cells, proofs):
+        if any(len(c) != 48 for c in commitments) or any(len(p) != 48 for p in proofs) or \
+                any(len(c) != BYTES_PER_CELL for c in cells):
+            raise OracleError(3)
+        idx = (C.c_uint64 * max(1, len(cell_indices)))(*cell_indices)
+        ok = C.c_int(0)
+        self._chk(self.lib.oracle_verify_cell_kzg_proof_batch(
+            self.ctx, C.c_size_t(len(commitments)), b"".join(commitments), C.c_size_t(len(cell_indices)), idx,
+            C.c_size_t(len(cells)), b"".join(cells), C.c_size_t(len(proofs)), b"".join(proofs), C.byref(ok)))
+        return bool(ok.value)
+
+    def recover_cells_and_kzg_proofs(self, cell_indices, cells):
+        if any(len(c) != BYTES_PER_CELL for c in cells):
+            raise OracleError(3)
+        idx = (C.c_uint64 * max(1, len(cell_indices)))(*cell_indices)
+        oc = C.create_string_buffer(CELLS * BYTES_PER_CELL)
+        op = C.create_string_buffer(CELLS * 48)
+        self._chk(self.lib.oracle_recover_cells_and_kzg_proofs(
+            self.ctx, C.c_size_t(len(cells)), b"".join(cells), C.c_size_t(len(cell_indices)), idx, oc, op))
+        return ([oc.raw[i * 2048:(i + 1) * 2048] for i in range(CELLS)],
+                [op.raw[i * 48:(i + 1) * 48] for i in range(CELLS)])
