@@ -1,0 +1,150 @@
+/*
+ * c_eth_kzg.h -- C ABI of the MI355X-native KZG engine.
+ *
+ * Drop-in for the header cbindgen generates for the reference's `c_eth_kzg` crate
+ * (reference: bindings/c/build.rs:24-29; symbols in bindings/c/src/lib.rs, mirrored by
+ * bindings/nim/nim_code/nim_eth_kzg/header.nim and bindings/csharp/.../native_methods.g.cs).
+ * Every `eth_kzg_*` prototype below has the reference's exact signature and calling
+ * convention; the citation after each one is the Rust definition it replaces.
+ * The `eth_kzg_amd_*` entry points are non-breaking additions: batched and
+ * device-resident forms of the same operations, which is what a GPU needs to be fed.
+ *
+ * Ownership: inputs are borrowed for the duration of the call; outputs are written into
+ * caller-allocated memory; only `CResult.error_msg` and the context are library-allocated
+ * (free with eth_kzg_free_error_message / eth_kzg_das_context_free).
+ * Threading: a context may be used from many threads at once (calls serialise on the GPU).
+ */
+#ifndef C_ETH_KZG_H
+#define C_ETH_KZG_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* bindings/c/src/lib.rs:119-123 */
+typedef enum CResultStatus {
+    Ok,
+    Err,
+} CResultStatus;
+
+/* bindings/c/src/lib.rs:128-132 */
+typedef struct CResult {
+    CResultStatus status;
+    char *error_msg;
+} CResult;
+
+/* bindings/c/src/lib.rs:50-52 (opaque) */
+typedef struct DASContext DASContext;
+
+/* bindings/c/src/lib.rs:79-92.  use_precomp = true selects width-8 window tables
+ * (RECOMMENDED_PRECOMP_WIDTH); the embedded mainnet trusted setup is loaded; GPU 0
+ * (or the ordinal in $ETH_KZG_AMD_DEVICE) is used. Aborts if no MI355X-class GPU is usable:
+ * there is no CPU fallback. */
+DASContext *eth_kzg_das_context_new(bool use_precomp);
+
+/* bindings/c/src/lib.rs:109-116.  NULL-safe. */
+void eth_kzg_das_context_free(DASContext *ctx);
+
+/* bindings/c/src/lib.rs:171-180.  NULL-safe. */
+void eth_kzg_free_error_message(char *c_message);
+
+/* bindings/c/src/lib.rs:196-205 -> blob_to_kzg_commitment.rs:8-38.
+ * blob: 131072 bytes; out: 48 bytes. */
+CResult eth_kzg_blob_to_kzg_commitment(const DASContext *ctx, const uint8_t *blob, uint8_t *out);
+
+/* bindings/c/src/lib.rs:226-236 -> compute_cells_and_kzg_proofs.rs:8-33.
+ * out_cells: 128 pointers to 2048-byte buffers; out_proofs: 128 pointers to 48-byte buffers. */
+CResult eth_kzg_compute_cells_and_kzg_proofs(const DASContext *ctx, const uint8_t *blob, uint8_t **out_cells,
+                                             uint8_t **out_proofs);
+
+/* bindings/c/src/lib.rs:255-263 */
+CResult eth_kzg_compute_cells(const DASContext *ctx, const uint8_t *blob, uint8_t **out_cells);
+
+/* bindings/c/src/lib.rs:309-335 -> verify_cells_and_kzg_proofs_batch.rs:9-49.
+ * commitments: one 48-byte commitment per cell (NOT deduplicated). An invalid proof is
+ * `Ok` with *verified = false; malformed input is `Err` (lib.rs:272-280). A zero length means
+ * the matching pointer is not dereferenced. */
+CResult eth_kzg_verify_cell_kzg_proof_batch(const DASContext *ctx, uint64_t commitments_length,
+                                            const uint8_t *const *commitments, uint64_t cell_indices_length,
+                                            const uint64_t *cell_indices, uint64_t cells_length,
+                                            const uint8_t *const *cells, uint64_t proofs_length,
+                                            const uint8_t *const *proofs, bool *verified);
+
+/* bindings/c/src/lib.rs:366-386 -> recover_cells_and_kzg_proofs.rs:10-39 */
+CResult eth_kzg_recover_cells_and_proofs(const DASContext *ctx, uint64_t cells_length, const uint8_t *const *cells,
+                                         uint64_t cell_indices_length, const uint64_t *cell_indices,
+                                         uint8_t **out_cells, uint8_t **out_proofs);
+
+/* bindings/c/src/lib.rs:395-405 */
+uint64_t eth_kzg_constant_bytes_per_cell(void);
+uint64_t eth_kzg_constant_bytes_per_proof(void);
+uint64_t eth_kzg_constant_cells_per_ext_blob(void);
+
+/* EIP-4844 operations (bindings/c/src/lib.rs:423-566).  Outside this build's hot-path scope
+ * (SURVEY.md section 8f "next"): present for link compatibility, they return `Err`
+ * ("not implemented in the MI355X build") until that row is built. */
+CResult eth_kzg_compute_kzg_proof(const DASContext *ctx, const uint8_t *blob, const uint8_t *z, uint8_t *out_proof,
+                                  uint8_t *out_y);
+CResult eth_kzg_compute_blob_kzg_proof(const DASContext *ctx, const uint8_t *blob, const uint8_t *commitment,
+                                       uint8_t *out);
+CResult eth_kzg_verify_kzg_proof(const DASContext *ctx, const uint8_t *commitment, const uint8_t *z, const uint8_t *y,
+                                 const uint8_t *proof, bool *verified);
+CResult eth_kzg_verify_blob_kzg_proof(const DASContext *ctx, const uint8_t *blob, const uint8_t *commitment,
+                                      const uint8_t *proof, bool *verified);
+CResult eth_kzg_verify_blob_kzg_proof_batch(const DASContext *ctx, uint64_t blobs_length, const uint8_t *const *blobs,
+                                            uint64_t commitments_length, const uint8_t *const *commitments,
+                                            uint64_t proofs_length, const uint8_t *const *proofs, bool *verified);
+
+/* ---------------------------------------------------------------------------------------------
+ * MI355X additions (no counterpart in the reference; its single-blob ABI cannot feed a GPU).
+ * Status arrays receive one int per blob: 0 ok, 1 = a field element >= r, 2 = bad G1 point,
+ * 3 = invalid input, 4 = recovery failed.  The CResult is `Err` only for call-level failures.
+ */
+
+/* Context on an explicit GPU ordinal (one process per GPU under torch.distributed/RCCL). */
+DASContext *eth_kzg_amd_das_context_new_on_device(bool use_precomp, int device_ordinal);
+
+/* Host-pointer batches: n blobs; out_cells[b] / out_proofs[b] are arrays of 128 pointers as in the
+ * single-blob calls (either may be NULL to skip that output). */
+CResult eth_kzg_amd_compute_cells_and_kzg_proofs_batch(const DASContext *ctx, uint64_t n, const uint8_t *const *blobs,
+                                                       uint8_t *const *const *out_cells,
+                                                       uint8_t *const *const *out_proofs, int32_t *status);
+CResult eth_kzg_amd_blob_to_kzg_commitment_batch(const DASContext *ctx, uint64_t n, const uint8_t *const *blobs,
+                                                 uint8_t *const *out, int32_t *status);
+
+/* Device-resident batches: flat buffers already in this GPU's HBM.
+ *   d_blobs        n * 131072 bytes
+ *   d_out_cells    n * 128 * 2048 bytes   (may be NULL)
+ *   d_out_proofs   n * 128 * 48 bytes     (may be NULL)
+ *   d_out          n * 48 bytes
+ *   status         n ints in HOST memory, or NULL: then nothing is copied back and, if
+ *                  `hip_stream` is non-NULL, the call returns without synchronising (work is
+ *                  enqueued on that hipStream_t; NULL = the context's own stream, synchronised). */
+CResult eth_kzg_amd_compute_cells_and_kzg_proofs_device(const DASContext *ctx, uint64_t n, const uint8_t *d_blobs,
+                                                        uint8_t *d_out_cells, uint8_t *d_out_proofs, int32_t *status,
+                                                        void *hip_stream);
+CResult eth_kzg_amd_blob_to_kzg_commitment_device(const DASContext *ctx, uint64_t n, const uint8_t *d_blobs,
+                                                  uint8_t *d_out, int32_t *status, void *hip_stream);
+
+/* Introspection used by bench.py / DESIGN.md: bytes of window tables resident in HBM, window width. */
+uint64_t eth_kzg_amd_table_bytes(const DASContext *ctx);
+int eth_kzg_amd_window_bits(const DASContext *ctx);
+
+/* Stage-level hooks for the kernel parity tests (tests/ only; canonical big-endian encodings).
+ * Return 0 on success. */
+int eth_kzg_amd_test_fr_ntt4096(const DASContext *ctx, const uint8_t *in, uint8_t *out, int inverse_dit);
+int eth_kzg_amd_test_g1_fft128(const DASContext *ctx, const uint8_t *in, uint8_t *out, int n_lanes, int inverse);
+int eth_kzg_amd_test_fixed_msm(const DASContext *ctx, const uint8_t *scalars, int n_msm, uint8_t *out);
+int eth_kzg_amd_test_g1_decompress(const DASContext *ctx, const uint8_t *in, int n, int subgroup_check, int32_t *status,
+                                   uint8_t *out);
+int eth_kzg_amd_test_field_mul(const DASContext *ctx, const uint8_t *a, const uint8_t *b, uint8_t *out, int n,
+                               int is_fp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C_ETH_KZG_H */

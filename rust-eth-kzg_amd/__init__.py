@@ -1,0 +1,249 @@
+"""rust-eth-kzg_amd -- Python binding of the MI355X-native KZG engine (libc_eth_kzg.so).
+
+Host-side mirror of the reference's `DASContext` API (reference: crates/eip7594/src/lib.rs:41-87,
+prover.rs:100-171, verifier.rs:72-112) over the drop-in C ABI declared in include/c_eth_kzg.h.
+Same method names, argument meaning and error behaviour as the reference bindings: an operation
+that the reference reports as `Err` raises `KzgError`; `verify_cell_kzg_proof_batch` returns False
+for an invalid proof and raises for malformed input.
+
+There is NO CPU fallback: importing works without a GPU, but creating a context requires the HIP
+library built by `rust-eth-kzg_amd/csrc/Makefile` and a gfx950 device, and fails loudly otherwise.
+
+(The directory name contains a hyphen, so load it with importlib:
+    kzg = importlib.import_module("rust-eth-kzg_amd") )
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libc_eth_kzg.so")
+
+BYTES_PER_BLOB = 131072
+BYTES_PER_CELL = 2048
+BYTES_PER_COMMITMENT = 48
+BYTES_PER_PROOF = 48
+CELLS_PER_EXT_BLOB = 128
+FIELD_ELEMENTS_PER_BLOB = 4096
+FIELD_ELEMENTS_PER_CELL = 64
+
+
+class KzgError(Exception):
+    """An operation the reference would report as `Err(..)` (CResult.status == Err)."""
+
+
+class CResult(C.Structure):
+    _fields_ = [("status", C.c_int), ("error_msg", C.c_void_p)]
+
+
+# every symbol include/c_eth_kzg.h declares (tests assert the library exports all of them)
+EXPORTED_SYMBOLS = [
+    "eth_kzg_das_context_new", "eth_kzg_das_context_free", "eth_kzg_free_error_message",
+    "eth_kzg_blob_to_kzg_commitment", "eth_kzg_compute_cells_and_kzg_proofs", "eth_kzg_compute_cells",
+    "eth_kzg_verify_cell_kzg_proof_batch", "eth_kzg_recover_cells_and_proofs",
+    "eth_kzg_constant_bytes_per_cell", "eth_kzg_constant_bytes_per_proof", "eth_kzg_constant_cells_per_ext_blob",
+    "eth_kzg_compute_kzg_proof", "eth_kzg_compute_blob_kzg_proof", "eth_kzg_verify_kzg_proof",
+    "eth_kzg_verify_blob_kzg_proof", "eth_kzg_verify_blob_kzg_proof_batch",
+    "eth_kzg_amd_das_context_new_on_device",
+    "eth_kzg_amd_compute_cells_and_kzg_proofs_batch", "eth_kzg_amd_blob_to_kzg_commitment_batch",
+    "eth_kzg_amd_compute_cells_and_kzg_proofs_device", "eth_kzg_amd_blob_to_kzg_commitment_device",
+    "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits",
+    "eth_kzg_amd_test_fr_ntt4096", "eth_kzg_amd_test_g1_fft128", "eth_kzg_amd_test_fixed_msm",
+    "eth_kzg_amd_test_g1_decompress", "eth_kzg_amd_test_field_mul",
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen libc_eth_kzg.so and declare the prototypes. Raises if the HIP extension is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C rust-eth-kzg_amd/csrc). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    P, U8P, U64 = C.c_void_p, C.c_char_p, C.c_uint64
+    lib.eth_kzg_das_context_new.restype = P
+    lib.eth_kzg_das_context_new.argtypes = [C.c_bool]
+    lib.eth_kzg_amd_das_context_new_on_device.restype = P
+    lib.eth_kzg_amd_das_context_new_on_device.argtypes = [C.c_bool, C.c_int]
+    lib.eth_kzg_das_context_free.argtypes = [P]
+    lib.eth_kzg_free_error_message.argtypes = [P]
+    for name, args in {
+        "eth_kzg_blob_to_kzg_commitment": [P, U8P, P],
+        "eth_kzg_compute_cells_and_kzg_proofs": [P, U8P, P, P],
+        "eth_kzg_compute_cells": [P, U8P, P],
+        "eth_kzg_verify_cell_kzg_proof_batch": [P, U64, P, U64, P, U64, P, U64, P, P],
+        "eth_kzg_recover_cells_and_proofs": [P, U64, P, U64, P, P, P],
+        "eth_kzg_compute_kzg_proof": [P, U8P, U8P, P, P],
+        "eth_kzg_compute_blob_kzg_proof": [P, U8P, U8P, P],
+        "eth_kzg_verify_kzg_proof": [P, U8P, U8P, U8P, U8P, P],
+        "eth_kzg_verify_blob_kzg_proof": [P, U8P, U8P, U8P, P],
+        "eth_kzg_verify_blob_kzg_proof_batch": [P, U64, P, U64, P, U64, P, P],
+        "eth_kzg_amd_compute_cells_and_kzg_proofs_batch": [P, U64, P, P, P, P],
+        "eth_kzg_amd_blob_to_kzg_commitment_batch": [P, U64, P, P, P],
+        "eth_kzg_amd_compute_cells_and_kzg_proofs_device": [P, U64, P, P, P, P, P],
+        "eth_kzg_amd_blob_to_kzg_commitment_device": [P, U64, P, P, P, P],
+    }.items():
+        fn = getattr(lib, name)
+        fn.restype = CResult
+        fn.argtypes = args
+    for name in ("eth_kzg_constant_bytes_per_cell", "eth_kzg_constant_bytes_per_proof",
+                 "eth_kzg_constant_cells_per_ext_blob"):
+        getattr(lib, name).restype = U64
+    lib.eth_kzg_amd_table_bytes.restype = U64
+    lib.eth_kzg_amd_table_bytes.argtypes = [P]
+    lib.eth_kzg_amd_window_bits.argtypes = [P]
+    lib.eth_kzg_amd_test_fr_ntt4096.argtypes = [P, U8P, P, C.c_int]
+    lib.eth_kzg_amd_test_g1_fft128.argtypes = [P, U8P, P, C.c_int, C.c_int]
+    lib.eth_kzg_amd_test_fixed_msm.argtypes = [P, U8P, C.c_int, P]
+    lib.eth_kzg_amd_test_g1_decompress.argtypes = [P, U8P, C.c_int, C.c_int, P, P]
+    lib.eth_kzg_amd_test_field_mul.argtypes = [P, U8P, U8P, P, C.c_int, C.c_int]
+    _lib = lib
+    return lib
+
+
+def _ptr_array(bufs):
+    """(array of char*, keep-alive list) over a list of bytes / ctypes buffers."""
+    arr = (C.c_void_p * max(1, len(bufs)))()
+    keep = []
+    for i, b in enumerate(bufs):
+        if isinstance(b, (bytes, bytearray)):
+            b = C.create_string_buffer(bytes(b), len(b))
+        keep.append(b)
+        arr[i] = C.addressof(b)
+    return arr, keep
+
+
+class DASContext:
+    """Mirror of `rust_eth_kzg::DASContext` (crates/eip7594/src/lib.rs:41-87)."""
+
+    def __init__(self, use_precomp=True, device=None):
+        self._lib = load_library()
+        if device is None:
+            self._ctx = C.c_void_p(self._lib.eth_kzg_das_context_new(bool(use_precomp)))
+        else:
+            self._ctx = C.c_void_p(self._lib.eth_kzg_amd_das_context_new_on_device(bool(use_precomp), int(device)))
+        if not self._ctx.value:
+            raise RuntimeError("eth_kzg_das_context_new returned NULL")
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.eth_kzg_das_context_free(self._ctx)
+            self._ctx = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._ctx
+
+    def _check(self, res):
+        if res.status != 0:
+            msg = C.string_at(res.error_msg).decode() if res.error_msg else "error"
+            self._lib.eth_kzg_free_error_message(res.error_msg)
+            raise KzgError(msg)
+
+    # ---- reference API -------------------------------------------------------------------
+    def blob_to_kzg_commitment(self, blob):
+        if len(blob) != BYTES_PER_BLOB:  # the reference bindings reject a wrong-length slice before the FFI call
+            raise KzgError("BlobHasInvalidLength")
+        out = C.create_string_buffer(48)
+        self._check(self._lib.eth_kzg_blob_to_kzg_commitment(self._ctx, bytes(blob), out))
+        return out.raw
+
+    def compute_cells_and_kzg_proofs(self, blob):
+        if len(blob) != BYTES_PER_BLOB:
+            raise KzgError("BlobHasInvalidLength")
+        cells = [C.create_string_buffer(BYTES_PER_CELL) for _ in range(CELLS_PER_EXT_BLOB)]
+        proofs = [C.create_string_buffer(48) for _ in range(CELLS_PER_EXT_BLOB)]
+        ca, _k1 = _ptr_array(cells)
+        pa, _k2 = _ptr_array(proofs)
+        self._check(self._lib.eth_kzg_compute_cells_and_kzg_proofs(self._ctx, bytes(blob), ca, pa))
+        return [c.raw for c in cells], [p.raw for p in proofs]
+
+    def compute_cells(self, blob):
+        if len(blob) != BYTES_PER_BLOB:
+            raise KzgError("BlobHasInvalidLength")
+        cells = [C.create_string_buffer(BYTES_PER_CELL) for _ in range(CELLS_PER_EXT_BLOB)]
+        ca, _k = _ptr_array(cells)
+        self._check(self._lib.eth_kzg_compute_cells(self._ctx, bytes(blob), ca))
+        return [c.raw for c in cells]
+
+    def verify_cell_kzg_proof_batch(self, commitments, cell_indices, cells, proofs):
+        if any(len(c) != 48 for c in commitments) or any(len(p) != 48 for p in proofs) \
+                or any(len(c) != BYTES_PER_CELL for c in cells):
+            raise KzgError("InvalidLength")
+        ca, _k1 = _ptr_array(commitments)
+        cla, _k2 = _ptr_array(cells)
+        pa, _k3 = _ptr_array(proofs)
+        idx = (C.c_uint64 * max(1, len(cell_indices)))(*cell_indices)
+        ok = C.c_bool(False)
+        self._check(self._lib.eth_kzg_verify_cell_kzg_proof_batch(
+            self._ctx, len(commitments), ca, len(cell_indices), idx, len(cells), cla, len(proofs), pa, C.byref(ok)))
+        return bool(ok.value)
+
+    def recover_cells_and_kzg_proofs(self, cell_indices, cells):
+        if any(len(c) != BYTES_PER_CELL for c in cells):
+            raise KzgError("InvalidLength")
+        cla, _k = _ptr_array(cells)
+        idx = (C.c_uint64 * max(1, len(cell_indices)))(*cell_indices)
+        out_cells = [C.create_string_buffer(BYTES_PER_CELL) for _ in range(CELLS_PER_EXT_BLOB)]
+        out_proofs = [C.create_string_buffer(48) for _ in range(CELLS_PER_EXT_BLOB)]
+        oca, _k1 = _ptr_array(out_cells)
+        opa, _k2 = _ptr_array(out_proofs)
+        self._check(self._lib.eth_kzg_recover_cells_and_proofs(
+            self._ctx, len(cells), cla, len(cell_indices), idx, oca, opa))
+        return [c.raw for c in out_cells], [p.raw for p in out_proofs]
+
+    # ---- batched additions ----------------------------------------------------------------
+    def compute_cells_and_kzg_proofs_batch(self, blobs):
+        """List of blobs -> (status list, cells[b][128], proofs[b][128]); host buffers."""
+        n = len(blobs)
+        ba, _kb = _ptr_array(blobs)
+        cells = [[C.create_string_buffer(BYTES_PER_CELL) for _ in range(128)] for _ in range(n)]
+        proofs = [[C.create_string_buffer(48) for _ in range(128)] for _ in range(n)]
+        keep, cpp, ppp = [], (C.c_void_p * max(1, n))(), (C.c_void_p * max(1, n))()
+        for b in range(n):
+            ca, k1 = _ptr_array(cells[b])
+            pa, k2 = _ptr_array(proofs[b])
+            keep += [ca, pa, k1, k2]
+            cpp[b], ppp[b] = C.addressof(ca), C.addressof(pa)
+        st = (C.c_int32 * max(1, n))()
+        self._check(self._lib.eth_kzg_amd_compute_cells_and_kzg_proofs_batch(self._ctx, n, ba, cpp, ppp, st))
+        return list(st)[:n], [[c.raw for c in cb] for cb in cells], [[p.raw for p in pb] for pb in proofs]
+
+    def blob_to_kzg_commitment_batch(self, blobs):
+        n = len(blobs)
+        ba, _kb = _ptr_array(blobs)
+        outs = [C.create_string_buffer(48) for _ in range(n)]
+        oa, _ko = _ptr_array(outs)
+        st = (C.c_int32 * max(1, n))()
+        self._check(self._lib.eth_kzg_amd_blob_to_kzg_commitment_batch(self._ctx, n, ba, oa, st))
+        return list(st)[:n], [o.raw for o in outs]
+
+    def compute_cells_and_kzg_proofs_device(self, n, d_blobs, d_cells, d_proofs, want_status=True, stream=None):
+        """Device-resident flat buffers (integer device addresses, e.g. torch tensor .data_ptr())."""
+        st = (C.c_int32 * max(1, n))() if want_status else None
+        self._check(self._lib.eth_kzg_amd_compute_cells_and_kzg_proofs_device(
+            self._ctx, n, C.c_void_p(d_blobs), C.c_void_p(d_cells) if d_cells else None,
+            C.c_void_p(d_proofs) if d_proofs else None, st, C.c_void_p(stream) if stream else None))
+        return list(st)[:n] if want_status else None
+
+    def blob_to_kzg_commitment_device(self, n, d_blobs, d_out, want_status=True, stream=None):
+        st = (C.c_int32 * max(1, n))() if want_status else None
+        self._check(self._lib.eth_kzg_amd_blob_to_kzg_commitment_device(
+            self._ctx, n, C.c_void_p(d_blobs), C.c_void_p(d_out), st, C.c_void_p(stream) if stream else None))
+        return list(st)[:n] if want_status else None
+
+    def table_bytes(self):
+        return int(self._lib.eth_kzg_amd_table_bytes(self._ctx))
+
+    def window_bits(self):
+        return int(self._lib.eth_kzg_amd_window_bits(self._ctx))

@@ -1,0 +1,203 @@
+// C ABI of the MI355X KZG engine: the reference's `eth_kzg_*` symbols (bindings/c/src/lib.rs) over
+// kzg::Engine, plus the batched / device-resident `eth_kzg_amd_*` additions.  See include/c_eth_kzg.h.
+#include "../../include/c_eth_kzg.h"
+#include "engine.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+struct DASContext {
+    kzg::Engine* engine;
+};
+
+namespace {
+
+constexpr int CELLS = 128;
+
+CResult ok() { return CResult{Ok, nullptr}; }
+CResult err(const std::string& m) {  // CResult::with_error, bindings/c/src/lib.rs:146-153
+    char* s = (char*)malloc(m.size() + 1);
+    memcpy(s, m.c_str(), m.size() + 1);
+    return CResult{Err, s};
+}
+const char* status_text(int st) {
+    switch (st) {
+        case kzg::ERR_SCALAR: return "Serialization(CouldNotDeserializeScalar)";
+        case kzg::ERR_G1: return "Serialization(CouldNotDeserializeG1Point)";
+        case kzg::ERR_INPUT: return "InvalidInput";
+        case kzg::ERR_RECOVERY: return "Recovery(PolynomialHasInvalidLength)";
+        default: return "DeviceError";
+    }
+}
+kzg::Engine* eng(const DASContext* ctx) {
+    // `assert!(!ctx.is_null())` in the reference (e.g. compute_cells_and_kzg_proofs.rs:14): abort, like a Rust panic across FFI
+    if (!ctx || !ctx->engine) {
+        fprintf(stderr, "c_eth_kzg: context pointer is null\n");
+        abort();
+    }
+    return ctx->engine;
+}
+CResult device_err(kzg::Engine* e) { return err("DeviceError(" + e->last_error() + ")"); }
+
+DASContext* make_ctx(bool use_precomp, int device) {
+    try {
+        auto* c = new DASContext{nullptr};
+        c->engine = new kzg::Engine(use_precomp, device);
+        return c;
+    } catch (const std::exception& e) {
+        // The reference panics when the context cannot be built (bad SRS); here: no usable GPU.  No CPU fallback.
+        fprintf(stderr, "c_eth_kzg: cannot create the MI355X context: %s\n", e.what());
+        abort();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+DASContext* eth_kzg_das_context_new(bool use_precomp) {
+    int dev = 0;
+    if (const char* s = getenv("ETH_KZG_AMD_DEVICE")) dev = atoi(s);
+    return make_ctx(use_precomp, dev);
+}
+DASContext* eth_kzg_amd_das_context_new_on_device(bool use_precomp, int device_ordinal) {
+    return make_ctx(use_precomp, device_ordinal);
+}
+void eth_kzg_das_context_free(DASContext* ctx) {
+    if (!ctx) return;
+    delete ctx->engine;
+    delete ctx;
+}
+void eth_kzg_free_error_message(char* c_message) {
+    if (c_message) free(c_message);
+}
+
+CResult eth_kzg_blob_to_kzg_commitment(const DASContext* ctx, const uint8_t* blob, uint8_t* out) {
+    kzg::Engine* e = eng(ctx);
+    int st = 0;
+    const uint8_t* blobs[1] = {blob};
+    uint8_t* outs[1] = {out};
+    if (e->blob_to_kzg_commitment_host(1, blobs, outs, &st)) return device_err(e);
+    return st ? err(status_text(st)) : ok();
+}
+
+CResult eth_kzg_compute_cells_and_kzg_proofs(const DASContext* ctx, const uint8_t* blob, uint8_t** out_cells,
+                                             uint8_t** out_proofs) {
+    kzg::Engine* e = eng(ctx);
+    int st = 0;
+    const uint8_t* blobs[1] = {blob};
+    uint8_t* const* cells[1] = {out_cells};
+    uint8_t* const* proofs[1] = {out_proofs};
+    if (e->compute_cells_and_kzg_proofs_host(1, blobs, cells, proofs, &st)) return device_err(e);
+    return st ? err(status_text(st)) : ok();
+}
+
+CResult eth_kzg_compute_cells(const DASContext* ctx, const uint8_t* blob, uint8_t** out_cells) {
+    kzg::Engine* e = eng(ctx);
+    int st = 0;
+    const uint8_t* blobs[1] = {blob};
+    uint8_t* const* cells[1] = {out_cells};
+    if (e->compute_cells_and_kzg_proofs_host(1, blobs, cells, nullptr, &st)) return device_err(e);
+    return st ? err(status_text(st)) : ok();
+}
+
+CResult eth_kzg_verify_cell_kzg_proof_batch(const DASContext* ctx, uint64_t commitments_length,
+                                            const uint8_t* const* commitments, uint64_t cell_indices_length,
+                                            const uint64_t* cell_indices, uint64_t cells_length,
+                                            const uint8_t* const* cells, uint64_t proofs_length,
+                                            const uint8_t* const* proofs, bool* verified) {
+    kzg::Engine* e = eng(ctx);
+    int ver = 0;
+    int st = e->verify_cell_kzg_proof_batch_host(commitments_length, commitments, cell_indices_length, cell_indices,
+                                                 cells_length, cells, proofs_length, proofs, &ver);
+    if (st == kzg::ERR_DEVICE) return device_err(e);
+    if (st) return err(status_text(st));
+    *verified = ver != 0;
+    return ok();
+}
+
+CResult eth_kzg_recover_cells_and_proofs(const DASContext* ctx, uint64_t cells_length, const uint8_t* const* cells,
+                                         uint64_t cell_indices_length, const uint64_t* cell_indices,
+                                         uint8_t** out_cells, uint8_t** out_proofs) {
+    kzg::Engine* e = eng(ctx);
+    int st = e->recover_cells_and_kzg_proofs_host(cells_length, cells, cell_indices_length, cell_indices, out_cells, out_proofs);
+    if (st == kzg::ERR_DEVICE) return device_err(e);
+    return st ? err(status_text(st)) : ok();
+}
+
+uint64_t eth_kzg_constant_bytes_per_cell(void) { return 2048; }
+uint64_t eth_kzg_constant_bytes_per_proof(void) { return 48; }
+uint64_t eth_kzg_constant_cells_per_ext_blob(void) { return CELLS; }
+
+static CResult not_built(const DASContext* ctx) {
+    (void)eng(ctx);
+    return err("NotImplemented(EIP-4844 single-point operations are outside the MI355X hot-path build; SURVEY.md 8f)");
+}
+CResult eth_kzg_compute_kzg_proof(const DASContext* ctx, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*) { return not_built(ctx); }
+CResult eth_kzg_compute_blob_kzg_proof(const DASContext* ctx, const uint8_t*, const uint8_t*, uint8_t*) { return not_built(ctx); }
+CResult eth_kzg_verify_kzg_proof(const DASContext* ctx, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, bool*) { return not_built(ctx); }
+CResult eth_kzg_verify_blob_kzg_proof(const DASContext* ctx, const uint8_t*, const uint8_t*, const uint8_t*, bool*) { return not_built(ctx); }
+CResult eth_kzg_verify_blob_kzg_proof_batch(const DASContext* ctx, uint64_t, const uint8_t* const*, uint64_t,
+                                            const uint8_t* const*, uint64_t, const uint8_t* const*, bool*) { return not_built(ctx); }
+
+// ---------------------------------------------------------------------------------------------
+CResult eth_kzg_amd_compute_cells_and_kzg_proofs_batch(const DASContext* ctx, uint64_t n, const uint8_t* const* blobs,
+                                                       uint8_t* const* const* out_cells, uint8_t* const* const* out_proofs,
+                                                       int32_t* status) {
+    kzg::Engine* e = eng(ctx);
+    std::vector<int> st(n);
+    if (e->compute_cells_and_kzg_proofs_host((int)n, blobs, out_cells, out_proofs, st.data())) return device_err(e);
+    if (status) for (uint64_t i = 0; i < n; i++) status[i] = st[i];
+    return ok();
+}
+CResult eth_kzg_amd_blob_to_kzg_commitment_batch(const DASContext* ctx, uint64_t n, const uint8_t* const* blobs,
+                                                 uint8_t* const* out, int32_t* status) {
+    kzg::Engine* e = eng(ctx);
+    std::vector<int> st(n);
+    if (e->blob_to_kzg_commitment_host((int)n, blobs, out, st.data())) return device_err(e);
+    if (status) for (uint64_t i = 0; i < n; i++) status[i] = st[i];
+    return ok();
+}
+CResult eth_kzg_amd_compute_cells_and_kzg_proofs_device(const DASContext* ctx, uint64_t n, const uint8_t* d_blobs,
+                                                        uint8_t* d_out_cells, uint8_t* d_out_proofs, int32_t* status,
+                                                        void* hip_stream) {
+    kzg::Engine* e = eng(ctx);
+    bool sync = hip_stream == nullptr;
+    if (e->compute_cells_and_kzg_proofs_device((int)n, d_blobs, d_out_cells, d_out_proofs, status, (hipStream_t)hip_stream, sync))
+        return device_err(e);
+    if (status) for (uint64_t i = 0; i < n; i++) status[i] = status[i] ? kzg::ERR_SCALAR : 0;
+    return ok();
+}
+CResult eth_kzg_amd_blob_to_kzg_commitment_device(const DASContext* ctx, uint64_t n, const uint8_t* d_blobs, uint8_t* d_out,
+                                                  int32_t* status, void* hip_stream) {
+    kzg::Engine* e = eng(ctx);
+    bool sync = hip_stream == nullptr;
+    if (e->blob_to_kzg_commitment_device((int)n, d_blobs, d_out, status, (hipStream_t)hip_stream, sync)) return device_err(e);
+    if (status) for (uint64_t i = 0; i < n; i++) status[i] = status[i] ? kzg::ERR_SCALAR : 0;
+    return ok();
+}
+uint64_t eth_kzg_amd_table_bytes(const DASContext* ctx) { return eng(ctx)->table_bytes(); }
+int eth_kzg_amd_window_bits(const DASContext* ctx) { return eng(ctx)->window_bits(); }
+
+int eth_kzg_amd_test_fr_ntt4096(const DASContext* ctx, const uint8_t* in, uint8_t* out, int inverse_dit) {
+    return eng(ctx)->test_fr_ntt4096(in, out, inverse_dit);
+}
+int eth_kzg_amd_test_g1_fft128(const DASContext* ctx, const uint8_t* in, uint8_t* out, int n_lanes, int inverse) {
+    return eng(ctx)->test_g1_fft128(in, out, n_lanes, inverse);
+}
+int eth_kzg_amd_test_fixed_msm(const DASContext* ctx, const uint8_t* scalars, int n_msm, uint8_t* out) {
+    return eng(ctx)->test_fixed_msm(scalars, n_msm, out);
+}
+int eth_kzg_amd_test_g1_decompress(const DASContext* ctx, const uint8_t* in, int n, int subgroup_check, int32_t* status,
+                                   uint8_t* out) {
+    return eng(ctx)->test_g1_decompress(in, n, subgroup_check, status, out);
+}
+int eth_kzg_amd_test_field_mul(const DASContext* ctx, const uint8_t* a, const uint8_t* b, uint8_t* out, int n, int is_fp) {
+    return eng(ctx)->test_field_mul(a, b, out, n, is_fp);
+}
+
+}  // extern "C"

@@ -1,0 +1,494 @@
+// Engine: context set-up and kernel orchestration for the KZG hot path on one MI355X.
+// Mirrors ProverContext::new / FK20Prover::new (reference: crates/eip7594/src/prover.rs:62-94,
+// crates/cryptography/kzg_multi_open/src/fk20/prover.rs:64-125, batch_toeplitz.rs:34-78) and the
+// per-blob pipeline of compute_multi_opening_proofs (fk20/prover.rs:173-228) as a batch of kernels.
+#include "engine.hpp"
+#include "curve.hpp"
+#include "launch.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+extern "C" const unsigned char kzg_srs_begin[];
+extern "C" const unsigned char kzg_srs_end[];
+
+namespace kzg {
+
+#define HIPCK(x)                                                                                              \
+    do {                                                                                                      \
+        hipError_t e_ = (x);                                                                                  \
+        if (e_ != hipSuccess)                                                                                 \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " + __FILE__ + ":" + \
+                                     std::to_string(__LINE__));                                               \
+    } while (0)
+
+static constexpr int N_BLOB = 4096, N_EXT = 8192, N_CELLS = 128, CELL_LEN = 64, BYTES_PER_BLOB = 131072, BYTES_PER_CELL = 2048;
+static_assert(sizeof(Fr) == launch::SIZEOF_FR && sizeof(G1Affine) == launch::SIZEOF_G1AFFINE && sizeof(G1Jac) == launch::SIZEOF_G1JAC, "layout");
+
+// ---------------------------------------------------------------------------------------------
+// host-side field helpers (field.hpp compiled for the host)
+static Fr fr_from_u64(uint64_t v) {
+    Fr a = zero<FrParams>();
+    a.v[0] = (uint32_t)v;
+    a.v[1] = (uint32_t)(v >> 32);
+    return to_mont(a);
+}
+static Fr fr_pow_limbs(const Fr& base, const uint32_t* e, int nl) {
+    Fr acc = one<FrParams>();
+    for (int i = 32 * nl - 1; i >= 0; i--) {
+        acc = sqr(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = mul(acc, base);
+    }
+    return acc;
+}
+// omega_n = 7^((r-1)/n)  (blstrs ROOT_OF_UNITY squared down; domain.rs:84-101)
+static Fr fr_root_of_unity(int log_n) {
+    uint32_t e[8];
+    for (int i = 0; i < 8; i++) e[i] = FrParams::MOD[i];
+    e[0] -= 1;
+    // e >>= log_n
+    for (int s = 0; s < log_n; s++) {
+        for (int i = 0; i < 8; i++) e[i] = (e[i] >> 1) | (i < 7 ? (e[i + 1] << 31) : 0);
+    }
+    return fr_pow_limbs(fr_from_u64(7), e, 8);
+}
+// NAF of a canonical 255-bit integer: nz[8] non-zero mask, sg[8] sign mask (bit i <-> digit i)
+static void naf_digits(const Fr& canon, uint32_t* nz, uint32_t* sg) {
+    uint32_t x[9];
+    for (int i = 0; i < 8; i++) x[i] = canon.v[i];
+    x[8] = 0;
+    for (int i = 0; i < 8; i++) nz[i] = sg[i] = 0;
+    for (int pos = 0; pos < 256; pos++) {
+        if (x[0] & 1) {
+            int d = 2 - (int)(x[0] & 3);  // +1 or -1
+            if (d == 1) x[0] -= 1;        // odd: no borrow
+            else {                         // x += 1
+                for (int i = 0; i < 9; i++) { if (++x[i] != 0) break; }
+            }
+            nz[pos >> 5] |= 1u << (pos & 31);
+            if (d < 0) sg[pos >> 5] |= 1u << (pos & 31);
+        }
+        for (int i = 0; i < 9; i++) x[i] = (x[i] >> 1) | (i < 8 ? (x[i + 1] << 31) : 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 8 : 4) {
+    HIPCK(hipSetDevice(dev_));
+    HIPCK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    launch::init_attributes();
+    init_constants();
+    init_srs();
+    init_fk20();
+    HIPCK(hipStreamSynchronize(stream_));
+}
+
+Engine::~Engine() {
+    hipSetDevice(dev_);
+    void* ptrs[] = {d_w8192_, d_naf_, d_srs_, d_fk_bases_, d_fk_table_, d_srs_table_, d_coeffs_, d_canon_,
+                    d_scalars_, d_X_, d_status_, d_in_, d_cells_, d_proofs_};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (stream_) hipStreamDestroy(stream_);
+}
+
+void Engine::init_constants() {
+    // omega_8192 powers (Domain::new roots, domain.rs:55-62)
+    std::vector<Fr> w(N_EXT);
+    Fr g = fr_root_of_unity(13);
+    w[0] = one<FrParams>();
+    for (int i = 1; i < N_EXT; i++) w[i] = mul(w[i - 1], g);
+    if (!eq(mul(w[N_EXT - 1], g), one<FrParams>())) throw std::runtime_error("omega_8192 has wrong order");
+    HIPCK(hipMalloc(&d_w8192_, N_EXT * sizeof(Fr)));
+    HIPCK(hipMemcpy(d_w8192_, w.data(), N_EXT * sizeof(Fr), hipMemcpyHostToDevice));
+    // NAF of omega_128^k = w[64k]
+    std::vector<uint32_t> naf(128 * 16);
+    for (int k = 0; k < 128; k++) naf_digits(from_mont(w[64 * k]), &naf[k * 16], &naf[k * 16 + 8]);
+    HIPCK(hipMalloc(&d_naf_, naf.size() * 4));
+    HIPCK(hipMemcpy(d_naf_, naf.data(), naf.size() * 4, hipMemcpyHostToDevice));
+    Fr i4096 = inv(fr_from_u64(N_BLOB)), i128 = inv(fr_from_u64(128));
+    memcpy(&n_inv4096_, &i4096, 32);
+    memcpy(&inv128_, &i128, 32);
+}
+
+void Engine::init_srs() {
+    // embedded trusted setup: "KZGSRS01" | n_g1 | n_g2 | g1 monomial (48 B each) | g2 monomial (96 B each)
+    const unsigned char* p = kzg_srs_begin;
+    size_t len = (size_t)(kzg_srs_end - kzg_srs_begin);
+    uint32_t n1, n2;
+    if (len < 16 || memcmp(p, "KZGSRS01", 8)) throw std::runtime_error("bad embedded SRS");
+    memcpy(&n1, p + 8, 4);
+    memcpy(&n2, p + 12, 4);
+    if (n1 != (uint32_t)N_BLOB || len != 16 + (size_t)n1 * 48 + (size_t)n2 * 96) throw std::runtime_error("bad embedded SRS size");
+    uint8_t* d_bytes;
+    int* d_st;
+    HIPCK(hipMalloc(&d_bytes, (size_t)N_BLOB * 48));
+    HIPCK(hipMalloc(&d_st, N_BLOB * sizeof(int)));
+    HIPCK(hipMalloc(&d_srs_, N_BLOB * sizeof(G1Affine)));
+    HIPCK(hipMemcpy(d_bytes, p + 16, (size_t)N_BLOB * 48, hipMemcpyHostToDevice));
+    launch::g1_decompress(d_bytes, d_srs_, d_st, N_BLOB, 0, stream_);
+    std::vector<int> st(N_BLOB);
+    HIPCK(hipMemcpyAsync(st.data(), d_st, N_BLOB * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    HIPCK(hipStreamSynchronize(stream_));
+    for (int s : st)
+        if (s) throw std::runtime_error("embedded SRS point failed to decompress");
+    HIPCK(hipFree(d_bytes));
+    HIPCK(hipFree(d_st));
+}
+
+static void build_table(int c, const void* bases, void** table, size_t* bytes, int n_groups, int nb, hipStream_t st) {
+    size_t entries = launch::table_entries(c, n_groups, nb);
+    void* scratch;
+    HIPCK(hipMalloc(table, entries * sizeof(G1Affine)));
+    HIPCK(hipMalloc(&scratch, entries * sizeof(G1Jac)));
+    launch::build_table(c, bases, *table, scratch, n_groups, nb, st);
+    HIPCK(hipStreamSynchronize(st));
+    HIPCK(hipFree(scratch));
+    *bytes = entries * sizeof(G1Affine);
+}
+
+void Engine::init_fk20() {
+    // 64 G1-FFT_128 of the SRS vectors: the 64 vectors ride on the 64 lanes of the FFT kernel.
+    void* X;
+    HIPCK(hipMalloc(&X, 128 * 64 * sizeof(G1Jac)));
+    HIPCK(hipMalloc(&d_fk_bases_, 128 * 64 * sizeof(G1Affine)));
+    launch::fk20_srs_vectors(d_srs_, X, stream_);
+    g1_fft128_full(X, 64, /*inverse=*/0, stream_);  // DIF: natural in, bit-reversed out
+    launch::fk20_gather_bases(X, d_fk_bases_, stream_);
+    HIPCK(hipStreamSynchronize(stream_));
+    HIPCK(hipFree(X));
+    build_table(c_, d_fk_bases_, &d_fk_table_, &fk_table_bytes_, 128, 64, stream_);
+    build_table(c_, d_srs_, &d_srs_table_, &srs_table_bytes_, 64, 64, stream_);  // SRS viewed as [64][64]
+}
+
+void Engine::ensure_workspace(int n) {
+    if (n <= cap_) return;
+    int cap = ((n + 63) / 64) * 64;
+    void** ptrs[] = {&d_coeffs_, &d_canon_, &d_scalars_, &d_X_, (void**)&d_status_};
+    for (void** p : ptrs)
+        if (*p) { HIPCK(hipFree(*p)); *p = nullptr; }
+    HIPCK(hipMalloc(&d_coeffs_, (size_t)cap * N_BLOB * sizeof(Fr)));
+    HIPCK(hipMalloc(&d_canon_, (size_t)cap * N_BLOB * sizeof(Fr)));
+    HIPCK(hipMalloc(&d_scalars_, (size_t)cap * 128 * 64 * sizeof(Fr)));
+    HIPCK(hipMalloc(&d_X_, (size_t)cap * 128 * sizeof(G1Jac)));
+    HIPCK(hipMalloc(&d_status_, (size_t)cap * sizeof(int)));
+    cap_ = cap;
+}
+
+// ---------------------------------------------------------------------------------------------
+void Engine::launch_msm(const void* scalars, const void* table, void* out, int n_groups, int n_slices, int out_stride,
+                        int brp_bits, hipStream_t st) {
+    launch::msm_fixed(c_, scalars, table, out, n_groups, n_slices, 64, out_stride, brp_bits, st);
+}
+
+// inverse FFT_128, DIT, input at bit-reversed positions, only outputs 0..63 produced (domain.rs:172-194;
+// the 128^-1 scaling is folded into the MSM scalars).
+void Engine::g1_ifft128_take64(void* X, int stride, hipStream_t st) {
+    for (int half = 1; half <= 32; half <<= 1)
+        launch::g1_fft_layer(X, stride, half, 128 / (2 * half), 1, 0, d_naf_, st);
+    launch::g1_fft_layer(X, stride, 64, 1, 1, 3, d_naf_, st);
+}
+// forward FFT_128 of (h || O): DIF, natural in, bit-reversed out = the proof order (prover.rs:214-222).
+void Engine::g1_fft128_from64(void* X, int stride, hipStream_t st) {
+    launch::g1_fft_layer(X, stride, 64, 1, 0, 2, d_naf_, st);
+    for (int half = 32; half >= 1; half >>= 1)
+        launch::g1_fft_layer(X, stride, half, 128 / (2 * half), 0, 1, d_naf_, st);
+}
+// full FFT_128.  forward: DIF natural -> bit-reversed.  inverse: DIT bit-reversed -> natural (no scaling).
+void Engine::g1_fft128_full(void* X, int stride, int inverse, hipStream_t st) {
+    if (!inverse) {
+        for (int half = 64; half >= 1; half >>= 1)
+            launch::g1_fft_layer(X, stride, half, 128 / (2 * half), 0, 1, d_naf_, st);
+    } else {
+        for (int half = 1; half <= 64; half <<= 1)
+            launch::g1_fft_layer(X, stride, half, 128 / (2 * half), 1, 0, d_naf_, st);
+    }
+}
+
+// stages C..G of SURVEY 3.2 from coefficients already in d_coeffs_
+void Engine::run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st) {
+    const int bp = ((n + 63) / 64) * 64;
+    launch::fk20_scalars(n, d_coeffs_, d_scalars_, d_w8192_, inv128_, st);
+    launch::g1_set_inf(d_X_, (size_t)128 * bp, st);
+    launch_msm(d_scalars_, d_fk_table_, d_X_, 128, n, bp, 7, st);
+    g1_ifft128_take64(d_X_, bp, st);
+    g1_fft128_from64(d_X_, bp, st);
+    launch::g1_compress(d_X_, d_proofs, 128, bp, n, st);
+}
+
+int Engine::compute_cells_and_kzg_proofs_device(int n, const uint8_t* d_blobs, uint8_t* d_cells, uint8_t* d_proofs,
+                                                int* h_status, hipStream_t st, bool sync) {
+    if (n <= 0) return OK;
+    std::lock_guard<std::mutex> lk(mu_);
+    try {
+        HIPCK(hipSetDevice(dev_));
+        if (!st) st = stream_;
+        ensure_workspace(n);
+        HIPCK(hipMemsetAsync(d_status_, 0, n * sizeof(int), st));
+        launch::blob_to_coeffs(n, d_blobs, d_coeffs_, nullptr, d_status_, d_w8192_, n_inv4096_, st);
+        if (d_cells) launch::coeffs_to_cells(n, d_coeffs_, d_cells, d_w8192_, st);
+        if (d_proofs) run_proofs_from_coeffs(n, d_proofs, st);
+        if (h_status) HIPCK(hipMemcpyAsync(h_status, d_status_, n * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCK(hipGetLastError());
+        if (sync || h_status) HIPCK(hipStreamSynchronize(st));
+    } catch (const std::exception& e) {
+        err_ = e.what();
+        return ERR_DEVICE;
+    }
+    return OK;
+}
+
+int Engine::blob_to_kzg_commitment_device(int n, const uint8_t* d_blobs, uint8_t* d_commitments, int* h_status,
+                                          hipStream_t st, bool sync) {
+    if (n <= 0) return OK;
+    std::lock_guard<std::mutex> lk(mu_);
+    try {
+        HIPCK(hipSetDevice(dev_));
+        if (!st) st = stream_;
+        ensure_workspace(n);
+        const int bp = ((n + 63) / 64) * 64;
+        HIPCK(hipMemsetAsync(d_status_, 0, n * sizeof(int), st));
+        // commit = MSM_4096(coeffs, g1_monomial)  (fk20/prover.rs:128-145, commit_key.rs:38-44):
+        // 64 groups of 64 bases through the window-table kernel, then a fold over the groups.
+        launch::blob_to_coeffs(n, d_blobs, d_coeffs_, d_canon_, d_status_, d_w8192_, n_inv4096_, st);
+        launch::g1_set_inf(d_X_, (size_t)64 * bp, st);
+        launch_msm(d_canon_, d_srs_table_, d_X_, 64, n, bp, 0, st);
+        launch::g1_sum_positions(d_X_, 64, bp, n, st);
+        launch::g1_compress(d_X_, d_commitments, 1, bp, n, st);
+        if (h_status) HIPCK(hipMemcpyAsync(h_status, d_status_, n * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCK(hipGetLastError());
+        if (sync || h_status) HIPCK(hipStreamSynchronize(st));
+    } catch (const std::exception& e) {
+        err_ = e.what();
+        return ERR_DEVICE;
+    }
+    return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-buffer entry points: stage through device buffers owned by the engine
+int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs, uint8_t* const* const* cells,
+                                              uint8_t* const* const* proofs, int* h_status) {
+    if (n <= 0) return OK;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        try {
+            HIPCK(hipSetDevice(dev_));
+            if (n > stage_cap_) {
+                if (d_in_) { HIPCK(hipFree(d_in_)); HIPCK(hipFree(d_cells_)); HIPCK(hipFree(d_proofs_)); }
+                HIPCK(hipMalloc(&d_in_, (size_t)n * BYTES_PER_BLOB));
+                HIPCK(hipMalloc(&d_cells_, (size_t)n * N_CELLS * BYTES_PER_CELL));
+                HIPCK(hipMalloc(&d_proofs_, (size_t)n * N_CELLS * 48));
+                stage_cap_ = n;
+            }
+            for (int b = 0; b < n; b++)
+                HIPCK(hipMemcpyAsync(d_in_ + (size_t)b * BYTES_PER_BLOB, blobs[b], BYTES_PER_BLOB, hipMemcpyHostToDevice, stream_));
+        } catch (const std::exception& e) {
+            err_ = e.what();
+            return ERR_DEVICE;
+        }
+    }
+    std::vector<int> st(n);
+    int rc = compute_cells_and_kzg_proofs_device(n, d_in_, cells ? d_cells_ : nullptr, proofs ? d_proofs_ : nullptr,
+                                                 st.data(), stream_, true);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(mu_);
+    try {
+        std::vector<uint8_t> hc, hp;
+        if (cells) {
+            hc.resize((size_t)n * N_CELLS * BYTES_PER_CELL);
+            HIPCK(hipMemcpy(hc.data(), d_cells_, hc.size(), hipMemcpyDeviceToHost));
+        }
+        if (proofs) {
+            hp.resize((size_t)n * N_CELLS * 48);
+            HIPCK(hipMemcpy(hp.data(), d_proofs_, hp.size(), hipMemcpyDeviceToHost));
+        }
+        for (int b = 0; b < n; b++) {
+            if (h_status) h_status[b] = st[b] ? ERR_SCALAR : OK;
+            if (st[b]) continue;
+            for (int k = 0; k < N_CELLS; k++) {
+                if (cells) memcpy(cells[b][k], hc.data() + ((size_t)b * N_CELLS + k) * BYTES_PER_CELL, BYTES_PER_CELL);
+                if (proofs) memcpy(proofs[b][k], hp.data() + ((size_t)b * N_CELLS + k) * 48, 48);
+            }
+        }
+    } catch (const std::exception& e) {
+        err_ = e.what();
+        return ERR_DEVICE;
+    }
+    return OK;
+}
+
+int Engine::blob_to_kzg_commitment_host(int n, const uint8_t* const* blobs, uint8_t* const* out, int* h_status) {
+    if (n <= 0) return OK;
+    uint8_t* d_out = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        try {
+            HIPCK(hipSetDevice(dev_));
+            if (n > stage_cap_) {
+                if (d_in_) { HIPCK(hipFree(d_in_)); HIPCK(hipFree(d_cells_)); HIPCK(hipFree(d_proofs_)); }
+                HIPCK(hipMalloc(&d_in_, (size_t)n * BYTES_PER_BLOB));
+                HIPCK(hipMalloc(&d_cells_, (size_t)n * N_CELLS * BYTES_PER_CELL));
+                HIPCK(hipMalloc(&d_proofs_, (size_t)n * N_CELLS * 48));
+                stage_cap_ = n;
+            }
+            for (int b = 0; b < n; b++)
+                HIPCK(hipMemcpyAsync(d_in_ + (size_t)b * BYTES_PER_BLOB, blobs[b], BYTES_PER_BLOB, hipMemcpyHostToDevice, stream_));
+            d_out = d_proofs_;  // reuse staging
+        } catch (const std::exception& e) {
+            err_ = e.what();
+            return ERR_DEVICE;
+        }
+    }
+    std::vector<int> st(n);
+    int rc = blob_to_kzg_commitment_device(n, d_in_, d_out, st.data(), stream_, true);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(mu_);
+    try {
+        std::vector<uint8_t> h((size_t)n * 48);
+        HIPCK(hipMemcpy(h.data(), d_out, h.size(), hipMemcpyDeviceToHost));
+        for (int b = 0; b < n; b++) {
+            if (h_status) h_status[b] = st[b] ? ERR_SCALAR : OK;
+            if (!st[b]) memcpy(out[b], h.data() + (size_t)b * 48, 48);
+        }
+    } catch (const std::exception& e) {
+        err_ = e.what();
+        return ERR_DEVICE;
+    }
+    return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage-level test hooks
+int Engine::test_fr_ntt4096(const uint8_t* in_be, uint8_t* out_be, int inverse_dit) {
+    std::lock_guard<std::mutex> lk(mu_);
+    try {
+        HIPCK(hipSetDevice(dev_));
+        uint8_t *di, *dout;
+        HIPCK(hipMalloc(&di, BYTES_PER_BLOB));
+        HIPCK(hipMalloc(&dout, BYTES_PER_BLOB));
+        HIPCK(hipMemcpy(di, in_be, BYTES_PER_BLOB, hipMemcpyHostToDevice));
+        launch::test_ntt4096(di, dout, d_w8192_, n_inv4096_, inverse_dit, stream_);
+        HIPCK(hipStreamSynchronize(stream_));
+        HIPCK(hipMemcpy(out_be, dout, BYTES_PER_BLOB, hipMemcpyDeviceToHost));
+        HIPCK(hipFree(di));
+        HIPCK(hipFree(dout));
+    } catch (const std::exception& e) {
+        err_ = e.what();
+        return ERR_DEVICE;
+    }
+    return OK;
+}
+
+// in/out: [lane][128][48 B]; both directions natural in -> natural out (inverse is unscaled)
+int Engine::test_g1_fft128(const uint8_t* in, uint8_t* out, int n_lanes, int inverse) {
+    std::lock_guard<std::mutex> lk(mu_);
+    try {
+        HIPCK(hipSetDevice(dev_));
+        int stride = ((n_lanes + 63) / 64) * 64;
+        size_t bytes = (size_t)n_lanes * 128 * 48;
+        uint8_t *di, *dout;
+        void* X;
+        HIPCK(hipMalloc(&di, bytes));
+        HIPCK(hipMalloc(&dout, bytes));
+        size_t nx = (size_t)128 * stride;
+        HIPCK(hipMalloc(&X, nx * sizeof(G1Jac)));
+        HIPCK(hipMemcpy(di, in, bytes, hipMemcpyHostToDevice));
+        launch::g1_set_inf(X, nx, stream_);
+        launch::test_load_points(di, X, n_lanes, stride, stream_);
+        HIPCK(hipStreamSynchronize(stream_));
+        std::vector<G1Jac> hx(nx), hy(nx);
+        auto brp = [](int v) { int r = 0; for (int i = 0; i < 7; i++) r |= ((v >> i) & 1) << (6 - i); return r; };
+        auto permute = [&]() {
+            HIPCK(hipMemcpy(hx.data(), X, nx * sizeof(G1Jac), hipMemcpyDeviceToHost));
+            for (int p = 0; p < 128; p++) memcpy(&hy[(size_t)brp(p) * stride], &hx[(size_t)p * stride], stride * sizeof(G1Jac));
+            HIPCK(hipMemcpy(X, hy.data(), nx * sizeof(G1Jac), hipMemcpyHostToDevice));
+        };
+        if (inverse) permute();  // DIT wants bit-reversed input
+        g1_fft128_full(X, stride, inverse, stream_);
+        HIPCK(hipStreamSynchronize(stream_));
+        if (!inverse) permute();  // DIF leaves bit-reversed output
+        launch::g1_compress(X, dout, 128, stride, n_lanes, stream_);
+        HIPCK(hipStreamSynchronize(stream_));
+        HIPCK(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+        HIPCK(hipFree(di)); HIPCK(hipFree(dout)); HIPCK(hipFree(X));
+    } catch (const std::exception& e) {
+        err_ = e.what();
+        return ERR_DEVICE;
+    }
+    return OK;
+}
+
+// scalars: [n_msm][128 groups][64] BE -> out [n_msm][128][48]: the 128 fixed-base MSMs of stage D
+int Engine::test_fixed_msm(const uint8_t* scalars_be, int n_msm, uint8_t* out) {
+    std::lock_guard<std::mutex> lk(mu_);
+    try {
+        HIPCK(hipSetDevice(dev_));
+        size_t ns = (size_t)n_msm * 128 * 64;
+        int stride = ((n_msm + 63) / 64) * 64;
+        uint8_t *di, *dout;
+        void *sc, *X;
+        HIPCK(hipMalloc(&di, ns * 32));
+        HIPCK(hipMalloc(&sc, ns * sizeof(Fr)));
+        HIPCK(hipMalloc(&X, (size_t)128 * stride * sizeof(G1Jac)));
+        HIPCK(hipMalloc(&dout, (size_t)n_msm * 128 * 48));
+        HIPCK(hipMemcpy(di, scalars_be, ns * 32, hipMemcpyHostToDevice));
+        launch::test_scalars_be(di, sc, ns, stream_);
+        launch::g1_set_inf(X, (size_t)128 * stride, stream_);
+        launch_msm(sc, d_fk_table_, X, 128, n_msm, stride, 0, stream_);
+        launch::g1_compress(X, dout, 128, stride, n_msm, stream_);
+        HIPCK(hipStreamSynchronize(stream_));
+        HIPCK(hipMemcpy(out, dout, (size_t)n_msm * 128 * 48, hipMemcpyDeviceToHost));
+        HIPCK(hipFree(di)); HIPCK(hipFree(sc)); HIPCK(hipFree(X)); HIPCK(hipFree(dout));
+    } catch (const std::exception& e) {
+        err_ = e.what();
+        return ERR_DEVICE;
+    }
+    return OK;
+}
+
+int Engine::test_g1_decompress(const uint8_t* in, int n, int subgroup_check, int* h_status, uint8_t* out) {
+    std::lock_guard<std::mutex> lk(mu_);
+    try {
+        HIPCK(hipSetDevice(dev_));
+        uint8_t *di, *dout;
+        void* pts;
+        int* st;
+        HIPCK(hipMalloc(&di, (size_t)n * 48)); HIPCK(hipMalloc(&dout, (size_t)n * 48));
+        HIPCK(hipMalloc(&pts, (size_t)n * sizeof(G1Affine))); HIPCK(hipMalloc(&st, n * sizeof(int)));
+        HIPCK(hipMemcpy(di, in, (size_t)n * 48, hipMemcpyHostToDevice));
+        launch::g1_decompress(di, pts, st, n, subgroup_check, stream_);
+        launch::test_recompress(pts, dout, n, stream_);
+        HIPCK(hipStreamSynchronize(stream_));
+        HIPCK(hipMemcpy(h_status, st, n * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(out, dout, (size_t)n * 48, hipMemcpyDeviceToHost));
+        HIPCK(hipFree(di)); HIPCK(hipFree(dout)); HIPCK(hipFree(pts)); HIPCK(hipFree(st));
+    } catch (const std::exception& e) {
+        err_ = e.what();
+        return ERR_DEVICE;
+    }
+    return OK;
+}
+
+int Engine::test_field_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, int n, int is_fp) {
+    std::lock_guard<std::mutex> lk(mu_);
+    try {
+        HIPCK(hipSetDevice(dev_));
+        size_t nb = (size_t)n * (is_fp ? 48 : 32);
+        uint8_t *da, *db, *dout;
+        HIPCK(hipMalloc(&da, nb)); HIPCK(hipMalloc(&db, nb)); HIPCK(hipMalloc(&dout, nb));
+        HIPCK(hipMemcpy(da, a, nb, hipMemcpyHostToDevice));
+        HIPCK(hipMemcpy(db, b, nb, hipMemcpyHostToDevice));
+        launch::test_field_mul(da, db, dout, n, is_fp, stream_);
+        HIPCK(hipStreamSynchronize(stream_));
+        HIPCK(hipMemcpy(out, dout, nb, hipMemcpyDeviceToHost));
+        HIPCK(hipFree(da)); HIPCK(hipFree(db)); HIPCK(hipFree(dout));
+    } catch (const std::exception& e) {
+        err_ = e.what();
+        return ERR_DEVICE;
+    }
+    return OK;
+}
+
+}  // namespace kzg

@@ -1,0 +1,92 @@
+// Fixed-base MSM over window tables (stage D of compute_cells_and_kzg_proofs; commitment MSM).
+#include "kcommon.hpp"
+#include "launch.hpp"
+
+namespace kzg {
+
+// ------------------------------------------------------------------------------------------------
+// Fixed-base MSM with window tables (replaces FixedBaseMSMPrecompWindow::msm,
+// fixed_base_msm_window.rs:102-168, and its batched affine adder batch_addition.rs:142-232).
+// The table holds, for every base P and every window w, the multiples d * 2^(c*w) * P, d = 1..2^(c-1),
+// so an MSM is a pure sum of table entries selected by the signed Booth digits of the scalars
+// (booth_encoding.rs:4-46): no doublings at run time.
+//   table index: (((group * W + w) * NB + i) << (c-1)) + (|d| - 1)
+// Thread (m, w) accumulates the NB entries of MSM m = (slice, group) for window w; the W partial
+// sums of an MSM sit in adjacent lanes and are folded through LDS.
+// scalars: [msm][NB] canonical Fr.  out[(perm(group)) * out_stride + slice] Jacobian.
+__device__ __forceinline__ int booth_digit(const uint32_t* sc, int w, int c) {
+    // (c+1)-bit window starting one bit below c*w; window 0 is padded with a zero bit
+    int lo = c * w - 1;
+    uint32_t x;
+    if (w == 0) x = sc[0] << 1;
+    else {
+        int word = lo >> 5, sh = lo & 31;
+        uint64_t two = sc[word];
+        if (word + 1 < 8) two |= (uint64_t)sc[word + 1] << 32;
+        x = (uint32_t)(two >> sh);
+    }
+    x &= (1u << (c + 1)) - 1;
+    int t = (int)((x + 1) >> 1);
+    return (x >> c) ? t - (1 << c) : t;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_msm_fixed(const Fr* __restrict__ scalars, const G1Affine* __restrict__ table,
+                                                   G1Jac* __restrict__ out, int n_groups, int n_slices, int nb,
+                                                   int out_stride, int brp_bits) {
+    constexpr int W = (255 + C) / C;  // number of Booth windows
+    constexpr int PER_BLOCK = 256 / W;
+    __shared__ G1Jac red[PER_BLOCK * W];
+    const int tid = threadIdx.x;
+    const int local = tid / W, w = tid % W;
+    const long m = (long)blockIdx.x * PER_BLOCK + local;  // MSM index = slice * n_groups + group
+    const long total = (long)n_groups * n_slices;
+    const bool active = local < PER_BLOCK && m < total;
+    G1Jac acc = jac_inf();
+    int group = 0, slice = 0;
+    if (active) {
+        slice = (int)(m / n_groups);
+        group = (int)(m % n_groups);
+        const Fr* sc = scalars + (size_t)m * nb;
+        const G1Affine* tb = table + (((size_t)group * W + w) * nb << (C - 1));
+        for (int i = 0; i < nb; i++) {
+            int d = booth_digit(sc[i].v, w, C);
+            if (d != 0) {
+                int ad = d < 0 ? -d : d;
+                G1Affine p = tb[((size_t)i << (C - 1)) + (ad - 1)];
+                if (d < 0) p.y = neg(p.y);
+                acc = add_mixed(acc, p);
+            }
+        }
+    }
+    if (local < PER_BLOCK) red[local * W + w] = acc;
+    __syncthreads();
+    // fold the W window sums of each MSM (W is not a power of two in general)
+    for (int span = 1; span < W; span <<= 1) {
+        if (local < PER_BLOCK && (w % (2 * span)) == 0 && w + span < W) {
+            red[local * W + w] = add(red[local * W + w], red[local * W + w + span]);
+        }
+        __syncthreads();
+    }
+    if (active && w == 0) {
+        int pos = brp_bits ? (int)(__brev((unsigned)group) >> (32 - brp_bits)) : group;
+        out[(size_t)pos * out_stride + slice] = red[local * W];
+    }
+}
+
+namespace launch {
+template <int C>
+static void msm_c(const void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,
+                  int brp_bits, hipStream_t st) {
+    constexpr int PB = 256 / ((255 + C) / C);
+    long total = (long)n_groups * n_slices;
+    k_msm_fixed<C><<<(unsigned)((total + PB - 1) / PB), 256, 0, st>>>((const Fr*)scalars, (const G1Affine*)table, (G1Jac*)out,
+                                                                     n_groups, n_slices, nb, out_stride, brp_bits);
+}
+void msm_fixed(int c, const void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,
+               int brp_bits, hipStream_t st) {
+    if (c == 8) msm_c<8>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
+    else msm_c<4>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
+}
+}  // namespace launch
+}  // namespace kzg

@@ -1,0 +1,48 @@
+// Host-callable launchers of the HIP kernels (one translation unit per kernel family so that
+// hipcc compiles them in parallel).  Pointers are device pointers; element types are noted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace kzg {
+struct Fr8;  // 8 x u32, Montgomery (engine.hpp)
+namespace launch {
+
+void init_attributes();  // opt in to 128 KiB dynamic LDS for the NTT kernels
+
+// k_ntt.hip
+void blob_to_coeffs(int n, const uint8_t* blobs, void* coeffs /*Fr*/, void* canon /*Fr or null*/, int* status,
+                    const void* w8192, const Fr8& n_inv, hipStream_t st);
+void coeffs_to_cells(int n, const void* coeffs, uint8_t* cells, const void* w8192, hipStream_t st);
+void fk20_scalars(int n, const void* coeffs, void* scalars /*Fr canonical*/, const void* w8192, const Fr8& inv128,
+                  hipStream_t st);
+void test_ntt4096(const uint8_t* in, uint8_t* out, const void* w8192, const Fr8& n_inv, int inverse_dit, hipStream_t st);
+void test_scalars_be(const uint8_t* in, void* out, size_t n, hipStream_t st);
+void test_field_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, int n, int is_fp, hipStream_t st);
+
+// k_msm.hip
+void msm_fixed(int c, const void* scalars, const void* table, void* out /*G1Jac*/, int n_groups, int n_slices, int nb,
+               int out_stride, int brp_bits, hipStream_t st);
+// k_table.hip
+size_t table_entries(int c, int n_groups, int nb);
+void build_table(int c, const void* bases /*G1Affine*/, void* table /*G1Affine*/, void* scratch /*G1Jac*/, int n_groups,
+                 int nb, hipStream_t st);
+
+// k_g1fft.hip
+void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int mode, const void* naf, hipStream_t st);
+
+// k_g1misc.hip
+void g1_set_inf(void* X, size_t n, hipStream_t st);
+void g1_compress(const void* X, uint8_t* out, int n_pos, int stride, int n_slices, hipStream_t st);
+void g1_sum_positions(void* X, int n_pos, int stride, int n_slices, hipStream_t st);
+void g1_decompress(const uint8_t* in, void* out /*G1Affine*/, int* status, int n, int subgroup_check, hipStream_t st);
+void fk20_srs_vectors(const void* srs, void* X, hipStream_t st);
+void fk20_gather_bases(const void* X, void* bases, hipStream_t st);
+void test_load_points(const uint8_t* in, void* X, int n_lanes, int stride, hipStream_t st);
+void test_recompress(const void* pts, uint8_t* out, int n, hipStream_t st);
+
+constexpr size_t SIZEOF_FR = 32, SIZEOF_G1AFFINE = 96, SIZEOF_G1JAC = 144;
+
+}  // namespace launch
+}  // namespace kzg

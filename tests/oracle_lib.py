@@ -85,3 +85,68 @@ class Oracle:
             self.ctx, C.c_size_t(len(cells)), b"".join(cells), C.c_size_t(len(cell_indices)), idx, oc, op))
         return ([oc.raw[i * 2048:(i + 1) * 2048] for i in range(CELLS)],
                 [op.raw[i * 48:(i + 1) * 48] for i in range(CELLS)])
+
+
+# ---- stage-level oracle entry points (canonical encodings; see oracle/kzg_oracle.h) ----
+def fr_ntt(data: bytes, inverse=False, coset=0) -> bytes:
+    lib = _lib()
+    n = len(data) // 32
+    buf = C.create_string_buffer(data, len(data))
+    rc = lib.oracle_fr_ntt(buf, C.c_size_t(n), int(inverse), int(coset))
+    if rc:
+        raise OracleError(rc)
+    return buf.raw
+
+
+def g1_fft(points: bytes, inverse=False) -> bytes:
+    lib = _lib()
+    n = len(points) // 48
+    buf = C.create_string_buffer(points, len(points))
+    rc = lib.oracle_g1_fft(buf, C.c_size_t(n), int(inverse))
+    if rc:
+        raise OracleError(rc)
+    return buf.raw
+
+
+def g1_msm(points: bytes, scalars: bytes) -> bytes:
+    lib = _lib()
+    n = len(points) // 48
+    out = C.create_string_buffer(48)
+    rc = lib.oracle_g1_msm(points, scalars, C.c_size_t(n), out)
+    if rc:
+        raise OracleError(rc)
+    return out.raw
+
+
+def g1_mul(point: bytes, scalar: bytes) -> bytes:
+    out = C.create_string_buffer(48)
+    rc = _lib().oracle_g1_mul(point, scalar, out)
+    if rc:
+        raise OracleError(rc)
+    return out.raw
+
+
+def g1_validate(point: bytes, subgroup_check=True) -> int:
+    return _lib().oracle_g1_validate(point, int(subgroup_check))
+
+
+def fr_mul(a: bytes, b: bytes) -> bytes:
+    out = C.create_string_buffer(32)
+    rc = _lib().oracle_fr_mul(a, b, out)
+    if rc:
+        raise OracleError(rc)
+    return out.raw
+
+
+def fp_mul(a: bytes, b: bytes) -> bytes:
+    out = C.create_string_buffer(48)
+    rc = _lib().oracle_fp_mul(a, b, out)
+    if rc:
+        raise OracleError(rc)
+    return out.raw
+
+
+def sha256(data: bytes) -> bytes:
+    out = C.create_string_buffer(32)
+    _lib().oracle_sha256(data, C.c_size_t(len(data)), out)
+    return out.raw
