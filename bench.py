@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- blobs/s of compute_cells_and_kzg_proofs on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (blob bytes -> 128 cells + 128 proofs per blob) over one batch of
+synthetic blobs that is already resident in HBM, through the device-pointer C ABI
+(eth_kzg_amd_compute_cells_and_kzg_proofs_device).  One process per GPU; the batch is sharded by
+contiguous blob index with no data-path collective; with N > 1 each step ends with one RCCL
+all-gather of the proof vectors (48 B x 128 per blob), which is the only exchange north_star names.
+Weak scaling: the per-GPU batch is fixed (default 2048 blobs: the batch that fills all 1024 SIMDs of the chip in
+the wave-per-butterfly G1-FFT stage; BASELINE.json's config-4 and config-2 sizes are reported alongside).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+BYTES_PER_BLOB, CELLS, BYTES_PER_CELL = 131072, 128, 2048
+ALG_BYTES_PER_BLOB = BYTES_PER_BLOB + CELLS * BYTES_PER_CELL + CELLS * 48  # 399,360 B
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_INT_PEAK_GOPS = 34000.0     # measured on MI355X with tools/ubench.hip: integer VALU ops (v_mad_u64_u32,
+                                 # v_addc_co_u32, ...) all issue at ~31-35 T lane-ops/s chip-wide
+
+
+def synth_blobs(n, seed):
+    """n valid blobs: every 32-byte element uniform in [0, 2^254) < r, deterministic in (seed)."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    a = rng.randint(0, 256, size=(n, 4096, 32), dtype=np.uint8)
+    a[:, :, 0] &= 0x3F
+    return a.reshape(n, BYTES_PER_BLOB)
+
+
+def cpu_baseline(blobs, budget_s=15.0):
+    """Time the CPU oracle (C restatement of the reference algorithm: FK20, width-8 window tables, batched
+    affine additions) on this box's host cores.  Two CPU configurations are timed on a bounded sample:
+      * blob-parallel: one single-threaded prover per worker thread, distinct blobs, all host cores busy
+        (the strongest CPU arrangement for a throughput metric) -> cpu_baseline.value
+      * rayon-like: one blob at a time with OpenMP threads over the axes maybe_rayon parallelises
+        (fk20/batch_toeplitz.rs:50,68,95,104,114; polynomial/src/fft.rs:72,119) -> cpu_baseline.rayon_like
+    """
+    import concurrent.futures as cf
+    cores = os.cpu_count() or 1
+    import oracle_lib
+    try:
+        # a native build of the same sources for this host (the prebuilt liboracle.so is generic x86-64)
+        native = os.path.join("/tmp", "liboracle_native_%d.so" % os.getuid())
+        src = [os.path.join(ROOT, "oracle", f) for f in ("field.c", "g1.c", "pairing.c", "sha256.c", "kzg.c")]
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-std=gnu11", "-shared", "-o", native] + src,
+                              stderr=subprocess.DEVNULL)
+        oracle_lib._SO = native
+    except Exception:
+        pass
+    from oracle_lib import Oracle
+    # --- rayon-like (intra-blob parallel), best of a few thread counts
+    rayon = {}
+    for th in sorted({min(cores, t) for t in (8, 16, 32)}):
+        o = Oracle(use_precomp=True, threads=th)
+        o.compute_cells_and_kzg_proofs(blobs[0])
+        n, t0 = 0, time.time()
+        while time.time() - t0 < budget_s / 6 and n < 200:
+            o.compute_cells_and_kzg_proofs(blobs[n % len(blobs)])
+            n += 1
+        rayon[th] = n / (time.time() - t0)
+        o.close()
+    best_th = max(rayon, key=rayon.get)
+    # --- blob-parallel over all cores (ctypes releases the GIL; the context is read-only while computing)
+    o = Oracle(use_precomp=True, threads=1)
+    workers = cores
+    per_worker = 2
+    def work(w):
+        for k in range(per_worker):
+            o.compute_cells_and_kzg_proofs(blobs[(w * per_worker + k) % len(blobs)])
+        return per_worker
+    t0 = time.time()
+    with cf.ThreadPoolExecutor(max_workers=workers) as ex:
+        done = sum(ex.map(work, range(workers)))
+    dt = time.time() - t0
+    o.close()
+    return {"value": done / dt, "unit": "blobs/s", "cores": workers, "kind": "port",
+            "sample": f"{done} x compute_cells_and_kzg_proofs over {len(blobs)} distinct synthetic blobs in {dt:.1f} s: one "
+                      f"single-threaded C-oracle prover per host thread ({workers} threads, width-8 tables, portable "
+                      f"__int128 field arithmetic -- not blst assembly)",
+            "rayon_like": {"value": rayon[best_th], "threads": best_th, "all": {str(k): round(v, 2) for k, v in rayon.items()},
+                           "note": "one blob at a time, OpenMP over the maybe_rayon axes"}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--blobs-per-gpu", type=int, default=int(os.environ.get("KZG_BENCH_BLOBS", "2048")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    kzg = importlib.import_module("rust-eth-kzg_amd")
+    ctx = kzg.DASContext(use_precomp=True, device=local_rank)  # no CPU fallback: raises/aborts without the HIP path
+
+    B = args.blobs_per_gpu
+    blobs_h = synth_blobs(B, seed=0x4B5A47 + rank)
+    d_blobs = torch.from_numpy(blobs_h).to(dev)
+    d_cells = torch.empty(B * CELLS * BYTES_PER_CELL, dtype=torch.uint8, device=dev)
+    d_proofs = torch.empty(B * CELLS * 48, dtype=torch.uint8, device=dev)
+    d_all_proofs = torch.empty(world * B * CELLS * 48, dtype=torch.uint8, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        ctx.compute_cells_and_kzg_proofs_device(B, d_blobs.data_ptr(), d_cells.data_ptr(), d_proofs.data_ptr(),
+                                                want_status=False, stream=stream.cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all_proofs, d_proofs)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # correctness gate on the first run (status + the data-in-first-half invariant, fk20/prover.rs:251-275)
+    st = ctx.compute_cells_and_kzg_proofs_device(B, d_blobs.data_ptr(), d_cells.data_ptr(), d_proofs.data_ptr(),
+                                                 want_status=True, stream=None)
+    assert st == [0] * B, "synthetic blobs rejected"
+    torch.cuda.synchronize(dev)
+    first_half = d_cells.view(B, 2, 64 * BYTES_PER_CELL)[:, 0, :]
+    assert torch.equal(first_half, d_blobs), "cells[0..63] != blob"
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.set_profiling(True)
+    ctx.get_stage_times()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    stages = ctx.get_stage_times()
+    ctx.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # single-blob latency (BASELINE.json config 2), outside the timed region
+    lat = []
+    for _ in range(3):
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        ctx.compute_cells_and_kzg_proofs_device(1, d_blobs.data_ptr(), d_cells.data_ptr(), d_proofs.data_ptr(),
+                                                want_status=False, stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        lat.append(time.perf_counter() - t1)
+
+    if rank == 0:
+        total_blobs = B * world * args.steps
+        value = total_blobs / dt
+        # dominant kernel = the one with the largest accumulated HIP-event time
+        dom = max(stages, key=lambda s: stages[s][0])
+        dom_ms, dom_launches = stages[dom]
+        per_launch_s = dom_ms * 1e-3 / max(1, dom_launches)
+        # algorithmic bytes per launch of each kernel family (DESIGN.md "kernels"):
+        alg_bytes = {
+            "blob_to_coeffs": B * (BYTES_PER_BLOB + 4096 * 32),
+            "coeffs_to_cells": B * (4096 * 32 * 2 + 8192 * 32),
+            "fk20_scalars": B * (4096 * 32 + 128 * 64 * 32),
+            # scalars in + one 96-B table entry per (scalar, window) + 128 Jacobian sums out
+            "msm_fixed": B * (128 * 64 * 32 + 128 * 64 * ((255 + ctx.window_bits()) // ctx.window_bits()) * 96 + 128 * 144),
+            # one radix-2 layer: 64 butterflies x (2 points in, 2 points out) x 144 B per blob
+            "g1_ifft": B * 64 * 4 * 144,
+            "g1_fft": B * 64 * 4 * 144,
+            "compress": B * 128 * (144 + 48),
+        }[dom]
+        achieved = alg_bytes / per_launch_s / 1e9
+        stage_ms_per_step = {s: round(stages[s][0] / args.steps, 3) for s in stages}
+        # integer-VALU view (the bound that actually binds): ~1.0e9 32x32 MACs per blob
+        mac_rate = value * 1.0e9 / 1e9
+        out = {
+            "metric": "blobs/sec compute_cells_and_kzg_proofs (4096-pt blob)",
+            "value": value, "unit": "blobs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32 limbs (381-bit Fp / 255-bit Fr Montgomery integers)", "data": "synthetic",
+            "config": {"workload": f"compute_cells_and_kzg_proofs, batch-saturated: {B} synthetic blobs per GPU per step "
+                                   f"(config 2's single blob is reported as single_blob_latency_ms)",
+                       "blobs_per_gpu": B, "use_precomp": True, "window_bits": ctx.window_bits(),
+                       "table_GB": round(ctx.table_bytes() / 1e9, 2),
+                       "exchange": "RCCL all-gather of proofs per step" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": per_launch_s * 1e3, "launches_per_step": dom_launches // max(1, args.steps),
+                         "note": "the path is integer-VALU bound, not HBM bound (SURVEY.md 8d); see roofline_valu"},
+            "roofline_valu": {"bound": "valu-int", "achieved": mac_rate, "peak": VALU_INT_PEAK_GOPS, "unit": "G int32-MAC/s",
+                              "frac": mac_rate / VALU_INT_PEAK_GOPS,
+                              "note": "blobs/s x 1.0e9 reference-algorithm MACs per blob / measured v_mad_u64_u32 issue rate"},
+            "whole_path_hbm_frac": value * ALG_BYTES_PER_BLOB / 1e9 / HBM_PEAK_GBS,
+            "stage_ms_per_step": stage_ms_per_step,
+            "single_blob_latency_ms": min(lat) * 1e3,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline([bytes(blobs_h[i].tobytes()) for i in range(min(B, 16))])
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -134,6 +134,13 @@ CResult eth_kzg_amd_blob_to_kzg_commitment_device(const DASContext *ctx, uint64_
 uint64_t eth_kzg_amd_table_bytes(const DASContext *ctx);
 int eth_kzg_amd_window_bits(const DASContext *ctx);
 
+/* Per-stage HIP-event timing for bench.py's roofline leg.  Stages, in order: blob_to_coeffs,
+ * coeffs_to_cells, fk20_scalars, msm_fixed, g1_ifft, g1_fft, compress.  get_stage_times writes the
+ * milliseconds and kernel-launch counts accumulated since the previous call (it synchronises the
+ * device) and returns the number of stages. */
+void eth_kzg_amd_set_profiling(const DASContext *ctx, int on);
+int eth_kzg_amd_get_stage_times(const DASContext *ctx, double *ms, uint64_t *launches, int n);
+
 /* Stage-level hooks for the kernel parity tests (tests/ only; canonical big-endian encodings).
  * Return 0 on success. */
 int eth_kzg_amd_test_fr_ntt4096(const DASContext *ctx, const uint8_t *in, uint8_t *out, int inverse_dit);

@@ -47,6 +47,7 @@ EXPORTED_SYMBOLS = [
     "eth_kzg_amd_compute_cells_and_kzg_proofs_batch", "eth_kzg_amd_blob_to_kzg_commitment_batch",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_device", "eth_kzg_amd_blob_to_kzg_commitment_device",
     "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits",
+    "eth_kzg_amd_set_profiling", "eth_kzg_amd_get_stage_times",
     "eth_kzg_amd_test_fr_ntt4096", "eth_kzg_amd_test_g1_fft128", "eth_kzg_amd_test_fixed_msm",
     "eth_kzg_amd_test_g1_decompress", "eth_kzg_amd_test_field_mul",
 ]
@@ -96,6 +97,9 @@ def load_library():
     lib.eth_kzg_amd_table_bytes.restype = U64
     lib.eth_kzg_amd_table_bytes.argtypes = [P]
     lib.eth_kzg_amd_window_bits.argtypes = [P]
+    lib.eth_kzg_amd_set_profiling.argtypes = [P, C.c_int]
+    lib.eth_kzg_amd_set_profiling.restype = None
+    lib.eth_kzg_amd_get_stage_times.argtypes = [P, P, P, C.c_int]
     lib.eth_kzg_amd_test_fr_ntt4096.argtypes = [P, U8P, P, C.c_int]
     lib.eth_kzg_amd_test_g1_fft128.argtypes = [P, U8P, P, C.c_int, C.c_int]
     lib.eth_kzg_amd_test_fixed_msm.argtypes = [P, U8P, C.c_int, P]
@@ -241,6 +245,19 @@ class DASContext:
         self._check(self._lib.eth_kzg_amd_blob_to_kzg_commitment_device(
             self._ctx, n, C.c_void_p(d_blobs), C.c_void_p(d_out), st, C.c_void_p(stream) if stream else None))
         return list(st)[:n] if want_status else None
+
+    STAGES = ["blob_to_coeffs", "coeffs_to_cells", "fk20_scalars", "msm_fixed", "g1_ifft", "g1_fft", "compress"]
+
+    def set_profiling(self, on):
+        self._lib.eth_kzg_amd_set_profiling(self._ctx, int(bool(on)))
+
+    def get_stage_times(self):
+        """{stage: (milliseconds, kernel launches)} accumulated since the previous call."""
+        n = len(self.STAGES)
+        ms = (C.c_double * n)()
+        ln = (C.c_uint64 * n)()
+        self._lib.eth_kzg_amd_get_stage_times(self._ctx, ms, ln, n)
+        return {s: (ms[i], int(ln[i])) for i, s in enumerate(self.STAGES)}
 
     def table_bytes(self):
         return int(self._lib.eth_kzg_amd_table_bytes(self._ctx))

@@ -180,6 +180,14 @@ CResult eth_kzg_amd_blob_to_kzg_commitment_device(const DASContext* ctx, uint64_
     if (status) for (uint64_t i = 0; i < n; i++) status[i] = status[i] ? kzg::ERR_SCALAR : 0;
     return ok();
 }
+void eth_kzg_amd_set_profiling(const DASContext* ctx, int on) { eng(ctx)->set_profiling(on != 0); }
+int eth_kzg_amd_get_stage_times(const DASContext* ctx, double* ms, uint64_t* launches, int n) {
+    double m[kzg::Engine::ST_COUNT];
+    uint64_t l[kzg::Engine::ST_COUNT];
+    eng(ctx)->get_stage_times(m, l);
+    for (int i = 0; i < n && i < kzg::Engine::ST_COUNT; i++) { ms[i] = m[i]; launches[i] = l[i]; }
+    return kzg::Engine::ST_COUNT;
+}
 uint64_t eth_kzg_amd_table_bytes(const DASContext* ctx) { return eng(ctx)->table_bytes(); }
 int eth_kzg_amd_window_bits(const DASContext* ctx) { return eng(ctx)->window_bits(); }
 

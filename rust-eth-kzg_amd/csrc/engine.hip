@@ -162,6 +162,34 @@ void Engine::init_fk20() {
     build_table(c_, d_srs_, &d_srs_table_, &srs_table_bytes_, 64, 64, stream_);  // SRS viewed as [64][64]
 }
 
+void Engine::set_profiling(bool on) { std::lock_guard<std::mutex> lk(mu_); profiling_ = on; }
+void Engine::mark_begin(int stage, hipStream_t st) {
+    if (!profiling_) return;
+    StageMark m{stage, 0, nullptr, nullptr};
+    HIPCK(hipEventCreate(&m.a));
+    HIPCK(hipEventCreate(&m.b));
+    HIPCK(hipEventRecord(m.a, st));
+    marks_.push_back(m);
+}
+void Engine::mark_end(int launches, hipStream_t st) {
+    if (!profiling_) return;
+    marks_.back().launches = launches;
+    HIPCK(hipEventRecord(marks_.back().b, st));
+}
+void Engine::get_stage_times(double* ms, uint64_t* launches) {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (int i = 0; i < ST_COUNT; i++) { ms[i] = 0; launches[i] = 0; }
+    hipSetDevice(dev_);
+    hipDeviceSynchronize();
+    for (auto& m : marks_) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, m.a, m.b) == hipSuccess) { ms[m.stage] += t; launches[m.stage] += m.launches; }
+        hipEventDestroy(m.a);
+        hipEventDestroy(m.b);
+    }
+    marks_.clear();
+}
+
 void Engine::ensure_workspace(int n) {
     if (n <= cap_) return;
     int cap = ((n + 63) / 64) * 64;
@@ -209,12 +237,22 @@ void Engine::g1_fft128_full(void* X, int stride, int inverse, hipStream_t st) {
 // stages C..G of SURVEY 3.2 from coefficients already in d_coeffs_
 void Engine::run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st) {
     const int bp = ((n + 63) / 64) * 64;
+    mark_begin(ST_FK20_SCALARS, st);
     launch::fk20_scalars(n, d_coeffs_, d_scalars_, d_w8192_, inv128_, st);
+    mark_end(1, st);
     launch::g1_set_inf(d_X_, (size_t)128 * bp, st);
+    mark_begin(ST_MSM_FIXED, st);
     launch_msm(d_scalars_, d_fk_table_, d_X_, 128, n, bp, 7, st);
+    mark_end(1, st);
+    mark_begin(ST_G1_IFFT, st);
     g1_ifft128_take64(d_X_, bp, st);
+    mark_end(7, st);
+    mark_begin(ST_G1_FFT, st);
     g1_fft128_from64(d_X_, bp, st);
+    mark_end(7, st);
+    mark_begin(ST_COMPRESS, st);
     launch::g1_compress(d_X_, d_proofs, 128, bp, n, st);
+    mark_end(1, st);
 }
 
 int Engine::compute_cells_and_kzg_proofs_device(int n, const uint8_t* d_blobs, uint8_t* d_cells, uint8_t* d_proofs,
@@ -226,8 +264,14 @@ int Engine::compute_cells_and_kzg_proofs_device(int n, const uint8_t* d_blobs, u
         if (!st) st = stream_;
         ensure_workspace(n);
         HIPCK(hipMemsetAsync(d_status_, 0, n * sizeof(int), st));
+        mark_begin(ST_BLOB_TO_COEFFS, st);
         launch::blob_to_coeffs(n, d_blobs, d_coeffs_, nullptr, d_status_, d_w8192_, n_inv4096_, st);
-        if (d_cells) launch::coeffs_to_cells(n, d_coeffs_, d_cells, d_w8192_, st);
+        mark_end(1, st);
+        if (d_cells) {
+            mark_begin(ST_COEFFS_TO_CELLS, st);
+            launch::coeffs_to_cells(n, d_coeffs_, d_cells, d_w8192_, st);
+            mark_end(1, st);
+        }
         if (d_proofs) run_proofs_from_coeffs(n, d_proofs, st);
         if (h_status) HIPCK(hipMemcpyAsync(h_status, d_status_, n * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCK(hipGetLastError());

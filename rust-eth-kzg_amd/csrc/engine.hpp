@@ -63,6 +63,13 @@ public:
     int test_g1_decompress(const uint8_t* in, int n, int subgroup_check, int* h_status, uint8_t* out_recompressed);
     int test_field_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, int n, int is_fp);
 
+    // ---- per-stage HIP-event timing (bench.py's roofline leg) ----
+    enum Stage { ST_BLOB_TO_COEFFS = 0, ST_COEFFS_TO_CELLS, ST_FK20_SCALARS, ST_MSM_FIXED, ST_G1_IFFT, ST_G1_FFT,
+                 ST_COMPRESS, ST_COUNT };
+    void set_profiling(bool on);
+    // sums since the last call: ms[ST_COUNT], launches[ST_COUNT]; synchronises the device
+    void get_stage_times(double* ms, uint64_t* launches);
+
     size_t table_bytes() const { return fk_table_bytes_ + srs_table_bytes_; }
     int window_bits() const { return c_; }
 
@@ -77,6 +84,12 @@ private:
     void g1_ifft128_take64(void* X, int stride, hipStream_t st);
     void g1_fft128_from64(void* X, int stride, hipStream_t st);
     void g1_fft128_full(void* X, int stride, int inverse, hipStream_t st);
+
+    struct StageMark { int stage; int launches; hipEvent_t a, b; };
+    void mark_begin(int stage, hipStream_t st);
+    void mark_end(int launches, hipStream_t st);
+    bool profiling_ = false;
+    std::vector<StageMark> marks_;
 
     int dev_ = 0;
     int c_ = 8;
