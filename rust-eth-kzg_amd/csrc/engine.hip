@@ -81,13 +81,14 @@ Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 8 
     init_constants();
     init_srs();
     init_fk20();
+    init_verifier();
     HIPCK(hipStreamSynchronize(stream_));
 }
 
 Engine::~Engine() {
     hipSetDevice(dev_);
     void* ptrs[] = {d_w8192_, d_naf_, d_srs_, d_fk_bases_, d_fk_table_, d_srs_table_, d_coeffs_, d_canon_,
-                    d_scalars_, d_X_, d_status_, d_in_, d_cells_, d_proofs_};
+                    d_scalars_, d_X_, d_status_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (stream_) hipStreamDestroy(stream_);

@@ -8,9 +8,11 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <memory>
 
 namespace kzg {
 
+namespace pairing { struct G2Prepared; }
 struct Fr8 { uint32_t v[8]; };
 
 enum Status : int {
@@ -77,6 +79,8 @@ private:
     void init_constants();
     void init_srs();
     void init_fk20();
+    void init_verifier();
+    int recover_to_coeffs(uint64_t n_cells, const uint8_t* const* cells, const uint64_t* cell_indices);
     void ensure_workspace(int n);
     void run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st);
     void launch_msm(const void* scalars, const void* table, void* out, int n_groups, int n_slices, int out_stride,
@@ -106,6 +110,12 @@ private:
     void* d_srs_table_ = nullptr; // window table over d_srs_ viewed as [64][64]
     size_t fk_table_bytes_ = 0, srs_table_bytes_ = 0;
     Fr8 n_inv4096_, inv128_;
+
+    // verifier / recovery constants
+    void* d_coset_ = nullptr;      // Fr[8192] 7^i      (ReedSolomon coset generator, reed_solomon.rs:129)
+    void* d_coset_inv_ = nullptr;  // Fr[8192] 7^-i
+    Fr8 inv64_, n_inv8192_;
+    std::shared_ptr<pairing::G2Prepared> g2_tau_, g2_neg_gen_;  // [tau^64]_2 and -[1]_2 (verifier.rs:88-90)
 
     // workspace (grown on demand, guarded by mu_)
     int cap_ = 0;

@@ -42,6 +42,21 @@ void fk20_gather_bases(const void* X, void* bases, hipStream_t st);
 void test_load_points(const uint8_t* in, void* X, int n_lanes, int stride, hipStream_t st);
 void test_recompress(const void* pts, uint8_t* out, int n, hipStream_t st);
 
+// k_verify.hip
+void init_attributes_verify();
+void cells_to_fr(const uint8_t* cells, void* evals, const int* slot_of, int* status, int n, hipStream_t st);
+void verify_scalars(const Fr8* pow_table24, const int* cell_idx, const void* w8192, void* rp_mont, void* s1, void* s2, int n,
+                    hipStream_t st);
+void verify_weights(const void* rp_mont, const int* row, void* weights, int n, int m, hipStream_t st);
+void interp(const void* evals, const int* cell_idx, const void* rp_mont, const void* w8192, const Fr8& inv64, void* partial,
+            int nblocks, void* out_neg_canon, int n, hipStream_t st);
+void lincomb_partial(const void* pts, const void* sc, int n, void* out_parts, hipStream_t st);
+void lincomb_final(const void* parts, int na, int nb, void* out_affine2, hipStream_t st);
+void rec_dit_half(int R, const void* V, const void* fac, void* T, const void* w8192, hipStream_t st);
+void rec_dit_last(int R, const void* T, const void* shift, const Fr8& n_inv, void* U, void* coeffs, int* status,
+                  const void* w8192, int final_pass, hipStream_t st);
+void rec_dif_half(int R, const void* U, const void* fac, void* V, const void* w8192, hipStream_t st);
+
 constexpr size_t SIZEOF_FR = 32, SIZEOF_G1AFFINE = 96, SIZEOF_G1JAC = 144;
 
 }  // namespace launch

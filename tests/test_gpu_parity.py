@@ -188,3 +188,64 @@ def test_use_precomp_false_gives_identical_results(oracle):
         assert c.blob_to_kzg_commitment(blob) == oracle.blob_to_kzg_commitment(blob)
     finally:
         c.close()
+
+
+# ------------------------------------------------------------------ verify / recover
+@pytest.mark.parametrize("name,case", sorted(vectors.load("verify_cell_kzg_proof_batch").items()))
+def test_verify_cell_kzg_proof_batch_vectors(ctx, name, case):
+    i = case["input"]
+    out = _call(ctx.verify_cell_kzg_proof_batch, i["commitments"], i["cell_indices"], i["cells"], i["proofs"])
+    assert out == case["output"]
+
+
+@pytest.mark.parametrize("name,case", sorted(vectors.load("recover_cells_and_kzg_proofs").items()))
+def test_recover_cells_and_kzg_proofs_vectors(ctx, name, case):
+    i = case["input"]
+    out = _call(ctx.recover_cells_and_kzg_proofs, i["cell_indices"], i["cells"])
+    exp = case["output"]
+    if exp is None:
+        assert out is None
+    else:
+        assert out is not None and out[0] == exp[0] and out[1] == exp[1]
+
+
+def test_verify_multi_blob_batch_and_tamper(ctx):
+    """BASELINE.json config 3 in miniature: several blobs x 128 cells in one call; then one tampered proof,
+    one tampered cell and a swapped commitment must each flip the result to False (not an error)."""
+    blobs = [synth.seeded_blob(20 + i) for i in range(3)]
+    st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs)
+    _, comms = ctx.blob_to_kzg_commitment_batch(blobs)
+    C, I, L, P = [], [], [], []
+    for b in range(len(blobs)):
+        for k in range(128):
+            C.append(comms[b]); I.append(k); L.append(cells[b][k]); P.append(proofs[b][k])
+    assert ctx.verify_cell_kzg_proof_batch(C, I, L, P) is True
+    P2 = list(P); P2[5] = proofs[1][7]
+    assert ctx.verify_cell_kzg_proof_batch(C, I, L, P2) is False
+    L2 = list(L); L2[300] = cells[0][1]
+    assert ctx.verify_cell_kzg_proof_batch(C, I, L2, P) is False
+    C2 = list(C); C2[0] = comms[2]
+    assert ctx.verify_cell_kzg_proof_batch(C2, I, L, P) is False
+    # ragged subset, arbitrary order, duplicates
+    sel = [3, 130, 131, 3, 383, 256]
+    assert ctx.verify_cell_kzg_proof_batch([C[s] for s in sel], [I[s] for s in sel], [L[s] for s in sel], [P[s] for s in sel]) is True
+
+
+@pytest.mark.parametrize("pattern", ["even", "first_half", "second_half", "random65", "all"])
+def test_recover_round_trip(ctx, oracle, pattern):
+    """encode -> erase -> decode round trip (BASELINE.json config 5 shape), checked against the oracle too."""
+    import random
+    blob = synth.seeded_blob(40)
+    cells, proofs = ctx.compute_cells_and_kzg_proofs(blob)
+    idx = {"even": list(range(0, 128, 2)), "first_half": list(range(64)), "second_half": list(range(64, 128)),
+           "random65": sorted(random.Random(1).sample(range(128), 65)), "all": list(range(128))}[pattern]
+    rc, rp = ctx.recover_cells_and_kzg_proofs(idx, [cells[i] for i in idx])
+    assert rc == cells and rp == proofs
+    oc, op = oracle.recover_cells_and_kzg_proofs(idx, [cells[i] for i in idx])
+    assert rc == oc and rp == op
+    # inconsistent data (a cell from another blob) must be rejected: recovered polynomial has degree >= 4096
+    other, _ = ctx.compute_cells_and_kzg_proofs(synth.seeded_blob(41))
+    if pattern != "all" and len(idx) > 64:
+        bad = [cells[i] for i in idx]
+        bad[0] = other[idx[0]]
+        assert _call(ctx.recover_cells_and_kzg_proofs, idx, bad) is None
