@@ -1,0 +1,52 @@
+"""Blob-batch sharding across the GPUs of one node (one process per GPU, torch.distributed).
+
+The hot path shards embarrassingly: every blob is independent, so a batch is split
+into contiguous slices, each rank runs its slice on its own GPU with a replicated context (SRS tables,
+twiddles), and the only exchange is ONE all-gather of the per-rank result slabs (RCCL over xGMI when the
+backend is "nccl"; the CPU tests use "gloo").  No collective sits inside the compute path.
+"""
+from typing import Callable, List, Sequence, Tuple
+
+
+def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """[lo, hi) of rank's contiguous slice; the first n % world ranks get one extra item."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_slabs(local: bytes, item_bytes: int, n_total: int, dist=None) -> bytes:
+    """All-gather variable-length per-rank slabs (len(local) = items_on_rank * item_bytes) into the
+    full [n_total * item_bytes] byte string on every rank.  Slabs are padded to the largest shard so a
+    single fixed-size all_gather does the exchange."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        assert len(local) == n_total * item_bytes
+        return local
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    max_items = max(shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0] for r in range(world))
+    backend = dist.get_backend()
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    buf = torch.zeros(max_items * item_bytes, dtype=torch.uint8, device=dev)
+    if local:
+        buf[:len(local)] = torch.frombuffer(bytearray(local), dtype=torch.uint8).to(dev)
+    out = torch.empty(world * max_items * item_bytes, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, buf)
+    out = out.cpu().numpy().tobytes()
+    parts = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, world, r)
+        parts.append(out[r * max_items * item_bytes: r * max_items * item_bytes + (hi - lo) * item_bytes])
+    return b"".join(parts)
+
+
+def run_sharded(compute: Callable[[Sequence[bytes]], List[bytes]], blobs: Sequence[bytes], item_bytes: int, dist=None) -> List[bytes]:
+    """Run `compute` (a per-rank batch function returning one item_bytes-long result per blob) on this rank's
+    slice and return the results for ALL blobs, in order, on every rank."""
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    lo, hi = shard_bounds(len(blobs), world, rank)
+    local = compute(blobs[lo:hi]) if hi > lo else []
+    assert all(len(x) == item_bytes for x in local)
+    full = gather_slabs(b"".join(local), item_bytes, len(blobs), dist)
+    return [full[i * item_bytes:(i + 1) * item_bytes] for i in range(len(blobs))]
