@@ -7,6 +7,7 @@
 #include "launch.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -53,28 +54,69 @@ static Fr fr_root_of_unity(int log_n) {
     }
     return fr_pow_limbs(fr_from_u64(7), e, 8);
 }
-// NAF of a canonical 255-bit integer: nz[8] non-zero mask, sg[8] sign mask (bit i <-> digit i)
-static void naf_digits(const Fr& canon, uint32_t* nz, uint32_t* sg) {
-    uint32_t x[9];
-    for (int i = 0; i < 8; i++) x[i] = canon.v[i];
-    x[8] = 0;
-    for (int i = 0; i < 8; i++) nz[i] = sg[i] = 0;
-    for (int pos = 0; pos < 256; pos++) {
-        if (x[0] & 1) {
-            int d = 2 - (int)(x[0] & 3);  // +1 or -1
-            if (d == 1) x[0] -= 1;        // odd: no borrow
-            else {                         // x += 1
-                for (int i = 0; i < 9; i++) { if (++x[i] != 0) break; }
-            }
-            nz[pos >> 5] |= 1u << (pos & 31);
-            if (d < 0) sg[pos >> 5] |= 1u << (pos & 31);
-        }
-        for (int i = 0; i < 9; i++) x[i] = (x[i] >> 1) | (i < 8 ? (x[i + 1] << 31) : 0);
+// GLV + joint sparse form of a public twiddle (host side, once per context).
+// phi(x, y) = (beta x, y) acts on G1 as multiplication by lambda = z^2 - 1 (z the BLS parameter), a 128-bit cube
+// root of unity mod r.  k = k1 + k2 lambda with k2 = floor(k / lambda), both < 2^128; the pair is then recoded
+// in Solinas' joint sparse form (digits in {-1,0,1}, about half of the <= 129 columns non-zero).
+// Table row per twiddle: 4 masks of 5 words: nz1, sg1, nz2, sg2 (bit i <-> column i).
+typedef unsigned __int128 u128;
+static const u128 GLV_LAMBDA = ((u128)0xac45a4010001a402ULL << 64) | 0x00000000ffffffffULL;
+static void glv_split(const Fr& canon, u128& k1, u128& k2) {
+    // binary long division of the 256-bit integer by lambda (remainder < lambda < 2^128; one extra carry bit)
+    u128 rem = 0, q = 0;
+    for (int i = 255; i >= 0; i--) {
+        bool top = (rem >> 127) & 1;
+        rem = (rem << 1) | ((canon.v[i >> 5] >> (i & 31)) & 1);
+        q <<= 1;  // quotient < 2^128: the bits shifted out here are zero
+        if (top || rem >= GLV_LAMBDA) { rem -= GLV_LAMBDA; q |= 1; }
     }
+    k1 = rem;
+    k2 = q;
+}
+static void jsf_digits(u128 k0, u128 k1, uint32_t* row /*20 words*/) {
+    for (int i = 0; i < 20; i++) row[i] = 0;
+    int d0 = 0, d1 = 0, j = 0;
+    auto digit = [](u128 l, u128 lo) -> int {
+        if ((l & 1) == 0) return 0;
+        int u = 2 - (int)(l & 3);
+        int m8 = (int)(l & 7);
+        if ((m8 == 3 || m8 == 5) && ((int)(lo & 3) == 2)) u = -u;
+        return u;
+    };
+    while (k0 + d0 > 0 || k1 + d1 > 0) {
+        u128 l0 = k0 + d0, l1 = k1 + d1;
+        int a = digit(l0, l1), b = digit(l1, l0);
+        if (j >= 160) throw std::runtime_error("JSF too long");
+        if (a) { row[0 + (j >> 5)] |= 1u << (j & 31); if (a < 0) row[5 + (j >> 5)] |= 1u << (j & 31); }
+        if (b) { row[10 + (j >> 5)] |= 1u << (j & 31); if (b < 0) row[15 + (j >> 5)] |= 1u << (j & 31); }
+        if (2 * d0 == 1 + a) d0 = 1 - d0;
+        if (2 * d1 == 1 + b) d1 = 1 - d1;
+        k0 >>= 1;
+        k1 >>= 1;
+        j++;
+    }
+}
+// check a JSF row against (k1, k2)
+static bool jsf_check(const uint32_t* row, u128 k1, u128 k2) {
+    __int128 s1 = 0, s2 = 0;
+    for (int j = 159; j >= 0; j--) {
+        int a = (row[0 + (j >> 5)] >> (j & 31)) & 1, an = (row[5 + (j >> 5)] >> (j & 31)) & 1;
+        int b = (row[10 + (j >> 5)] >> (j & 31)) & 1, bn = (row[15 + (j >> 5)] >> (j & 31)) & 1;
+        s1 = s1 * 2 + (a ? (an ? -1 : 1) : 0);
+        s2 = s2 * 2 + (b ? (bn ? -1 : 1) : 0);
+    }
+    return s1 == (__int128)k1 && s2 == (__int128)k2;
 }
 
 // ---------------------------------------------------------------------------------------------
-Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 8 : 4) {
+Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 12 : 4) {
+    if (use_precomp) {
+        if (const char* s = getenv("ETH_KZG_AMD_WINDOW")) {  // tuning knob: FK20 table window width (8, 10 or 12)
+            int c = atoi(s);
+            if (c == 8 || c == 10 || c == 12) c_ = c;
+        }
+    }
+    srs_c_ = use_precomp ? 8 : 4;
     HIPCK(hipSetDevice(dev_));
     HIPCK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     launch::init_attributes();
@@ -103,11 +145,27 @@ void Engine::init_constants() {
     if (!eq(mul(w[N_EXT - 1], g), one<FrParams>())) throw std::runtime_error("omega_8192 has wrong order");
     HIPCK(hipMalloc(&d_w8192_, N_EXT * sizeof(Fr)));
     HIPCK(hipMemcpy(d_w8192_, w.data(), N_EXT * sizeof(Fr), hipMemcpyHostToDevice));
-    // NAF of omega_128^k = w[64k]
-    std::vector<uint32_t> naf(128 * 16);
-    for (int k = 0; k < 128; k++) naf_digits(from_mont(w[64 * k]), &naf[k * 16], &naf[k * 16 + 8]);
-    HIPCK(hipMalloc(&d_naf_, naf.size() * 4));
-    HIPCK(hipMemcpy(d_naf_, naf.data(), naf.size() * 4, hipMemcpyHostToDevice));
+    // GLV/JSF recoding of omega_128^k = w[64k] (the G1-FFT twiddles)
+    {
+        Fr lam = zero<FrParams>();
+        for (int i = 0; i < 4; i++) lam.v[i] = (uint32_t)(GLV_LAMBDA >> (32 * i));
+        Fr lm = to_mont(lam);
+        if (!is_zero(add(add(sqr(lm), lm), one<FrParams>()))) throw std::runtime_error("GLV lambda is not a cube root of unity");
+        std::vector<uint32_t> jsf(128 * 20);
+        for (int k = 0; k < 128; k++) {
+            Fr canon = from_mont(w[64 * k]);
+            u128 k1, k2;
+            glv_split(canon, k1, k2);
+            // k1 + k2 * lambda == k (mod r), in Fr
+            Fr a1 = zero<FrParams>(), a2 = zero<FrParams>();
+            for (int i = 0; i < 4; i++) { a1.v[i] = (uint32_t)(k1 >> (32 * i)); a2.v[i] = (uint32_t)(k2 >> (32 * i)); }
+            if (!eq(add(to_mont(a1), mul(to_mont(a2), lm)), w[64 * k])) throw std::runtime_error("GLV split failed");
+            jsf_digits(k1, k2, &jsf[k * 20]);
+            if (!jsf_check(&jsf[k * 20], k1, k2)) throw std::runtime_error("JSF recoding failed");
+        }
+        HIPCK(hipMalloc(&d_naf_, jsf.size() * 4));
+        HIPCK(hipMemcpy(d_naf_, jsf.data(), jsf.size() * 4, hipMemcpyHostToDevice));
+    }
     Fr i4096 = inv(fr_from_u64(N_BLOB)), i128 = inv(fr_from_u64(128));
     memcpy(&n_inv4096_, &i4096, 32);
     memcpy(&inv128_, &i128, 32);
@@ -136,6 +194,18 @@ void Engine::init_srs() {
         if (s) throw std::runtime_error("embedded SRS point failed to decompress");
     HIPCK(hipFree(d_bytes));
     HIPCK(hipFree(d_st));
+    // beta: the cube root of unity in Fp with (beta x, y) = [lambda](x, y); pick it by testing on [tau]_1
+    {
+        G1Affine P;
+        HIPCK(hipMemcpy(&P, (const G1Affine*)d_srs_ + 1, sizeof(G1Affine), hipMemcpyDeviceToHost));
+        uint32_t lam[4];
+        for (int i = 0; i < 4; i++) lam[i] = (uint32_t)(GLV_LAMBDA >> (32 * i));
+        G1Affine Q = to_affine(scalar_mul<4>(to_jac(P), lam));
+        Fp bx = mul(Q.x, inv(P.x));  // beta = x(lambda P) / x(P)
+        Fp b3 = mul(sqr(bx), bx);
+        if (!eq(b3, one<FpParams>()) || eq(bx, one<FpParams>()) || !eq(Q.y, P.y)) throw std::runtime_error("GLV endomorphism check failed");
+        memcpy(&beta_, &bx, 48);
+    }
 }
 
 static void build_table(int c, const void* bases, void** table, size_t* bytes, int n_groups, int nb, hipStream_t st) {
@@ -160,7 +230,7 @@ void Engine::init_fk20() {
     HIPCK(hipStreamSynchronize(stream_));
     HIPCK(hipFree(X));
     build_table(c_, d_fk_bases_, &d_fk_table_, &fk_table_bytes_, 128, 64, stream_);
-    build_table(c_, d_srs_, &d_srs_table_, &srs_table_bytes_, 64, 64, stream_);  // SRS viewed as [64][64]
+    build_table(srs_c_, d_srs_, &d_srs_table_, &srs_table_bytes_, 64, 64, stream_);  // SRS viewed as [64][64]
 }
 
 void Engine::set_profiling(bool on) { std::lock_guard<std::mutex> lk(mu_); profiling_ = on; }
@@ -208,30 +278,30 @@ void Engine::ensure_workspace(int n) {
 // ---------------------------------------------------------------------------------------------
 void Engine::launch_msm(const void* scalars, const void* table, void* out, int n_groups, int n_slices, int out_stride,
                         int brp_bits, hipStream_t st) {
-    launch::msm_fixed(c_, scalars, table, out, n_groups, n_slices, 64, out_stride, brp_bits, st);
+    launch::msm_fixed(table == d_srs_table_ ? srs_c_ : c_, scalars, table, out, n_groups, n_slices, 64, out_stride, brp_bits, st);
 }
 
 // inverse FFT_128, DIT, input at bit-reversed positions, only outputs 0..63 produced (domain.rs:172-194;
 // the 128^-1 scaling is folded into the MSM scalars).
 void Engine::g1_ifft128_take64(void* X, int stride, hipStream_t st) {
     for (int half = 1; half <= 32; half <<= 1)
-        launch::g1_fft_layer(X, stride, half, 128 / (2 * half), 1, 0, d_naf_, st);
-    launch::g1_fft_layer(X, stride, 64, 1, 1, 3, d_naf_, st);
+        launch::g1_fft_layer(X, stride, half, 128 / (2 * half), 1, 0, d_naf_, beta_, st);
+    launch::g1_fft_layer(X, stride, 64, 1, 1, 3, d_naf_, beta_, st);
 }
 // forward FFT_128 of (h || O): DIF, natural in, bit-reversed out = the proof order (prover.rs:214-222).
 void Engine::g1_fft128_from64(void* X, int stride, hipStream_t st) {
-    launch::g1_fft_layer(X, stride, 64, 1, 0, 2, d_naf_, st);
+    launch::g1_fft_layer(X, stride, 64, 1, 0, 2, d_naf_, beta_, st);
     for (int half = 32; half >= 1; half >>= 1)
-        launch::g1_fft_layer(X, stride, half, 128 / (2 * half), 0, 1, d_naf_, st);
+        launch::g1_fft_layer(X, stride, half, 128 / (2 * half), 0, 1, d_naf_, beta_, st);
 }
 // full FFT_128.  forward: DIF natural -> bit-reversed.  inverse: DIT bit-reversed -> natural (no scaling).
 void Engine::g1_fft128_full(void* X, int stride, int inverse, hipStream_t st) {
     if (!inverse) {
         for (int half = 64; half >= 1; half >>= 1)
-            launch::g1_fft_layer(X, stride, half, 128 / (2 * half), 0, 1, d_naf_, st);
+            launch::g1_fft_layer(X, stride, half, 128 / (2 * half), 0, 1, d_naf_, beta_, st);
     } else {
         for (int half = 1; half <= 64; half <<= 1)
-            launch::g1_fft_layer(X, stride, half, 128 / (2 * half), 1, 0, d_naf_, st);
+            launch::g1_fft_layer(X, stride, half, 128 / (2 * half), 1, 0, d_naf_, beta_, st);
     }
 }
 
@@ -247,7 +317,7 @@ void Engine::run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st) {
     mark_end(1, st);
     mark_begin(ST_G1_IFFT, st);
     g1_ifft128_take64(d_X_, bp, st);
-    mark_end(7, st);
+    mark_end(7, st);  // 7 layers (each = one twiddle-multiplication launch + one butterfly launch)
     mark_begin(ST_G1_FFT, st);
     g1_fft128_from64(d_X_, bp, st);
     mark_end(7, st);

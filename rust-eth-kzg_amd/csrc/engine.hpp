@@ -14,6 +14,7 @@ namespace kzg {
 
 namespace pairing { struct G2Prepared; }
 struct Fr8 { uint32_t v[8]; };
+struct Fp12w { uint32_t v[12]; };
 
 enum Status : int {
     OK = 0,
@@ -96,14 +97,16 @@ private:
     std::vector<StageMark> marks_;
 
     int dev_ = 0;
-    int c_ = 8;
+    int c_ = 8;      // window width of the FK20 table
+    int srs_c_ = 8;  // window width of the commitment (monomial SRS) table
     hipStream_t stream_ = nullptr;
     std::mutex mu_;
     std::string err_;
 
     // constants in HBM
     void* d_w8192_ = nullptr;     // Fr[8192] omega_8192^k, Montgomery
-    void* d_naf_ = nullptr;       // u32[128][16] NAF digits of omega_128^k
+    void* d_naf_ = nullptr;       // u32[128][20] GLV + joint-sparse-form digits of omega_128^k
+    Fp12w beta_;                  // cube root of unity in Fp: (beta x, y) = [lambda](x, y)
     void* d_srs_ = nullptr;       // G1Affine[4096] monomial SRS
     void* d_fk_bases_ = nullptr;  // G1Affine[128][64] FFT'd SRS vectors (batch_toeplitz.rs:46-61)
     void* d_fk_table_ = nullptr;  // window table over d_fk_bases_

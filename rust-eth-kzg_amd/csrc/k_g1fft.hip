@@ -1,6 +1,7 @@
 // G1 FFT over 128 positions, batched over blobs (stages E and F of compute_cells_and_kzg_proofs;
 // also the set-up FFTs of the SRS vectors).  Reference: fft_inplace<G1Projective> via
 // Domain::{fft_g1, ifft_g1_take_n} (crates/cryptography/polynomial/src/domain.rs:149-194, fft.rs:46-177).
+#include "engine.hpp"
 #include "kcommon.hpp"
 #include "launch.hpp"
 
@@ -8,80 +9,119 @@ namespace kzg {
 
 // Data layout: X[pos * stride + lane], lane = blob index inside the batch (stride = batch padded to a
 // multiple of 64), so all 64 lanes of a wave run the SAME butterfly and the twiddle is wave-uniform.
-// `b * twiddle` (fft.rs:164-177) is a 255-bit scalar multiplication by a public constant: its NAF digits
-// are precomputed on the host (naf[k] for omega_128^k: 8 words non-zero mask, 8 words sign mask) and every
-// digit test is a scalar branch -- no lane divergence.
-__device__ __forceinline__ G1Jac mul_by_twiddle(const G1Jac& p, const uint32_t* __restrict__ naf, int k) {
+// `b * twiddle` (fft.rs:164-177) is a 255-bit scalar multiplication by a PUBLIC constant, so the scalar is
+// recoded once on the host: GLV split k = k1 + k2*lambda (phi(x,y) = (beta x, y) = [lambda](x,y)) and the joint
+// sparse form of (k1, k2): <= 129 doublings and ~64 additions of one of {P, phi P, P + phi P, P - phi P}
+// (vs 255 doublings + ~85 additions for a plain NAF).  Every digit test is a scalar branch on wave-uniform
+// masks: no lane divergence.  jsf[k] = 4 masks x 5 words: nz1, sg1, nz2, sg2.
+__device__ __forceinline__ G1Jac select(bool c, const G1Jac& a, const G1Jac& b) {
+    G1Jac r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        r.x.v[i] = c ? a.x.v[i] : b.x.v[i];
+        r.y.v[i] = c ? a.y.v[i] : b.y.v[i];
+        r.z.v[i] = c ? a.z.v[i] : b.z.v[i];
+    }
+    return r;
+}
+__device__ __forceinline__ G1Jac mul_by_twiddle(const G1Jac& p, const uint32_t* __restrict__ jsf, const Fp& beta, int k) {
     // k is wave-uniform; 0 -> identity map, 64 -> negation (omega_128^64 = -1)
     if (k == 0) return p;
     if (k == 64) return neg(p);
-    uint32_t nz[8], sg[8];
+    uint32_t m[20];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        nz[i] = __builtin_amdgcn_readfirstlane(naf[(size_t)k * 16 + i]);
-        sg[i] = __builtin_amdgcn_readfirstlane(naf[(size_t)k * 16 + 8 + i]);
-    }
-    G1Jac np = neg(p);
+    for (int i = 0; i < 20; i++) m[i] = __builtin_amdgcn_readfirstlane(jsf[(size_t)k * 20 + i]);
+    G1Jac t2 = p;
+    t2.x = mul(p.x, beta);          // phi(P), Jacobian: (beta X, Y, Z)
+    G1Jac t3 = add(p, t2);          // P + phi P
+    G1Jac t4 = add(p, neg(t2));     // P - phi P
     G1Jac acc = jac_inf();
     bool started = false;
 #pragma unroll 1
-    for (int wd = 7; wd >= 0; wd--) {
-        uint32_t nzw = nz[wd], sgw = sg[wd];
+    for (int wd = 4; wd >= 0; wd--) {
+        const uint32_t nz1 = m[wd], sg1 = m[5 + wd], nz2 = m[10 + wd], sg2 = m[15 + wd];
 #pragma unroll 1
         for (int bit = 31; bit >= 0; bit--) {
             if (started) acc = dbl(acc);
-            if ((nzw >> bit) & 1) {
-                bool minus = (sgw >> bit) & 1;
-                if (!started) { acc = minus ? np : p; started = true; }
-                else acc = add(acc, minus ? np : p);
+            const bool a = (nz1 >> bit) & 1, b = (nz2 >> bit) & 1;
+            if (a | b) {
+                const bool an = (sg1 >> bit) & 1, bn = (sg2 >> bit) & 1;
+                // (u1,u2): (+-1,0) -> +-P; (0,+-1) -> +-phi P; equal signs -> +-(P + phi P); else +-(P - phi P)
+                G1Jac op = select(a && b, select(an == bn, t3, t4), select(a, p, t2));
+                const bool minus = a ? an : bn;
+                if (minus) op.y = neg(op.y);
+                if (!started) { acc = op; started = true; }
+                else acc = add(acc, op);
             }
         }
     }
     return acc;
 }
 
-// One radix-2 layer.  MODE 0: DIT butterfly (a, b) -> (a + w b, a - w b)      [inverse FFT, natural out]
-//                     MODE 1: DIF butterfly (a, b) -> (a + b, (a - b) w)      [forward FFT, bit-reversed out]
-//                     MODE 2: DIF first layer with b == identity: (a, -) -> (a, a w)   (input h || 0)
-//                     MODE 3: DIT last layer keeping only the first half: a <- a + w b
+// One radix-2 layer = two small kernels, so that each heavy primitive (Jacobian add / double) is inlined once:
+//   k_g1_twiddle_mul : X[i1] <- w^e * X[src]      (src = i1, or i0 for the (h || 0) first DIF layer)
+//   k_g1_butterfly   : (X[i0], X[i1]) <- (X[i0] + X[i1], X[i0] - X[i1])   (difference optional)
+// DIT layer (inverse FFT, natural out):      twiddle_mul on b, then butterfly.
+// DIF layer (forward FFT, bit-reversed out): butterfly, then twiddle_mul on b.
 // q = butterfly index; half = butterfly span; twiddle exponent = j * tw_step (128 - that when inverse).
-// grid = (n_bfly, stride/64), block = 64.
-template <int MODE>
-__global__ __launch_bounds__(64) void k_g1_fft_layer(G1Jac* __restrict__ X, int stride, int half, int tw_step, int inverse,
-                                                     const uint32_t* __restrict__ naf) {
+// grid = (n_bfly = 64, stride/64), block = 64 (one wave = one butterfly x 64 blobs).
+__global__ __launch_bounds__(64, 2) void k_g1_twiddle_mul(G1Jac* __restrict__ X, int stride, int half, int tw_step, int inverse,
+                                                       int from_a, const uint32_t* __restrict__ jsf, Fp beta) {
     const int q = blockIdx.x, lane = blockIdx.y * 64 + threadIdx.x;
     const int j = q & (half - 1);
     const int i0 = ((q - j) << 1) + j, i1 = i0 + half;
     int e = (j * tw_step) & 127;
     if (inverse) e = (128 - e) & 127;
+    if (e == 0 && !from_a) return;  // multiplication by one, in place: nothing to do (wave-uniform)
+    const G1Jac src = X[(size_t)(from_a ? i0 : i1) * stride + lane];
+    X[(size_t)i1 * stride + lane] = mul_by_twiddle(src, jsf, beta, e);
+}
+__global__ __launch_bounds__(64) void k_g1_butterfly(G1Jac* __restrict__ X, int stride, int half, int want_diff) {
+    const int q = blockIdx.x, lane = blockIdx.y * 64 + threadIdx.x;
+    const int j = q & (half - 1);
+    const int i0 = ((q - j) << 1) + j, i1 = i0 + half;
     G1Jac* pa = X + (size_t)i0 * stride + lane;
     G1Jac* pb = X + (size_t)i1 * stride + lane;
-    if (MODE == 0) {
-        G1Jac a = *pa, t = mul_by_twiddle(*pb, naf, e);
-        *pa = add(a, t);
-        *pb = add(a, neg(t));
-    } else if (MODE == 1) {
-        G1Jac a = *pa, b = *pb;
-        *pa = add(a, b);
-        *pb = mul_by_twiddle(add(a, neg(b)), naf, e);
-    } else if (MODE == 2) {
-        *pb = mul_by_twiddle(*pa, naf, e);
-    } else {
-        G1Jac a = *pa, t = mul_by_twiddle(*pb, naf, e);
-        *pa = add(a, t);
+    const G1Jac a = *pa;
+    G1Jac b = *pb;
+#pragma unroll 1
+    for (int s = 0; s < 2; s++) {  // one inlined add serves both the sum and the difference
+        if (s == 1) {
+            if (!want_diff) break;
+            b.y = neg(b.y);
+        }
+        G1Jac r = add(a, b);
+        if (s == 0) *pa = r;
+        else *pb = r;
     }
 }
 
 namespace launch {
-void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int mode, const void* naf, hipStream_t st) {
+// mode 0: DIT butterfly (a, b) -> (a + w b, a - w b);  mode 1: DIF butterfly (a, b) -> (a + b, (a - b) w);
+// mode 2: DIF first layer with b == identity: b <- a w;  mode 3: DIT last layer keeping only a <- a + w b.
+void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int mode, const void* jsf, const Fp12w& beta,
+                  hipStream_t st) {
+    Fp bt;
+    for (int i = 0; i < 12; i++) bt.v[i] = beta.v[i];
     dim3 grid(64, stride / 64);
     G1Jac* x = (G1Jac*)X;
-    const uint32_t* nf = (const uint32_t*)naf;
+    const uint32_t* js = (const uint32_t*)jsf;
     switch (mode) {
-        case 0: k_g1_fft_layer<0><<<grid, 64, 0, st>>>(x, stride, half, tw_step, inverse, nf); break;
-        case 1: k_g1_fft_layer<1><<<grid, 64, 0, st>>>(x, stride, half, tw_step, inverse, nf); break;
-        case 2: k_g1_fft_layer<2><<<grid, 64, 0, st>>>(x, stride, half, tw_step, inverse, nf); break;
-        default: k_g1_fft_layer<3><<<grid, 64, 0, st>>>(x, stride, half, tw_step, inverse, nf); break;
+        case 0:
+            k_g1_twiddle_mul<<<grid, 64, 0, st>>>(x, stride, half, tw_step, inverse, 0, js, bt);
+            k_g1_butterfly<<<grid, 64, 0, st>>>(x, stride, half, 1);
+            break;
+        case 1:
+            k_g1_butterfly<<<grid, 64, 0, st>>>(x, stride, half, 1);
+            k_g1_twiddle_mul<<<grid, 64, 0, st>>>(x, stride, half, tw_step, inverse, 0, js, bt);
+            break;
+        case 2:
+            k_g1_twiddle_mul<<<grid, 64, 0, st>>>(x, stride, half, tw_step, inverse, 1, js, bt);
+            break;
+        default:
+            k_g1_twiddle_mul<<<grid, 64, 0, st>>>(x, stride, half, tw_step, inverse, 0, js, bt);
+            k_g1_butterfly<<<grid, 64, 0, st>>>(x, stride, half, 0);
+            break;
     }
 }
 }  // namespace launch

@@ -86,6 +86,8 @@ static void msm_c(const void* scalars, const void* table, void* out, int n_group
 void msm_fixed(int c, const void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,
                int brp_bits, hipStream_t st) {
     if (c == 8) msm_c<8>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
+    else if (c == 12) msm_c<12>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
+    else if (c == 10) msm_c<10>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
     else msm_c<4>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
 }
 }  // namespace launch

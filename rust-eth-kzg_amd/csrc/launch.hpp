@@ -6,7 +6,8 @@
 #include <cstdint>
 
 namespace kzg {
-struct Fr8;  // 8 x u32, Montgomery (engine.hpp)
+struct Fr8;    // 8 x u32, Montgomery (engine.hpp)
+struct Fp12w;  // 12 x u32, Montgomery
 namespace launch {
 
 void init_attributes();  // opt in to 128 KiB dynamic LDS for the NTT kernels
@@ -30,7 +31,8 @@ void build_table(int c, const void* bases /*G1Affine*/, void* table /*G1Affine*/
                  int nb, hipStream_t st);
 
 // k_g1fft.hip
-void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int mode, const void* naf, hipStream_t st);
+void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int mode, const void* jsf, const Fp12w& beta,
+                  hipStream_t st);
 
 // k_g1misc.hip
 void g1_set_inf(void* X, size_t n, hipStream_t st);
