@@ -1,0 +1,174 @@
+// G1 group law over the unsaturated field (fp29.hpp) for the hot kernels.
+// Same formulas as curve.hpp (dbl-2009-l, add-2007-bl, madd-2007-bl) rearranged so that
+//   * Z3 is always 2 * (a product): bound 4, so "Z == 0 mod p" is four 14-word compares;
+//   * NO exceptional-case test sits on the hot path: every degenerate addition (an identity operand,
+//     P + P, P + (-P)) makes Z3 = 2 Z1 (Z2) H vanish, so one cheap test of Z3 after the fact routes those
+//     rare cases to an exact slow path.  The constant / all-zero / two-valued fixture blobs reach it.
+// Stored coordinates: x, y < 64 p, z < 4 p, limbs normalised.
+#pragma once
+#include "curve.hpp"
+#include "fp29.hpp"
+
+namespace kzg {
+
+constexpr int XB = 64;  // bound of stored x / y coordinates (in units of p)
+constexpr int ZB = 4;   // bound of stored z
+
+struct AffQ {  // canonical coordinates; identity = (0, 0)
+    Fq<1> x, y;
+};
+struct JacQ {  // identity <=> z == 0 mod p
+    Fq<XB> x, y;
+    Fq<ZB> z;
+};
+
+HD bool is_inf(const AffQ& p) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < QL; i++) d |= p.x.v[i] | p.y.v[i];
+    return d == 0;
+}
+HD bool is_inf(const JacQ& p) { return is_zero(p.z); }
+HD JacQ jacq_inf() {
+    JacQ r;
+    r.x = relax<XB>(fq_one());
+    r.y = relax<XB>(fq_one());
+    r.z = relax<ZB>(fq_zero());
+    return r;
+}
+HD JacQ to_jacq(const AffQ& a) {
+    if (is_inf(a)) return jacq_inf();
+    JacQ r;
+    r.x = relax<XB>(a.x);
+    r.y = relax<XB>(a.y);
+    r.z = relax<ZB>(fq_one());
+    return r;
+}
+// Negating a stored coordinate would double its bound, so the hot paths never negate a point: add / add_mixed take
+// a `negq` flag and negate the product S2 instead (bound 2 -> 4, no reduction).  neg() itself goes through one
+// multiplication by R to return to a canonical value; it is used off the hot path only.
+HD JacQ neg(const JacQ& p) {
+    JacQ r = p;
+    r.y = relax<XB>(canonical(neg(p.y)));
+    return r;
+}
+template <int B>
+HD Fq<B> select(bool c, const Fq<B>& a, const Fq<B>& b) {
+    Fq<B> r;
+#pragma unroll
+    for (int i = 0; i < QL; i++) r.v[i] = c ? a.v[i] : b.v[i];
+    return r;
+}
+
+// dbl-2009-l with D = 4 X Y^2 written as a product: 3M + 4S
+HD JacQ dbl(const JacQ& p) {
+    Fq<2> A = sqr(p.x), B = sqr(p.y), C = sqr(B);
+    Fq<8> D = dbl(dbl(mul(p.x, B)));
+    Fq<6> E = add(dbl(A), A);
+    Fq<2> F = sqr(E);
+    JacQ r;
+    auto x3 = sub(F, dbl(D));                                   // < 2 + 32
+    auto y3 = sub(mul(E, sub(D, x3)), dbl(dbl(dbl(C))));        // < 2 + 32
+    r.x = relax<XB>(x3);
+    r.y = relax<XB>(y3);
+    r.z = dbl(mul(p.y, p.z));                                   // identity stays identity: z = 0 -> z3 = 0
+    return r;
+}
+
+// exact slow paths ------------------------------------------------------------------------------------------
+HD JacQ add_slow(const JacQ& p, const JacQ& q, bool negq);
+HD JacQ add_mixed_slow(const JacQ& p, const AffQ& q, bool negq);
+
+// add-2007-bl: 12M + 4S, no branches on the hot path except the final Z3 test
+// (p + q, or p - q when negq)
+HD JacQ add(const JacQ& p, const JacQ& q, bool negq = false) {
+    Fq<2> z1z1 = sqr(p.z), z2z2 = sqr(q.z);
+    Fq<2> u1 = mul(p.x, z2z2), u2 = mul(q.x, z1z1);
+    Fq<2> s1 = mul(mul(p.y, q.z), z2z2), s2p = mul(mul(q.y, p.z), z1z1);
+    Fq<4> s2 = select(negq, neg(s2p), relax<4>(s2p));
+    auto h = sub(u2, u1);            // < 6
+    auto rr = dbl(sub(s2, s1));      // < 16
+    Fq<2> i = sqr(dbl(h));
+    Fq<2> j = mul(h, i);
+    Fq<2> v = mul(u1, i);
+    JacQ r;
+    auto x3 = sub(sub(sqr(rr), j), dbl(v));                       // < 2 + 4 + 8
+    auto y3 = sub(mul(rr, sub(v, x3)), dbl(mul(s1, j)));          // < 2 + 8
+    r.x = relax<XB>(x3);
+    r.y = relax<XB>(y3);
+    r.z = dbl(mul(mul(p.z, q.z), h));
+    if (is_zero(r.z)) return add_slow(p, q, negq);
+    return r;
+}
+
+// madd-2007-bl with Z3 = 2 Z1 H: 8M + 3S
+HD JacQ add_mixed(const JacQ& p, const AffQ& q, bool negq = false) {
+    if (is_inf(q)) return p;  // an affine identity (0,0) does not make Z3 vanish: test it up front (28 ORs)
+    Fq<2> z1z1 = sqr(p.z);
+    Fq<2> u2 = mul(q.x, z1z1);
+    Fq<2> s2p = mul(mul(q.y, p.z), z1z1);
+    Fq<4> s2 = select(negq, neg(s2p), relax<4>(s2p));
+    auto h = sub(u2, p.x);           // < 2 + 128
+    auto rr = dbl(sub(s2, p.y));     // < 264
+    Fq<2> hh = sqr(h);
+    Fq<8> i = dbl(dbl(hh));
+    Fq<2> j = mul(h, i);
+    Fq<2> v = mul(p.x, i);
+    JacQ r;
+    auto x3 = sub(sub(sqr(rr), j), dbl(v));                       // < 2 + 4 + 8
+    auto y3 = sub(mul(rr, sub(v, x3)), dbl(mul(p.y, j)));         // < 2 + 8
+    r.x = relax<XB>(x3);
+    r.y = relax<XB>(y3);
+    r.z = dbl(mul(p.z, h));
+    if (is_zero(r.z)) return add_mixed_slow(p, q, negq);
+    return r;
+}
+
+HD JacQ add_slow(const JacQ& p, const JacQ& q, bool negq) {
+    if (is_inf(p)) return negq ? neg(q) : q;
+    if (is_inf(q)) return p;
+    // Z3 = 2 Z1 Z2 H == 0 with Z1, Z2 != 0  =>  H == 0: same x.  Same y -> doubling, opposite y -> identity.
+    Fq<2> z1z1 = sqr(p.z), z2z2 = sqr(q.z);
+    Fq<2> s1 = mul(mul(p.y, q.z), z2z2), s2p = mul(mul(q.y, p.z), z1z1);
+    Fq<4> s2 = select(negq, neg(s2p), relax<4>(s2p));
+    if (is_zero_slow(sub(s2, s1))) return dbl(p);
+    return jacq_inf();
+}
+HD JacQ add_mixed_slow(const JacQ& p, const AffQ& q, bool negq) {
+    if (is_inf(q)) return p;
+    if (is_inf(p)) {
+        JacQ r = to_jacq(q);
+        return negq ? neg(r) : r;
+    }
+    Fq<2> z1z1 = sqr(p.z);
+    Fq<2> s2p = mul(mul(q.y, p.z), z1z1);
+    Fq<4> s2 = select(negq, neg(s2p), relax<4>(s2p));
+    if (is_zero_slow(sub(s2, p.y))) return dbl(p);
+    return jacq_inf();
+}
+
+// conversions ------------------------------------------------------------------------------------------------
+HD AffQ affq_from_affine(const G1Affine& a) {  // a canonical Montgomery-384; identity (0,0) maps to (0,0)
+    AffQ r;
+    r.x = fq_from_fp(a.x);
+    r.y = fq_from_fp(a.y);
+    return r;
+}
+HD JacQ jacq_from_jac(const G1Jac& p) {
+    if (is_inf(p)) return jacq_inf();
+    JacQ r;
+    r.x = relax<XB>(fq_from_fp(p.x));
+    r.y = relax<XB>(fq_from_fp(p.y));
+    r.z = relax<ZB>(fq_from_fp(p.z));
+    return r;
+}
+HD G1Jac jac_from_jacq(const JacQ& p) {
+    if (is_inf(p)) return jac_inf();
+    G1Jac r;
+    r.x = fp_from_fq(p.x);
+    r.y = fp_from_fq(p.y);
+    r.z = fp_from_fq(p.z);
+    return r;
+}
+
+}  // namespace kzg

@@ -211,18 +211,18 @@ void Engine::init_srs() {
 static void build_table(int c, const void* bases, void** table, size_t* bytes, int n_groups, int nb, hipStream_t st) {
     size_t entries = launch::table_entries(c, n_groups, nb);
     void* scratch;
-    HIPCK(hipMalloc(table, entries * sizeof(G1Affine)));
+    HIPCK(hipMalloc(table, entries * launch::SIZEOF_AFFQ));
     HIPCK(hipMalloc(&scratch, entries * sizeof(G1Jac)));
     launch::build_table(c, bases, *table, scratch, n_groups, nb, st);
     HIPCK(hipStreamSynchronize(st));
     HIPCK(hipFree(scratch));
-    *bytes = entries * sizeof(G1Affine);
+    *bytes = entries * launch::SIZEOF_AFFQ;
 }
 
 void Engine::init_fk20() {
     // 64 G1-FFT_128 of the SRS vectors: the 64 vectors ride on the 64 lanes of the FFT kernel.
     void* X;
-    HIPCK(hipMalloc(&X, 128 * 64 * sizeof(G1Jac)));
+    HIPCK(hipMalloc(&X, 128 * 64 * launch::SIZEOF_JACQ));
     HIPCK(hipMalloc(&d_fk_bases_, 128 * 64 * sizeof(G1Affine)));
     launch::fk20_srs_vectors(d_srs_, X, stream_);
     g1_fft128_full(X, 64, /*inverse=*/0, stream_);  // DIF: natural in, bit-reversed out
@@ -270,7 +270,7 @@ void Engine::ensure_workspace(int n) {
     HIPCK(hipMalloc(&d_coeffs_, (size_t)cap * N_BLOB * sizeof(Fr)));
     HIPCK(hipMalloc(&d_canon_, (size_t)cap * N_BLOB * sizeof(Fr)));
     HIPCK(hipMalloc(&d_scalars_, (size_t)cap * 128 * 64 * sizeof(Fr)));
-    HIPCK(hipMalloc(&d_X_, (size_t)cap * 128 * sizeof(G1Jac)));
+    HIPCK(hipMalloc(&d_X_, (size_t)cap * 128 * launch::SIZEOF_JACQ));
     HIPCK(hipMalloc(&d_status_, (size_t)cap * sizeof(int)));
     cap_ = cap;
 }
@@ -508,17 +508,18 @@ int Engine::test_g1_fft128(const uint8_t* in, uint8_t* out, int n_lanes, int inv
         HIPCK(hipMalloc(&di, bytes));
         HIPCK(hipMalloc(&dout, bytes));
         size_t nx = (size_t)128 * stride;
-        HIPCK(hipMalloc(&X, nx * sizeof(G1Jac)));
+        const size_t PS = launch::SIZEOF_JACQ;
+        HIPCK(hipMalloc(&X, nx * PS));
         HIPCK(hipMemcpy(di, in, bytes, hipMemcpyHostToDevice));
         launch::g1_set_inf(X, nx, stream_);
         launch::test_load_points(di, X, n_lanes, stride, stream_);
         HIPCK(hipStreamSynchronize(stream_));
-        std::vector<G1Jac> hx(nx), hy(nx);
+        std::vector<uint8_t> hx(nx * PS), hy(nx * PS);
         auto brp = [](int v) { int r = 0; for (int i = 0; i < 7; i++) r |= ((v >> i) & 1) << (6 - i); return r; };
         auto permute = [&]() {
-            HIPCK(hipMemcpy(hx.data(), X, nx * sizeof(G1Jac), hipMemcpyDeviceToHost));
-            for (int p = 0; p < 128; p++) memcpy(&hy[(size_t)brp(p) * stride], &hx[(size_t)p * stride], stride * sizeof(G1Jac));
-            HIPCK(hipMemcpy(X, hy.data(), nx * sizeof(G1Jac), hipMemcpyHostToDevice));
+            HIPCK(hipMemcpy(hx.data(), X, nx * PS, hipMemcpyDeviceToHost));
+            for (int p = 0; p < 128; p++) memcpy(&hy[(size_t)brp(p) * stride * PS], &hx[(size_t)p * stride * PS], stride * PS);
+            HIPCK(hipMemcpy(X, hy.data(), nx * PS, hipMemcpyHostToDevice));
         };
         if (inverse) permute();  // DIT wants bit-reversed input
         g1_fft128_full(X, stride, inverse, stream_);
@@ -546,7 +547,7 @@ int Engine::test_fixed_msm(const uint8_t* scalars_be, int n_msm, uint8_t* out) {
         void *sc, *X;
         HIPCK(hipMalloc(&di, ns * 32));
         HIPCK(hipMalloc(&sc, ns * sizeof(Fr)));
-        HIPCK(hipMalloc(&X, (size_t)128 * stride * sizeof(G1Jac)));
+        HIPCK(hipMalloc(&X, (size_t)128 * stride * launch::SIZEOF_JACQ));
         HIPCK(hipMalloc(&dout, (size_t)n_msm * 128 * 48));
         HIPCK(hipMemcpy(di, scalars_be, ns * 32, hipMemcpyHostToDevice));
         launch::test_scalars_be(di, sc, ns, stream_);

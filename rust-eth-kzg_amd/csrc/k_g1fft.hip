@@ -3,6 +3,7 @@
 // Domain::{fft_g1, ifft_g1_take_n} (crates/cryptography/polynomial/src/domain.rs:149-194, fft.rs:46-177).
 #include "engine.hpp"
 #include "kcommon.hpp"
+#include "curve29.hpp"
 #include "launch.hpp"
 
 namespace kzg {
@@ -14,28 +15,25 @@ namespace kzg {
 // sparse form of (k1, k2): <= 129 doublings and ~64 additions of one of {P, phi P, P + phi P, P - phi P}
 // (vs 255 doublings + ~85 additions for a plain NAF).  Every digit test is a scalar branch on wave-uniform
 // masks: no lane divergence.  jsf[k] = 4 masks x 5 words: nz1, sg1, nz2, sg2.
-__device__ __forceinline__ G1Jac select(bool c, const G1Jac& a, const G1Jac& b) {
-    G1Jac r;
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        r.x.v[i] = c ? a.x.v[i] : b.x.v[i];
-        r.y.v[i] = c ? a.y.v[i] : b.y.v[i];
-        r.z.v[i] = c ? a.z.v[i] : b.z.v[i];
-    }
+__device__ __forceinline__ JacQ select(bool c, const JacQ& a, const JacQ& b) {
+    JacQ r;
+    r.x = select(c, a.x, b.x);
+    r.y = select(c, a.y, b.y);
+    r.z = select(c, a.z, b.z);
     return r;
 }
-__device__ __forceinline__ G1Jac mul_by_twiddle(const G1Jac& p, const uint32_t* __restrict__ jsf, const Fp& beta, int k) {
+__device__ __forceinline__ JacQ mul_by_twiddle(const JacQ& p, const uint32_t* __restrict__ jsf, const Fq<1>& beta, int k) {
     // k is wave-uniform; 0 -> identity map, 64 -> negation (omega_128^64 = -1)
     if (k == 0) return p;
     if (k == 64) return neg(p);
     uint32_t m[20];
 #pragma unroll
     for (int i = 0; i < 20; i++) m[i] = __builtin_amdgcn_readfirstlane(jsf[(size_t)k * 20 + i]);
-    G1Jac t2 = p;
-    t2.x = mul(p.x, beta);          // phi(P), Jacobian: (beta X, Y, Z)
-    G1Jac t3 = add(p, t2);          // P + phi P
-    G1Jac t4 = add(p, neg(t2));     // P - phi P
-    G1Jac acc = jac_inf();
+    JacQ t2 = p;
+    t2.x = relax<XB>(mul(p.x, beta));  // phi(P), Jacobian: (beta X, Y, Z)
+    JacQ t3 = add(p, t2);              // P + phi P
+    JacQ t4 = add(p, t2, true);        // P - phi P
+    JacQ acc = jacq_inf();
     bool started = false;
 #pragma unroll 1
     for (int wd = 4; wd >= 0; wd--) {
@@ -47,11 +45,10 @@ __device__ __forceinline__ G1Jac mul_by_twiddle(const G1Jac& p, const uint32_t* 
             if (a | b) {
                 const bool an = (sg1 >> bit) & 1, bn = (sg2 >> bit) & 1;
                 // (u1,u2): (+-1,0) -> +-P; (0,+-1) -> +-phi P; equal signs -> +-(P + phi P); else +-(P - phi P)
-                G1Jac op = select(a && b, select(an == bn, t3, t4), select(a, p, t2));
+                JacQ op = select(a && b, select(an == bn, t3, t4), select(a, p, t2));
                 const bool minus = a ? an : bn;
-                if (minus) op.y = neg(op.y);
-                if (!started) { acc = op; started = true; }
-                else acc = add(acc, op);
+                if (!started) { acc = minus ? neg(op) : op; started = true; }
+                else acc = add(acc, op, minus);
             }
         }
     }
@@ -65,32 +62,29 @@ __device__ __forceinline__ G1Jac mul_by_twiddle(const G1Jac& p, const uint32_t* 
 // DIF layer (forward FFT, bit-reversed out): butterfly, then twiddle_mul on b.
 // q = butterfly index; half = butterfly span; twiddle exponent = j * tw_step (128 - that when inverse).
 // grid = (n_bfly = 64, stride/64), block = 64 (one wave = one butterfly x 64 blobs).
-__global__ __launch_bounds__(64, 2) void k_g1_twiddle_mul(G1Jac* __restrict__ X, int stride, int half, int tw_step, int inverse,
-                                                       int from_a, const uint32_t* __restrict__ jsf, Fp beta) {
+__global__ __launch_bounds__(64, 2) void k_g1_twiddle_mul(JacQ* __restrict__ X, int stride, int half, int tw_step, int inverse,
+                                                          int from_a, const uint32_t* __restrict__ jsf, Fq<1> beta) {
     const int q = blockIdx.x, lane = blockIdx.y * 64 + threadIdx.x;
     const int j = q & (half - 1);
     const int i0 = ((q - j) << 1) + j, i1 = i0 + half;
     int e = (j * tw_step) & 127;
     if (inverse) e = (128 - e) & 127;
     if (e == 0 && !from_a) return;  // multiplication by one, in place: nothing to do (wave-uniform)
-    const G1Jac src = X[(size_t)(from_a ? i0 : i1) * stride + lane];
+    const JacQ src = X[(size_t)(from_a ? i0 : i1) * stride + lane];
     X[(size_t)i1 * stride + lane] = mul_by_twiddle(src, jsf, beta, e);
 }
-__global__ __launch_bounds__(64) void k_g1_butterfly(G1Jac* __restrict__ X, int stride, int half, int want_diff) {
+__global__ __launch_bounds__(64) void k_g1_butterfly(JacQ* __restrict__ X, int stride, int half, int want_diff) {
     const int q = blockIdx.x, lane = blockIdx.y * 64 + threadIdx.x;
     const int j = q & (half - 1);
     const int i0 = ((q - j) << 1) + j, i1 = i0 + half;
-    G1Jac* pa = X + (size_t)i0 * stride + lane;
-    G1Jac* pb = X + (size_t)i1 * stride + lane;
-    const G1Jac a = *pa;
-    G1Jac b = *pb;
+    JacQ* pa = X + (size_t)i0 * stride + lane;
+    JacQ* pb = X + (size_t)i1 * stride + lane;
+    const JacQ a = *pa;
+    const JacQ b = *pb;
 #pragma unroll 1
     for (int s = 0; s < 2; s++) {  // one inlined add serves both the sum and the difference
-        if (s == 1) {
-            if (!want_diff) break;
-            b.y = neg(b.y);
-        }
-        G1Jac r = add(a, b);
+        if (s == 1 && !want_diff) break;
+        JacQ r = add(a, b, s == 1);
         if (s == 0) *pa = r;
         else *pb = r;
     }
@@ -101,10 +95,11 @@ namespace launch {
 // mode 2: DIF first layer with b == identity: b <- a w;  mode 3: DIT last layer keeping only a <- a + w b.
 void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int mode, const void* jsf, const Fp12w& beta,
                   hipStream_t st) {
-    Fp bt;
-    for (int i = 0; i < 12; i++) bt.v[i] = beta.v[i];
+    Fp b384;
+    for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
+    const Fq<1> bt = fq_from_fp(b384);  // host-side conversion to the 14 x 29-bit Montgomery-406 form
     dim3 grid(64, stride / 64);
-    G1Jac* x = (G1Jac*)X;
+    JacQ* x = (JacQ*)X;
     const uint32_t* js = (const uint32_t*)jsf;
     switch (mode) {
         case 0:

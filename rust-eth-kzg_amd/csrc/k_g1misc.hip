@@ -2,22 +2,24 @@
 // Reference: g1_batch_normalize (crates/cryptography/bls12_381/src/lib.rs:56-104), serialize_g1_compressed /
 // deserialize_compressed_g1 (crates/serialization/src/lib.rs:69-99), SRS vectors (fk20/prover.rs:88-104).
 #include "kcommon.hpp"
+#include "curve29.hpp"
 #include "launch.hpp"
 
 namespace kzg {
 
-__global__ void k_g1_set_inf(G1Jac* X, size_t n) {
+// The batched point arrays X[pos * stride + lane] hold JacQ (unsaturated Montgomery-406 coordinates, 168 B).
+__global__ void k_g1_set_inf(JacQ* X, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) X[i] = jac_inf();
+    if (i < n) X[i] = jacq_inf();
 }
 
 // Stage G+I: normalise and compress (lib.rs:56-104, serialization/src/lib.rs:84-86).
 // X[pos * stride + slice] -> out[(slice * n_pos + pos) * 48]
-__global__ __launch_bounds__(64) void k_g1_compress(const G1Jac* __restrict__ X, uint8_t* __restrict__ out, int n_pos,
+__global__ __launch_bounds__(64) void k_g1_compress(const JacQ* __restrict__ X, uint8_t* __restrict__ out, int n_pos,
                                                     int stride, int n_slices) {
     const int pos = blockIdx.x, slice = blockIdx.y * 64 + threadIdx.x;
     if (slice >= n_slices) return;
-    G1Affine a = to_affine(X[(size_t)pos * stride + slice]);
+    G1Affine a = to_affine(jac_from_jacq(X[(size_t)pos * stride + slice]));
     uint8_t buf[48];
     g1_compress(buf, a);
     uint32_t* dst = reinterpret_cast<uint32_t*>(out + ((size_t)slice * n_pos + pos) * 48);
@@ -27,10 +29,10 @@ __global__ __launch_bounds__(64) void k_g1_compress(const G1Jac* __restrict__ X,
 }
 
 // sum over positions: out[slice] = sum_pos X[pos*stride + slice]   (final fold of the commitment MSM)
-__global__ __launch_bounds__(64) void k_g1_sum_positions(G1Jac* __restrict__ X, int n_pos, int stride, int n_slices) {
+__global__ __launch_bounds__(64) void k_g1_sum_positions(JacQ* __restrict__ X, int n_pos, int stride, int n_slices) {
     const int slice = blockIdx.x * 64 + threadIdx.x;
     if (slice >= n_slices) return;
-    G1Jac acc = X[slice];
+    JacQ acc = X[slice];
     for (int p = 1; p < n_pos; p++) acc = add(acc, X[(size_t)p * stride + slice]);
     X[slice] = acc;
 }
@@ -58,31 +60,31 @@ __global__ void k_jac_to_affine(const G1Jac* __restrict__ in, G1Affine* __restri
 }
 
 // SRS vectors of FK20 (fk20/prover.rs:88-104): t = reverse(g1s)[64:], S_i = t[i::64] (63 points) || O.
-__global__ void k_fk20_srs_vectors(const G1Affine* __restrict__ srs, G1Jac* __restrict__ X) {
+__global__ void k_fk20_srs_vectors(const G1Affine* __restrict__ srs, JacQ* __restrict__ X) {
     // X[pos * 64 + i], pos < 128, i < 64
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 128 * 64) return;
     int pos = idx >> 6, i = idx & 63;
     int m = i + 64 * pos;  // index into t
-    G1Jac v = jac_inf();
-    if (pos < 63) v = to_jac(srs[N_BLOB - 1 - CELL_LEN - m]);
+    JacQ v = jacq_inf();
+    if (pos < 63) v = jacq_from_jac(to_jac(srs[N_BLOB - 1 - CELL_LEN - m]));
     X[idx] = v;
 }
 // bases[j][i] = affine(X[brp7(j) * 64 + i])   (transpose of batch_toeplitz.rs:61)
-__global__ void k_fk20_gather_bases(const G1Jac* __restrict__ X, G1Affine* __restrict__ bases) {
+__global__ void k_fk20_gather_bases(const JacQ* __restrict__ X, G1Affine* __restrict__ bases) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 128 * 64) return;
     int j = idx >> 6, i = idx & 63;
     int q = (int)(__brev((unsigned)j) >> 25);
-    bases[idx] = to_affine(X[q * 64 + i]);
+    bases[idx] = to_affine(jac_from_jacq(X[q * 64 + i]));
 }
-__global__ void k_test_load_points(const uint8_t* in, G1Jac* X, int n_lanes, int stride) {
+__global__ void k_test_load_points(const uint8_t* in, JacQ* X, int n_lanes, int stride) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 128 * n_lanes) return;
     int pos = idx / n_lanes, lane = idx % n_lanes;
     G1Affine a;
     if (g1_decompress(a, in + ((size_t)lane * 128 + pos) * 48)) a = aff_inf();
-    X[(size_t)pos * stride + lane] = to_jac(a);
+    X[(size_t)pos * stride + lane] = jacq_from_jac(to_jac(a));
 }
 __global__ void k_test_recompress(const G1Affine* in, uint8_t* out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -93,20 +95,20 @@ __global__ void k_test_recompress(const G1Affine* in, uint8_t* out, int n) {
 }
 
 namespace launch {
-void g1_set_inf(void* X, size_t n, hipStream_t st) { k_g1_set_inf<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((G1Jac*)X, n); }
+void g1_set_inf(void* X, size_t n, hipStream_t st) { k_g1_set_inf<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((JacQ*)X, n); }
 void g1_compress(const void* X, uint8_t* out, int n_pos, int stride, int n_slices, hipStream_t st) {
-    k_g1_compress<<<dim3(n_pos, stride / 64), 64, 0, st>>>((const G1Jac*)X, out, n_pos, stride, n_slices);
+    k_g1_compress<<<dim3(n_pos, stride / 64), 64, 0, st>>>((const JacQ*)X, out, n_pos, stride, n_slices);
 }
 void g1_sum_positions(void* X, int n_pos, int stride, int n_slices, hipStream_t st) {
-    k_g1_sum_positions<<<stride / 64, 64, 0, st>>>((G1Jac*)X, n_pos, stride, n_slices);
+    k_g1_sum_positions<<<stride / 64, 64, 0, st>>>((JacQ*)X, n_pos, stride, n_slices);
 }
 void g1_decompress(const uint8_t* in, void* out, int* status, int n, int subgroup_check, hipStream_t st) {
     k_g1_decompress<<<(n + 63) / 64, 64, 0, st>>>(in, (G1Affine*)out, status, n, subgroup_check);
 }
-void fk20_srs_vectors(const void* srs, void* X, hipStream_t st) { k_fk20_srs_vectors<<<128 * 64 / 256, 256, 0, st>>>((const G1Affine*)srs, (G1Jac*)X); }
-void fk20_gather_bases(const void* X, void* bases, hipStream_t st) { k_fk20_gather_bases<<<128 * 64 / 256, 256, 0, st>>>((const G1Jac*)X, (G1Affine*)bases); }
+void fk20_srs_vectors(const void* srs, void* X, hipStream_t st) { k_fk20_srs_vectors<<<128 * 64 / 256, 256, 0, st>>>((const G1Affine*)srs, (JacQ*)X); }
+void fk20_gather_bases(const void* X, void* bases, hipStream_t st) { k_fk20_gather_bases<<<128 * 64 / 256, 256, 0, st>>>((const JacQ*)X, (G1Affine*)bases); }
 void test_load_points(const uint8_t* in, void* X, int n_lanes, int stride, hipStream_t st) {
-    k_test_load_points<<<(128 * n_lanes + 255) / 256, 256, 0, st>>>(in, (G1Jac*)X, n_lanes, stride);
+    k_test_load_points<<<(128 * n_lanes + 255) / 256, 256, 0, st>>>(in, (JacQ*)X, n_lanes, stride);
 }
 void test_recompress(const void* pts, uint8_t* out, int n, hipStream_t st) { k_test_recompress<<<(n + 63) / 64, 64, 0, st>>>((const G1Affine*)pts, out, n); }
 }  // namespace launch

@@ -1,5 +1,6 @@
 // Fixed-base MSM over window tables (stage D of compute_cells_and_kzg_proofs; commitment MSM).
 #include "kcommon.hpp"
+#include "curve29.hpp"
 #include "launch.hpp"
 
 namespace kzg {
@@ -14,6 +15,7 @@ namespace kzg {
 // Thread (m, w) accumulates the NB entries of MSM m = (slice, group) for window w; the W partial
 // sums of an MSM sit in adjacent lanes and are folded through LDS.
 // scalars: [msm][NB] canonical Fr.  out[(perm(group)) * out_stride + slice] Jacobian.
+// Arithmetic in the unsaturated 14 x 29-bit field (fp29.hpp): table entries are AffQ (112 B), sums JacQ (168 B).
 __device__ __forceinline__ int booth_digit(const uint32_t* sc, int w, int c) {
     // (c+1)-bit window starting one bit below c*w; window 0 is padded with a zero bit
     int lo = c * w - 1;
@@ -31,31 +33,30 @@ __device__ __forceinline__ int booth_digit(const uint32_t* sc, int w, int c) {
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void k_msm_fixed(const Fr* __restrict__ scalars, const G1Affine* __restrict__ table,
-                                                   G1Jac* __restrict__ out, int n_groups, int n_slices, int nb,
+__global__ __launch_bounds__(256, 2) void k_msm_fixed(const Fr* __restrict__ scalars, const AffQ* __restrict__ table,
+                                                   JacQ* __restrict__ out, int n_groups, int n_slices, int nb,
                                                    int out_stride, int brp_bits) {
     constexpr int W = (255 + C) / C;  // number of Booth windows
     constexpr int PER_BLOCK = 256 / W;
-    __shared__ G1Jac red[PER_BLOCK * W];
+    __shared__ JacQ red[PER_BLOCK * W];
     const int tid = threadIdx.x;
     const int local = tid / W, w = tid % W;
     const long m = (long)blockIdx.x * PER_BLOCK + local;  // MSM index = slice * n_groups + group
     const long total = (long)n_groups * n_slices;
     const bool active = local < PER_BLOCK && m < total;
-    G1Jac acc = jac_inf();
+    JacQ acc = jacq_inf();
     int group = 0, slice = 0;
     if (active) {
         slice = (int)(m / n_groups);
         group = (int)(m % n_groups);
         const Fr* sc = scalars + (size_t)m * nb;
-        const G1Affine* tb = table + (((size_t)group * W + w) * nb << (C - 1));
+        const AffQ* tb = table + (((size_t)group * W + w) * nb << (C - 1));
         for (int i = 0; i < nb; i++) {
             int d = booth_digit(sc[i].v, w, C);
             if (d != 0) {
                 int ad = d < 0 ? -d : d;
-                G1Affine p = tb[((size_t)i << (C - 1)) + (ad - 1)];
-                if (d < 0) p.y = neg(p.y);
-                acc = add_mixed(acc, p);
+                AffQ p = tb[((size_t)i << (C - 1)) + (ad - 1)];
+                acc = add_mixed(acc, p, d < 0);
             }
         }
     }
@@ -80,7 +81,7 @@ static void msm_c(const void* scalars, const void* table, void* out, int n_group
                   int brp_bits, hipStream_t st) {
     constexpr int PB = 256 / ((255 + C) / C);
     long total = (long)n_groups * n_slices;
-    k_msm_fixed<C><<<(unsigned)((total + PB - 1) / PB), 256, 0, st>>>((const Fr*)scalars, (const G1Affine*)table, (G1Jac*)out,
+    k_msm_fixed<C><<<(unsigned)((total + PB - 1) / PB), 256, 0, st>>>((const Fr*)scalars, (const AffQ*)table, (JacQ*)out,
                                                                      n_groups, n_slices, nb, out_stride, brp_bits);
 }
 void msm_fixed(int c, const void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,

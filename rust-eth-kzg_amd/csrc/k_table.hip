@@ -1,5 +1,6 @@
 // One-time construction of the fixed-base window tables (context set-up).
 #include "kcommon.hpp"
+#include "curve29.hpp"
 #include "launch.hpp"
 
 namespace kzg {
@@ -8,7 +9,7 @@ namespace kzg {
 // normalised to affine with one inversion per thread (Montgomery's trick over the thread's entries).
 // bases: [n_groups][nb] affine.  scratch: one Fp per table entry (prefix products of the Z's).
 template <int C>
-__global__ __launch_bounds__(64) void k_build_table(const G1Affine* __restrict__ bases, G1Affine* __restrict__ table,
+__global__ __launch_bounds__(64) void k_build_table(const G1Affine* __restrict__ bases, AffQ* __restrict__ table,
                                                     G1Jac* __restrict__ scratch, int n_groups, int nb) {
     constexpr int W = (255 + C) / C;
     constexpr int T = 1 << (C - 1);
@@ -19,10 +20,10 @@ __global__ __launch_bounds__(64) void k_build_table(const G1Affine* __restrict__
     long bi = t / W;
     int i = (int)(bi % nb), group = (int)(bi / nb);
     G1Affine P = bases[bi];
-    G1Affine* dst = table + ((((size_t)group * W + w) * nb + i) << (C - 1));
+    AffQ* dst = table + ((((size_t)group * W + w) * nb + i) << (C - 1));
     G1Jac* scr = scratch + ((((size_t)group * W + w) * nb + i) << (C - 1));
     if (is_inf(P)) {
-        for (int d = 0; d < T; d++) dst[d] = aff_inf();
+        for (int d = 0; d < T; d++) dst[d] = affq_from_affine(aff_inf());
         return;
     }
     G1Jac Q = to_jac(P);
@@ -37,18 +38,18 @@ __global__ __launch_bounds__(64) void k_build_table(const G1Affine* __restrict__
     // pass 2: prefix products of the Z's, parked in the x slot of the destination entries
     Fp prod = one<FpParams>();
     for (int d = 0; d < T; d++) {
-        dst[d].x = prod;
+        *reinterpret_cast<Fp*>(&dst[d]) = prod;  // parked in the (larger) destination slot until the back sweep
         prod = mul(prod, scr[d].z);
     }
     Fp invp = inv(prod);
     for (int d = T - 1; d >= 0; d--) {
-        Fp zi = mul(invp, dst[d].x);
+        Fp zi = mul(invp, *reinterpret_cast<const Fp*>(&dst[d]));
         invp = mul(invp, scr[d].z);
         Fp zi2 = sqr(zi);
         G1Affine a;
         a.x = mul(scr[d].x, zi2);
         a.y = mul(scr[d].y, mul(zi2, zi));
-        dst[d] = a;
+        dst[d] = affq_from_affine(a);  // canonical, Montgomery-406, 14 x 29-bit limbs
     }
 }
 
@@ -61,10 +62,10 @@ void build_table(int c, const void* bases, void* table, void* scratch, int n_gro
     int W = (255 + c) / c;
     long threads = (long)n_groups * nb * W;
     unsigned blocks = (unsigned)((threads + 63) / 64);
-    if (c == 8) k_build_table<8><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (G1Affine*)table, (G1Jac*)scratch, n_groups, nb);
-    else if (c == 12) k_build_table<12><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (G1Affine*)table, (G1Jac*)scratch, n_groups, nb);
-    else if (c == 10) k_build_table<10><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (G1Affine*)table, (G1Jac*)scratch, n_groups, nb);
-    else k_build_table<4><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (G1Affine*)table, (G1Jac*)scratch, n_groups, nb);
+    if (c == 8) k_build_table<8><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)table, (G1Jac*)scratch, n_groups, nb);
+    else if (c == 12) k_build_table<12><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)table, (G1Jac*)scratch, n_groups, nb);
+    else if (c == 10) k_build_table<10><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)table, (G1Jac*)scratch, n_groups, nb);
+    else k_build_table<4><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)table, (G1Jac*)scratch, n_groups, nb);
 }
 }  // namespace launch
 }  // namespace kzg

@@ -60,6 +60,7 @@ void rec_dit_last(int R, const void* T, const void* shift, const Fr8& n_inv, voi
 void rec_dif_half(int R, const void* U, const void* fac, void* V, const void* w8192, hipStream_t st);
 
 constexpr size_t SIZEOF_FR = 32, SIZEOF_G1AFFINE = 96, SIZEOF_G1JAC = 144;
+constexpr size_t SIZEOF_AFFQ = 112, SIZEOF_JACQ = 168;  // unsaturated 14 x 29-bit forms (curve29.hpp): table entries, FFT arrays
 
 }  // namespace launch
 }  // namespace kzg
