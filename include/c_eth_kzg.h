@@ -116,6 +116,15 @@ CResult eth_kzg_amd_compute_cells_and_kzg_proofs_batch(const DASContext *ctx, ui
 CResult eth_kzg_amd_blob_to_kzg_commitment_batch(const DASContext *ctx, uint64_t n, const uint8_t *const *blobs,
                                                  uint8_t *const *out, int32_t *status);
 
+/* n independent recoveries in one pass (BASELINE.json config 5). Blob b supplies cells_lengths[b] cells
+ * (cells[b][k], 2048 B each) with indices cell_indices[b][k]; outputs as in the batch call above. status[b] = 0 ok,
+ * 1 a cell holds a non-canonical field element, 3 invalid indices / counts, 4 the cells are not consistent. */
+CResult eth_kzg_amd_recover_cells_and_proofs_batch(const DASContext *ctx, uint64_t n, const uint64_t *cells_lengths,
+                                                   const uint8_t *const *const *cells,
+                                                   const uint64_t *cell_indices_lengths,
+                                                   const uint64_t *const *cell_indices, uint8_t *const *const *out_cells,
+                                                   uint8_t *const *const *out_proofs, int32_t *status);
+
 /* Device-resident batches: flat buffers already in this GPU's HBM.
  *   d_blobs        n * 131072 bytes
  *   d_out_cells    n * 128 * 2048 bytes   (may be NULL)

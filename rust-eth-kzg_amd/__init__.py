@@ -45,6 +45,7 @@ EXPORTED_SYMBOLS = [
     "eth_kzg_verify_blob_kzg_proof", "eth_kzg_verify_blob_kzg_proof_batch",
     "eth_kzg_amd_das_context_new_on_device",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_batch", "eth_kzg_amd_blob_to_kzg_commitment_batch",
+    "eth_kzg_amd_recover_cells_and_proofs_batch",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_device", "eth_kzg_amd_blob_to_kzg_commitment_device",
     "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits",
     "eth_kzg_amd_set_profiling", "eth_kzg_amd_get_stage_times",
@@ -85,6 +86,7 @@ def load_library():
         "eth_kzg_verify_blob_kzg_proof_batch": [P, U64, P, U64, P, U64, P, P],
         "eth_kzg_amd_compute_cells_and_kzg_proofs_batch": [P, U64, P, P, P, P],
         "eth_kzg_amd_blob_to_kzg_commitment_batch": [P, U64, P, P, P],
+        "eth_kzg_amd_recover_cells_and_proofs_batch": [P, U64, P, P, P, P, P, P, P],
         "eth_kzg_amd_compute_cells_and_kzg_proofs_device": [P, U64, P, P, P, P, P],
         "eth_kzg_amd_blob_to_kzg_commitment_device": [P, U64, P, P, P, P],
     }.items():
@@ -231,6 +233,32 @@ class DASContext:
         st = (C.c_int32 * max(1, n))()
         self._check(self._lib.eth_kzg_amd_blob_to_kzg_commitment_batch(self._ctx, n, ba, oa, st))
         return list(st)[:n], [o.raw for o in outs]
+
+    def recover_cells_and_kzg_proofs_batch(self, batch):
+        """batch = [(cell_indices, cells), ...] -> (status list, cells[b][128], proofs[b][128])."""
+        n = len(batch)
+        keep = []
+        lens = (C.c_uint64 * max(1, n))(*[len(c) for _, c in batch])
+        ilens = (C.c_uint64 * max(1, n))(*[len(i) for i, _ in batch])
+        cpp, ipp = (C.c_void_p * max(1, n))(), (C.c_void_p * max(1, n))()
+        for b, (idx, cells) in enumerate(batch):
+            if any(len(c) != BYTES_PER_CELL for c in cells):
+                raise KzgError("InvalidLength")
+            ca, k1 = _ptr_array(cells)
+            ia = (C.c_uint64 * max(1, len(idx)))(*idx)
+            keep += [ca, k1, ia]
+            cpp[b], ipp[b] = C.addressof(ca), C.addressof(ia)
+        out_cells = [[C.create_string_buffer(BYTES_PER_CELL) for _ in range(128)] for _ in range(n)]
+        out_proofs = [[C.create_string_buffer(48) for _ in range(128)] for _ in range(n)]
+        ocp, opp = (C.c_void_p * max(1, n))(), (C.c_void_p * max(1, n))()
+        for b in range(n):
+            ca, k1 = _ptr_array(out_cells[b])
+            pa, k2 = _ptr_array(out_proofs[b])
+            keep += [ca, pa, k1, k2]
+            ocp[b], opp[b] = C.addressof(ca), C.addressof(pa)
+        st = (C.c_int32 * max(1, n))()
+        self._check(self._lib.eth_kzg_amd_recover_cells_and_proofs_batch(self._ctx, n, lens, cpp, ilens, ipp, ocp, opp, st))
+        return list(st)[:n], [[c.raw for c in cb] for cb in out_cells], [[p.raw for p in pb] for pb in out_proofs]
 
     def compute_cells_and_kzg_proofs_device(self, n, d_blobs, d_cells, d_proofs, want_status=True, stream=None):
         """Device-resident flat buffers (integer device addresses, e.g. torch tensor .data_ptr())."""

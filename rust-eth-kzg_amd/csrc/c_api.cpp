@@ -162,6 +162,18 @@ CResult eth_kzg_amd_blob_to_kzg_commitment_batch(const DASContext* ctx, uint64_t
     if (status) for (uint64_t i = 0; i < n; i++) status[i] = st[i];
     return ok();
 }
+CResult eth_kzg_amd_recover_cells_and_proofs_batch(const DASContext* ctx, uint64_t n, const uint64_t* cells_lengths,
+                                                   const uint8_t* const* const* cells, const uint64_t* cell_indices_lengths,
+                                                   const uint64_t* const* cell_indices, uint8_t* const* const* out_cells,
+                                                   uint8_t* const* const* out_proofs, int32_t* status) {
+    kzg::Engine* e = eng(ctx);
+    std::vector<int> st(n);
+    if (e->recover_cells_and_kzg_proofs_batch_host((int)n, cells_lengths, cells, cell_indices_lengths, cell_indices, out_cells,
+                                                   out_proofs, st.data()))
+        return device_err(e);
+    if (status) for (uint64_t i = 0; i < n; i++) status[i] = st[i];
+    return ok();
+}
 CResult eth_kzg_amd_compute_cells_and_kzg_proofs_device(const DASContext* ctx, uint64_t n, const uint8_t* d_blobs,
                                                         uint8_t* d_out_cells, uint8_t* d_out_proofs, int32_t* status,
                                                         void* hip_stream) {

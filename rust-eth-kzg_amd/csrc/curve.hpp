@@ -222,4 +222,29 @@ HD bool g1_in_subgroup(const G1Affine& a) {
     return is_inf(r);
 }
 
+// Endomorphism subgroup test (the method blst uses; M. Scott, "A note on group membership tests for G1, G2 and GT
+// on BLS pairing-friendly curves", 2021): with phi(x, y) = (beta x, y) acting on G1 as [lambda], lambda = z^2 - 1,
+// a curve point P lies in G1 iff [z^2]P - P == phi(P).  [z^2]P = [|z|]([|z|]P): 126 doublings + 10 additions
+// (|z| = 0xd201000000010000 has weight 6) instead of the 255-bit [r]P.  The definitional test stays available
+// (g1_in_subgroup) and the GPU tests check that both agree on points outside the subgroup.
+HD G1Jac mul_by_z_abs(const G1Jac& p) {
+    constexpr uint64_t Z = 0xd201000000010000ULL;
+    G1Jac acc = p;
+    for (int i = 62; i >= 0; i--) {
+        acc = dbl(acc);
+        if ((Z >> i) & 1) acc = add(acc, p);
+    }
+    return acc;
+}
+HD bool g1_in_subgroup_endo(const G1Affine& a, const Fp& beta) {
+    if (is_inf(a)) return true;
+    G1Jac p = to_jac(a);
+    G1Jac q = mul_by_z_abs(mul_by_z_abs(p));  // [z^2]P
+    G1Jac r = add(q, neg(p));                 // [z^2 - 1]P
+    if (is_inf(r)) return false;
+    Fp zz = sqr(r.z);
+    if (!eq(r.x, mul(mul(a.x, beta), zz))) return false;
+    return eq(r.y, mul(a.y, mul(zz, r.z)));
+}
+
 }  // namespace kzg

@@ -133,6 +133,8 @@ Engine::~Engine() {
                     d_scalars_, d_X_, d_status_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_};
     for (void* p : ptrs)
         if (p) hipFree(p);
+    if (v_dev_) hipFree(v_dev_);
+    if (v_pin_) hipHostFree(v_pin_);
     if (stream_) hipStreamDestroy(stream_);
 }
 
@@ -186,7 +188,10 @@ void Engine::init_srs() {
     HIPCK(hipMalloc(&d_st, N_BLOB * sizeof(int)));
     HIPCK(hipMalloc(&d_srs_, N_BLOB * sizeof(G1Affine)));
     HIPCK(hipMemcpy(d_bytes, p + 16, (size_t)N_BLOB * 48, hipMemcpyHostToDevice));
-    launch::g1_decompress(d_bytes, d_srs_, d_st, N_BLOB, 0, stream_);
+    {
+        Fp12w nobeta{};
+        launch::g1_decompress(d_bytes, d_srs_, d_st, N_BLOB, 0, nobeta, stream_);
+    }
     std::vector<int> st(N_BLOB);
     HIPCK(hipMemcpyAsync(st.data(), d_st, N_BLOB * sizeof(int), hipMemcpyDeviceToHost, stream_));
     HIPCK(hipStreamSynchronize(stream_));
@@ -574,7 +579,7 @@ int Engine::test_g1_decompress(const uint8_t* in, int n, int subgroup_check, int
         HIPCK(hipMalloc(&di, (size_t)n * 48)); HIPCK(hipMalloc(&dout, (size_t)n * 48));
         HIPCK(hipMalloc(&pts, (size_t)n * sizeof(G1Affine))); HIPCK(hipMalloc(&st, n * sizeof(int)));
         HIPCK(hipMemcpy(di, in, (size_t)n * 48, hipMemcpyHostToDevice));
-        launch::g1_decompress(di, pts, st, n, subgroup_check, stream_);
+        launch::g1_decompress(di, pts, st, n, subgroup_check, beta_, stream_);
         launch::test_recompress(pts, dout, n, stream_);
         HIPCK(hipStreamSynchronize(stream_));
         HIPCK(hipMemcpy(h_status, st, n * sizeof(int), hipMemcpyDeviceToHost));

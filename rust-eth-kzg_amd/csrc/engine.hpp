@@ -59,6 +59,12 @@ public:
                                           const uint64_t* cell_indices, uint8_t* const* out_cells,
                                           uint8_t* const* out_proofs);
 
+    // batched form: R independent recoveries in one pass (ragged cell lists); status[r] per blob
+    int recover_cells_and_kzg_proofs_batch_host(int R, const uint64_t* n_cells, const uint8_t* const* const* cells,
+                                                const uint64_t* n_indices, const uint64_t* const* cell_indices,
+                                                uint8_t* const* const* out_cells, uint8_t* const* const* out_proofs,
+                                                int* status);
+
     // ---- stage-level hooks for the kernel parity tests (host buffers, canonical encodings) ----
     int test_fr_ntt4096(const uint8_t* in_be, uint8_t* out_be, int inverse_dit);
     int test_g1_fft128(const uint8_t* in_compressed, uint8_t* out_compressed, int n_lanes, int inverse);
@@ -81,7 +87,8 @@ private:
     void init_srs();
     void init_fk20();
     void init_verifier();
-    int recover_to_coeffs(uint64_t n_cells, const uint8_t* const* cells, const uint64_t* cell_indices);
+    int recover_batch_to_coeffs(int R, const uint64_t* n_cells, const uint8_t* const* const* cells,
+                                const uint64_t* const* cell_indices, int* st_out);
     void ensure_workspace(int n);
     void run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st);
     void launch_msm(const void* scalars, const void* table, void* out, int n_groups, int n_slices, int out_stride,
@@ -119,6 +126,12 @@ private:
     void* d_coset_inv_ = nullptr;  // Fr[8192] 7^-i
     Fr8 inv64_, n_inv8192_;
     std::shared_ptr<pairing::G2Prepared> g2_tau_, g2_neg_gen_;  // [tau^64]_2 and -[1]_2 (verifier.rs:88-90)
+
+    // verify workspace: one device arena + one pinned host staging buffer, grown on demand (guarded by mu_)
+    void* v_dev_ = nullptr;
+    size_t v_dev_cap_ = 0;
+    uint8_t* v_pin_ = nullptr;
+    size_t v_pin_cap_ = 0;
 
     // workspace (grown on demand, guarded by mu_)
     int cap_ = 0;

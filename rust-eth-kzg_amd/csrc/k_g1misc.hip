@@ -1,6 +1,7 @@
 // G1 helpers: identity fill, normalise + compress, decompression, small set-up gathers.
 // Reference: g1_batch_normalize (crates/cryptography/bls12_381/src/lib.rs:56-104), serialize_g1_compressed /
 // deserialize_compressed_g1 (crates/serialization/src/lib.rs:69-99), SRS vectors (fk20/prover.rs:88-104).
+#include "engine.hpp"
 #include "kcommon.hpp"
 #include "curve29.hpp"
 #include "launch.hpp"
@@ -38,13 +39,15 @@ __global__ __launch_bounds__(64) void k_g1_sum_positions(JacQ* __restrict__ X, i
 }
 
 // Unchecked decompression of the SRS (trusted_setup/src/lib.rs:80-86): thread per point.
+// subgroup_check: 0 none, 1 endomorphism test (production), 2 definitional [r]P == O (tests)
 __global__ void k_g1_decompress(const uint8_t* __restrict__ in, G1Affine* __restrict__ out, int* __restrict__ status,
-                                int n, int subgroup_check) {
+                                int n, int subgroup_check, Fp beta) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     G1Affine a;
     int rc = g1_decompress(a, in + (size_t)i * 48);
-    if (rc == 0 && subgroup_check && !g1_in_subgroup(a)) rc = 2;
+    if (rc == 0 && subgroup_check == 1 && !g1_in_subgroup_endo(a, beta)) rc = 2;
+    if (rc == 0 && subgroup_check == 2 && !g1_in_subgroup(a)) rc = 2;
     if (rc) { status[i] = rc; a = aff_inf(); } else status[i] = 0;
     out[i] = a;
 }
@@ -102,8 +105,10 @@ void g1_compress(const void* X, uint8_t* out, int n_pos, int stride, int n_slice
 void g1_sum_positions(void* X, int n_pos, int stride, int n_slices, hipStream_t st) {
     k_g1_sum_positions<<<stride / 64, 64, 0, st>>>((JacQ*)X, n_pos, stride, n_slices);
 }
-void g1_decompress(const uint8_t* in, void* out, int* status, int n, int subgroup_check, hipStream_t st) {
-    k_g1_decompress<<<(n + 63) / 64, 64, 0, st>>>(in, (G1Affine*)out, status, n, subgroup_check);
+void g1_decompress(const uint8_t* in, void* out, int* status, int n, int subgroup_check, const Fp12w& beta, hipStream_t st) {
+    Fp b;
+    for (int i = 0; i < 12; i++) b.v[i] = beta.v[i];
+    k_g1_decompress<<<(n + 63) / 64, 64, 0, st>>>(in, (G1Affine*)out, status, n, subgroup_check, b);
 }
 void fk20_srs_vectors(const void* srs, void* X, hipStream_t st) { k_fk20_srs_vectors<<<128 * 64 / 256, 256, 0, st>>>((const G1Affine*)srs, (JacQ*)X); }
 void fk20_gather_bases(const void* X, void* bases, hipStream_t st) { k_fk20_gather_bases<<<128 * 64 / 256, 256, 0, st>>>((const JacQ*)X, (G1Affine*)bases); }

@@ -5,6 +5,7 @@
 // recover_evaluations_in_domain_order (fk20/cosets.rs:141-198), deserialize_cells (serialization/src/lib.rs:107-114).
 #include "engine.hpp"
 #include "kcommon.hpp"
+#include "curve29.hpp"
 #include "launch.hpp"
 
 namespace kzg {
@@ -54,12 +55,12 @@ __device__ __forceinline__ void v_dif_forward4096(uint32_t* s, const Fr* __restr
 // slot_of == nullptr: slot = cell number (verify).  Otherwise the cell lands at slot_of[k] (recover scatter,
 // cosets.rs:170-175); evals must be zero-filled first.
 __global__ void k_cells_to_fr(const uint8_t* __restrict__ cells, Fr* __restrict__ evals, const int* __restrict__ slot_of,
-                              int* __restrict__ status, int n) {
+                              int* __restrict__ status, const int* __restrict__ status_of, int n) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * CELL_LEN) return;
     int k = idx >> 6, e = idx & 63;
     Fr x = load_fr_be(cells + (size_t)idx * 32);
-    if (geq_mod<FrParams>(x.v)) atomicOr(status, 1);
+    if (geq_mod<FrParams>(x.v)) atomicOr(status + (status_of ? status_of[k] : 0), 1);
     int slot = slot_of ? slot_of[k] : k;
     evals[(size_t)slot * CELL_LEN + e] = to_mont(x);
 }
@@ -139,39 +140,137 @@ __global__ __launch_bounds__(64) void k_interp_fold(const Fr* __restrict__ parti
     out_neg_canon[i] = from_mont(neg(acc));  // the interpolation commitment enters the pairing input with a minus sign
 }
 
-// Variable-base lincomb (g1_lincomb): every thread computes k_i * P_i by double-and-add, the block folds its
-// 64 products through LDS, out[block] receives the block sum.  Zero scalars / identity points contribute O.
-__global__ __launch_bounds__(64) void k_lincomb_partial(const G1Affine* __restrict__ pts, const Fr* __restrict__ sc_canon,
-                                                        int n, G1Jac* __restrict__ out) {
-    __shared__ G1Jac red[64];
-    int i = blockIdx.x * 64 + threadIdx.x;
-    G1Jac acc = jac_inf();
-    if (i < n) {
-        G1Affine p = pts[i];
-        Fr k = sc_canon[i];
-        if (!is_inf(p)) {
-            for (int b = 254; b >= 0; b--) {
-                acc = dbl(acc);
-                if ((k.v[b >> 5] >> (b & 31)) & 1) acc = add_mixed(acc, p);
-            }
-        }
-    }
-    red[threadIdx.x] = acc;
+// ------------------------------------------------------------------------------------------------
+// Variable-base lincombs of the verifier (g1_lincomb -> blst Pippenger, lincomb.rs:7-30; call sites
+// verifier.rs:186,200,224,235) as a bucket MSM on the GPU, two jobs at once (blockIdx.y):
+//   job 0: sum_k r^k pi_k                                   (n points)
+//   job 1: sum_k r^k h_k^64 pi_k + sum_row w_row C_row - sum_i I_i [tau^i]_1   (n + m + 64 points, one array)
+// Unsigned 8-bit windows (32 of them), 255 buckets per window; arithmetic in the unsaturated field.
+//   k_pip_sort    : per (window, job): LDS histogram of the digits, exclusive scan, bucket-ordered index list
+//   k_pip_buckets : thread = (window, bucket): sum of its points (mixed additions)
+//   k_pip_window  : per (window, job): S_w = sum_b b * B_b by a suffix scan + tree fold in LDS
+//   k_pip_final   : sum_w 2^(8w) S_w (lane w doubles 8w times, LDS fold), converted to affine Montgomery-384
+constexpr int PIP_C = 8, PIP_W = 32, PIP_B = 256;
+struct PipJob {
+    const Fr* scalars;  // canonical
+    int n;
+};
+__global__ void k_pip_to_affq(const G1Affine* __restrict__ in, AffQ* __restrict__ out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = affq_from_affine(in[i]);
+}
+__device__ __forceinline__ int pip_digit(const Fr& s, int w) { return (s.v[w >> 2] >> ((w & 3) * 8)) & 255; }
+// idx: [job][window][n_max]; start: [job][window][257]
+__global__ __launch_bounds__(256) void k_pip_sort(PipJob j0, PipJob j1, int n_max, int* __restrict__ idx, int* __restrict__ start) {
+    __shared__ int hist[PIP_B], cursor[PIP_B];
+    const int w = blockIdx.x, job = blockIdx.y, t = threadIdx.x;
+    const PipJob jb = job ? j1 : j0;
+    hist[t] = 0;
     __syncthreads();
-    for (int span = 32; span >= 1; span >>= 1) {
-        if (threadIdx.x < span) red[threadIdx.x] = add(red[threadIdx.x], red[threadIdx.x + span]);
+    for (int k = t; k < jb.n; k += 256) atomicAdd(&hist[pip_digit(jb.scalars[k], w)], 1);
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+        for (int b = 0; b < PIP_B; b++) { cursor[b] = acc; acc += hist[b]; }
+    }
+    __syncthreads();
+    int* st = start + ((size_t)job * PIP_W + w) * (PIP_B + 1);
+    st[t] = cursor[t];
+    if (t == 0) st[PIP_B] = jb.n;
+    __syncthreads();
+    int* out = idx + ((size_t)job * PIP_W + w) * n_max;
+    for (int k = t; k < jb.n; k += 256) {
+        int d = pip_digit(jb.scalars[k], w);
+        out[atomicAdd(&cursor[d], 1)] = k;
+    }
+}
+// buckets: [job][window][256] JacQ
+__global__ __launch_bounds__(64) void k_pip_buckets(const AffQ* __restrict__ pts, const int* __restrict__ idx,
+                                                    const int* __restrict__ start, int n_max, JacQ* __restrict__ buckets) {
+    const int job = blockIdx.y;
+    const int g = blockIdx.x * 64 + threadIdx.x;  // window * 256 + bucket
+    if (g >= PIP_W * PIP_B) return;
+    const int w = g >> 8, b = g & 255;
+    JacQ acc = jacq_inf();
+    if (b) {
+        const int* st = start + ((size_t)job * PIP_W + w) * (PIP_B + 1);
+        const int* ix = idx + ((size_t)job * PIP_W + w) * n_max;
+        for (int p = st[b]; p < st[b + 1]; p++) acc = add_mixed(acc, pts[ix[p]]);
+    }
+    buckets[(size_t)job * PIP_W * PIP_B + g] = acc;
+}
+__global__ __launch_bounds__(256) void k_pip_window(const JacQ* __restrict__ buckets, JacQ* __restrict__ wsum) {
+    __shared__ JacQ T[PIP_B];
+    const int w = blockIdx.x, job = blockIdx.y, t = threadIdx.x;
+    T[t] = buckets[((size_t)job * PIP_W + w) * PIP_B + t];  // bucket 0 is the identity
+    __syncthreads();
+    // suffix sums T[b] = sum_{j >= b} B_j  (Hillis-Steele), then sum_b T[b] = sum_b b * B_b
+    for (int off = 1; off < PIP_B; off <<= 1) {
+        JacQ v = T[t];
+        bool has = t + off < PIP_B;
+        JacQ o = has ? T[t + off] : v;
+        __syncthreads();
+        if (has) T[t] = add(v, o);
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+    if (t == 0) T[0] = jacq_inf();  // T[0] counted bucket 0's suffix; the weighted sum starts at b = 1
+    __syncthreads();
+    for (int span = PIP_B / 2; span >= 1; span >>= 1) {
+        if (t < span) T[t] = add(T[t], T[t + span]);
+        __syncthreads();
+    }
+    if (t == 0) wsum[job * PIP_W + w] = T[0];
 }
-// out_affine[0] = sum of parts[0..na) ; out_affine[1] = sum of parts[na..na+nb)
-__global__ void k_lincomb_final(const G1Jac* __restrict__ parts, int na, int nb, G1Affine* __restrict__ out_affine) {
-    int t = threadIdx.x;
-    if (t >= 2) return;
-    int lo = t == 0 ? 0 : na, hi = t == 0 ? na : na + nb;
-    G1Jac acc = jac_inf();
-    for (int i = lo; i < hi; i++) acc = add(acc, parts[i]);
-    out_affine[t] = to_affine(acc);
+__global__ __launch_bounds__(64) void k_pip_final(const JacQ* __restrict__ wsum, G1Affine* __restrict__ out_affine) {
+    __shared__ JacQ T[PIP_W];
+    const int job = blockIdx.x, t = threadIdx.x;
+    if (t < PIP_W) {
+        JacQ acc = wsum[job * PIP_W + t];
+        for (int k = 0; k < PIP_C * t; k++) acc = dbl(acc);
+        T[t] = acc;
+    }
+    __syncthreads();
+    for (int span = PIP_W / 2; span >= 1; span >>= 1) {
+        if (t < span) T[t] = add(T[t], T[t + span]);
+        __syncthreads();
+    }
+    if (t == 0) out_affine[job] = to_affine(jac_from_jacq(T[0]));
+}
+// points[dst_off + i] = src[i] (device gather of the 64 SRS points behind the proofs/commitments)
+__global__ void k_copy_affine(const G1Affine* __restrict__ src, G1Affine* __restrict__ dst, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// Per-cell values of the vanishing polynomial for a batch of R recoveries (one thread per (blob, cell)).
+// zp[r][0..deg_r] = coefficients of Z'_r(y) = prod over missing domain-order indices (y - omega_128^i)
+// (vanishing_poly, polynomial/src/poly_coeff.rs:109-115, built on the host: <= 64 roots).
+//   zeval[r][c] = Z'(omega_128^brp7(c))            (zero exactly on the missing cells)
+//   zcinv[r][c] = 1 / Z'(7^64 * omega_128^brp7(c)) (never zero: the coset has no roots of Z, reed_solomon.rs:356-357)
+__global__ void k_rec_vanishing(const Fr* __restrict__ zp, const int* __restrict__ deg, const Fr* __restrict__ w8192,
+                                Fr seven64, Fr* __restrict__ zeval, Fr* __restrict__ zcinv, int R) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * N_CELLS) return;
+    int r = idx >> 7, c = idx & 127;
+    const Fr* z = zp + (size_t)r * 65;
+    int d = deg[r];
+    int bc = (int)(__brev((unsigned)c) >> 25);
+    Fr x = w8192[64 * bc], xc = mul(seven64, x);
+    Fr a = zero<FrParams>(), b = zero<FrParams>();
+    for (int k = d; k >= 0; k--) {
+        a = add(mul(a, x), z[k]);
+        b = add(mul(b, xc), z[k]);
+    }
+    zeval[idx] = a;
+    // Fermat inversion b^(r-2)
+    uint32_t e[8], two[8] = {2, 0, 0, 0, 0, 0, 0, 0};
+    sub_limbs<8>(e, FrParams::MOD, two);
+    Fr acc = one<FrParams>();
+    for (int i = 254; i >= 0; i--) {
+        acc = sqr(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = mul(acc, b);
+    }
+    zcinv[idx] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -241,8 +340,8 @@ void init_attributes_verify() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_rec_dit_half), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_NTT);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_rec_dif_half), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_NTT);
 }
-void cells_to_fr(const uint8_t* cells, void* evals, const int* slot_of, int* status, int n, hipStream_t st) {
-    k_cells_to_fr<<<(n * CELL_LEN + 255) / 256, 256, 0, st>>>(cells, (Fr*)evals, slot_of, status, n);
+void cells_to_fr(const uint8_t* cells, void* evals, const int* slot_of, int* status, const int* status_of, int n, hipStream_t st) {
+    k_cells_to_fr<<<(n * CELL_LEN + 255) / 256, 256, 0, st>>>(cells, (Fr*)evals, slot_of, status, status_of, n);
 }
 void verify_scalars(const Fr8* pow_table24, const int* cell_idx, const void* w8192, void* rp_mont, void* s1, void* s2, int n,
                     hipStream_t st) {
@@ -258,11 +357,35 @@ void interp(const void* evals, const int* cell_idx, const void* rp_mont, const v
     k_interp<<<nblocks, 64, 0, st>>>((const Fr*)evals, cell_idx, (const Fr*)rp_mont, (const Fr*)w8192, as_fr2(inv64), (Fr*)partial, n);
     k_interp_fold<<<1, 64, 0, st>>>((const Fr*)partial, nblocks, (Fr*)out_neg_canon);
 }
-void lincomb_partial(const void* pts, const void* sc, int n, void* out_parts, hipStream_t st) {
-    if (n > 0) k_lincomb_partial<<<(n + 63) / 64, 64, 0, st>>>((const G1Affine*)pts, (const Fr*)sc, n, (G1Jac*)out_parts);
+size_t pip_workspace_bytes(int n_max) {
+    return (size_t)n_max * SIZEOF_AFFQ + (size_t)2 * PIP_W * n_max * sizeof(int) + (size_t)2 * PIP_W * (PIP_B + 1) * sizeof(int) +
+           (size_t)2 * PIP_W * PIP_B * SIZEOF_JACQ + (size_t)2 * PIP_W * SIZEOF_JACQ + 256;
 }
-void lincomb_final(const void* parts, int na, int nb, void* out_affine2, hipStream_t st) {
-    k_lincomb_final<<<1, 64, 0, st>>>((const G1Jac*)parts, na, nb, (G1Affine*)out_affine2);
+void copy_affine(const void* src, void* dst, int n, hipStream_t st) {
+    k_copy_affine<<<(n + 63) / 64, 64, 0, st>>>((const G1Affine*)src, (G1Affine*)dst, n);
+}
+// two bucket MSMs over a shared point array: job 0 uses points[0..n0) with sc0, job 1 points[0..n1) with sc1
+void msm_pippenger2(const void* points, const void* sc0, int n0, const void* sc1, int n1, void* workspace, void* out_affine2,
+                    hipStream_t st) {
+    const int n_max = n1 > n0 ? n1 : n0;
+    char* p = (char*)workspace;
+    AffQ* pts = (AffQ*)p; p += (size_t)n_max * SIZEOF_AFFQ;
+    int* idx = (int*)p; p += (size_t)2 * PIP_W * n_max * sizeof(int);
+    int* start = (int*)p; p += (size_t)2 * PIP_W * (PIP_B + 1) * sizeof(int);
+    p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    JacQ* buckets = (JacQ*)p; p += (size_t)2 * PIP_W * PIP_B * SIZEOF_JACQ;
+    JacQ* wsum = (JacQ*)p;
+    k_pip_to_affq<<<(n_max + 63) / 64, 64, 0, st>>>((const G1Affine*)points, pts, n_max);
+    PipJob j0{(const Fr*)sc0, n0}, j1{(const Fr*)sc1, n1};
+    k_pip_sort<<<dim3(PIP_W, 2), 256, 0, st>>>(j0, j1, n_max, idx, start);
+    k_pip_buckets<<<dim3(PIP_W * PIP_B / 64, 2), 64, 0, st>>>(pts, idx, start, n_max, buckets);
+    k_pip_window<<<dim3(PIP_W, 2), 256, 0, st>>>(buckets, wsum);
+    k_pip_final<<<2, 64, 0, st>>>(wsum, (G1Affine*)out_affine2);
+}
+void rec_vanishing(const void* zp, const int* deg, const void* w8192, const Fr8& seven64, void* zeval, void* zcinv, int R,
+                   hipStream_t st) {
+    k_rec_vanishing<<<(R * N_CELLS + 127) / 128, 128, 0, st>>>((const Fr*)zp, deg, (const Fr*)w8192, as_fr2(seven64), (Fr*)zeval,
+                                                              (Fr*)zcinv, R);
 }
 void rec_dit_half(int R, const void* V, const void* fac, void* T, const void* w8192, hipStream_t st) {
     k_rec_dit_half<<<dim3(R, 2), 1024, LDS_NTT, st>>>((const Fr*)V, (const Fr*)fac, (Fr*)T, (const Fr*)w8192);

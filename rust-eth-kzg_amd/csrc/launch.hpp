@@ -38,7 +38,9 @@ void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int m
 void g1_set_inf(void* X, size_t n, hipStream_t st);
 void g1_compress(const void* X, uint8_t* out, int n_pos, int stride, int n_slices, hipStream_t st);
 void g1_sum_positions(void* X, int n_pos, int stride, int n_slices, hipStream_t st);
-void g1_decompress(const uint8_t* in, void* out /*G1Affine*/, int* status, int n, int subgroup_check, hipStream_t st);
+// subgroup_check: 0 none, 1 endomorphism test, 2 definitional [r]P == O
+void g1_decompress(const uint8_t* in, void* out /*G1Affine*/, int* status, int n, int subgroup_check, const Fp12w& beta,
+                   hipStream_t st);
 void fk20_srs_vectors(const void* srs, void* X, hipStream_t st);
 void fk20_gather_bases(const void* X, void* bases, hipStream_t st);
 void test_load_points(const uint8_t* in, void* X, int n_lanes, int stride, hipStream_t st);
@@ -46,14 +48,19 @@ void test_recompress(const void* pts, uint8_t* out, int n, hipStream_t st);
 
 // k_verify.hip
 void init_attributes_verify();
-void cells_to_fr(const uint8_t* cells, void* evals, const int* slot_of, int* status, int n, hipStream_t st);
+// slot_of: destination cell slot per input cell (null = identity); status_of: status word per input cell (null = word 0)
+void cells_to_fr(const uint8_t* cells, void* evals, const int* slot_of, int* status, const int* status_of, int n, hipStream_t st);
+void rec_vanishing(const void* zp, const int* deg, const void* w8192, const Fr8& seven64, void* zeval, void* zcinv, int R,
+                   hipStream_t st);
 void verify_scalars(const Fr8* pow_table24, const int* cell_idx, const void* w8192, void* rp_mont, void* s1, void* s2, int n,
                     hipStream_t st);
 void verify_weights(const void* rp_mont, const int* row, void* weights, int n, int m, hipStream_t st);
 void interp(const void* evals, const int* cell_idx, const void* rp_mont, const void* w8192, const Fr8& inv64, void* partial,
             int nblocks, void* out_neg_canon, int n, hipStream_t st);
-void lincomb_partial(const void* pts, const void* sc, int n, void* out_parts, hipStream_t st);
-void lincomb_final(const void* parts, int na, int nb, void* out_affine2, hipStream_t st);
+size_t pip_workspace_bytes(int n_max);
+void copy_affine(const void* src, void* dst, int n, hipStream_t st);
+void msm_pippenger2(const void* points, const void* sc0, int n0, const void* sc1, int n1, void* workspace, void* out_affine2,
+                    hipStream_t st);
 void rec_dit_half(int R, const void* V, const void* fac, void* T, const void* w8192, hipStream_t st);
 void rec_dit_last(int R, const void* T, const void* shift, const Fr8& n_inv, void* U, void* coeffs, int* status,
                   const void* w8192, int final_pass, hipStream_t st);

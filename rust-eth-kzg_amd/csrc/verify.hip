@@ -12,6 +12,9 @@
 #include "launch.hpp"
 #include "sha256.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -108,37 +111,84 @@ int Engine::verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8
     if (n == 0) { *verified = 1; return OK; }  // verifier.rs:90-93
 
     std::lock_guard<std::mutex> lk(mu_);
+    const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[verify] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
     try {
         HIPCK(hipSetDevice(dev_));
         hipStream_t st = stream_;
-        // ---- stage inputs
-        std::vector<uint8_t> hc((size_t)m * 48), hp((size_t)n * 48), hcells((size_t)n * BYTES_PER_CELL);
-        std::vector<int> hidx(n);
-        for (int i = 0; i < m; i++) memcpy(&hc[(size_t)i * 48], uniq[i], 48);
-        for (int k = 0; k < n; k++) {
-            memcpy(&hp[(size_t)k * 48], proofs[k], 48);
-            memcpy(&hcells[(size_t)k * BYTES_PER_CELL], cells[k], BYTES_PER_CELL);
-            hidx[k] = (int)cell_indices[k];
+        // ---- stage inputs: gather the caller's scattered buffers into ONE pinned host slab, one async copy to a
+        // persistent device arena (no per-call hipMalloc)
+        const size_t sz_c = (size_t)m * 48, sz_p = (size_t)n * 48, sz_cells = (size_t)n * BYTES_PER_CELL, sz_i = (size_t)n * sizeof(int);
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t off_c = 0, off_p = off_c + up(sz_c), off_cells = off_p + up(sz_p), off_idx = off_cells + up(sz_cells),
+                     off_row = off_idx + up(sz_i), in_bytes = off_row + up(sz_i);
+        // pinned read-back area behind the inputs: statuses (m + n + 1 ints) and the two result points
+        const size_t off_hst = in_bytes, pin_bytes = off_hst + up(((size_t)m + n + 1) * sizeof(int)) + 256;
+        const size_t npts = (size_t)n + m + 64;
+        const int ib = n < 256 ? n : 256;
+        size_t o = up(in_bytes);
+        const size_t off_pts = o; o += up(npts * sizeof(G1Affine));
+        const size_t off_evals = o; o += up((size_t)n * CELL_LEN * sizeof(Fr));
+        const size_t off_stc = o; o += up((size_t)m * sizeof(int));
+        const size_t off_stp = o; o += up(sz_i);
+        const size_t off_ste = o; o += 256;
+        const size_t off_rp = o; o += up((size_t)n * sizeof(Fr));
+        const size_t off_s1 = o; o += up((size_t)n * sizeof(Fr));
+        const size_t off_sB = o; o += up(npts * sizeof(Fr));
+        const size_t off_part = o; o += up((size_t)ib * 64 * sizeof(Fr));
+        const size_t off_ws = o; o += up(launch::pip_workspace_bytes((int)npts));
+        const size_t off_out = o; o += 256;
+        if (o > v_dev_cap_) {
+            if (v_dev_) HIPCK(hipFree(v_dev_));
+            v_dev_ = nullptr;
+            HIPCK(hipMalloc(&v_dev_, o + (o >> 2)));
+            v_dev_cap_ = o + (o >> 2);
         }
-        DevBuf d_cb(hc.size()), d_pb(hp.size()), d_cellb(hcells.size());
-        DevBuf d_comm((size_t)m * sizeof(G1Affine)), d_prf((size_t)n * sizeof(G1Affine)), d_evals((size_t)n * CELL_LEN * sizeof(Fr));
-        DevBuf d_stc((size_t)m * sizeof(int)), d_stp((size_t)n * sizeof(int)), d_ste(sizeof(int));
-        DevBuf d_idx((size_t)n * sizeof(int)), d_row((size_t)n * sizeof(int));
-        HIPCK(hipMemcpyAsync(d_cb.p, hc.data(), hc.size(), hipMemcpyHostToDevice, st));
-        HIPCK(hipMemcpyAsync(d_pb.p, hp.data(), hp.size(), hipMemcpyHostToDevice, st));
-        HIPCK(hipMemcpyAsync(d_cellb.p, hcells.data(), hcells.size(), hipMemcpyHostToDevice, st));
-        HIPCK(hipMemcpyAsync(d_idx.p, hidx.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
-        HIPCK(hipMemcpyAsync(d_row.p, row.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+        if (pin_bytes > v_pin_cap_) {
+            if (v_pin_) HIPCK(hipHostFree(v_pin_));
+            v_pin_ = nullptr;
+            HIPCK(hipHostMalloc((void**)&v_pin_, pin_bytes + (pin_bytes >> 2), hipHostMallocDefault));
+            v_pin_cap_ = pin_bytes + (pin_bytes >> 2);
+        }
+        uint8_t* hb = v_pin_;
+        uint8_t* db = (uint8_t*)v_dev_;
+        uint8_t *hc = hb + off_c, *hp = hb + off_p, *hcells = hb + off_cells;
+        int* hidx = (int*)(hb + off_idx);
+        int* hrow = (int*)(hb + off_row);
+        for (int i = 0; i < m; i++) memcpy(hc + (size_t)i * 48, uniq[i], 48);
+        for (int k = 0; k < n; k++) {
+            memcpy(hp + (size_t)k * 48, proofs[k], 48);
+            memcpy(hcells + (size_t)k * BYTES_PER_CELL, cells[k], BYTES_PER_CELL);
+            hidx[k] = (int)cell_indices[k];
+            hrow[k] = row[k];
+        }
+        lap("gather host inputs");
+        HIPCK(hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, st));
+        struct View { void* p; };
+        View d_cb{db + off_c}, d_pb{db + off_p}, d_cellb{db + off_cells}, d_idx{db + off_idx}, d_row{db + off_row};
+        View d_pts{db + off_pts}, d_evals{db + off_evals}, d_stc{db + off_stc}, d_stp{db + off_stp}, d_ste{db + off_ste};
+        // one point array [proofs n | commitments m | 64 SRS points] so that the second lincomb is a single MSM
+        G1Affine* d_prf_p = (G1Affine*)d_pts.p;
+        G1Affine* d_comm_p = d_prf_p + n;
         HIPCK(hipMemsetAsync(d_ste.p, 0, sizeof(int), st));
         // ---- deserialisation with on-curve + subgroup checks (serialization/src/lib.rs:69-99), on the GPU
-        launch::g1_decompress((const uint8_t*)d_cb.p, d_comm.p, (int*)d_stc.p, m, 1, st);
-        launch::g1_decompress((const uint8_t*)d_pb.p, d_prf.p, (int*)d_stp.p, n, 1, st);
-        launch::cells_to_fr((const uint8_t*)d_cellb.p, d_evals.p, nullptr, (int*)d_ste.p, n, st);
-        std::vector<int> stc(m), stp(n);
-        int ste = 0;
-        HIPCK(hipMemcpyAsync(stc.data(), d_stc.p, m * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCK(hipMemcpyAsync(stp.data(), d_stp.p, n * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCK(hipMemcpyAsync(&ste, d_ste.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        launch::g1_decompress((const uint8_t*)d_cb.p, d_comm_p, (int*)d_stc.p, m, 1, beta_, st);
+        launch::g1_decompress((const uint8_t*)d_pb.p, d_prf_p, (int*)d_stp.p, n, 1, beta_, st);
+        launch::copy_affine(d_srs_, d_comm_p + m, 64, st);  // vk.g1s: the first 64 SRS points (verification_key.rs:66-70)
+        launch::cells_to_fr((const uint8_t*)d_cellb.p, d_evals.p, nullptr, (int*)d_ste.p, nullptr, n, st);
+        int* stc = (int*)(hb + off_hst);  // pinned: the copies below do not block, so the host hashes meanwhile
+        int* stp = stc + m;
+        int* ste_p = stp + n;
+        HIPCK(hipMemcpyAsync(stc, d_stc.p, m * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCK(hipMemcpyAsync(stp, d_stp.p, n * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCK(hipMemcpyAsync(ste_p, d_ste.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        lap("H2D + launch decompress");
         // ---- Fiat-Shamir challenge on the host while the GPU decompresses (verifier.rs:269-328).
         // Valid inputs are canonical encodings, so the transcript is the input bytes themselves.
         Sha256 sh;
@@ -147,47 +197,48 @@ int Engine::verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8
         memcpy(hdr, "RCKZGCBATCH__V1_", 16);
         be64(N_BLOB, hdr + 16); be64(CELL_LEN, hdr + 24); be64((uint64_t)m, hdr + 32); be64((uint64_t)n, hdr + 40);
         sh.update(hdr, sizeof hdr);
-        sh.update(hc.data(), hc.size());
+        sh.update(hc, sz_c);
         for (int k = 0; k < n; k++) {
             uint8_t ix[16];
             be64((uint64_t)row[k], ix); be64(cell_indices[k], ix + 8);
             sh.update(ix, 16);
-            sh.update(&hcells[(size_t)k * BYTES_PER_CELL], BYTES_PER_CELL);
-            sh.update(&hp[(size_t)k * 48], 48);
+            sh.update(hcells + (size_t)k * BYTES_PER_CELL, BYTES_PER_CELL);
+            sh.update(hp + (size_t)k * 48, 48);
         }
         uint8_t dig[32];
         sh.finish(dig);
         Fr r = reduce_be32(dig);
+        lap("sha256 transcript (host)");
         HIPCK(hipStreamSynchronize(st));
-        for (int s : stc) if (s) return ERR_G1;      // order of the reference: commitments, proofs, cells
-        for (int s : stp) if (s) return ERR_G1;
-        if (ste) return ERR_SCALAR;
+        lap("wait decompress/deserialise");
+        for (int i = 0; i < m; i++) if (stc[i]) return ERR_G1;  // order of the reference: commitments, proofs, cells
+        for (int i = 0; i < n; i++) if (stp[i]) return ERR_G1;
+        if (*ste_p) return ERR_SCALAR;
 
         // ---- scalars
         Fr8 tab[24];
         Fr cur = r;
         for (int i = 0; i < 24; i++) { tab[i] = to8(cur); cur = sqr(cur); }
-        DevBuf d_rp((size_t)n * sizeof(Fr)), d_s1((size_t)n * sizeof(Fr)), d_s2((size_t)n * sizeof(Fr)), d_w((size_t)m * sizeof(Fr));
-        launch::verify_scalars(tab, (const int*)d_idx.p, d_w8192_, d_rp.p, d_s1.p, d_s2.p, n, st);
-        launch::verify_weights(d_rp.p, (const int*)d_row.p, d_w.p, n, m, st);
-        const int ib = n < 256 ? n : 256;
-        DevBuf d_part((size_t)ib * 64 * sizeof(Fr)), d_interp(64 * sizeof(Fr));
-        launch::interp(d_evals.p, (const int*)d_idx.p, d_rp.p, d_w8192_, inv64_, d_part.p, ib, d_interp.p, n, st);
-        // ---- the four lincombs (verifier.rs:186,200,224,235): block partial sums, then two totals
-        const int pb_n = (n + 63) / 64, pb_m = (m + 63) / 64;
-        DevBuf d_parts((size_t)(2 * pb_n + pb_m + 1) * sizeof(G1Jac)), d_out(2 * sizeof(G1Affine));
-        G1Jac* parts = (G1Jac*)d_parts.p;
-        launch::lincomb_partial(d_prf.p, d_s1.p, n, parts, st);                       // sum r^k pi_k
-        launch::lincomb_partial(d_prf.p, d_s2.p, n, parts + pb_n, st);                // sum r^k h^64 pi_k
-        launch::lincomb_partial(d_comm.p, d_w.p, m, parts + 2 * pb_n, st);            // sum w_row C_row
-        launch::lincomb_partial(d_srs_, d_interp.p, 64, parts + 2 * pb_n + pb_m, st); // - commit(interpolation poly)
-        launch::lincomb_final(parts, pb_n, pb_n + pb_m + 1, d_out.p, st);
+        View d_rp{db + off_rp}, d_s1{db + off_s1}, d_sB{db + off_sB};
+        Fr* d_s2 = (Fr*)d_sB.p;
+        Fr* d_w = d_s2 + n;
+        Fr* d_interp = d_w + m;
+        launch::verify_scalars(tab, (const int*)d_idx.p, d_w8192_, d_rp.p, d_s1.p, d_s2, n, st);
+        launch::verify_weights(d_rp.p, (const int*)d_row.p, d_w, n, m, st);
+        View d_part{db + off_part};
+        launch::interp(d_evals.p, (const int*)d_idx.p, d_rp.p, d_w8192_, inv64_, d_part.p, ib, d_interp, n, st);
+        // ---- the four lincombs (verifier.rs:186,200,224,235) as two bucket MSMs over the shared point array:
+        //   out[0] = sum r^k pi_k;   out[1] = sum r^k h^64 pi_k + sum w_row C_row - commit(interpolation poly)
+        View d_ws{db + off_ws}, d_out{db + off_out};
+        launch::msm_pippenger2(d_pts.p, d_s1.p, n, d_sB.p, n + m + 64, d_ws.p, d_out.p, st);
         G1Affine out[2];
         HIPCK(hipMemcpyAsync(out, d_out.p, sizeof out, hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
+        lap("scalars+interp+lincombs (GPU)");
         // ---- pairing check e(sum r^k pi_k, [tau^64]_2) * e(C - I + weighted proofs, -[1]_2) == 1 (verifier.rs:242-259)
         const pairing::G2Prepared* q[2] = {g2_tau_.get(), g2_neg_gen_.get()};
         *verified = pairing::product_is_one(out, q, 2) ? 1 : 0;
+        lap("pairing check (host)");
     } catch (const std::exception& e) {
         err_ = e.what();
         return ERR_DEVICE;
@@ -196,15 +247,13 @@ int Engine::verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8
 }
 
 // ------------------------------------------------------------------------------------------------
-// recovery: returns a Status; on OK the 4096 coefficients of the blob polynomial are in d_coeffs_[0].
-int Engine::recover_to_coeffs(uint64_t n_cells, const uint8_t* const* cells, const uint64_t* cell_indices) {
+// Recovery of R blobs at once.  Per blob: validated cell list -> coefficients in d_coeffs_[r].
+// Returns per-blob statuses in `st_out`; blobs that fail validation / decoding are skipped by the caller.
+int Engine::recover_batch_to_coeffs(int R, const uint64_t* n_cells, const uint8_t* const* const* cells,
+                                    const uint64_t* const* cell_indices, int* st_out) {
     hipStream_t st = stream_;
-    const int n = (int)n_cells;
-    ensure_workspace(1);
-    // Z'(y) = prod_{missing i} (y - omega_128^i) in domain order (recovery.rs:43-58, reed_solomon.rs:236-241,
-    // poly_coeff.rs:109-115); indices in domain order are the bit-reversed cell indices (cosets.rs:186-195).
-    bool present[N_CELLS] = {false};
-    for (int k = 0; k < n; k++) present[brp7((int)cell_indices[k])] = true;
+    ensure_workspace(R);
+    // host: Z'_r coefficients (<= 64 roots each), flattened cell list
     Fr w128 = one<FrParams>();
     {   // omega_128 = 7^((r-1)/128)
         uint32_t e[8];
@@ -219,84 +268,126 @@ int Engine::recover_to_coeffs(uint64_t n_cells, const uint8_t* const* cells, con
     std::vector<Fr> roots(N_CELLS);
     roots[0] = one<FrParams>();
     for (int i = 1; i < N_CELLS; i++) roots[i] = mul(roots[i - 1], w128);
-    std::vector<Fr> zp(1, one<FrParams>());
-    for (int i = 0; i < N_CELLS; i++) {
-        if (present[i]) continue;
-        Fr nr = neg(roots[i]);
-        zp.push_back(zp.back());
-        for (size_t k = zp.size() - 2; k >= 1; k--) zp[k] = add(mul(zp[k], nr), zp[k - 1]);
-        zp[0] = mul(zp[0], nr);
+    std::vector<Fr> zp((size_t)R * 65, zero<FrParams>());
+    std::vector<int> deg(R, 0), slot, stof;
+    size_t total_cells = 0;
+    for (int r = 0; r < R; r++) total_cells += st_out[r] == OK ? n_cells[r] : 0;
+    std::vector<uint8_t> hcells(total_cells * BYTES_PER_CELL);
+    slot.reserve(total_cells);
+    stof.reserve(total_cells);
+    size_t pos = 0;
+    for (int r = 0; r < R; r++) {
+        Fr* z = &zp[(size_t)r * 65];
+        z[0] = one<FrParams>();
+        if (st_out[r] != OK) continue;
+        // domain-order index of a cell = bit-reversed cell index (cosets.rs:186-195); missing = complement (recovery.rs:69-75)
+        bool present[N_CELLS] = {false};
+        for (uint64_t k = 0; k < n_cells[r]; k++) present[brp7((int)cell_indices[r][k])] = true;
+        int d = 0;
+        for (int i = 0; i < N_CELLS; i++) {
+            if (present[i]) continue;
+            Fr nr = neg(roots[i]);  // multiply by (y - root): vanishing_poly, poly_coeff.rs:109-115
+            z[d + 1] = z[d];
+            for (int k = d; k >= 1; k--) z[k] = add(mul(z[k], nr), z[k - 1]);
+            z[0] = mul(z[0], nr);
+            d++;
+        }
+        deg[r] = d;
+        for (uint64_t k = 0; k < n_cells[r]; k++) {
+            memcpy(&hcells[pos * BYTES_PER_CELL], cells[r][k], BYTES_PER_CELL);
+            slot.push_back(r * N_CELLS + (int)cell_indices[r][k]);  // scatter into blob r's 128 cell slots (cosets.rs:170-175)
+            stof.push_back(r);
+            pos++;
+        }
     }
-    // per-cell values of Z on the domain and inverse values on the coset 7 * domain:
-    //   Z(omega_8192^n) = Z'(omega_128^(n mod 128)),  Z(7 omega_8192^n) = Z'(7^64 omega_128^(n mod 128)),
-    // and position q of the bit-reversed (cell-order) array has n mod 128 = brp7(q / 64).
-    Fr seven64 = one<FrParams>();
-    { Fr b = fr_u64(7); for (int i = 0; i < 6; i++) b = sqr(b); seven64 = b; }
-    auto horner = [&](const Fr& x) { Fr acc = zero<FrParams>(); for (size_t k = zp.size(); k-- > 0;) acc = add(mul(acc, x), zp[k]); return acc; };
-    std::vector<Fr> zeval(N_CELLS), zcinv(N_CELLS);
-    for (int c = 0; c < N_CELLS; c++) {
-        Fr x = roots[brp7(c)];
-        zeval[c] = horner(x);
-        zcinv[c] = inv(horner(mul(seven64, x)));  // never zero: Z has no roots on the coset (reed_solomon.rs:356-357)
+    const int n = (int)total_cells;
+    Fr seven64 = fr_u64(7);
+    for (int i = 0; i < 6; i++) seven64 = sqr(seven64);
+    DevBuf d_cellb(hcells.size()), d_slot((size_t)n * sizeof(int)), d_stof((size_t)n * sizeof(int));
+    DevBuf d_E((size_t)R * N_EXT * sizeof(Fr)), d_T((size_t)R * N_EXT * sizeof(Fr)), d_U((size_t)R * N_EXT * sizeof(Fr));
+    DevBuf d_zp(zp.size() * sizeof(Fr)), d_deg(R * sizeof(int));
+    DevBuf d_zeval((size_t)R * N_CELLS * sizeof(Fr)), d_zcinv((size_t)R * N_CELLS * sizeof(Fr)), d_st(R * sizeof(int));
+    if (n) {
+        HIPCK(hipMemcpyAsync(d_cellb.p, hcells.data(), hcells.size(), hipMemcpyHostToDevice, st));
+        HIPCK(hipMemcpyAsync(d_slot.p, slot.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCK(hipMemcpyAsync(d_stof.p, stof.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
     }
-    std::vector<uint8_t> hcells((size_t)n * BYTES_PER_CELL);
-    std::vector<int> slot(n);
-    for (int k = 0; k < n; k++) { memcpy(&hcells[(size_t)k * BYTES_PER_CELL], cells[k], BYTES_PER_CELL); slot[k] = (int)cell_indices[k]; }
-    DevBuf d_cellb(hcells.size()), d_slot(n * sizeof(int)), d_E(N_EXT * sizeof(Fr)), d_T(N_EXT * sizeof(Fr)), d_U(N_EXT * sizeof(Fr));
-    DevBuf d_zeval(N_CELLS * sizeof(Fr)), d_zcinv(N_CELLS * sizeof(Fr)), d_st(sizeof(int));
-    HIPCK(hipMemcpyAsync(d_cellb.p, hcells.data(), hcells.size(), hipMemcpyHostToDevice, st));
-    HIPCK(hipMemcpyAsync(d_slot.p, slot.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCK(hipMemcpyAsync(d_zeval.p, zeval.data(), N_CELLS * sizeof(Fr), hipMemcpyHostToDevice, st));
-    HIPCK(hipMemcpyAsync(d_zcinv.p, zcinv.data(), N_CELLS * sizeof(Fr), hipMemcpyHostToDevice, st));
-    HIPCK(hipMemsetAsync(d_E.p, 0, N_EXT * sizeof(Fr), st));
-    HIPCK(hipMemsetAsync(d_st.p, 0, sizeof(int), st));
-    launch::cells_to_fr((const uint8_t*)d_cellb.p, d_E.p, (const int*)d_slot.p, (int*)d_st.p, n, st);   // E in cell order
-    launch::rec_dit_half(1, d_E.p, d_zeval.p, d_T.p, d_w8192_, st);                                      // (E*Z) -> IFFT ...
-    launch::rec_dit_last(1, d_T.p, d_coset_, n_inv8192_, d_U.p, nullptr, nullptr, d_w8192_, 0, st);      // ... * 7^i
-    launch::rec_dif_half(1, d_U.p, d_zcinv.p, d_E.p, d_w8192_, st);                                      // coset FFT, / Z
-    launch::rec_dit_half(1, d_E.p, nullptr, d_T.p, d_w8192_, st);                                        // coset IFFT ...
-    launch::rec_dit_last(1, d_T.p, d_coset_inv_, n_inv8192_, nullptr, d_coeffs_, (int*)d_st.p, d_w8192_, 1, st);  // ... * 7^-i
-    int hst = 0;
-    HIPCK(hipMemcpyAsync(&hst, d_st.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCK(hipMemcpyAsync(d_zp.p, zp.data(), zp.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
+    HIPCK(hipMemcpyAsync(d_deg.p, deg.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCK(hipMemsetAsync(d_E.p, 0, (size_t)R * N_EXT * sizeof(Fr), st));
+    HIPCK(hipMemsetAsync(d_st.p, 0, R * sizeof(int), st));
+    if (n) launch::cells_to_fr((const uint8_t*)d_cellb.p, d_E.p, (const int*)d_slot.p, (int*)d_st.p, (const int*)d_stof.p, n, st);  // E in cell order
+    launch::rec_vanishing(d_zp.p, (const int*)d_deg.p, d_w8192_, to8(seven64), d_zeval.p, d_zcinv.p, R, st);
+    launch::rec_dit_half(R, d_E.p, d_zeval.p, d_T.p, d_w8192_, st);                                      // (E*Z) -> IFFT ...
+    launch::rec_dit_last(R, d_T.p, d_coset_, n_inv8192_, d_U.p, nullptr, nullptr, d_w8192_, 0, st);      // ... * 7^i
+    launch::rec_dif_half(R, d_U.p, d_zcinv.p, d_E.p, d_w8192_, st);                                      // coset FFT, / Z
+    launch::rec_dit_half(R, d_E.p, nullptr, d_T.p, d_w8192_, st);                                        // coset IFFT ...
+    launch::rec_dit_last(R, d_T.p, d_coset_inv_, n_inv8192_, nullptr, d_coeffs_, (int*)d_st.p, d_w8192_, 1, st);  // ... * 7^-i
+    std::vector<int> hst(R);
+    HIPCK(hipMemcpyAsync(hst.data(), d_st.p, R * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCK(hipStreamSynchronize(st));
-    if (hst & 1) return ERR_SCALAR;
-    if (hst & 4) return ERR_RECOVERY;
+    for (int r = 0; r < R; r++) {
+        if (st_out[r] != OK) continue;
+        if (hst[r] & 1) st_out[r] = ERR_SCALAR;
+        else if (hst[r] & 4) st_out[r] = ERR_RECOVERY;
+    }
     return OK;
 }
 
-int Engine::recover_cells_and_kzg_proofs_host(uint64_t n_cells, const uint8_t* const* cells, uint64_t n_indices,
-                                              const uint64_t* cell_indices, uint8_t* const* out_cells,
-                                              uint8_t* const* out_proofs) {
-    // validate_recovery_inputs (recovery.rs:90-146)
+// validate_recovery_inputs (recovery.rs:90-146)
+static int validate_recovery(uint64_t n_cells, uint64_t n_indices, const uint64_t* cell_indices) {
     if (n_indices != n_cells) return ERR_INPUT;
     for (uint64_t i = 0; i < n_indices; i++)
         if (cell_indices[i] >= (uint64_t)N_CELLS) return ERR_INPUT;
     for (uint64_t i = 1; i < n_indices; i++)
         if (!(cell_indices[i - 1] < cell_indices[i])) return ERR_INPUT;
     if (n_indices < (uint64_t)N_CELLS / 2 || n_indices > (uint64_t)N_CELLS) return ERR_INPUT;
+    return OK;
+}
 
+int Engine::recover_cells_and_kzg_proofs_batch_host(int R, const uint64_t* n_cells, const uint8_t* const* const* cells,
+                                                    const uint64_t* n_indices, const uint64_t* const* cell_indices,
+                                                    uint8_t* const* const* out_cells, uint8_t* const* const* out_proofs,
+                                                    int* status) {
+    if (R <= 0) return OK;
+    for (int r = 0; r < R; r++) status[r] = validate_recovery(n_cells[r], n_indices[r], cell_indices[r]);
     std::lock_guard<std::mutex> lk(mu_);
     try {
         HIPCK(hipSetDevice(dev_));
-        int rc = recover_to_coeffs(n_cells, cells, cell_indices);
+        int rc = recover_batch_to_coeffs(R, n_cells, cells, cell_indices, status);
         if (rc) return rc;
-        // compute_multi_opening_proofs(Input::PolyCoeff) = stages C..I (prover.rs:164-170)
-        DevBuf d_c((size_t)N_CELLS * BYTES_PER_CELL), d_p((size_t)N_CELLS * 48);
-        launch::coeffs_to_cells(1, d_coeffs_, (uint8_t*)d_c.p, d_w8192_, stream_);
-        run_proofs_from_coeffs(1, (uint8_t*)d_p.p, stream_);
-        std::vector<uint8_t> hc((size_t)N_CELLS * BYTES_PER_CELL), hp((size_t)N_CELLS * 48);
+        // compute_multi_opening_proofs(Input::PolyCoeff) = stages C..I (prover.rs:164-170) for the whole batch
+        DevBuf d_c((size_t)R * N_CELLS * BYTES_PER_CELL), d_p((size_t)R * N_CELLS * 48);
+        launch::coeffs_to_cells(R, d_coeffs_, (uint8_t*)d_c.p, d_w8192_, stream_);
+        run_proofs_from_coeffs(R, (uint8_t*)d_p.p, stream_);
+        std::vector<uint8_t> hc((size_t)R * N_CELLS * BYTES_PER_CELL), hp((size_t)R * N_CELLS * 48);
         HIPCK(hipMemcpyAsync(hc.data(), d_c.p, hc.size(), hipMemcpyDeviceToHost, stream_));
         HIPCK(hipMemcpyAsync(hp.data(), d_p.p, hp.size(), hipMemcpyDeviceToHost, stream_));
         HIPCK(hipStreamSynchronize(stream_));
-        for (int k = 0; k < N_CELLS; k++) {
-            memcpy(out_cells[k], &hc[(size_t)k * BYTES_PER_CELL], BYTES_PER_CELL);
-            memcpy(out_proofs[k], &hp[(size_t)k * 48], 48);
+        for (int r = 0; r < R; r++) {
+            if (status[r] != OK) continue;
+            for (int k = 0; k < N_CELLS; k++) {
+                memcpy(out_cells[r][k], &hc[((size_t)r * N_CELLS + k) * BYTES_PER_CELL], BYTES_PER_CELL);
+                memcpy(out_proofs[r][k], &hp[((size_t)r * N_CELLS + k) * 48], 48);
+            }
         }
     } catch (const std::exception& e) {
         err_ = e.what();
         return ERR_DEVICE;
     }
     return OK;
+}
+
+int Engine::recover_cells_and_kzg_proofs_host(uint64_t n_cells, const uint8_t* const* cells, uint64_t n_indices,
+                                              const uint64_t* cell_indices, uint8_t* const* out_cells,
+                                              uint8_t* const* out_proofs) {
+    int st = OK;
+    const uint8_t* const* cl[1] = {cells};
+    const uint64_t* ix[1] = {cell_indices};
+    uint8_t* const* oc[1] = {out_cells};
+    uint8_t* const* op[1] = {out_proofs};
+    int rc = recover_cells_and_kzg_proofs_batch_host(1, &n_cells, cl, &n_indices, ix, oc, op, &st);
+    return rc ? rc : st;
 }
 
 }  // namespace kzg

@@ -96,9 +96,20 @@ def test_g1_decompress_matches_oracle(ctx):
             for b in case["input"]["commitments"] + case["input"]["proofs"]:
                 if len(b) == 48:
                     bad.append(b)
+    # random on-curve points: almost surely OUTSIDE the r-torsion (cofactor ~2^126); the production endomorphism
+    # test (mode 1) and the definitional [r]P == O test (mode 2) must both agree with the oracle on them
+    import hashlib
+    k = 0
+    while len(bad) < 160:
+        x = int.from_bytes(hashlib.sha512(b"curve-point-%d" % k).digest(), "big") % synth.P
+        k += 1
+        cand = bytearray(x.to_bytes(48, "big"))
+        cand[0] |= 0x80 | (0x20 if k & 1 else 0)
+        if oracle_lib.g1_validate(bytes(cand), False) == 0:
+            bad.append(bytes(cand))
     allp = pts + bad
     n = len(allp)
-    for check in (0, 1):
+    for check in (0, 1, 2):
         st = (C.c_int32 * n)()
         out = C.create_string_buffer(n * 48)
         assert lib.eth_kzg_amd_test_g1_decompress(ctx.handle, b"".join(allp), n, check, st, out) == 0
@@ -249,3 +260,20 @@ def test_recover_round_trip(ctx, oracle, pattern):
         bad = [cells[i] for i in idx]
         bad[0] = other[idx[0]]
         assert _call(ctx.recover_cells_and_kzg_proofs, idx, bad) is None
+
+
+def test_recover_batch_ragged(ctx, oracle):
+    """Batched recovery: different erasure patterns per blob, one inconsistent and one invalid entry in the batch."""
+    import random
+    blobs = [synth.seeded_blob(60 + i) for i in range(4)]
+    _, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs)
+    pats = [list(range(0, 128, 2)), list(range(64, 128)), sorted(random.Random(5).sample(range(128), 90)), list(range(128))]
+    batch = [(pats[b], [cells[b][i] for i in pats[b]]) for b in range(4)]
+    bad_cells = [cells[0][i] for i in pats[2]]
+    bad_cells[3] = cells[1][pats[2][3]]
+    batch.append((pats[2], bad_cells))                      # inconsistent -> status 4
+    batch.append(([1, 0] + list(range(2, 70)), [cells[0][i] for i in [1, 0] + list(range(2, 70))]))  # not ascending -> 3
+    st, rc, rp = ctx.recover_cells_and_kzg_proofs_batch(batch)
+    assert st[:4] == [0, 0, 0, 0] and st[4] == 4 and st[5] == 3
+    for b in range(4):
+        assert rc[b] == cells[b] and rp[b] == proofs[b]

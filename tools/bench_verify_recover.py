@@ -1,0 +1,36 @@
+"""Timing of BASELINE.json configs 3 (verify 64 blobs x 128 cells) and 5 (recover, 50 % erasure) through the C ABI."""
+import importlib, os, sys, time, json
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+kzg = importlib.import_module("rust-eth-kzg_amd")
+ctx = kzg.DASContext(True)
+nb = int(os.environ.get("NB", "64"))
+rng = np.random.RandomState(7)
+a = rng.randint(0, 256, size=(nb, 4096, 32), dtype=np.uint8); a[:, :, 0] &= 0x3F
+blobs = [a[i].tobytes() for i in range(nb)]
+t = time.time(); st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs); t_cp = time.time() - t
+_, comms = ctx.blob_to_kzg_commitment_batch(blobs)
+C, I, L, P = [], [], [], []
+for b in range(nb):
+    for k in range(128):
+        C.append(comms[b]); I.append(k); L.append(cells[b][k]); P.append(proofs[b][k])
+out = {"blobs": nb, "cells": len(L), "compute_batch_host_api_s": round(t_cp, 3)}
+ts = []
+for r in range(3):
+    t = time.time(); ok = ctx.verify_cell_kzg_proof_batch(C, I, L, P); ts.append(time.time() - t); assert ok
+out["verify_s"] = [round(x, 4) for x in ts]
+P2 = list(P); P2[77] = P[78]
+t = time.time(); ok = ctx.verify_cell_kzg_proof_batch(C, I, L, P2); out["verify_tampered_s"] = round(time.time() - t, 4); assert ok is False
+ts = []
+for b in range(min(nb, 8)):
+    idx = list(range(0, 128, 2))
+    t = time.time(); rc, rp = ctx.recover_cells_and_kzg_proofs(idx, [cells[b][i] for i in idx]); ts.append(time.time() - t)
+    assert rc == cells[b] and rp == proofs[b]
+out["recover_even_cells_per_blob_s"] = [round(x, 4) for x in ts]
+print(json.dumps(out))
+nbr = min(nb, 256)
+batch = [(list(range(0, 128, 2)), [cells[b][i] for i in range(0, 128, 2)]) for b in range(nbr)]
+t = time.time(); st, rc, rp = ctx.recover_cells_and_kzg_proofs_batch(batch); dt = time.time() - t
+assert st == [0] * nbr and all(rc[b] == cells[b] and rp[b] == proofs[b] for b in range(nbr))
+print(json.dumps({"recover_batch_blobs": nbr, "recover_batch_s": round(dt, 3), "blobs_per_s": round(nbr / dt, 1)}))
