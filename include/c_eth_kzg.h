@@ -84,9 +84,9 @@ uint64_t eth_kzg_constant_bytes_per_cell(void);
 uint64_t eth_kzg_constant_bytes_per_proof(void);
 uint64_t eth_kzg_constant_cells_per_ext_blob(void);
 
-/* EIP-4844 operations (bindings/c/src/lib.rs:423-566).  Outside this build's hot-path scope
- * (SURVEY.md section 8f "next"): present for link compatibility, they return `Err`
- * ("not implemented in the MI355X build") until that row is built. */
+/* EIP-4844 single-point operations (bindings/c/src/lib.rs:423-566 -> compute_kzg_proof.rs, compute_blob_kzg_proof.rs,
+ * verify_kzg_proof.rs, verify_blob_kzg_proof.rs, verify_blob_kzg_proof_batch.rs), on the same GPU kernels.
+ * z, y: 32-byte big-endian field elements; invalid proof => `Ok` + *verified = false; malformed input => `Err`. */
 CResult eth_kzg_compute_kzg_proof(const DASContext *ctx, const uint8_t *blob, const uint8_t *z, uint8_t *out_proof,
                                   uint8_t *out_y);
 CResult eth_kzg_compute_blob_kzg_proof(const DASContext *ctx, const uint8_t *blob, const uint8_t *commitment,

@@ -280,7 +280,7 @@ static void multi_batch_addition(g1a_t **buckets, size_t *cnt, size_t nb, g1_t *
 struct oracle_ctx {
     int use_precomp, threads;
     g1a_t *g1s;      /* 4096 monomial SRS points */
-    g2a_t tau_pow_n, neg_g2_gen;
+    g2a_t tau_pow_n, neg_g2_gen, tau_g2;  /* [tau^64]_2, -[1]_2, [tau]_2 */
     domain_t d128, d4096, d8192, d64;
     g1a_t *fft_srs;  /* [128][64]: row j = the 64 bases of MSM j (batch_toeplitz.rs:61) */
     g1a_t *tables;   /* [128][64][128] width-8 tables (fixed_base_msm_window.rs:69-82) or NULL */
@@ -336,6 +336,7 @@ static int load_srs(oracle_ctx *c, const uint8_t *srs, size_t len) {
     if (g2_decompress(&gen, g2)) return -1;              /* [1]_2 */
     if (g2_decompress(&c->tau_pow_n, g2 + 96 * CELL_LEN)) return -1; /* [tau^64]_2 (verifier.rs:88) */
     g2_neg(&c->neg_g2_gen, &gen);                          /* -[1]_2 (verifier.rs:90) */
+    if (g2_decompress(&c->tau_g2, g2 + 96)) return -1;     /* [tau]_2 (eip4844 verification key) */
     return 0;
 }
 
@@ -619,6 +620,157 @@ int oracle_recover_cells_and_kzg_proofs(const oracle_ctx *c, size_t n_cells, con
     if (rc == ORACLE_OK) proofs_and_cells_from_poly(c, e, out_cells, out_proofs);
 done:
     free(e); free(z); free(zc);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ */
+/* EIP-4844 single-point operations (crates/eip4844/src/{prover,verifier}.rs,
+   crates/cryptography/kzg_single_open/src/{prover,verifier}.rs) */
+
+/* divide_by_linear (kzg_single_open/src/prover.rs:50-65): quotient of poly by (X - z) and remainder y = poly(z) */
+static void divide_by_linear(const fr_t *poly, size_t n, const fr_t *z, fr_t *quotient /*n-1*/, fr_t *y) {
+    fr_t k = FR_ZERO;
+    for (size_t i = n; i-- > 0;) {
+        fr_t t; fr_add(&t, &poly[i], &k);
+        if (i > 0) quotient[i - 1] = t; else *y = t;
+        fr_mul(&k, z, &t);
+    }
+}
+/* compute_fiat_shamir_challenge (eip4844/src/verifier.rs:155-196) */
+static void fs_challenge_4844(fr_t *z, const uint8_t *blob, const uint8_t *commitment) {
+    size_t len = 16 + 16 + 131072 + 48;
+    uint8_t *in = malloc(len);
+    memcpy(in, "FSBLOBVERIFY_V1_", 16);
+    memset(in + 16, 0, 16); in[16 + 14] = 0x10; /* u128 big-endian 4096 */
+    memcpy(in + 32, blob, 131072);
+    memcpy(in + 32 + 131072, commitment, 48);
+    uint8_t dig[32]; sha256(dig, in, len);
+    fr_from_be_reduce(z, dig);
+    free(in);
+}
+/* Prover::compute_kzg_proof (kzg_single_open/src/prover.rs:33-46) on a polynomial in monomial form */
+static void kzg_proof_from_poly(const oracle_ctx *c, const fr_t *poly, const fr_t *z, uint8_t *out_proof, fr_t *y) {
+    fr_t *q = malloc(N_BLOB * sizeof(fr_t));
+    divide_by_linear(poly, N_BLOB, z, q, y);
+    g1_t r; g1a_t a;
+    g1_msm(&r, c->g1s, q, N_BLOB - 1);
+    g1_to_affine(&a, &r); g1_compress(out_proof, &a);
+    free(q);
+}
+int oracle_compute_kzg_proof(const oracle_ctx *c, const uint8_t *blob, const uint8_t *z_bytes, uint8_t *out_proof, uint8_t *out_y) {
+    fr_t *v = malloc(N_BLOB * sizeof(fr_t)), z, y;
+    int rc = deserialize_scalars(v, blob, N_BLOB);
+    if (rc == ORACLE_OK && fr_from_be(&z, z_bytes)) rc = ORACLE_ERR_SCALAR;
+    if (rc == ORACLE_OK) { data_to_poly(c, v); kzg_proof_from_poly(c, v, &z, out_proof, &y); fr_to_be(out_y, &y); }
+    free(v);
+    return rc;
+}
+int oracle_compute_blob_kzg_proof(const oracle_ctx *c, const uint8_t *blob, const uint8_t *commitment, uint8_t *out_proof) {
+    fr_t *v = malloc(N_BLOB * sizeof(fr_t)), z, y;
+    g1a_t cm;
+    int rc = deserialize_scalars(v, blob, N_BLOB);
+    if (rc == ORACLE_OK && g1_decompress(&cm, commitment, 1)) rc = ORACLE_ERR_G1;
+    if (rc == ORACLE_OK) { data_to_poly(c, v); fs_challenge_4844(&z, blob, commitment); kzg_proof_from_poly(c, v, &z, out_proof, &y); }
+    free(v);
+    return rc;
+}
+/* Verifier::verify_kzg_proof (kzg_single_open/src/verifier.rs:33-57).  The reference pairs (C - yG, -G2) with
+   (pi, [tau - z]_2); by bilinearity that product equals e(C - yG + z pi, -G2) * e(pi, [tau]_2), which needs no G2
+   arithmetic (the same rearrangement the reference's own batch verifier uses, verifier.rs:76-107). */
+static int verify_single(const oracle_ctx *c, const g1a_t *cm, const fr_t *z, const fr_t *y, const g1a_t *pi) {
+    g1a_t pts[3] = {*cm, c->g1s[0], *pi};
+    fr_t sc[3] = {FR_ONE, FR_ZERO, *z};
+    fr_neg(&sc[1], y);
+    g1_t lhs; g1_msm(&lhs, pts, sc, 3);
+    g1_t both[2]; both[0] = lhs; g1_from_affine(&both[1], pi);
+    g1a_t aff[2]; g1_batch_normalize(aff, both, 2);
+    g2a_t q[2] = {c->neg_g2_gen, c->tau_g2};
+    return pairing_product_is_one(aff, q, 2);
+}
+int oracle_verify_kzg_proof(const oracle_ctx *c, const uint8_t *commitment, const uint8_t *z_bytes, const uint8_t *y_bytes,
+                            const uint8_t *proof, int *verified) {
+    g1a_t cm, pi; fr_t z, y;
+    *verified = 0;
+    if (g1_decompress(&cm, commitment, 1)) return ORACLE_ERR_G1;
+    if (g1_decompress(&pi, proof, 1)) return ORACLE_ERR_G1;
+    if (fr_from_be(&z, z_bytes) || fr_from_be(&y, y_bytes)) return ORACLE_ERR_SCALAR;
+    *verified = verify_single(c, &cm, &z, &y, &pi);
+    return ORACLE_OK;
+}
+/* PolyCoeff::eval (polynomial/src/poly_coeff.rs:59-65) */
+static void poly_eval(fr_t *out, const fr_t *poly, size_t n, const fr_t *x) {
+    fr_t r = FR_ZERO;
+    for (size_t i = n; i-- > 0;) { fr_mul(&r, &r, x); fr_add(&r, &r, &poly[i]); }
+    *out = r;
+}
+int oracle_verify_blob_kzg_proof(const oracle_ctx *c, const uint8_t *blob, const uint8_t *commitment, const uint8_t *proof, int *verified) {
+    fr_t *v = malloc(N_BLOB * sizeof(fr_t)), z, y;
+    g1a_t cm, pi;
+    *verified = 0;
+    int rc = deserialize_scalars(v, blob, N_BLOB);
+    if (rc == ORACLE_OK && g1_decompress(&cm, commitment, 1)) rc = ORACLE_ERR_G1;
+    if (rc == ORACLE_OK && g1_decompress(&pi, proof, 1)) rc = ORACLE_ERR_G1;
+    if (rc == ORACLE_OK) {
+        fs_challenge_4844(&z, blob, commitment);
+        data_to_poly(c, v);
+        poly_eval(&y, v, N_BLOB, &z);
+        *verified = verify_single(c, &cm, &z, &y, &pi);
+    }
+    free(v);
+    return rc;
+}
+/* verify_blob_kzg_proof_batch (eip4844/src/verifier.rs:81-143, :201-262; kzg_single_open/src/verifier.rs:59-108) */
+int oracle_verify_blob_kzg_proof_batch(const oracle_ctx *c, size_t n_blobs, const uint8_t *blobs, size_t n_commitments,
+                                       const uint8_t *commitments, size_t n_proofs, const uint8_t *proofs, int *verified) {
+    *verified = 0;
+    if (!(n_blobs == n_commitments && n_blobs == n_proofs)) return ORACLE_ERR_INPUT;
+    size_t n = n_blobs;
+    int rc = ORACLE_OK;
+    fr_t *polys = malloc((n * N_BLOB + 1) * sizeof(fr_t));
+    g1a_t *cm = malloc((n + 1) * sizeof(g1a_t)), *pi = malloc((n + 1) * sizeof(g1a_t));
+    fr_t *zs = malloc((n + 1) * sizeof(fr_t)), *ys = malloc((n + 1) * sizeof(fr_t));
+    for (size_t i = 0; i < n && rc == ORACLE_OK; i++) rc = deserialize_scalars(polys + i * N_BLOB, blobs + i * 131072, N_BLOB);
+    for (size_t i = 0; i < n && rc == ORACLE_OK; i++) if (g1_decompress(&cm[i], commitments + 48 * i, 1)) rc = ORACLE_ERR_G1;
+    for (size_t i = 0; i < n && rc == ORACLE_OK; i++) if (g1_decompress(&pi[i], proofs + 48 * i, 1)) rc = ORACLE_ERR_G1;
+    if (rc == ORACLE_OK) {
+        for (size_t i = 0; i < n; i++) {
+            fs_challenge_4844(&zs[i], blobs + i * 131072, commitments + 48 * i);
+            data_to_poly(c, polys + i * N_BLOB);
+            poly_eval(&ys[i], polys + i * N_BLOB, N_BLOB, &zs[i]);
+        }
+        /* compute_r_powers_for_verify_kzg_proof_batch */
+        size_t hlen = 16 + 8 + 8 + n * (48 + 32 + 32 + 48), off = 0;
+        uint8_t *hin = malloc(hlen);
+        memcpy(hin, "RCKZGBATCH___V1_", 16); off = 16;
+        uint64_t hdr[2] = {N_BLOB, n};
+        for (int k = 0; k < 2; k++) for (int b = 0; b < 8; b++) hin[off++] = (uint8_t)(hdr[k] >> (56 - 8 * b));
+        for (size_t i = 0; i < n; i++) {
+            memcpy(hin + off, commitments + 48 * i, 48); off += 48;
+            fr_to_be(hin + off, &zs[i]); off += 32;
+            fr_to_be(hin + off, &ys[i]); off += 32;
+            memcpy(hin + off, proofs + 48 * i, 48); off += 48;
+        }
+        uint8_t dig[32]; sha256(dig, hin, hlen); free(hin);
+        fr_t r; fr_from_be_reduce(&r, dig);
+        /* lhs = sum r^i C_i - (sum r^i y_i) G + sum r^i z_i pi_i ; rhs = sum r^i pi_i */
+        g1a_t *pts = malloc((2 * n + 1) * sizeof(g1a_t)); fr_t *sc = malloc((2 * n + 1) * sizeof(fr_t));
+        fr_t cur = FR_ONE, ysum = FR_ZERO;
+        for (size_t i = 0; i < n; i++) {
+            pts[i] = cm[i]; sc[i] = cur;
+            pts[n + 1 + i] = pi[i]; fr_mul(&sc[n + 1 + i], &cur, &zs[i]);
+            fr_t t; fr_mul(&t, &cur, &ys[i]); fr_add(&ysum, &ysum, &t);
+            fr_mul(&cur, &cur, &r);
+        }
+        pts[n] = c->g1s[0]; fr_neg(&sc[n], &ysum);
+        g1_t both[2];
+        g1_msm(&both[0], pts, sc, 2 * n + 1);
+        g1_msm(&both[1], pi, sc, n);   /* sc[0..n) = r^i */
+        g1a_t aff[2]; g1_batch_normalize(aff, both, 2);
+        g2a_t q[2] = {c->neg_g2_gen, c->tau_g2};
+        *verified = pairing_product_is_one(aff, q, 2);
+        free(pts); free(sc);
+    }
+    free(polys); free(cm); free(pi); free(zs); free(ys);
     return rc;
 }
 

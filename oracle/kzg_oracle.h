@@ -48,6 +48,14 @@ int oracle_recover_cells_and_kzg_proofs(const oracle_ctx *ctx, size_t n_cells, c
                                         size_t n_indices, const uint64_t *cell_indices,
                                         uint8_t *out_cells, uint8_t *out_proofs);
 
+/* EIP-4844 single-point operations (crates/eip4844); flat arrays as above */
+int oracle_compute_kzg_proof(const oracle_ctx *ctx, const uint8_t *blob, const uint8_t *z /*32*/, uint8_t *out_proof /*48*/, uint8_t *out_y /*32*/);
+int oracle_compute_blob_kzg_proof(const oracle_ctx *ctx, const uint8_t *blob, const uint8_t *commitment /*48*/, uint8_t *out_proof /*48*/);
+int oracle_verify_kzg_proof(const oracle_ctx *ctx, const uint8_t *commitment, const uint8_t *z, const uint8_t *y, const uint8_t *proof, int *verified);
+int oracle_verify_blob_kzg_proof(const oracle_ctx *ctx, const uint8_t *blob, const uint8_t *commitment, const uint8_t *proof, int *verified);
+int oracle_verify_blob_kzg_proof_batch(const oracle_ctx *ctx, size_t n_blobs, const uint8_t *blobs, size_t n_commitments,
+                                       const uint8_t *commitments, size_t n_proofs, const uint8_t *proofs, int *verified);
+
 /* ---- stage-level entry points used by the kernel parity tests (canonical encodings) ---- */
 /* Fr NTT over n = 2^k elements given as 32-byte big-endian canonical scalars.
    inverse != 0: multiply by n^-1 afterwards (Domain::ifft_scalars). coset: 0 none,

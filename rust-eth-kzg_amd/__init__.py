@@ -208,6 +208,47 @@ class DASContext:
             self._ctx, len(cells), cla, len(cell_indices), idx, oca, opa))
         return [c.raw for c in out_cells], [p.raw for p in out_proofs]
 
+    # ---- EIP-4844 single-point operations (crates/eip4844/src/{prover,verifier}.rs) ----
+    def compute_kzg_proof(self, blob, z):
+        if len(blob) != BYTES_PER_BLOB or len(z) != 32:
+            raise KzgError("InvalidLength")
+        proof, y = C.create_string_buffer(48), C.create_string_buffer(32)
+        self._check(self._lib.eth_kzg_compute_kzg_proof(self._ctx, bytes(blob), bytes(z), proof, y))
+        return proof.raw, y.raw
+
+    def compute_blob_kzg_proof(self, blob, commitment):
+        if len(blob) != BYTES_PER_BLOB or len(commitment) != 48:
+            raise KzgError("InvalidLength")
+        proof = C.create_string_buffer(48)
+        self._check(self._lib.eth_kzg_compute_blob_kzg_proof(self._ctx, bytes(blob), bytes(commitment), proof))
+        return proof.raw
+
+    def verify_kzg_proof(self, commitment, z, y, proof):
+        if len(commitment) != 48 or len(proof) != 48 or len(z) != 32 or len(y) != 32:
+            raise KzgError("InvalidLength")
+        ok = C.c_bool(False)
+        self._check(self._lib.eth_kzg_verify_kzg_proof(self._ctx, bytes(commitment), bytes(z), bytes(y), bytes(proof), C.byref(ok)))
+        return bool(ok.value)
+
+    def verify_blob_kzg_proof(self, blob, commitment, proof):
+        if len(blob) != BYTES_PER_BLOB or len(commitment) != 48 or len(proof) != 48:
+            raise KzgError("InvalidLength")
+        ok = C.c_bool(False)
+        self._check(self._lib.eth_kzg_verify_blob_kzg_proof(self._ctx, bytes(blob), bytes(commitment), bytes(proof), C.byref(ok)))
+        return bool(ok.value)
+
+    def verify_blob_kzg_proof_batch(self, blobs, commitments, proofs):
+        if any(len(b) != BYTES_PER_BLOB for b in blobs) or any(len(c) != 48 for c in commitments) \
+                or any(len(p) != 48 for p in proofs):
+            raise KzgError("InvalidLength")
+        ba, _k1 = _ptr_array(blobs)
+        ca, _k2 = _ptr_array(commitments)
+        pa, _k3 = _ptr_array(proofs)
+        ok = C.c_bool(False)
+        self._check(self._lib.eth_kzg_verify_blob_kzg_proof_batch(self._ctx, len(blobs), ba, len(commitments), ca, len(proofs), pa,
+                                                                  C.byref(ok)))
+        return bool(ok.value)
+
     # ---- batched additions ----------------------------------------------------------------
     def compute_cells_and_kzg_proofs_batch(self, blobs):
         """List of blobs -> (status list, cells[b][128], proofs[b][128]); host buffers."""

@@ -133,16 +133,44 @@ uint64_t eth_kzg_constant_bytes_per_cell(void) { return 2048; }
 uint64_t eth_kzg_constant_bytes_per_proof(void) { return 48; }
 uint64_t eth_kzg_constant_cells_per_ext_blob(void) { return CELLS; }
 
-static CResult not_built(const DASContext* ctx) {
-    (void)eng(ctx);
-    return err("NotImplemented(EIP-4844 single-point operations are outside the MI355X hot-path build; SURVEY.md 8f)");
+// EIP-4844 single-point operations (bindings/c/src/lib.rs:423-566)
+static CResult finish(kzg::Engine* e, int st) {
+    if (st == kzg::ERR_DEVICE) return device_err(e);
+    return st ? err(status_text(st)) : ok();
 }
-CResult eth_kzg_compute_kzg_proof(const DASContext* ctx, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*) { return not_built(ctx); }
-CResult eth_kzg_compute_blob_kzg_proof(const DASContext* ctx, const uint8_t*, const uint8_t*, uint8_t*) { return not_built(ctx); }
-CResult eth_kzg_verify_kzg_proof(const DASContext* ctx, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, bool*) { return not_built(ctx); }
-CResult eth_kzg_verify_blob_kzg_proof(const DASContext* ctx, const uint8_t*, const uint8_t*, const uint8_t*, bool*) { return not_built(ctx); }
-CResult eth_kzg_verify_blob_kzg_proof_batch(const DASContext* ctx, uint64_t, const uint8_t* const*, uint64_t,
-                                            const uint8_t* const*, uint64_t, const uint8_t* const*, bool*) { return not_built(ctx); }
+CResult eth_kzg_compute_kzg_proof(const DASContext* ctx, const uint8_t* blob, const uint8_t* z, uint8_t* out_proof, uint8_t* out_y) {
+    kzg::Engine* e = eng(ctx);
+    return finish(e, e->compute_kzg_proof_host(blob, z, out_proof, out_y));
+}
+CResult eth_kzg_compute_blob_kzg_proof(const DASContext* ctx, const uint8_t* blob, const uint8_t* commitment, uint8_t* out) {
+    kzg::Engine* e = eng(ctx);
+    return finish(e, e->compute_blob_kzg_proof_host(blob, commitment, out));
+}
+CResult eth_kzg_verify_kzg_proof(const DASContext* ctx, const uint8_t* commitment, const uint8_t* z, const uint8_t* y,
+                                 const uint8_t* proof, bool* verified) {
+    kzg::Engine* e = eng(ctx);
+    int ver = 0;
+    int st = e->verify_kzg_proof_host(commitment, z, y, proof, &ver);
+    if (!st) *verified = ver != 0;
+    return finish(e, st);
+}
+CResult eth_kzg_verify_blob_kzg_proof(const DASContext* ctx, const uint8_t* blob, const uint8_t* commitment, const uint8_t* proof,
+                                      bool* verified) {
+    kzg::Engine* e = eng(ctx);
+    int ver = 0;
+    int st = e->verify_blob_kzg_proof_host(blob, commitment, proof, &ver);
+    if (!st) *verified = ver != 0;
+    return finish(e, st);
+}
+CResult eth_kzg_verify_blob_kzg_proof_batch(const DASContext* ctx, uint64_t blobs_length, const uint8_t* const* blobs,
+                                            uint64_t commitments_length, const uint8_t* const* commitments, uint64_t proofs_length,
+                                            const uint8_t* const* proofs, bool* verified) {
+    kzg::Engine* e = eng(ctx);
+    int ver = 0;
+    int st = e->verify_blob_kzg_proof_batch_host(blobs_length, blobs, commitments_length, commitments, proofs_length, proofs, &ver);
+    if (!st) *verified = ver != 0;
+    return finish(e, st);
+}
 
 // ---------------------------------------------------------------------------------------------
 CResult eth_kzg_amd_compute_cells_and_kzg_proofs_batch(const DASContext* ctx, uint64_t n, const uint8_t* const* blobs,

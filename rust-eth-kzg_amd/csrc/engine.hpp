@@ -59,6 +59,15 @@ public:
                                           const uint64_t* cell_indices, uint8_t* const* out_cells,
                                           uint8_t* const* out_proofs);
 
+    // EIP-4844 single-point operations (crates/eip4844/src/{prover,verifier}.rs); Status returns
+    int compute_kzg_proof_host(const uint8_t* blob, const uint8_t* z, uint8_t* out_proof, uint8_t* out_y);
+    int compute_blob_kzg_proof_host(const uint8_t* blob, const uint8_t* commitment, uint8_t* out_proof);
+    int verify_kzg_proof_host(const uint8_t* commitment, const uint8_t* z, const uint8_t* y, const uint8_t* proof, int* verified);
+    int verify_blob_kzg_proof_host(const uint8_t* blob, const uint8_t* commitment, const uint8_t* proof, int* verified);
+    int verify_blob_kzg_proof_batch_host(uint64_t n_blobs, const uint8_t* const* blobs, uint64_t n_commitments,
+                                         const uint8_t* const* commitments, uint64_t n_proofs, const uint8_t* const* proofs,
+                                         int* verified);
+
     // batched form: R independent recoveries in one pass (ragged cell lists); status[r] per blob
     int recover_cells_and_kzg_proofs_batch_host(int R, const uint64_t* n_cells, const uint8_t* const* const* cells,
                                                 const uint64_t* n_indices, const uint64_t* const* cell_indices,
@@ -87,6 +96,9 @@ private:
     void init_srs();
     void init_fk20();
     void init_verifier();
+    int open_blobs_at(int n, const uint8_t* const* blobs, const Fr8* z_mont, bool want_proofs, uint8_t* h_proofs, Fr8* h_y_canon,
+                      int* h_status);
+    int pairing_check_4844(const void* d_points, const std::vector<Fr8>& sc0, const std::vector<Fr8>& sc1);
     int recover_batch_to_coeffs(int R, const uint64_t* n_cells, const uint8_t* const* const* cells,
                                 const uint64_t* const* cell_indices, int* st_out);
     void ensure_workspace(int n);
@@ -126,6 +138,7 @@ private:
     void* d_coset_inv_ = nullptr;  // Fr[8192] 7^-i
     Fr8 inv64_, n_inv8192_;
     std::shared_ptr<pairing::G2Prepared> g2_tau_, g2_neg_gen_;  // [tau^64]_2 and -[1]_2 (verifier.rs:88-90)
+    std::shared_ptr<pairing::G2Prepared> g2_tau1_;             // [tau]_2 (EIP-4844 verification key)
 
     // verify workspace: one device arena + one pinned host staging buffer, grown on demand (guarded by mu_)
     void* v_dev_ = nullptr;

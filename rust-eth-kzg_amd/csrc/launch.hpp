@@ -66,6 +66,9 @@ void rec_dit_last(int R, const void* T, const void* shift, const Fr8& n_inv, voi
                   const void* w8192, int final_pass, hipStream_t st);
 void rec_dif_half(int R, const void* U, const void* fac, void* V, const void* w8192, hipStream_t st);
 
+// k_4844.hip
+void quotient_by_linear(int n, const void* coeffs, const void* z_mont, void* quotient, void* y_out, hipStream_t st);
+
 constexpr size_t SIZEOF_FR = 32, SIZEOF_G1AFFINE = 96, SIZEOF_G1JAC = 144;
 constexpr size_t SIZEOF_AFFQ = 112, SIZEOF_JACQ = 168;  // unsaturated 14 x 29-bit forms (curve29.hpp): table entries, FFT arrays
 

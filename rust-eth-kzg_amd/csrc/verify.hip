@@ -61,6 +61,9 @@ void Engine::init_verifier() {
         throw std::runtime_error("embedded SRS: G2 point failed to decompress");
     g2_tau_ = std::make_shared<pairing::G2Prepared>(pairing::prepare(tau));
     g2_neg_gen_ = std::make_shared<pairing::G2Prepared>(pairing::prepare(pairing::g2_neg(gen)));
+    pairing::G2Affine tau1;
+    if (!pairing::g2_decompress(tau1, g2 + 96)) throw std::runtime_error("embedded SRS: [tau]_2 failed to decompress");
+    g2_tau1_ = std::make_shared<pairing::G2Prepared>(pairing::prepare(tau1));
     // coset shift tables 7^i, 7^-i
     std::vector<Fr> c(N_EXT), ci(N_EXT);
     Fr g = fr_u64(7), gi = inv(g);

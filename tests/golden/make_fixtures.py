@@ -4,7 +4,9 @@
 Source (read only in the build container, never at test time):
     /root/reference/test_vectors/<family>/kzg-mainnet/<case>/data.y{a,}ml
 families: blob_to_kzg_commitment, compute_cells_and_kzg_proofs,
-          verify_cell_kzg_proof_batch, recover_cells_and_kzg_proofs
+          verify_cell_kzg_proof_batch, recover_cells_and_kzg_proofs,
+          compute_kzg_proof, compute_blob_kzg_proof, verify_kzg_proof, verify_blob_kzg_proof,
+          verify_blob_kzg_proof_batch (crates/eip4844/tests/*.rs)
 (the vectors the reference's own integration tests replay:
  crates/eip7594/tests/{blob_to_kzg_commitment,compute_cells_and_kzg_proofs,
  verify_cell_kzg_proof_batch,recover_cells_and_kzg_proofs}.rs)
@@ -26,7 +28,10 @@ REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 FAMILIES = ["blob_to_kzg_commitment", "compute_cells_and_kzg_proofs",
-            "verify_cell_kzg_proof_batch", "recover_cells_and_kzg_proofs"]
+            "verify_cell_kzg_proof_batch", "recover_cells_and_kzg_proofs",
+            # EIP-4844 single-point families
+            "compute_kzg_proof", "compute_blob_kzg_proof", "verify_kzg_proof", "verify_blob_kzg_proof",
+            "verify_blob_kzg_proof_batch"]
 
 pool, pool_ix = [], {}
 

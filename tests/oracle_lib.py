@@ -150,3 +150,53 @@ def sha256(data: bytes) -> bytes:
     out = C.create_string_buffer(32)
     _lib().oracle_sha256(data, C.c_size_t(len(data)), out)
     return out.raw
+
+
+# ---- EIP-4844 single-point operations on the Oracle object ----
+def _o_compute_kzg_proof(self, blob, z):
+    if len(blob) != BYTES_PER_BLOB or len(z) != 32:
+        raise OracleError(3)
+    p, y = C.create_string_buffer(48), C.create_string_buffer(32)
+    self._chk(self.lib.oracle_compute_kzg_proof(self.ctx, blob, z, p, y))
+    return p.raw, y.raw
+
+
+def _o_compute_blob_kzg_proof(self, blob, commitment):
+    if len(blob) != BYTES_PER_BLOB or len(commitment) != 48:
+        raise OracleError(3)
+    p = C.create_string_buffer(48)
+    self._chk(self.lib.oracle_compute_blob_kzg_proof(self.ctx, blob, commitment, p))
+    return p.raw
+
+
+def _o_verify_kzg_proof(self, commitment, z, y, proof):
+    if len(commitment) != 48 or len(proof) != 48 or len(z) != 32 or len(y) != 32:
+        raise OracleError(3)
+    ok = C.c_int(0)
+    self._chk(self.lib.oracle_verify_kzg_proof(self.ctx, commitment, z, y, proof, C.byref(ok)))
+    return bool(ok.value)
+
+
+def _o_verify_blob_kzg_proof(self, blob, commitment, proof):
+    if len(blob) != BYTES_PER_BLOB or len(commitment) != 48 or len(proof) != 48:
+        raise OracleError(3)
+    ok = C.c_int(0)
+    self._chk(self.lib.oracle_verify_blob_kzg_proof(self.ctx, blob, commitment, proof, C.byref(ok)))
+    return bool(ok.value)
+
+
+def _o_verify_blob_kzg_proof_batch(self, blobs, commitments, proofs):
+    if any(len(b) != BYTES_PER_BLOB for b in blobs) or any(len(c) != 48 for c in commitments) or any(len(p) != 48 for p in proofs):
+        raise OracleError(3)
+    ok = C.c_int(0)
+    self._chk(self.lib.oracle_verify_blob_kzg_proof_batch(
+        self.ctx, C.c_size_t(len(blobs)), b"".join(blobs), C.c_size_t(len(commitments)), b"".join(commitments),
+        C.c_size_t(len(proofs)), b"".join(proofs), C.byref(ok)))
+    return bool(ok.value)
+
+
+Oracle.compute_kzg_proof = _o_compute_kzg_proof
+Oracle.compute_blob_kzg_proof = _o_compute_blob_kzg_proof
+Oracle.verify_kzg_proof = _o_verify_kzg_proof
+Oracle.verify_blob_kzg_proof = _o_verify_blob_kzg_proof
+Oracle.verify_blob_kzg_proof_batch = _o_verify_blob_kzg_proof_batch

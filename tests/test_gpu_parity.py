@@ -277,3 +277,49 @@ def test_recover_batch_ragged(ctx, oracle):
     assert st[:4] == [0, 0, 0, 0] and st[4] == 4 and st[5] == 3
     for b in range(4):
         assert rc[b] == cells[b] and rp[b] == proofs[b]
+
+
+# ------------------------------------------------------------------ EIP-4844 single-point operations
+@pytest.mark.parametrize("name,case", sorted(vectors.load("compute_kzg_proof").items()))
+def test_compute_kzg_proof_vectors(ctx, name, case):
+    i = case["input"]
+    out = _call(ctx.compute_kzg_proof, i["blob"], i["z"])
+    assert (list(out) if out is not None else None) == case["output"]
+
+
+@pytest.mark.parametrize("name,case", sorted(vectors.load("compute_blob_kzg_proof").items()))
+def test_compute_blob_kzg_proof_vectors(ctx, name, case):
+    i = case["input"]
+    assert _call(ctx.compute_blob_kzg_proof, i["blob"], i["commitment"]) == case["output"]
+
+
+@pytest.mark.parametrize("name,case", sorted(vectors.load("verify_kzg_proof").items()))
+def test_verify_kzg_proof_vectors(ctx, name, case):
+    i = case["input"]
+    assert _call(ctx.verify_kzg_proof, i["commitment"], i["z"], i["y"], i["proof"]) == case["output"]
+
+
+@pytest.mark.parametrize("name,case", sorted(vectors.load("verify_blob_kzg_proof").items()))
+def test_verify_blob_kzg_proof_vectors(ctx, name, case):
+    i = case["input"]
+    assert _call(ctx.verify_blob_kzg_proof, i["blob"], i["commitment"], i["proof"]) == case["output"]
+
+
+@pytest.mark.parametrize("name,case", sorted(vectors.load("verify_blob_kzg_proof_batch").items()))
+def test_verify_blob_kzg_proof_batch_vectors(ctx, name, case):
+    i = case["input"]
+    assert _call(ctx.verify_blob_kzg_proof_batch, i["blobs"], i["commitments"], i["proofs"]) == case["output"]
+
+
+def test_eip4844_round_trip_on_synthetic_blobs(ctx, oracle):
+    blobs = [synth.seeded_blob(80 + i) for i in range(3)]
+    _, comms = ctx.blob_to_kzg_commitment_batch(blobs)
+    proofs = [ctx.compute_blob_kzg_proof(b, c) for b, c in zip(blobs, comms)]
+    assert proofs == [oracle.compute_blob_kzg_proof(b, c) for b, c in zip(blobs, comms)]
+    assert ctx.verify_blob_kzg_proof_batch(blobs, comms, proofs) is True
+    assert ctx.verify_blob_kzg_proof_batch(blobs, comms, proofs[::-1]) is False
+    z = synth.seeded_scalars(1, b"z4844")[0]
+    p, y = ctx.compute_kzg_proof(blobs[0], z)
+    assert (p, y) == oracle.compute_kzg_proof(blobs[0], z)
+    assert ctx.verify_kzg_proof(comms[0], z, y, p) is True
+    assert ctx.verify_kzg_proof(comms[1], z, y, p) is False

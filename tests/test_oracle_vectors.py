@@ -57,3 +57,35 @@ def test_recover_cells_and_kzg_proofs(oracle, name, case):
         assert out is None
     else:
         assert out is not None and out[0] == exp[0] and out[1] == exp[1]
+
+
+# ---- EIP-4844 single-point families (crates/eip4844/tests/*.rs) ----
+@pytest.mark.parametrize("name,case", sorted(vectors.load("compute_kzg_proof").items()))
+def test_compute_kzg_proof(oracle, name, case):
+    i = case["input"]
+    out = _call(oracle.compute_kzg_proof, i["blob"], i["z"])
+    assert (list(out) if out is not None else None) == case["output"]
+
+
+@pytest.mark.parametrize("name,case", sorted(vectors.load("compute_blob_kzg_proof").items()))
+def test_compute_blob_kzg_proof(oracle, name, case):
+    i = case["input"]
+    assert _call(oracle.compute_blob_kzg_proof, i["blob"], i["commitment"]) == case["output"]
+
+
+@pytest.mark.parametrize("name,case", sorted(vectors.load("verify_kzg_proof").items()))
+def test_verify_kzg_proof(oracle, name, case):
+    i = case["input"]
+    assert _call(oracle.verify_kzg_proof, i["commitment"], i["z"], i["y"], i["proof"]) == case["output"]
+
+
+@pytest.mark.parametrize("name,case", sorted(vectors.load("verify_blob_kzg_proof").items()))
+def test_verify_blob_kzg_proof(oracle, name, case):
+    i = case["input"]
+    assert _call(oracle.verify_blob_kzg_proof, i["blob"], i["commitment"], i["proof"]) == case["output"]
+
+
+@pytest.mark.parametrize("name,case", sorted(vectors.load("verify_blob_kzg_proof_batch").items()))
+def test_verify_blob_kzg_proof_batch(oracle, name, case):
+    i = case["input"]
+    assert _call(oracle.verify_blob_kzg_proof_batch, i["blobs"], i["commitments"], i["proofs"]) == case["output"]
