@@ -144,7 +144,9 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     kzg = importlib.import_module("rust-eth-kzg_amd")
+    t_ctx = time.perf_counter()
     ctx = kzg.DASContext(use_precomp=True, device=local_rank)  # no CPU fallback: raises/aborts without the HIP path
+    t_ctx = time.perf_counter() - t_ctx
 
     B = args.blobs_per_gpu
     blobs_h = synth_blobs(B, seed=0x4B5A47 + rank)
@@ -226,8 +228,8 @@ def main():
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r1b_pmc_fetch_write_b2048.json")))["kernels"]
-            key = {"msm_fixed": "void kzg::k_msm_fixed<12>", "g1_ifft": "kzg::k_g1_twiddle_mul", "g1_fft": "kzg::k_g1_twiddle_mul"}.get(dom)
-            if key in pm and B == 2048 and ctx.window_bits() == 12:
+            key = {"msm_fixed": "void kzg::k_msm_fixed<14>", "g1_ifft": "kzg::k_g1_twiddle_mul", "g1_fft": "kzg::k_g1_twiddle_mul"}.get(dom)
+            if key in pm and B == 2048 and ctx.window_bits() == 14:
                 traffic = (pm[key]["FETCH_SIZE_KB_per_launch_max"] + pm[key]["WRITE_SIZE_KB_per_launch_max"]) * 1024.0
         except Exception:
             pass
@@ -258,6 +260,7 @@ def main():
             "whole_path_hbm_frac": value * ALG_BYTES_PER_BLOB / 1e9 / HBM_PEAK_GBS,
             "stage_ms_per_step": stage_ms_per_step,
             "single_blob_latency_ms": min(lat) * 1e3,
+            "context_creation_s": round(t_ctx, 2),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline([bytes(blobs_h[i].tobytes()) for i in range(min(B, 16))])

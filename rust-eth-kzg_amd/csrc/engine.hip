@@ -109,11 +109,12 @@ static bool jsf_check(const uint32_t* row, u128 k1, u128 k2) {
 }
 
 // ---------------------------------------------------------------------------------------------
-Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 12 : 4) {
+Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14 : 4) {
     if (use_precomp) {
-        if (const char* s = getenv("ETH_KZG_AMD_WINDOW")) {  // tuning knob: FK20 table window width (8, 10 or 12)
+        // default width 14: 145 GB of window tables, 19 windows -> 1216 gathered additions per MSM (HBM is 288 GB).
+        if (const char* s = getenv("ETH_KZG_AMD_WINDOW")) {  // tuning knob: FK20 table window width (8, 10, 12, 13, 14)
             int c = atoi(s);
-            if (c == 8 || c == 10 || c == 12) c_ = c;
+            if (c == 8 || c == 10 || c == 12 || c == 13 || c == 14) c_ = c;
         }
     }
     srs_c_ = use_precomp ? 8 : 4;
@@ -214,12 +215,21 @@ void Engine::init_srs() {
 }
 
 static void build_table(int c, const void* bases, void** table, size_t* bytes, int n_groups, int nb, hipStream_t st) {
-    size_t entries = launch::table_entries(c, n_groups, nb);
+    // groups are built in chunks so that the Jacobian scratch (144 B per entry) stays below ~24 GB
+    const size_t per_group = launch::table_entries(c, 1, nb);
+    int chunk = (int)((24ull << 30) / (per_group * sizeof(G1Jac)));
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_groups) chunk = n_groups;
+    const size_t entries = per_group * n_groups;
     void* scratch;
     HIPCK(hipMalloc(table, entries * launch::SIZEOF_AFFQ));
-    HIPCK(hipMalloc(&scratch, entries * sizeof(G1Jac)));
-    launch::build_table(c, bases, *table, scratch, n_groups, nb, st);
-    HIPCK(hipStreamSynchronize(st));
+    HIPCK(hipMalloc(&scratch, per_group * chunk * sizeof(G1Jac)));
+    for (int g0 = 0; g0 < n_groups; g0 += chunk) {
+        int g = n_groups - g0 < chunk ? n_groups - g0 : chunk;
+        launch::build_table(c, (const char*)bases + (size_t)g0 * nb * sizeof(G1Affine),
+                            (char*)*table + (size_t)g0 * per_group * launch::SIZEOF_AFFQ, scratch, g, nb, st);
+        HIPCK(hipStreamSynchronize(st));
+    }
     HIPCK(hipFree(scratch));
     *bytes = entries * launch::SIZEOF_AFFQ;
 }

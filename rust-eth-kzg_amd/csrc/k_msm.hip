@@ -88,6 +88,8 @@ void msm_fixed(int c, const void* scalars, const void* table, void* out, int n_g
                int brp_bits, hipStream_t st) {
     if (c == 8) msm_c<8>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
     else if (c == 12) msm_c<12>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
+    else if (c == 13) msm_c<13>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
+    else if (c == 14) msm_c<14>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
     else if (c == 10) msm_c<10>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
     else msm_c<4>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
 }

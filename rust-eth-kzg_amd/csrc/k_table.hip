@@ -64,6 +64,8 @@ void build_table(int c, const void* bases, void* table, void* scratch, int n_gro
     unsigned blocks = (unsigned)((threads + 63) / 64);
     if (c == 8) k_build_table<8><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)table, (G1Jac*)scratch, n_groups, nb);
     else if (c == 12) k_build_table<12><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)table, (G1Jac*)scratch, n_groups, nb);
+    else if (c == 13) k_build_table<13><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)table, (G1Jac*)scratch, n_groups, nb);
+    else if (c == 14) k_build_table<14><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)table, (G1Jac*)scratch, n_groups, nb);
     else if (c == 10) k_build_table<10><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)table, (G1Jac*)scratch, n_groups, nb);
     else k_build_table<4><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)table, (G1Jac*)scratch, n_groups, nb);
 }
