@@ -131,7 +131,7 @@ Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14
 Engine::~Engine() {
     hipSetDevice(dev_);
     void* ptrs[] = {d_w8192_, d_naf_, d_srs_, d_fk_bases_, d_fk_table_, d_srs_table_, d_coeffs_, d_canon_,
-                    d_scalars_, d_X_, d_status_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_};
+                    d_scalars_, d_X_, d_status_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_dft_tmp_, d_dft_prod_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (v_dev_) hipFree(v_dev_);
@@ -327,15 +327,29 @@ void Engine::run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st) {
     launch::fk20_scalars(n, d_coeffs_, d_scalars_, d_w8192_, inv128_, st);
     mark_end(1, st);
     launch::g1_set_inf(d_X_, (size_t)128 * bp, st);
+    const bool latency_mode = bp == 64;  // one 64-blob group: direct 8 x 16 transforms, 4 rounds instead of 14
     mark_begin(ST_MSM_FIXED, st);
-    launch_msm(d_scalars_, d_fk_table_, d_X_, 128, n, bp, 7, st);
+    launch_msm(d_scalars_, d_fk_table_, d_X_, 128, n, bp, latency_mode ? 0 : 7, st);
     mark_end(1, st);
-    mark_begin(ST_G1_IFFT, st);
-    g1_ifft128_take64(d_X_, bp, st);
-    mark_end(7, st);  // 7 layers (each = one twiddle-multiplication launch + one butterfly launch)
-    mark_begin(ST_G1_FFT, st);
-    g1_fft128_from64(d_X_, bp, st);
-    mark_end(7, st);
+    if (latency_mode) {
+        if (!d_dft_tmp_) {
+            HIPCK(hipMalloc(&d_dft_tmp_, (size_t)128 * 64 * launch::SIZEOF_JACQ));
+            HIPCK(hipMalloc(&d_dft_prod_, (size_t)128 * 16 * 64 * launch::SIZEOF_JACQ));
+        }
+        mark_begin(ST_G1_IFFT, st);
+        launch::g1_dft128_direct(d_X_, d_dft_tmp_, d_dft_prod_, 128, 64, 1, 0, d_naf_, beta_, st);  // h = first 64 outputs
+        mark_end(2, st);
+        mark_begin(ST_G1_FFT, st);
+        launch::g1_dft128_direct(d_X_, d_dft_tmp_, d_dft_prod_, 64, 128, 0, 1, d_naf_, beta_, st);  // proofs, bit-reversed
+        mark_end(2, st);
+    } else {
+        mark_begin(ST_G1_IFFT, st);
+        g1_ifft128_take64(d_X_, bp, st);
+        mark_end(7, st);  // 7 layers (each = one twiddle-multiplication launch + one butterfly launch)
+        mark_begin(ST_G1_FFT, st);
+        g1_fft128_from64(d_X_, bp, st);
+        mark_end(7, st);
+    }
     mark_begin(ST_COMPRESS, st);
     launch::g1_compress(d_X_, d_proofs, 128, bp, n, st);
     mark_end(1, st);

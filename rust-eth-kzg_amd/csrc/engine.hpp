@@ -146,6 +146,8 @@ private:
     uint8_t* v_pin_ = nullptr;
     size_t v_pin_cap_ = 0;
 
+    void *d_dft_tmp_ = nullptr, *d_dft_prod_ = nullptr;  // latency-mode G1 transforms (one 64-blob group)
+
     // workspace (grown on demand, guarded by mu_)
     int cap_ = 0;
     void *d_coeffs_ = nullptr, *d_canon_ = nullptr, *d_scalars_ = nullptr, *d_X_ = nullptr;

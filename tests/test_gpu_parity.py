@@ -323,3 +323,23 @@ def test_eip4844_round_trip_on_synthetic_blobs(ctx, oracle):
     assert (p, y) == oracle.compute_kzg_proof(blobs[0], z)
     assert ctx.verify_kzg_proof(comms[0], z, y, p) is True
     assert ctx.verify_kzg_proof(comms[1], z, y, p) is False
+
+
+def test_batch_larger_than_one_lane_group(ctx, oracle):
+    """70 blobs: more than one 64-lane group, so the radix-2 G1-FFT network runs (batches <= 64 use the
+    direct 8x16 latency mode). Spot-check against the oracle and check the data-in-first-half invariant on all."""
+    import numpy as np
+    rng = np.random.RandomState(123)
+    a = rng.randint(0, 256, size=(70, 4096, 32), dtype=np.uint8)
+    a[:, :, 0] &= 0x3F
+    blobs = [a[i].tobytes() for i in range(70)]
+    blobs[1] = blobs[0]                                   # duplicate blob
+    blobs[65] = vectors.load("compute_cells_and_kzg_proofs")["valid_419245fbfe69f145"]["input"]["blob"]  # all r-1: identity proofs
+    st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs)
+    assert st == [0] * 70
+    for b in range(70):
+        assert b"".join(cells[b][:64]) == blobs[b]
+    assert cells[0] == cells[1] and proofs[0] == proofs[1]
+    for b in (0, 63, 64, 65, 69):
+        ec, ep = oracle.compute_cells_and_kzg_proofs(blobs[b])
+        assert cells[b] == ec and proofs[b] == ep, b
