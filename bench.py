@@ -229,10 +229,10 @@ def main():
         # valid only for the configuration they were collected on
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1b_pmc_fetch_write_b2048.json")))["kernels"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1c_pmc_b2048_w14.json")))["kernels"]
             key = {"msm_fixed": "void kzg::k_msm_fixed<14>", "g1_ifft": "kzg::k_g1_twiddle_mul", "g1_fft": "kzg::k_g1_twiddle_mul"}.get(dom)
             if key in pm and B == 2048 and ctx.window_bits() == 14:
-                traffic = (pm[key]["FETCH_SIZE_KB_per_launch_max"] + pm[key]["WRITE_SIZE_KB_per_launch_max"]) * 1024.0
+                traffic = (pm[key]["FETCH_SIZE_per_launch_max"] + pm[key]["WRITE_SIZE_per_launch_max"]) * 1024.0
         except Exception:
             pass
         stage_ms_per_step = {s: round(stages[s][0] / args.steps, 3) for s in stages}

@@ -5,8 +5,12 @@ import importlib
 import os
 import re
 
+import subprocess
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 kzg = importlib.import_module("rust-eth-kzg_amd")
+if not os.path.exists(kzg.LIB_PATH):  # fresh checkout: cross-compile the HIP extension (no GPU needed, a few minutes)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "rust-eth-kzg_amd", "csrc"), "-j", str(min(8, os.cpu_count() or 1))])
 
 
 def _declared_symbols():
