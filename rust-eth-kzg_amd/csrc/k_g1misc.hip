@@ -52,16 +52,6 @@ __global__ void k_g1_decompress(const uint8_t* __restrict__ in, G1Affine* __rest
     out[i] = a;
 }
 
-// affine -> X[pos*stride + slice] Jacobian scatter used to seed setup FFTs
-__global__ void k_affine_to_jac(const G1Affine* __restrict__ in, G1Jac* __restrict__ out, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = to_jac(in[i]);
-}
-__global__ void k_jac_to_affine(const G1Jac* __restrict__ in, G1Affine* __restrict__ out, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = to_affine(in[i]);
-}
-
 // SRS vectors of FK20 (fk20/prover.rs:88-104): t = reverse(g1s)[64:], S_i = t[i::64] (63 points) || O.
 __global__ void k_fk20_srs_vectors(const G1Affine* __restrict__ srs, JacQ* __restrict__ X) {
     // X[pos * 64 + i], pos < 128, i < 64
