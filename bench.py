@@ -244,7 +244,7 @@ def main():
             "metric": "blobs/sec compute_cells_and_kzg_proofs (4096-pt blob)",
             "value": value, "unit": "blobs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32 limbs (381-bit Fp / 255-bit Fr Montgomery integers)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u32", "dtype_note": "381-bit Fp as 14x29-bit / 12x32-bit limbs, 255-bit Fr as 8x32-bit limbs, Montgomery integers; exact arithmetic", "data": "synthetic",
             "config": {"workload": f"compute_cells_and_kzg_proofs, batch-saturated: {B} synthetic blobs per GPU per step "
                                    f"(config 2's single blob is reported as single_blob_latency_ms)",
                        "blobs_per_gpu": B, "use_precomp": True, "window_bits": ctx.window_bits(),
