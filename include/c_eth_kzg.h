@@ -132,7 +132,9 @@ CResult eth_kzg_amd_recover_cells_and_proofs_batch(const DASContext *ctx, uint64
  *   d_out          n * 48 bytes
  *   status         n ints in HOST memory, or NULL: then nothing is copied back and, if
  *                  `hip_stream` is non-NULL, the call returns without synchronising (work is
- *                  enqueued on that hipStream_t; NULL = the context's own stream, synchronised). */
+ *                  enqueued on that hipStream_t; NULL = the context's own stream, synchronised).
+ * A context owns ONE set of intermediate buffers: asynchronous calls on the same context must use the same
+ * stream (they are then ordered); use one context per stream for concurrent pipelines. */
 CResult eth_kzg_amd_compute_cells_and_kzg_proofs_device(const DASContext *ctx, uint64_t n, const uint8_t *d_blobs,
                                                         uint8_t *d_out_cells, uint8_t *d_out_proofs, int32_t *status,
                                                         void *hip_stream);

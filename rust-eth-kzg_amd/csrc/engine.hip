@@ -216,16 +216,27 @@ void Engine::init_srs() {
     }
 }
 
-static void build_table(int c, const void* bases, void** table, size_t* bytes, int n_groups, int nb, hipStream_t st) {
+// returns false (and leaves *table null) if the device cannot hold the table + scratch
+static bool build_table(int c, const void* bases, void** table, size_t* bytes, int n_groups, int nb, hipStream_t st) {
     // groups are built in chunks so that the Jacobian scratch (144 B per entry) stays below ~24 GB
     const size_t per_group = launch::table_entries(c, 1, nb);
     int chunk = (int)((24ull << 30) / (per_group * sizeof(G1Jac)));
     if (chunk < 1) chunk = 1;
     if (chunk > n_groups) chunk = n_groups;
     const size_t entries = per_group * n_groups;
-    void* scratch;
-    HIPCK(hipMalloc(table, entries * launch::SIZEOF_AFFQ));
-    HIPCK(hipMalloc(&scratch, per_group * chunk * sizeof(G1Jac)));
+    void* scratch = nullptr;
+    *table = nullptr;
+    size_t free_b = 0, total_b = 0;
+    HIPCK(hipMemGetInfo(&free_b, &total_b));
+    const size_t need = entries * launch::SIZEOF_AFFQ + per_group * chunk * sizeof(G1Jac) + (8ull << 30);  // + head-room for batches
+    if (need > free_b) return false;
+    if (hipMalloc(table, entries * launch::SIZEOF_AFFQ) != hipSuccess) { (void)hipGetLastError(); *table = nullptr; return false; }
+    if (hipMalloc(&scratch, per_group * chunk * sizeof(G1Jac)) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCK(hipFree(*table));
+        *table = nullptr;
+        return false;
+    }
     for (int g0 = 0; g0 < n_groups; g0 += chunk) {
         int g = n_groups - g0 < chunk ? n_groups - g0 : chunk;
         launch::build_table(c, (const char*)bases + (size_t)g0 * nb * sizeof(G1Affine),
@@ -234,6 +245,7 @@ static void build_table(int c, const void* bases, void** table, size_t* bytes, i
     }
     HIPCK(hipFree(scratch));
     *bytes = entries * launch::SIZEOF_AFFQ;
+    return true;
 }
 
 void Engine::init_fk20() {
@@ -246,8 +258,16 @@ void Engine::init_fk20() {
     launch::fk20_gather_bases(X, d_fk_bases_, stream_);
     HIPCK(hipStreamSynchronize(stream_));
     HIPCK(hipFree(X));
-    build_table(c_, d_fk_bases_, &d_fk_table_, &fk_table_bytes_, 128, 64, stream_);
-    build_table(srs_c_, d_srs_, &d_srs_table_, &srs_table_bytes_, 64, 64, stream_);  // SRS viewed as [64][64]
+    if (!build_table(srs_c_, d_srs_, &d_srs_table_, &srs_table_bytes_, 64, 64, stream_))  // SRS viewed as [64][64]
+        throw std::runtime_error("not enough device memory for the commitment window table");
+    // the widest FK20 table that fits (another context or process may already hold part of the HBM)
+    static const int widths[] = {14, 13, 12, 10, 8, 4};
+    bool ok = false;
+    for (int w : widths) {
+        if (w > c_) continue;
+        if (build_table(w, d_fk_bases_, &d_fk_table_, &fk_table_bytes_, 128, 64, stream_)) { c_ = w; ok = true; break; }
+    }
+    if (!ok) throw std::runtime_error("not enough device memory for the FK20 window table");
 }
 
 void Engine::set_profiling(bool on) { std::lock_guard<std::mutex> lk(mu_); profiling_ = on; }

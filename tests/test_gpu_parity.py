@@ -343,3 +343,15 @@ def test_batch_larger_than_one_lane_group(ctx, oracle):
     for b in (0, 63, 64, 65, 69):
         ec, ep = oracle.compute_cells_and_kzg_proofs(blobs[b])
         assert cells[b] == ec and proofs[b] == ep, b
+
+
+def test_second_context_falls_back_to_a_narrower_table(ctx, oracle):
+    """A second use_precomp context while the first holds its 145 GB table must still come up (narrower window)
+    and give identical results."""
+    c2 = kzg.DASContext(use_precomp=True)
+    try:
+        assert c2.window_bits() <= ctx.window_bits()
+        blob = synth.seeded_blob(90)
+        assert c2.compute_cells_and_kzg_proofs(blob) == ctx.compute_cells_and_kzg_proofs(blob)
+    finally:
+        c2.close()
