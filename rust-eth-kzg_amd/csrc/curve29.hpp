@@ -1,6 +1,7 @@
 // G1 group law over the unsaturated field (fp29.hpp) for the hot kernels.
 // Same formulas as curve.hpp (dbl-2009-l, add-2007-bl, madd-2007-bl) rearranged so that
-//   * Z3 is always 2 * (a product): bound 4, so "Z == 0 mod p" is four 14-word compares;
+//   * Z3 is always 2 * (a product): bound 4, so "Z == 0 mod p" is four 14-word compares (kept branch-free:
+//     an early-out on the low limb looked cheaper but its extra control flow made hipcc spill 4x more VGPRs);
 //   * NO exceptional-case test sits on the hot path: every degenerate addition (an identity operand,
 //     P + P, P + (-P)) makes Z3 = 2 Z1 (Z2) H vanish, so one cheap test of Z3 after the fact routes those
 //     rare cases to an exact slow path.  The constant / all-zero / two-valued fixture blobs reach it.
@@ -63,12 +64,12 @@ HD Fq<B> select(bool c, const Fq<B>& a, const Fq<B>& b) {
 // dbl-2009-l with D = 4 X Y^2 written as a product: 3M + 4S
 HD JacQ dbl(const JacQ& p) {
     Fq<2> A = sqr(p.x), B = sqr(p.y), C = sqr(B);
-    Fq<8> D = dbl(dbl(mul(p.x, B)));
+    Fq<8> D = dbl2(mul(p.x, B));
     Fq<6> E = add(dbl(A), A);
     Fq<2> F = sqr(E);
     JacQ r;
-    auto x3 = sub(F, dbl(D));                                   // < 2 + 32
-    auto y3 = sub(mul(E, sub(D, x3)), dbl(dbl(dbl(C))));        // < 2 + 32
+    auto x3 = sub2(F, D);                                       // F - 2D < 2 + 32
+    auto y3 = sub2(mul(E, sub(D, x3)), dbl2(C));                // E(D - x3) - 8C < 2 + 32
     r.x = relax<XB>(x3);
     r.y = relax<XB>(y3);
     r.z = dbl(mul(p.y, p.z));                                   // identity stays identity: z = 0 -> z3 = 0
@@ -85,15 +86,14 @@ HD JacQ add(const JacQ& p, const JacQ& q, bool negq = false) {
     Fq<2> z1z1 = sqr(p.z), z2z2 = sqr(q.z);
     Fq<2> u1 = mul(p.x, z2z2), u2 = mul(q.x, z1z1);
     Fq<2> s1 = mul(mul(p.y, q.z), z2z2), s2p = mul(mul(q.y, p.z), z1z1);
-    Fq<4> s2 = select(negq, neg(s2p), relax<4>(s2p));
-    auto h = sub(u2, u1);            // < 6
-    auto rr = dbl(sub(s2, s1));      // < 16
+    auto h = sub(u2, u1);                         // < 6
+    auto rr = dbl(signed_sub(negq, s2p, s1));     // 2(+-S2 - S1) < 16
     Fq<2> i = sqr(dbl(h));
     Fq<2> j = mul(h, i);
     Fq<2> v = mul(u1, i);
     JacQ r;
-    auto x3 = sub(sub(sqr(rr), j), dbl(v));                       // < 2 + 4 + 8
-    auto y3 = sub(mul(rr, sub(v, x3)), dbl(mul(s1, j)));          // < 2 + 8
+    auto x3 = sub_sub2(sqr(rr), j, v);                            // rr^2 - J - 2V < 2 + 4 + 8
+    auto y3 = sub2(mul(rr, sub(v, x3)), mul(s1, j));              // rr(V - X3) - 2 S1 J < 2 + 8
     r.x = relax<XB>(x3);
     r.y = relax<XB>(y3);
     r.z = dbl(mul(mul(p.z, q.z), h));
@@ -107,20 +107,19 @@ HD JacQ add_mixed(const JacQ& p, const AffQ& q, bool negq = false) {
     Fq<2> z1z1 = sqr(p.z);
     Fq<2> u2 = mul(q.x, z1z1);
     Fq<2> s2p = mul(mul(q.y, p.z), z1z1);
-    Fq<4> s2 = select(negq, neg(s2p), relax<4>(s2p));
-    auto h = sub(u2, p.x);           // < 2 + 128
-    auto rr = dbl(sub(s2, p.y));     // < 264
+    auto h = sub(u2, p.x);                        // < 2 + 128
+    auto rr = dbl(signed_sub(negq, s2p, p.y));    // 2(+-S2 - Y1) < 264
     Fq<2> hh = sqr(h);
-    Fq<8> i = dbl(dbl(hh));
+    Fq<8> i = dbl2(hh);
     Fq<2> j = mul(h, i);
     Fq<2> v = mul(p.x, i);
     JacQ r;
-    auto x3 = sub(sub(sqr(rr), j), dbl(v));                       // < 2 + 4 + 8
-    auto y3 = sub(mul(rr, sub(v, x3)), dbl(mul(p.y, j)));         // < 2 + 8
+    auto x3 = sub_sub2(sqr(rr), j, v);                            // rr^2 - J - 2V < 2 + 4 + 8
+    auto y3 = sub2(mul(rr, sub(v, x3)), mul(p.y, j));             // rr(V - X3) - 2 Y1 J < 2 + 8
     r.x = relax<XB>(x3);
     r.y = relax<XB>(y3);
     r.z = dbl(mul(p.z, h));
-    if (is_zero(r.z)) return add_mixed_slow(p, q, negq);
+        if (is_zero(r.z)) return add_mixed_slow(p, q, negq);
     return r;
 }
 

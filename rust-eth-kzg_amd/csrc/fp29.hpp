@@ -93,6 +93,55 @@ HD Fq<pow2_at_least(2 * B)> neg(const Fq<B>& b) {
     return r;
 }
 
+// ---- fused forms: several additive steps, ONE carry sweep (limbs have 3 spare bits: lazy sums stay below 8 * 2^29) ----
+// 4a
+template <int A>
+HD Fq<4 * A> dbl2(const Fq<A>& a) {
+    Fq<4 * A> r;
+#pragma unroll
+    for (int i = 0; i < QL; i++) r.v[i] = a.v[i] << 2;
+    normalise(r);
+    return r;
+}
+// a - b - 2c   (+ multiples of p)
+template <int A, int B, int C>
+HD Fq<A + pow2_at_least(2 * B) + pow2_at_least(4 * C)> sub_sub2(const Fq<A>& a, const Fq<B>& b, const Fq<C>& c) {
+    constexpr int K1 = pow2_at_least(2 * B), K2 = pow2_at_least(4 * C);
+    constexpr int E1 = log2_exact(K1), E2 = log2_exact(K2);
+    static_assert(E1 >= 1 && E1 <= 12 && E2 >= 1 && E2 <= 12, "subtrahend bound too large");
+    Fq<A + K1 + K2> r;
+#pragma unroll
+    for (int i = 0; i < QL; i++) r.v[i] = a.v[i] + q29::SUBK[E1 - 1][i] - b.v[i] + q29::SUBK[E2 - 1][i] - (c.v[i] << 1);
+    normalise(r);
+    return r;
+}
+// a - 2c
+template <int A, int C>
+HD Fq<A + pow2_at_least(4 * C)> sub2(const Fq<A>& a, const Fq<C>& c) {
+    constexpr int K = pow2_at_least(4 * C);
+    constexpr int E = log2_exact(K);
+    static_assert(E >= 1 && E <= 12, "subtrahend bound too large");
+    Fq<A + K> r;
+#pragma unroll
+    for (int i = 0; i < QL; i++) r.v[i] = a.v[i] + q29::SUBK[E - 1][i] - (c.v[i] << 1);
+    normalise(r);
+    return r;
+}
+// (negate ? -a : a) - b   (+ multiples of p); `negate` may be wave-uniform or per-lane
+template <int A, int B>
+HD Fq<pow2_at_least(2 * A) + pow2_at_least(2 * B)> signed_sub(bool negate, const Fq<A>& a, const Fq<B>& b) {
+    constexpr int KA = pow2_at_least(2 * A), KB = pow2_at_least(2 * B);
+    constexpr int EA = log2_exact(KA), EB = log2_exact(KB);
+    static_assert(EA >= 1 && EA <= 12 && EB >= 1 && EB <= 12, "bound too large");
+    Fq<KA + KB> r;
+#pragma unroll
+    for (int i = 0; i < QL; i++) {
+        uint32_t t = negate ? q29::SUBK[EA - 1][i] - a.v[i] : a.v[i];
+        r.v[i] = t + q29::SUBK[EB - 1][i] - b.v[i];
+    }
+    normalise(r);
+    return r;
+}
 // Montgomery product scanning, single 64-bit accumulator per column.
 template <int A, int B>
 HD Fq<2> mul(const Fq<A>& a, const Fq<B>& b) {
