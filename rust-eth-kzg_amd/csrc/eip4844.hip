@@ -103,7 +103,7 @@ int Engine::open_blobs_at(int n, const uint8_t* const* blobs, const Fr8* z_mont,
 }
 
 int Engine::compute_kzg_proof_host(const uint8_t* blob, const uint8_t* z_bytes, uint8_t* out_proof, uint8_t* out_y) {
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         HIPCK(hipSetDevice(dev_));
         Fr z;
@@ -138,7 +138,7 @@ static void check_points(Engine* eng, const uint8_t* bytes, int n, void* d_out_a
 }
 
 int Engine::compute_blob_kzg_proof_host(const uint8_t* blob, const uint8_t* commitment, uint8_t* out_proof) {
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         HIPCK(hipSetDevice(dev_));
         Fr z = fs_challenge(blob, commitment);
@@ -184,7 +184,7 @@ static Fr8 canon8(const Fr& mont) { Fr c = from_mont(mont); Fr8 r; memcpy(&r, &c
 int Engine::verify_kzg_proof_host(const uint8_t* commitment, const uint8_t* z_bytes, const uint8_t* y_bytes, const uint8_t* proof,
                                   int* verified) {
     *verified = 0;
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         HIPCK(hipSetDevice(dev_));
         // point array [pi | C | G]
@@ -216,7 +216,7 @@ int Engine::verify_blob_kzg_proof_batch_host(uint64_t n_blobs, const uint8_t* co
     *verified = 0;
     if (!(n_blobs == n_commitments && n_blobs == n_proofs)) return ERR_INPUT;  // eip4844/src/verifier.rs:87-95
     const int n = (int)n_blobs;
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         HIPCK(hipSetDevice(dev_));
         // challenges z_i and evaluations y_i = p_i(z_i)
@@ -278,10 +278,11 @@ int Engine::verify_blob_kzg_proof_batch_host(uint64_t n_blobs, const uint8_t* co
 // verify_blob_kzg_proof (eip4844/src/verifier.rs:50-76): single-opening check at the Fiat-Shamir point
 int Engine::verify_blob_kzg_proof_host(const uint8_t* blob, const uint8_t* commitment, const uint8_t* proof, int* verified) {
     *verified = 0;
+    std::lock_guard<std::recursive_mutex> whole_call(mu_);
     int st = OK;
     Fr z, y;
     {
-        std::lock_guard<std::mutex> lk(mu_);
+        std::lock_guard<std::recursive_mutex> lk(mu_);
         try {
             HIPCK(hipSetDevice(dev_));
             z = fs_challenge(blob, commitment);

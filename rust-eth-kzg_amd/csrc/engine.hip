@@ -270,7 +270,7 @@ void Engine::init_fk20() {
     if (!ok) throw std::runtime_error("not enough device memory for the FK20 window table");
 }
 
-void Engine::set_profiling(bool on) { std::lock_guard<std::mutex> lk(mu_); profiling_ = on; }
+void Engine::set_profiling(bool on) { std::lock_guard<std::recursive_mutex> lk(mu_); profiling_ = on; }
 void Engine::mark_begin(int stage, hipStream_t st) {
     if (!profiling_) return;
     StageMark m{stage, 0, nullptr, nullptr};
@@ -285,7 +285,7 @@ void Engine::mark_end(int launches, hipStream_t st) {
     HIPCK(hipEventRecord(marks_.back().b, st));
 }
 void Engine::get_stage_times(double* ms, uint64_t* launches) {
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     for (int i = 0; i < ST_COUNT; i++) { ms[i] = 0; launches[i] = 0; }
     hipSetDevice(dev_);
     hipDeviceSynchronize();
@@ -380,7 +380,7 @@ void Engine::run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st) {
 int Engine::compute_cells_and_kzg_proofs_device(int n, const uint8_t* d_blobs, uint8_t* d_cells, uint8_t* d_proofs,
                                                 int* h_status, hipStream_t st, bool sync) {
     if (n <= 0) return OK;
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         HIPCK(hipSetDevice(dev_));
         if (!st) st = stream_;
@@ -408,7 +408,7 @@ int Engine::compute_cells_and_kzg_proofs_device(int n, const uint8_t* d_blobs, u
 int Engine::blob_to_kzg_commitment_device(int n, const uint8_t* d_blobs, uint8_t* d_commitments, int* h_status,
                                           hipStream_t st, bool sync) {
     if (n <= 0) return OK;
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         HIPCK(hipSetDevice(dev_));
         if (!st) st = stream_;
@@ -437,8 +437,9 @@ int Engine::blob_to_kzg_commitment_device(int n, const uint8_t* d_blobs, uint8_t
 int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs, uint8_t* const* const* cells,
                                               uint8_t* const* const* proofs, int* h_status) {
     if (n <= 0) return OK;
+    std::lock_guard<std::recursive_mutex> whole_call(mu_);  // staging buffers are shared: one host call at a time
     {
-        std::lock_guard<std::mutex> lk(mu_);
+        std::lock_guard<std::recursive_mutex> lk(mu_);
         try {
             HIPCK(hipSetDevice(dev_));
             if (n > stage_cap_) {
@@ -459,7 +460,7 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
     int rc = compute_cells_and_kzg_proofs_device(n, d_in_, cells ? d_cells_ : nullptr, proofs ? d_proofs_ : nullptr,
                                                  st.data(), stream_, true);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         std::vector<uint8_t> hc, hp;
         if (cells) {
@@ -487,9 +488,10 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
 
 int Engine::blob_to_kzg_commitment_host(int n, const uint8_t* const* blobs, uint8_t* const* out, int* h_status) {
     if (n <= 0) return OK;
+    std::lock_guard<std::recursive_mutex> whole_call(mu_);
     uint8_t* d_out = nullptr;
     {
-        std::lock_guard<std::mutex> lk(mu_);
+        std::lock_guard<std::recursive_mutex> lk(mu_);
         try {
             HIPCK(hipSetDevice(dev_));
             if (n > stage_cap_) {
@@ -510,7 +512,7 @@ int Engine::blob_to_kzg_commitment_host(int n, const uint8_t* const* blobs, uint
     std::vector<int> st(n);
     int rc = blob_to_kzg_commitment_device(n, d_in_, d_out, st.data(), stream_, true);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         std::vector<uint8_t> h((size_t)n * 48);
         HIPCK(hipMemcpy(h.data(), d_out, h.size(), hipMemcpyDeviceToHost));
@@ -528,7 +530,7 @@ int Engine::blob_to_kzg_commitment_host(int n, const uint8_t* const* blobs, uint
 // ---------------------------------------------------------------------------------------------
 // stage-level test hooks
 int Engine::test_fr_ntt4096(const uint8_t* in_be, uint8_t* out_be, int inverse_dit) {
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         HIPCK(hipSetDevice(dev_));
         uint8_t *di, *dout;
@@ -549,7 +551,7 @@ int Engine::test_fr_ntt4096(const uint8_t* in_be, uint8_t* out_be, int inverse_d
 
 // in/out: [lane][128][48 B]; both directions natural in -> natural out (inverse is unscaled)
 int Engine::test_g1_fft128(const uint8_t* in, uint8_t* out, int n_lanes, int inverse) {
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         HIPCK(hipSetDevice(dev_));
         int stride = ((n_lanes + 63) / 64) * 64;
@@ -589,7 +591,7 @@ int Engine::test_g1_fft128(const uint8_t* in, uint8_t* out, int n_lanes, int inv
 
 // scalars: [n_msm][128 groups][64] BE -> out [n_msm][128][48]: the 128 fixed-base MSMs of stage D
 int Engine::test_fixed_msm(const uint8_t* scalars_be, int n_msm, uint8_t* out) {
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         HIPCK(hipSetDevice(dev_));
         size_t ns = (size_t)n_msm * 128 * 64;
@@ -616,7 +618,7 @@ int Engine::test_fixed_msm(const uint8_t* scalars_be, int n_msm, uint8_t* out) {
 }
 
 int Engine::test_g1_decompress(const uint8_t* in, int n, int subgroup_check, int* h_status, uint8_t* out) {
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         HIPCK(hipSetDevice(dev_));
         uint8_t *di, *dout;
@@ -639,7 +641,7 @@ int Engine::test_g1_decompress(const uint8_t* in, int n, int subgroup_check, int
 }
 
 int Engine::test_field_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, int n, int is_fp) {
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         HIPCK(hipSetDevice(dev_));
         size_t nb = (size_t)n * (is_fp ? 48 : 32);

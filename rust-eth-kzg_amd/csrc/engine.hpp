@@ -119,7 +119,7 @@ private:
     int c_ = 8;      // window width of the FK20 table
     int srs_c_ = 8;  // window width of the commitment (monomial SRS) table
     hipStream_t stream_ = nullptr;
-    std::mutex mu_;
+    std::recursive_mutex mu_;  // recursive: host-pointer entry points hold it across staging + the device call + read-back
     std::string err_;
 
     // constants in HBM

@@ -113,7 +113,7 @@ int Engine::verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8
     const int n = (int)n_cells, m = (int)uniq.size();
     if (n == 0) { *verified = 1; return OK; }  // verifier.rs:90-93
 
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
@@ -354,7 +354,7 @@ int Engine::recover_cells_and_kzg_proofs_batch_host(int R, const uint64_t* n_cel
                                                     int* status) {
     if (R <= 0) return OK;
     for (int r = 0; r < R; r++) status[r] = validate_recovery(n_cells[r], n_indices[r], cell_indices[r]);
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         HIPCK(hipSetDevice(dev_));
         int rc = recover_batch_to_coeffs(R, n_cells, cells, cell_indices, status);

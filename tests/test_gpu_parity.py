@@ -355,3 +355,38 @@ def test_second_context_falls_back_to_a_narrower_table(ctx, oracle):
         assert c2.compute_cells_and_kzg_proofs(blob) == ctx.compute_cells_and_kzg_proofs(blob)
     finally:
         c2.close()
+
+
+def test_context_is_usable_from_many_threads(ctx, oracle):
+    """The reference's context is shared across threads (node async_* methods, Java tests): concurrent calls on one
+    context must all return correct results (calls serialise inside the library)."""
+    import concurrent.futures as cf
+    blobs = [synth.seeded_blob(200 + i) for i in range(6)]
+    expected = [oracle.blob_to_kzg_commitment(b) for b in blobs]
+    cells0, proofs0 = ctx.compute_cells_and_kzg_proofs(blobs[0])
+
+    def work(i):
+        if i % 2 == 0:
+            return ("c", i, ctx.blob_to_kzg_commitment(blobs[i % 6]))
+        c, p = ctx.compute_cells_and_kzg_proofs(blobs[0])
+        return ("p", i, (c, p))
+
+    with cf.ThreadPoolExecutor(max_workers=8) as ex:
+        for kind, i, out in ex.map(work, range(24)):
+            if kind == "c":
+                assert out == expected[i % 6]
+            else:
+                assert out == (cells0, proofs0)
+
+
+def test_empty_and_degenerate_batches(ctx):
+    assert ctx.compute_cells_and_kzg_proofs_batch([]) == ([], [], [])
+    assert ctx.blob_to_kzg_commitment_batch([]) == ([], [])
+    assert ctx.recover_cells_and_kzg_proofs_batch([]) == ([], [], [])
+    assert ctx.verify_cell_kzg_proof_batch([], [], [], []) is True
+    assert ctx.verify_blob_kzg_proof_batch([], [], []) is True
+    zero = b"\x00" * 131072
+    cells, proofs = ctx.compute_cells_and_kzg_proofs(zero)       # all-zero blob: identity commitment and proofs
+    assert all(p == b"\xc0" + b"\x00" * 47 for p in proofs) and all(c == b"\x00" * 2048 for c in cells)
+    assert ctx.blob_to_kzg_commitment(zero) == b"\xc0" + b"\x00" * 47
+    assert ctx.verify_cell_kzg_proof_batch([b"\xc0" + b"\x00" * 47] * 128, list(range(128)), cells, proofs) is True
