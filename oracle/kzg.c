@@ -840,3 +840,7 @@ int oracle_fp_mul(const uint8_t *a, const uint8_t *b, uint8_t *out) {
     fp_mul(&x, &x, &y); fp_to_be(out, &x); return 0;
 }
 void oracle_sha256(const uint8_t *data, size_t len, uint8_t *out) { sha256(out, data, len); }
+/* get_booth_index (booth_encoding.rs:4-46) on a 32-byte little-endian scalar */
+int oracle_booth_index(unsigned window_index, unsigned window_size, const uint8_t *el_le32) { return get_booth_index(window_index, window_size, el_le32); }
+/* reduce_bytes_to_scalar_bias (bls12_381/src/lib.rs:128-140): 32-byte BE in, canonical 32-byte BE out */
+void oracle_reduce_bytes_to_scalar(const uint8_t *in_be32, uint8_t *out_be32) { bls_init(); fr_t x; fr_from_be_reduce(&x, in_be32); fr_to_be(out_be32, &x); }

@@ -74,6 +74,8 @@ int oracle_fr_mul(const uint8_t *a, const uint8_t *b, uint8_t *out);
 /* a*b mod p on 48-B BE canonical */
 int oracle_fp_mul(const uint8_t *a, const uint8_t *b, uint8_t *out);
 void oracle_sha256(const uint8_t *data, size_t len, uint8_t *out);
+int oracle_booth_index(unsigned window_index, unsigned window_size, const uint8_t *el_le32);
+void oracle_reduce_bytes_to_scalar(const uint8_t *in_be32, uint8_t *out_be32);
 
 #ifdef __cplusplus
 }
