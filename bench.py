@@ -146,6 +146,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     kzg = importlib.import_module("rust-eth-kzg_amd")
+    sharding = importlib.import_module("rust-eth-kzg_amd.sharding")
     t_ctx = time.perf_counter()
     ctx = kzg.DASContext(use_precomp=True, device=local_rank)  # no CPU fallback: raises/aborts without the HIP path
     t_ctx = time.perf_counter() - t_ctx
@@ -162,7 +163,7 @@ def main():
         ctx.compute_cells_and_kzg_proofs_device(B, d_blobs.data_ptr(), d_cells.data_ptr(), d_proofs.data_ptr(),
                                                 want_status=False, stream=stream.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(d_all_proofs, d_proofs)
+            sharding.all_gather_flat(d_proofs, d_all_proofs, dist)  # the only exchange: proof vectors over RCCL/xGMI
 
     def fence():
         torch.cuda.synchronize(dev)

@@ -15,6 +15,18 @@ def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def all_gather_flat(local, out=None, dist=None):
+    """The one exchange of the sharded path: all-gather equal-size per-rank result tensors (proofs: 128 x 48 B per blob)
+    into `out` ([world * local.numel()], allocated if None).  RCCL over xGMI with the "nccl" backend; gloo on CPU."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local if out is None else out.copy_(local)
+    if out is None:
+        out = torch.empty(dist.get_world_size() * local.numel(), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.reshape(-1))
+    return out
+
+
 def gather_slabs(local: bytes, item_bytes: int, n_total: int, dist=None) -> bytes:
     """All-gather variable-length per-rank slabs (len(local) = items_on_rank * item_bytes) into the
     full [n_total * item_bytes] byte string on every rank.  Slabs are padded to the largest shard so a

@@ -36,6 +36,10 @@ def _worker(rank, world, port, n_blobs, q):
     o = Oracle(use_precomp=False, threads=1)
     blobs = [synth.seeded_blob(100 + i) for i in range(n_blobs)]
     res = sh.run_sharded(lambda bs: [o.blob_to_kzg_commitment(b) for b in bs], blobs, 48, dist)
+    # bench.py's exchange: equal-size per-rank proof slabs through all_gather_flat
+    mine = torch.full((6,), rank + 1, dtype=torch.uint8)
+    allp = sh.all_gather_flat(mine, None, dist)
+    assert allp.tolist() == [1] * 6 + [2] * 6
     if rank == 0:
         q.put(res)
     dist.barrier()
