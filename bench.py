@@ -157,13 +157,14 @@ def main():
     d_cells = torch.empty(B * CELLS * BYTES_PER_CELL, dtype=torch.uint8, device=dev)
     d_proofs = torch.empty(B * CELLS * 48, dtype=torch.uint8, device=dev)
     d_all_proofs = torch.empty(world * B * CELLS * 48, dtype=torch.uint8, device=dev) if world > 1 else None
-    stream = torch.cuda.current_stream(dev)
+    stream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream: kernels are enqueued on it without host syncs
 
     def step():
-        ctx.compute_cells_and_kzg_proofs_device(B, d_blobs.data_ptr(), d_cells.data_ptr(), d_proofs.data_ptr(),
-                                                want_status=False, stream=stream.cuda_stream)
-        if world > 1:
-            sharding.all_gather_flat(d_proofs, d_all_proofs, dist)  # the only exchange: proof vectors over RCCL/xGMI
+        with torch.cuda.stream(stream):
+            ctx.compute_cells_and_kzg_proofs_device(B, d_blobs.data_ptr(), d_cells.data_ptr(), d_proofs.data_ptr(),
+                                                    want_status=False, stream=stream.cuda_stream)
+            if world > 1:
+                sharding.all_gather_flat(d_proofs, d_all_proofs, dist)  # the only exchange: proof vectors over RCCL/xGMI
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -201,8 +202,9 @@ def main():
     for _ in range(0 if args.no_latency_probe else 3):
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
-        ctx.compute_cells_and_kzg_proofs_device(1, d_blobs.data_ptr(), d_cells.data_ptr(), d_proofs.data_ptr(),
-                                                want_status=False, stream=stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            ctx.compute_cells_and_kzg_proofs_device(1, d_blobs.data_ptr(), d_cells.data_ptr(), d_proofs.data_ptr(),
+                                                    want_status=False, stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
         lat.append(time.perf_counter() - t1)
 
