@@ -125,6 +125,24 @@ CResult eth_kzg_amd_recover_cells_and_proofs_batch(const DASContext *ctx, uint64
                                                    const uint64_t *const *cell_indices, uint8_t *const *const *out_cells,
                                                    uint8_t *const *const *out_proofs, int32_t *status);
 
+/* verify_cell_kzg_proof_batch sharded over GPUs (BASELINE.json config 3).  The verification
+ * equation of crates/cryptography/kzg_multi_open/src/fk20/verifier.rs:139-260 is linear in the cells once the
+ * Fiat-Shamir challenge (taken over the WHOLE batch) is fixed, so each rank evaluates its slice
+ * [shard_begin, shard_end) of the cell list and emits a 96-byte record (two compressed G1 partial sums);
+ * the records of all ranks are all-gathered and handed to _combine, which adds them and runs the one pairing check.
+ * Arguments before shard_begin are exactly those of eth_kzg_verify_cell_kzg_proof_batch and must describe the whole
+ * batch on every rank.  Malformed input in the rank's slice (or in the shared lengths / indices) => Err.
+ * The union of the slices must be [0, cells_length); an empty slice is fine. */
+#define ETH_KZG_AMD_VERIFY_PARTIAL_BYTES 96
+CResult eth_kzg_amd_verify_cell_kzg_proof_batch_partial(const DASContext *ctx, uint64_t commitments_length,
+                                                        const uint8_t *const *commitments, uint64_t cell_indices_length,
+                                                        const uint64_t *cell_indices, uint64_t cells_length,
+                                                        const uint8_t *const *cells, uint64_t proofs_length,
+                                                        const uint8_t *const *proofs, uint64_t shard_begin,
+                                                        uint64_t shard_end, uint8_t *out_partial /* 96 */);
+CResult eth_kzg_amd_verify_cell_kzg_proof_batch_combine(const DASContext *ctx, uint64_t n_partials,
+                                                        const uint8_t *partials /* n_partials * 96 */, bool *verified);
+
 /* Device-resident batches: flat buffers already in this GPU's HBM.
  *   d_blobs        n * 131072 bytes
  *   d_out_cells    n * 128 * 2048 bytes   (may be NULL)

@@ -36,6 +36,8 @@ class CResult(C.Structure):
 
 
 # every symbol include/c_eth_kzg.h declares (tests assert the library exports all of them)
+VERIFY_PARTIAL_BYTES = 96
+
 EXPORTED_SYMBOLS = [
     "eth_kzg_das_context_new", "eth_kzg_das_context_free", "eth_kzg_free_error_message",
     "eth_kzg_blob_to_kzg_commitment", "eth_kzg_compute_cells_and_kzg_proofs", "eth_kzg_compute_cells",
@@ -46,6 +48,7 @@ EXPORTED_SYMBOLS = [
     "eth_kzg_amd_das_context_new_on_device",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_batch", "eth_kzg_amd_blob_to_kzg_commitment_batch",
     "eth_kzg_amd_recover_cells_and_proofs_batch",
+    "eth_kzg_amd_verify_cell_kzg_proof_batch_partial", "eth_kzg_amd_verify_cell_kzg_proof_batch_combine",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_device", "eth_kzg_amd_blob_to_kzg_commitment_device",
     "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits",
     "eth_kzg_amd_set_profiling", "eth_kzg_amd_get_stage_times",
@@ -87,6 +90,8 @@ def load_library():
         "eth_kzg_amd_compute_cells_and_kzg_proofs_batch": [P, U64, P, P, P, P],
         "eth_kzg_amd_blob_to_kzg_commitment_batch": [P, U64, P, P, P],
         "eth_kzg_amd_recover_cells_and_proofs_batch": [P, U64, P, P, P, P, P, P, P],
+        "eth_kzg_amd_verify_cell_kzg_proof_batch_partial": [P, U64, P, U64, P, U64, P, U64, P, U64, U64, P],
+        "eth_kzg_amd_verify_cell_kzg_proof_batch_combine": [P, U64, U8P, P],
         "eth_kzg_amd_compute_cells_and_kzg_proofs_device": [P, U64, P, P, P, P, P],
         "eth_kzg_amd_blob_to_kzg_commitment_device": [P, U64, P, P, P, P],
     }.items():
@@ -193,6 +198,32 @@ class DASContext:
         ok = C.c_bool(False)
         self._check(self._lib.eth_kzg_verify_cell_kzg_proof_batch(
             self._ctx, len(commitments), ca, len(cell_indices), idx, len(cells), cla, len(proofs), pa, C.byref(ok)))
+        return bool(ok.value)
+
+    def verify_cell_kzg_proof_batch_partial(self, commitments, cell_indices, cells, proofs, shard_begin, shard_end):
+        """This rank's share of a sharded verification: the whole batch goes in (the challenge hashes all of it), the
+        cells [shard_begin, shard_end) are evaluated, 96 bytes come back (sharding.verify_cell_kzg_proof_batch_sharded)."""
+        if any(len(c) != 48 for c in commitments) or any(len(p) != 48 for p in proofs) \
+                or any(len(c) != BYTES_PER_CELL for c in cells):
+            raise KzgError("InvalidLength")
+        ca, _k1 = _ptr_array(commitments)
+        cla, _k2 = _ptr_array(cells)
+        pa, _k3 = _ptr_array(proofs)
+        idx = (C.c_uint64 * max(1, len(cell_indices)))(*cell_indices)
+        out = C.create_string_buffer(VERIFY_PARTIAL_BYTES)
+        self._check(self._lib.eth_kzg_amd_verify_cell_kzg_proof_batch_partial(
+            self._ctx, len(commitments), ca, len(cell_indices), idx, len(cells), cla, len(proofs), pa,
+            int(shard_begin), int(shard_end), out))
+        return out.raw
+
+    def verify_cell_kzg_proof_batch_combine(self, partials):
+        """Add the gathered 96-byte partials of all ranks and run the pairing check."""
+        blob = b"".join(partials)
+        if len(blob) % VERIFY_PARTIAL_BYTES:
+            raise KzgError("InvalidLength")
+        ok = C.c_bool(False)
+        self._check(self._lib.eth_kzg_amd_verify_cell_kzg_proof_batch_combine(
+            self._ctx, len(blob) // VERIFY_PARTIAL_BYTES, blob, C.byref(ok)))
         return bool(ok.value)
 
     def recover_cells_and_kzg_proofs(self, cell_indices, cells):

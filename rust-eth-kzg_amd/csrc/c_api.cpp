@@ -120,6 +120,31 @@ CResult eth_kzg_verify_cell_kzg_proof_batch(const DASContext* ctx, uint64_t comm
     return ok();
 }
 
+// Sharded verification: per-rank partial, then one combine over the gathered records.
+CResult eth_kzg_amd_verify_cell_kzg_proof_batch_partial(const DASContext* ctx, uint64_t commitments_length,
+                                                        const uint8_t* const* commitments, uint64_t cell_indices_length,
+                                                        const uint64_t* cell_indices, uint64_t cells_length,
+                                                        const uint8_t* const* cells, uint64_t proofs_length,
+                                                        const uint8_t* const* proofs, uint64_t shard_begin,
+                                                        uint64_t shard_end, uint8_t* out_partial) {
+    kzg::Engine* e = eng(ctx);
+    int st = e->verify_cell_kzg_proof_batch_partial_host(commitments_length, commitments, cell_indices_length, cell_indices,
+                                                         cells_length, cells, proofs_length, proofs, shard_begin, shard_end,
+                                                         out_partial);
+    if (st == kzg::ERR_DEVICE) return device_err(e);
+    return st ? err(status_text(st)) : ok();
+}
+
+CResult eth_kzg_amd_verify_cell_kzg_proof_batch_combine(const DASContext* ctx, uint64_t n_partials, const uint8_t* partials,
+                                                        bool* verified) {
+    kzg::Engine* e = eng(ctx);
+    int ver = 0;
+    int st = e->verify_cell_kzg_proof_batch_combine_host(n_partials, partials, &ver);
+    if (st) return err(status_text(st));
+    *verified = ver != 0;
+    return ok();
+}
+
 CResult eth_kzg_recover_cells_and_proofs(const DASContext* ctx, uint64_t cells_length, const uint8_t* const* cells,
                                          uint64_t cell_indices_length, const uint64_t* cell_indices,
                                          uint8_t** out_cells, uint8_t** out_proofs) {

@@ -13,6 +13,7 @@
 namespace kzg {
 
 namespace pairing { struct G2Prepared; }
+struct G1Affine;  // curve.hpp
 struct Fr8 { uint32_t v[8]; };
 struct Fp12w { uint32_t v[12]; };
 
@@ -54,6 +55,13 @@ public:
     int verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,
                                          const uint64_t* cell_indices, uint64_t n_cells, const uint8_t* const* cells,
                                          uint64_t n_proofs, const uint8_t* const* proofs, int* verified);
+    // the same check sharded over ranks: every rank passes the WHOLE batch (the Fiat-Shamir transcript covers it) and its
+    // slice [lo, hi) of the cell list, gets 96 bytes back; the gathered records go to _combine on any rank.
+    int verify_cell_kzg_proof_batch_partial_host(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,
+                                                 const uint64_t* cell_indices, uint64_t n_cells, const uint8_t* const* cells,
+                                                 uint64_t n_proofs, const uint8_t* const* proofs, uint64_t lo, uint64_t hi,
+                                                 uint8_t* out96);
+    int verify_cell_kzg_proof_batch_combine_host(uint64_t n_partials, const uint8_t* partials96, int* verified);
     // recover_cells_and_kzg_proofs (eip7594/src/prover.rs:156-171)
     int recover_cells_and_kzg_proofs_host(uint64_t n_cells, const uint8_t* const* cells, uint64_t n_indices,
                                           const uint64_t* cell_indices, uint8_t* const* out_cells,
@@ -99,6 +107,10 @@ private:
     int open_blobs_at(int n, const uint8_t* const* blobs, const Fr8* z_mont, bool want_proofs, uint8_t* h_proofs, Fr8* h_y_canon,
                       int* h_status);
     int pairing_check_4844(const void* d_points, const std::vector<Fr8>& sc0, const std::vector<Fr8>& sc1);
+    int verify_cells_partial(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,
+                             const uint64_t* cell_indices, uint64_t n_cells, const uint8_t* const* cells, uint64_t n_proofs,
+                             const uint8_t* const* proofs, uint64_t lo, uint64_t hi, G1Affine* out2, bool* empty);
+    bool verify_cells_pairing(const G1Affine* pts2) const;
     int recover_batch_to_coeffs(int R, const uint64_t* n_cells, const uint8_t* const* const* cells,
                                 const uint64_t* const* cell_indices, int* st_out);
     void ensure_workspace(int n);

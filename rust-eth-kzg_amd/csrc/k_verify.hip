@@ -68,13 +68,15 @@ __global__ void k_cells_to_fr(const uint8_t* __restrict__ cells, Fr* __restrict_
 // r^k for k < n from the table r^(2^i) (compute_powers, verifier.rs:333-343), plus the scalars of the
 // two proof MSMs: s1[k] = r^k, s2[k] = r^k * h_{idx_k}^64 (verifier.rs:186-201), both out of Montgomery form.
 struct PowTable { Fr p[24]; };
-__global__ void k_verify_scalars(PowTable tab, const int* __restrict__ cell_idx, const Fr* __restrict__ w8192,
+// k0: global position of this shard's first cell (0 for an unsharded batch).
+__global__ void k_verify_scalars(PowTable tab, int k0, const int* __restrict__ cell_idx, const Fr* __restrict__ w8192,
                                  Fr* __restrict__ rp_mont, Fr* __restrict__ s1, Fr* __restrict__ s2, int n) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     Fr acc = one<FrParams>();
+    const int e = k0 + k;
     for (int i = 0; i < 24; i++)
-        if ((k >> i) & 1) acc = mul(acc, tab.p[i]);
+        if ((e >> i) & 1) acc = mul(acc, tab.p[i]);
     rp_mont[k] = acc;
     s1[k] = from_mont(acc);
     // coset generator h_c = omega_8192^brp7(c) (cosets.rs:89-112); h_c^64 = omega_128^brp7(c) = w8192[64 * brp7(c)]
@@ -343,11 +345,11 @@ void init_attributes_verify() {
 void cells_to_fr(const uint8_t* cells, void* evals, const int* slot_of, int* status, const int* status_of, int n, hipStream_t st) {
     k_cells_to_fr<<<(n * CELL_LEN + 255) / 256, 256, 0, st>>>(cells, (Fr*)evals, slot_of, status, status_of, n);
 }
-void verify_scalars(const Fr8* pow_table24, const int* cell_idx, const void* w8192, void* rp_mont, void* s1, void* s2, int n,
-                    hipStream_t st) {
+void verify_scalars(const Fr8* pow_table24, int k0, const int* cell_idx, const void* w8192, void* rp_mont, void* s1, void* s2,
+                    int n, hipStream_t st) {
     PowTable t;
     for (int i = 0; i < 24; i++) t.p[i] = as_fr2(pow_table24[i]);
-    k_verify_scalars<<<(n + 255) / 256, 256, 0, st>>>(t, cell_idx, (const Fr*)w8192, (Fr*)rp_mont, (Fr*)s1, (Fr*)s2, n);
+    k_verify_scalars<<<(n + 255) / 256, 256, 0, st>>>(t, k0, cell_idx, (const Fr*)w8192, (Fr*)rp_mont, (Fr*)s1, (Fr*)s2, n);
 }
 void verify_weights(const void* rp_mont, const int* row, void* weights, int n, int m, hipStream_t st) {
     k_verify_weights<<<(m + 63) / 64, 64, 0, st>>>((const Fr*)rp_mont, row, (Fr*)weights, n, m);

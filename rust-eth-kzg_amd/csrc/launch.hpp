@@ -55,8 +55,8 @@ void init_attributes_verify();
 void cells_to_fr(const uint8_t* cells, void* evals, const int* slot_of, int* status, const int* status_of, int n, hipStream_t st);
 void rec_vanishing(const void* zp, const int* deg, const void* w8192, const Fr8& seven64, void* zeval, void* zcinv, int R,
                    hipStream_t st);
-void verify_scalars(const Fr8* pow_table24, const int* cell_idx, const void* w8192, void* rp_mont, void* s1, void* s2, int n,
-                    hipStream_t st);
+void verify_scalars(const Fr8* pow_table24, int k0, const int* cell_idx, const void* w8192, void* rp_mont, void* s1, void* s2,
+                    int n, hipStream_t st);
 void verify_weights(const void* rp_mont, const int* row, void* weights, int n, int m, hipStream_t st);
 void interp(const void* evals, const int* cell_idx, const void* rp_mont, const void* w8192, const Fr8& inv64, void* partial,
             int nblocks, void* out_neg_canon, int n, hipStream_t st);

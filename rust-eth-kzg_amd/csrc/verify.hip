@@ -90,10 +90,16 @@ static Fr reduce_be32(const uint8_t* b) {
     return to_mont(x);
 }
 
-int Engine::verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,
-                                             const uint64_t* cell_indices, uint64_t n_cells, const uint8_t* const* cells,
-                                             uint64_t n_proofs, const uint8_t* const* proofs, int* verified) {
-    *verified = 0;
+// The verification equation is linear in the cells: with the challenge r taken over the WHOLE batch, the two G1
+// pairing inputs are sums of per-cell terms, so a shard [lo, hi) of the cell list yields two partial points and the
+// partials of all shards add up to the pairing inputs of the full batch.
+// `out` receives the two partial points; *empty is set when the batch has no cells at all (verifier.rs:90-93).
+int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,
+                                 const uint64_t* cell_indices, uint64_t n_cells, const uint8_t* const* cells,
+                                 uint64_t n_proofs, const uint8_t* const* proofs, uint64_t lo, uint64_t hi,
+                                 G1Affine* out, bool* empty) {
+    *empty = false;
+    out[0] = out[1] = aff_inf();
     // deduplicate_with_indices (verifier.rs:49-65): byte equality, first-occurrence order
     std::vector<const uint8_t*> uniq;
     std::vector<int> row(n_commitments);
@@ -110,8 +116,11 @@ int Engine::verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8
     if (!(n_commitments == n_indices && n_commitments == n_cells && n_commitments == n_proofs)) return ERR_INPUT;
     for (uint64_t i = 0; i < n_indices; i++)
         if (cell_indices[i] >= (uint64_t)N_CELLS) return ERR_INPUT;
-    const int n = (int)n_cells, m = (int)uniq.size();
-    if (n == 0) { *verified = 1; return OK; }  // verifier.rs:90-93
+    if (lo > hi || hi > n_cells) return ERR_INPUT;
+    const int n_all = (int)n_cells, m = (int)uniq.size();
+    if (n_all == 0) { *empty = true; return OK; }  // verifier.rs:90-93
+    if (lo == hi) return OK;                       // an empty shard contributes the identity twice
+    const int n = (int)(hi - lo), k0 = (int)lo;    // this shard: cells k0 .. k0+n, global exponents r^(k0+k)
 
     std::lock_guard<std::recursive_mutex> lk(mu_);
     const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
@@ -166,10 +175,10 @@ int Engine::verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8
         int* hrow = (int*)(hb + off_row);
         for (int i = 0; i < m; i++) memcpy(hc + (size_t)i * 48, uniq[i], 48);
         for (int k = 0; k < n; k++) {
-            memcpy(hp + (size_t)k * 48, proofs[k], 48);
-            memcpy(hcells + (size_t)k * BYTES_PER_CELL, cells[k], BYTES_PER_CELL);
-            hidx[k] = (int)cell_indices[k];
-            hrow[k] = row[k];
+            memcpy(hp + (size_t)k * 48, proofs[k0 + k], 48);
+            memcpy(hcells + (size_t)k * BYTES_PER_CELL, cells[k0 + k], BYTES_PER_CELL);
+            hidx[k] = (int)cell_indices[k0 + k];
+            hrow[k] = row[k0 + k];
         }
         lap("gather host inputs");
         HIPCK(hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, st));
@@ -198,15 +207,15 @@ int Engine::verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8
         auto be64 = [](uint64_t v, uint8_t* o) { for (int b = 0; b < 8; b++) o[b] = (uint8_t)(v >> (56 - 8 * b)); };
         uint8_t hdr[16 + 32];
         memcpy(hdr, "RCKZGCBATCH__V1_", 16);
-        be64(N_BLOB, hdr + 16); be64(CELL_LEN, hdr + 24); be64((uint64_t)m, hdr + 32); be64((uint64_t)n, hdr + 40);
+        be64(N_BLOB, hdr + 16); be64(CELL_LEN, hdr + 24); be64((uint64_t)m, hdr + 32); be64((uint64_t)n_all, hdr + 40);
         sh.update(hdr, sizeof hdr);
         sh.update(hc, sz_c);
-        for (int k = 0; k < n; k++) {
+        for (int k = 0; k < n_all; k++) {  // the transcript always covers the whole batch, whatever the shard
             uint8_t ix[16];
             be64((uint64_t)row[k], ix); be64(cell_indices[k], ix + 8);
             sh.update(ix, 16);
-            sh.update(hcells + (size_t)k * BYTES_PER_CELL, BYTES_PER_CELL);
-            sh.update(hp + (size_t)k * 48, 48);
+            sh.update(cells[k], BYTES_PER_CELL);
+            sh.update(proofs[k], 48);
         }
         uint8_t dig[32];
         sh.finish(dig);
@@ -226,7 +235,7 @@ int Engine::verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8
         Fr* d_s2 = (Fr*)d_sB.p;
         Fr* d_w = d_s2 + n;
         Fr* d_interp = d_w + m;
-        launch::verify_scalars(tab, (const int*)d_idx.p, d_w8192_, d_rp.p, d_s1.p, d_s2, n, st);
+        launch::verify_scalars(tab, k0, (const int*)d_idx.p, d_w8192_, d_rp.p, d_s1.p, d_s2, n, st);
         launch::verify_weights(d_rp.p, (const int*)d_row.p, d_w, n, m, st);
         View d_part{db + off_part};
         launch::interp(d_evals.p, (const int*)d_idx.p, d_rp.p, d_w8192_, inv64_, d_part.p, ib, d_interp, n, st);
@@ -234,18 +243,64 @@ int Engine::verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8
         //   out[0] = sum r^k pi_k;   out[1] = sum r^k h^64 pi_k + sum w_row C_row - commit(interpolation poly)
         View d_ws{db + off_ws}, d_out{db + off_out};
         launch::msm_pippenger2(d_pts.p, d_s1.p, n, d_sB.p, n + m + 64, d_ws.p, d_out.p, st);
-        G1Affine out[2];
-        HIPCK(hipMemcpyAsync(out, d_out.p, sizeof out, hipMemcpyDeviceToHost, st));
+        HIPCK(hipMemcpyAsync(out, d_out.p, 2 * sizeof(G1Affine), hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
         lap("scalars+interp+lincombs (GPU)");
-        // ---- pairing check e(sum r^k pi_k, [tau^64]_2) * e(C - I + weighted proofs, -[1]_2) == 1 (verifier.rs:242-259)
-        const pairing::G2Prepared* q[2] = {g2_tau_.get(), g2_neg_gen_.get()};
-        *verified = pairing::product_is_one(out, q, 2) ? 1 : 0;
-        lap("pairing check (host)");
     } catch (const std::exception& e) {
         err_ = e.what();
         return ERR_DEVICE;
     }
+    return OK;
+}
+
+// pairing check e(sum r^k pi_k, [tau^64]_2) * e(C - I + weighted proofs, -[1]_2) == 1 (verifier.rs:242-259)
+bool Engine::verify_cells_pairing(const G1Affine* pts) const {
+    const pairing::G2Prepared* q[2] = {g2_tau_.get(), g2_neg_gen_.get()};
+    return pairing::product_is_one(pts, q, 2);
+}
+
+int Engine::verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,
+                                             const uint64_t* cell_indices, uint64_t n_cells, const uint8_t* const* cells,
+                                             uint64_t n_proofs, const uint8_t* const* proofs, int* verified) {
+    *verified = 0;
+    G1Affine pts[2];
+    bool empty = false;
+    int st = verify_cells_partial(n_commitments, commitments, n_indices, cell_indices, n_cells, cells, n_proofs, proofs, 0,
+                                  n_cells, pts, &empty);
+    if (st) return st;
+    *verified = (empty || verify_cells_pairing(pts)) ? 1 : 0;
+    return OK;
+}
+
+// Sharded form, step 1: this rank's cells [lo, hi) of the batch -> 96 bytes (two compressed G1 partial sums).
+int Engine::verify_cell_kzg_proof_batch_partial_host(uint64_t n_commitments, const uint8_t* const* commitments,
+                                                     uint64_t n_indices, const uint64_t* cell_indices, uint64_t n_cells,
+                                                     const uint8_t* const* cells, uint64_t n_proofs,
+                                                     const uint8_t* const* proofs, uint64_t lo, uint64_t hi, uint8_t* out96) {
+    G1Affine pts[2];
+    bool empty = false;
+    int st = verify_cells_partial(n_commitments, commitments, n_indices, cell_indices, n_cells, cells, n_proofs, proofs, lo, hi,
+                                  pts, &empty);
+    if (st) return st;
+    g1_compress(out96, pts[0]);
+    g1_compress(out96 + 48, pts[1]);
+    return OK;
+}
+
+// Sharded form, step 2: add the partials of all shards (group addition is not an RCCL reduction, so the gathered
+// 96-byte records are summed on the host) and run the one pairing check.
+int Engine::verify_cell_kzg_proof_batch_combine_host(uint64_t n_partials, const uint8_t* partials96, int* verified) {
+    *verified = 0;
+    G1Jac acc[2] = {jac_inf(), jac_inf()};
+    for (uint64_t i = 0; i < n_partials; i++)
+        for (int j = 0; j < 2; j++) {
+            G1Affine a;
+            if (g1_decompress(a, partials96 + i * 96 + 48 * j) != 0) return ERR_G1;
+            acc[j] = add_mixed(acc[j], a);
+        }
+    G1Affine pts[2] = {to_affine(acc[0]), to_affine(acc[1])};
+    // no cells anywhere => both sums are the identity and the product of pairings is 1, as the reference's early return
+    *verified = verify_cells_pairing(pts) ? 1 : 0;
     return OK;
 }
 

@@ -62,3 +62,38 @@ def run_sharded(compute: Callable[[Sequence[bytes]], List[bytes]], blobs: Sequen
     assert all(len(x) == item_bytes for x in local)
     full = gather_slabs(b"".join(local), item_bytes, len(blobs), dist)
     return [full[i * item_bytes:(i + 1) * item_bytes] for i in range(len(blobs))]
+
+
+VERIFY_RECORD_BYTES = 104  # 96-byte partial + status byte, padded to 8
+
+
+def verify_cell_kzg_proof_batch_sharded(ctx, commitments, cell_indices, cells, proofs, dist=None) -> bool:
+    """verify_cell_kzg_proof_batch with the cell list split over the ranks.
+
+    Every rank passes the same full batch.  Rank r evaluates cells shard_bounds(n, world, r) on its GPU
+    (ctx.verify_cell_kzg_proof_batch_partial: two G1 partial sums, 96 B), the records are all-gathered (< 1 KB per
+    rank - the only exchange), and every rank adds them and runs the pairing check (ctx.verify_cell_kzg_proof_batch_combine).
+    A rank whose slice is malformed still takes part in the gather, so no rank is left waiting; the error is then
+    raised on all ranks, as the unsharded call would raise it."""
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    lo, hi = shard_bounds(len(cells), world, rank)
+    status, partial, message = 0, bytes(96), ""
+    try:
+        partial = ctx.verify_cell_kzg_proof_batch_partial(commitments, cell_indices, cells, proofs, lo, hi)
+    except Exception as e:  # reported after the gather
+        status, message = 1, str(e)
+    record = partial + bytes([status]) + bytes(VERIFY_RECORD_BYTES - 97)
+    if world > 1:
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        local = torch.frombuffer(bytearray(record), dtype=torch.uint8).to(dev)
+        gathered = all_gather_flat(local, None, dist).cpu().numpy().tobytes()
+    else:
+        gathered = record
+    records = [gathered[i * VERIFY_RECORD_BYTES:(i + 1) * VERIFY_RECORD_BYTES] for i in range(world)]
+    failed = [r for r, rec in enumerate(records) if rec[96]]
+    if failed:
+        from . import KzgError
+        raise KzgError(message or f"verify_cell_kzg_proof_batch: malformed input in the slice of rank {failed[0]}")
+    return ctx.verify_cell_kzg_proof_batch_combine([rec[:96] for rec in records])

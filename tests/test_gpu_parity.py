@@ -209,6 +209,48 @@ def test_verify_cell_kzg_proof_batch_vectors(ctx, name, case):
     assert out == case["output"]
 
 
+def _verify_in_shards(ctx, world, C_, I_, L_, P_):
+    """What `world` ranks would do, run one after another on this GPU: a partial per slice, then the combine."""
+    sh = importlib.import_module("rust-eth-kzg_amd.sharding")
+    parts = [ctx.verify_cell_kzg_proof_batch_partial(C_, I_, L_, P_, *sh.shard_bounds(len(L_), world, r)) for r in range(world)]
+    return ctx.verify_cell_kzg_proof_batch_combine(parts)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("name,case", sorted(vectors.load("verify_cell_kzg_proof_batch").items()))
+def test_verify_cell_kzg_proof_batch_vectors_sharded(ctx, name, case, world):
+    """The reference's verify vectors through the multi-GPU form: true / false / error must
+    come out exactly as in the unsharded call, for every way of slicing the cell list."""
+    i = case["input"]
+    out = _call(_verify_in_shards, ctx, world, i["commitments"], i["cell_indices"], i["cells"], i["proofs"])
+    assert out == case["output"]
+
+
+def test_verify_sharded_partials_are_additive(ctx):
+    """3 blobs x 128 cells: uneven slices, an empty slice and a single-cell slice all combine to the unsharded verdict;
+    a tampered cell flips the verdict whichever slice holds it."""
+    blobs = [synth.seeded_blob(20 + i) for i in range(3)]
+    st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs)
+    _, comms = ctx.blob_to_kzg_commitment_batch(blobs)
+    C_, I_, L_, P_ = [], [], [], []
+    for b in range(3):
+        for k in range(128):
+            C_.append(comms[b]); I_.append(k); L_.append(cells[b][k]); P_.append(proofs[b][k])
+    cuts = [0, 1, 1, 200, 384]
+    parts = [ctx.verify_cell_kzg_proof_batch_partial(C_, I_, L_, P_, a, b) for a, b in zip(cuts, cuts[1:])]
+    assert parts[1] == (b"\xc0" + bytes(47)) * 2  # the empty slice contributes the identity twice
+    assert ctx.verify_cell_kzg_proof_batch_combine(parts) is True
+    L2 = list(L_); L2[300] = cells[0][1]
+    assert _verify_in_shards(ctx, 4, C_, I_, L2, P_) is False
+    bad = [ctx.verify_cell_kzg_proof_batch_partial(C_, I_, L2, P_, a, b) for a, b in zip(cuts, cuts[1:])]
+    assert ctx.verify_cell_kzg_proof_batch_combine(bad) is False
+    # every slice is a weighted sum of per-cell equations, so the slices without the tampered cell still balance
+    assert ctx.verify_cell_kzg_proof_batch_combine(bad[:-1]) is True
+    assert _verify_in_shards(ctx, 1, C_, I_, L_, P_) is True
+    with pytest.raises(kzg.KzgError):
+        ctx.verify_cell_kzg_proof_batch_partial(C_, I_, L_, P_, 5, 385)
+
+
 @pytest.mark.parametrize("name,case", sorted(vectors.load("recover_cells_and_kzg_proofs").items()))
 def test_recover_cells_and_kzg_proofs_vectors(ctx, name, case):
     i = case["input"]

@@ -40,6 +40,27 @@ def _worker(rank, world, port, n_blobs, q):
     mine = torch.full((6,), rank + 1, dtype=torch.uint8)
     allp = sh.all_gather_flat(mine, None, dist)
     assert allp.tolist() == [1] * 6 + [2] * 6
+    # sharded verification: the host logic around the two engine calls (slice bounds, the one gather, error fan-out)
+    class FakeEngine:
+        """Stands in for the GPU context: a partial records its slice, the combine checks that the slices tile [0, n)."""
+        def verify_cell_kzg_proof_batch_partial(self, commitments, cell_indices, cells, proofs, lo, hi):
+            if any(c == b"bad" for c in cells[lo:hi]):
+                raise ValueError("malformed cell")
+            return lo.to_bytes(48, "big") + hi.to_bytes(48, "big")
+
+        def verify_cell_kzg_proof_batch_combine(self, partials):
+            spans = [(int.from_bytes(p[:48], "big"), int.from_bytes(p[48:], "big")) for p in partials]
+            return spans[0][0] == 0 and all(a[1] == b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] == 7
+
+    cells = [b"c%d" % i for i in range(7)]
+    assert sh.verify_cell_kzg_proof_batch_sharded(FakeEngine(), [b""] * 7, list(range(7)), cells, [b""] * 7, dist) is True
+    bad = list(cells); bad[5] = b"bad"  # lies in rank 1's slice; BOTH ranks must raise, neither may hang
+    try:
+        sh.verify_cell_kzg_proof_batch_sharded(FakeEngine(), [b""] * 7, list(range(7)), bad, [b""] * 7, dist)
+        raised = False
+    except Exception:
+        raised = True
+    assert raised
     if rank == 0:
         q.put(res)
     dist.barrier()

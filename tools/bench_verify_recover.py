@@ -3,6 +3,8 @@ import importlib, os, sys, time, json
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
+import torch
+torch.cuda.init()  # before the engine touches HIP
 kzg = importlib.import_module("rust-eth-kzg_amd")
 ctx = kzg.DASContext(True)
 nb = int(os.environ.get("NB", "64"))
@@ -34,3 +36,34 @@ batch = [(list(range(0, 128, 2)), [cells[b][i] for i in range(0, 128, 2)]) for b
 t = time.time(); st, rc, rp = ctx.recover_cells_and_kzg_proofs_batch(batch); dt = time.time() - t
 assert st == [0] * nbr and all(rc[b] == cells[b] and rp[b] == proofs[b] for b in range(nbr))
 print(json.dumps({"recover_batch_blobs": nbr, "recover_batch_s": round(dt, 3), "blobs_per_s": round(nbr / dt, 1)}))
+
+# sharded verification run on one GPU: per-slice partial times (what each of `world` ranks would spend) and the combine
+sh = importlib.import_module("rust-eth-kzg_amd.sharding")
+for world in (2, 8):
+    tp = []
+    parts = []
+    for r in range(world):
+        lo, hi = sh.shard_bounds(len(L), world, r)
+        t = time.time(); parts.append(ctx.verify_cell_kzg_proof_batch_partial(C, I, L, P, lo, hi)); tp.append(time.time() - t)
+    t = time.time(); ok = ctx.verify_cell_kzg_proof_batch_combine(parts); tc = time.time() - t
+    assert ok
+    print(json.dumps({"verify_sharded_world": world, "partial_s_max": round(max(tp), 4), "partial_s_min": round(min(tp), 4), "combine_s": round(tc, 4)}))
+
+# compute_cells fast path: device-resident blobs -> cells only, no FK20 stages
+B = int(os.environ.get("NB_CELLS", "2048"))
+dev = torch.device("cuda", 0)
+src = torch.from_numpy(np.frombuffer(b"".join(blobs), dtype=np.uint8).copy()).to(dev)
+d_blobs = src.repeat((B + nb - 1) // nb)[: B * 131072].contiguous()
+d_cells = torch.empty(B * 128 * 2048, dtype=torch.uint8, device=dev)
+for _ in range(2):
+    ctx.compute_cells_and_kzg_proofs_device(B, d_blobs.data_ptr(), d_cells.data_ptr(), 0, want_status=False)
+torch.cuda.synchronize()
+t = time.time()
+reps = 10
+for _ in range(reps):
+    ctx.compute_cells_and_kzg_proofs_device(B, d_blobs.data_ptr(), d_cells.data_ptr(), 0, want_status=False)
+torch.cuda.synchronize()
+dt = (time.time() - t) / reps
+assert bytes(d_cells[:128 * 2048].cpu().numpy()) == b"".join(cells[0])
+gb = B * (131072 + 262144) / 1e9
+print(json.dumps({"compute_cells_blobs": B, "ms": round(dt * 1e3, 3), "blobs_per_s": round(B / dt), "algorithmic_GB_per_s": round(gb / dt, 1)}))
