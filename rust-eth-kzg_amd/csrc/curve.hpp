@@ -9,6 +9,7 @@
 //  crates/cryptography/bls12_381/src/lib.rs:56-104).
 #pragma once
 #include "field.hpp"
+#include "inverse.hpp"
 
 namespace kzg {
 
@@ -127,7 +128,7 @@ HD bool eq(const G1Jac& p, const G1Jac& q) {
 
 HD G1Affine to_affine(const G1Jac& p) {
     if (is_inf(p)) return aff_inf();
-    Fp zi = inv(p.z), zi2 = sqr(zi);
+    Fp zi = inv_fast(p.z), zi2 = sqr(zi);  // binary-GCD inversion (inverse.hpp)
     G1Affine r;
     r.x = mul(p.x, zi2);
     r.y = mul(p.y, mul(zi2, zi));

@@ -25,6 +25,7 @@ namespace kzg {
     } while (0)
 
 // batches up to this many lanes (blobs rounded up to 64) use the direct 8 x 16 G1 transforms (k_g1fft.hip)
+static constexpr int FLAT_MSM_MAX_SLICES = 8;  // measured: 1 blob 0.23 ms (vs 1.0), 16 blobs 1.6 ms (vs 1.06): one block per MSM pays while the chip is not full
 static constexpr int LATENCY_MODE_MAX_LANES = 128;  // measured: 64 -> 13.4 ms, 128 -> 22.3 ms, 192 -> 30.1 ms vs 26.5 ms for the radix-2 network
 static constexpr int N_BLOB = 4096, N_EXT = 8192, N_CELLS = 128, CELL_LEN = 64, BYTES_PER_BLOB = 131072, BYTES_PER_CELL = 2048;
 static_assert(sizeof(Fr) == launch::SIZEOF_FR && sizeof(G1Affine) == launch::SIZEOF_G1AFFINE && sizeof(G1Jac) == launch::SIZEOF_G1JAC, "layout");
@@ -120,6 +121,10 @@ Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14
         }
     }
     srs_c_ = use_precomp ? 8 : 4;
+    if (const char* s = getenv("ETH_KZG_AMD_CIRC_MAX")) {  // tuning knob: largest batch served by the circulant form (0 disables it)
+        int v = atoi(s);
+        if (v >= 0 && v <= 64) circ_max_ = v;
+    }
     HIPCK(hipSetDevice(dev_));
     HIPCK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     launch::init_attributes();
@@ -133,7 +138,7 @@ Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14
 Engine::~Engine() {
     hipSetDevice(dev_);
     void* ptrs[] = {d_w8192_, d_naf_, d_srs_, d_fk_bases_, d_fk_table_, d_srs_table_, d_coeffs_, d_canon_,
-                    d_scalars_, d_X_, d_status_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_dft_tmp_, d_dft_prod_};
+                    d_scalars_, d_X_, d_status_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_dft_tmp_, d_dft_prod_, d_circ_terms_, d_circ_table_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (v_dev_) hipFree(v_dev_);
@@ -170,6 +175,43 @@ void Engine::init_constants() {
         }
         HIPCK(hipMalloc(&d_naf_, jsf.size() * 4));
         HIPCK(hipMemcpy(d_naf_, jsf.data(), jsf.size() * 4, hipMemcpyHostToDevice));
+        // Small-batch circulant form (k_g1circ.hip): symbol c_d = sum_{t<64} omega_128^(d t); its non-zero entries,
+        // GLV-split and NAF-recoded, become one flat list of +-D[k-d][half][t] terms dealt round-robin to 256 lanes.
+        std::vector<uint32_t> plus, minus;
+        int max_t = 0;
+        for (int d = 0; d < 128; d++) {
+            Fr c = zero<FrParams>();
+            for (int t = 0; t < 64; t++) c = add(c, w[(64 * d * t) & (N_EXT - 1)]);
+            if (d != 0 && (d & 1) == 0) {
+                if (!is_zero(c)) throw std::runtime_error("circulant symbol: even entry is not zero");
+                continue;
+            }
+            u128 kk[2];
+            glv_split(from_mont(c), kk[0], kk[1]);
+            Fr back = zero<FrParams>();  // the recoded terms must add up to c_d again
+            for (int half = 0; half < 2; half++) {
+                u128 k = kk[half];
+                Fr pw = half ? lm : one<FrParams>();  // 2^t (half 0) or 2^t lambda (half 1)
+                for (int t = 0; k != 0; t++, k >>= 1, pw = add(pw, pw)) {
+                    if (!(k & 1)) continue;
+                    const int dg = 2 - (int)(k & 3);  // NAF digit +-1
+                    if (dg < 0) k += 1;               // k - dg; the shift then drops the zero low bit
+                    const uint32_t word = (uint32_t)d | ((uint32_t)t << 7) | ((uint32_t)half << 15) | ((dg < 0 ? 1u : 0u) << 16) | (1u << 17);
+                    (dg < 0 ? minus : plus).push_back(word);
+                    back = dg < 0 ? sub(back, pw) : add(back, pw);
+                    if (t > max_t) max_t = t;
+                }
+            }
+            if (!eq(back, c)) throw std::runtime_error("circulant term list does not reproduce its symbol");
+        }
+        if ((int)plus.size() < launch::CIRC_LANES || max_t >= 255) throw std::runtime_error("circulant term list is malformed");
+        std::vector<uint32_t> all(plus);  // positive terms first: row 0 (every lane's starting value) needs no negation
+        all.insert(all.end(), minus.begin(), minus.end());
+        circ_T_ = max_t + 1;
+        circ_per_lane_ = ((int)all.size() + launch::CIRC_LANES - 1) / launch::CIRC_LANES;
+        all.resize((size_t)circ_per_lane_ * launch::CIRC_LANES, 0u);  // padding: valid bit clear
+        HIPCK(hipMalloc(&d_circ_terms_, all.size() * 4));
+        HIPCK(hipMemcpy(d_circ_terms_, all.data(), all.size() * 4, hipMemcpyHostToDevice));
     }
     Fr i4096 = inv(fr_from_u64(N_BLOB)), i128 = inv(fr_from_u64(128));
     memcpy(&n_inv4096_, &i4096, 32);
@@ -315,7 +357,9 @@ void Engine::ensure_workspace(int n) {
 // ---------------------------------------------------------------------------------------------
 void Engine::launch_msm(const void* scalars, const void* table, void* out, int n_groups, int n_slices, int out_stride,
                         int brp_bits, hipStream_t st) {
-    launch::msm_fixed(table == d_srs_table_ ? srs_c_ : c_, scalars, table, out, n_groups, n_slices, 64, out_stride, brp_bits, st);
+    const int c = table == d_srs_table_ ? srs_c_ : c_;
+    if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) launch::msm_fixed_flat(c, scalars, table, out, n_groups, n_slices, 64, out_stride, brp_bits, st);
+    else launch::msm_fixed(c, scalars, table, out, n_groups, n_slices, 64, out_stride, brp_bits, st);
 }
 
 // inverse FFT_128, DIT, input at bit-reversed positions, only outputs 0..63 produced (domain.rs:172-194;
@@ -353,7 +397,12 @@ void Engine::run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st) {
     mark_begin(ST_MSM_FIXED, st);
     launch_msm(d_scalars_, d_fk_table_, d_X_, 128, n, bp, latency_mode ? 0 : 7, st);
     mark_end(1, st);
-    if (latency_mode) {
+    if (n <= circ_max_) {  // a handful of blobs: the two transforms as one circulant product (k_g1circ.hip)
+        if (!d_circ_table_) HIPCK(hipMalloc(&d_circ_table_, launch::g1_circ_table_bytes(circ_max_, circ_T_)));
+        mark_begin(ST_G1_IFFT, st);
+        launch::g1_circ128(d_X_, bp, n, d_circ_table_, circ_T_, d_circ_terms_, circ_per_lane_, beta_, st);
+        mark_end(2, st);
+    } else if (latency_mode) {
         if (!d_dft_tmp_) {
             HIPCK(hipMalloc(&d_dft_tmp_, (size_t)128 * LATENCY_MODE_MAX_LANES * launch::SIZEOF_JACQ));
             HIPCK(hipMalloc(&d_dft_prod_, (size_t)128 * 16 * LATENCY_MODE_MAX_LANES * launch::SIZEOF_JACQ));

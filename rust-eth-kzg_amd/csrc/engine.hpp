@@ -158,6 +158,9 @@ private:
     uint8_t* v_pin_ = nullptr;
     size_t v_pin_cap_ = 0;
 
+    // small-batch circulant form of the two G1 transforms: term list, doubling tables (allocated on first use)
+    void *d_circ_terms_ = nullptr, *d_circ_table_ = nullptr;
+    int circ_T_ = 0, circ_per_lane_ = 0, circ_max_ = 16;
     void *d_dft_tmp_ = nullptr, *d_dft_prod_ = nullptr;  // latency-mode G1 transforms (one 64-blob group)
 
     // workspace (grown on demand, guarded by mu_)

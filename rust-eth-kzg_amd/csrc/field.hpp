@@ -19,6 +19,7 @@ namespace kzg {
 // them as scalar literals (SGPR moves), never as memory loads.
 struct FpParams {
     static constexpr int N = 12;
+    static constexpr int BITS = 381;
     static constexpr uint32_t MOD[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
                                          0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
     static constexpr uint32_t N0 = 0xfffcfffdu;  // -p^-1 mod 2^32
@@ -30,6 +31,7 @@ struct FpParams {
 };
 struct FrParams {
     static constexpr int N = 8;
+    static constexpr int BITS = 255;
     static constexpr uint32_t MOD[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u,
                                         0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
     static constexpr uint32_t N0 = 0xffffffffu;  // -r^-1 mod 2^32

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void k_build_table(const G1Affine* __restrict__
         *reinterpret_cast<Fp*>(&dst[d]) = prod;  // parked in the (larger) destination slot until the back sweep
         prod = mul(prod, scr[d].z);
     }
-    Fp invp = inv(prod);
+    Fp invp = inv_fast(prod);
     for (int d = T - 1; d >= 0; d--) {
         Fp zi = mul(invp, *reinterpret_cast<const Fp*>(&dst[d]));
         invp = mul(invp, scr[d].z);

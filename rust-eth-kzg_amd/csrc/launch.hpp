@@ -25,6 +25,8 @@ void test_field_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, int n, int
 // k_msm.hip
 void msm_fixed(int c, const void* scalars, const void* table, void* out /*G1Jac*/, int n_groups, int n_slices, int nb,
                int out_stride, int brp_bits, hipStream_t st);
+void msm_fixed_flat(int c, const void* scalars, const void* table, void* out /*G1Jac*/, int n_groups, int n_slices, int nb,
+               int out_stride, int brp_bits, hipStream_t st);
 // k_table.hip
 size_t table_entries(int c, int n_groups, int nb);
 void build_table(int c, const void* bases /*G1Affine*/, void* table /*G1Affine*/, void* scratch /*G1Jac*/, int n_groups,
@@ -49,6 +51,10 @@ void fk20_gather_bases(const void* X, void* bases, hipStream_t st);
 void test_load_points(const uint8_t* in, void* X, int n_lanes, int stride, hipStream_t st);
 void test_recompress(const void* pts, uint8_t* out, int n, hipStream_t st);
 
+// k_g1circ.hip
+constexpr int CIRC_LANES = 256;
+size_t g1_circ_table_bytes(int n, int T);
+void g1_circ128(void* X, int stride, int n, void* D, int T, const void* terms, int per_lane, const Fp12w& beta, hipStream_t st);
 // k_verify.hip
 void init_attributes_verify();
 // slot_of: destination cell slot per input cell (null = identity); status_of: status word per input cell (null = word 0)
