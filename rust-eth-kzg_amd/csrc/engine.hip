@@ -6,10 +6,15 @@
 #include "curve.hpp"
 #include "launch.hpp"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
+#include <tuple>
 
 extern "C" const unsigned char kzg_srs_begin[];
 extern "C" const unsigned char kzg_srs_end[];
@@ -125,19 +130,32 @@ Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14
         int v = atoi(s);
         if (v >= 0 && v <= 64) circ_max_ = v;
     }
+    const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[context] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
     HIPCK(hipSetDevice(dev_));
     HIPCK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     launch::init_attributes();
+    lap("HIP runtime + stream");
     init_constants();
+    lap("twiddles, recodings");
     init_srs();
+    lap("SRS decompress");
     init_fk20();
+    lap("FK20 bases + window tables");
     init_verifier();
     HIPCK(hipStreamSynchronize(stream_));
+    lap("verifier (G2 lines, cosets)");
 }
 
 Engine::~Engine() {
     hipSetDevice(dev_);
-    void* ptrs[] = {d_w8192_, d_naf_, d_srs_, d_fk_bases_, d_fk_table_, d_srs_table_, d_coeffs_, d_canon_,
+    void* ptrs[] = {d_w8192_, d_naf_, d_srs_, d_fk_bases_, d_coeffs_, d_canon_,
                     d_scalars_, d_X_, d_status_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_dft_tmp_, d_dft_prod_, d_circ_terms_, d_circ_table_};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -258,6 +276,20 @@ void Engine::init_srs() {
     }
 }
 
+// Window tables are immutable once built and depend only on (device, which bases, width), so the contexts of one
+// process share them: the second DASContext on a GPU costs neither another 145 GB nor another build
+// (the reference's Java test creates several contexts, LibEthKZGTest.java:32).  The last context to go frees the table.
+struct Engine::SharedTable {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int dev = 0;
+    ~SharedTable() {
+        if (p) { (void)hipSetDevice(dev); (void)hipFree(p); }
+    }
+};
+static std::mutex g_tables_mu;
+static std::map<std::tuple<int, int, int>, std::weak_ptr<Engine::SharedTable>> g_tables;  // (device, kind, width)
+
 // returns false (and leaves *table null) if the device cannot hold the table + scratch
 static bool build_table(int c, const void* bases, void** table, size_t* bytes, int n_groups, int nb, hipStream_t st) {
     // groups are built in chunks so that the Jacobian scratch (144 B per entry) stays below ~24 GB
@@ -272,6 +304,8 @@ static bool build_table(int c, const void* bases, void** table, size_t* bytes, i
     HIPCK(hipMemGetInfo(&free_b, &total_b));
     const size_t need = entries * launch::SIZEOF_AFFQ + per_group * chunk * sizeof(G1Jac) + (8ull << 30);  // + head-room for batches
     if (need > free_b) return false;
+    const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
     if (hipMalloc(table, entries * launch::SIZEOF_AFFQ) != hipSuccess) { (void)hipGetLastError(); *table = nullptr; return false; }
     if (hipMalloc(&scratch, per_group * chunk * sizeof(G1Jac)) != hipSuccess) {
         (void)hipGetLastError();
@@ -279,13 +313,17 @@ static bool build_table(int c, const void* bases, void** table, size_t* bytes, i
         *table = nullptr;
         return false;
     }
+    if (trace) fprintf(stderr, "[context]   table c=%d: hipMalloc %.1f GB  %8.1f ms\n", c, (entries * launch::SIZEOF_AFFQ + per_group * chunk * sizeof(G1Jac)) / 1e9,
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     for (int g0 = 0; g0 < n_groups; g0 += chunk) {
         int g = n_groups - g0 < chunk ? n_groups - g0 : chunk;
         launch::build_table(c, (const char*)bases + (size_t)g0 * nb * sizeof(G1Affine),
                             (char*)*table + (size_t)g0 * per_group * launch::SIZEOF_AFFQ, scratch, g, nb, st);
         HIPCK(hipStreamSynchronize(st));
     }
+    if (trace) fprintf(stderr, "[context]   table c=%d: built            %8.1f ms\n", c, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     HIPCK(hipFree(scratch));
+    if (trace) fprintf(stderr, "[context]   table c=%d: scratch freed    %8.1f ms\n", c, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     *bytes = entries * launch::SIZEOF_AFFQ;
     return true;
 }
@@ -300,16 +338,29 @@ void Engine::init_fk20() {
     launch::fk20_gather_bases(X, d_fk_bases_, stream_);
     HIPCK(hipStreamSynchronize(stream_));
     HIPCK(hipFree(X));
-    if (!build_table(srs_c_, d_srs_, &d_srs_table_, &srs_table_bytes_, 64, 64, stream_))  // SRS viewed as [64][64]
-        throw std::runtime_error("not enough device memory for the commitment window table");
-    // the widest FK20 table that fits (another context or process may already hold part of the HBM)
+    std::lock_guard<std::mutex> lk(g_tables_mu);  // one builder at a time per process
+    auto obtain = [&](int kind, int w, const void* bases, int n_groups) -> std::shared_ptr<SharedTable> {
+        auto key = std::make_tuple(dev_, kind, w);
+        if (auto live = g_tables[key].lock()) return live;
+        auto t = std::make_shared<SharedTable>();
+        t->dev = dev_;
+        if (!build_table(w, bases, &t->p, &t->bytes, n_groups, 64, stream_)) return nullptr;
+        g_tables[key] = t;
+        return t;
+    };
+    srs_tab_ = obtain(0, srs_c_, d_srs_, 64);  // SRS viewed as [64][64]
+    if (!srs_tab_) throw std::runtime_error("not enough device memory for the commitment window table");
+    d_srs_table_ = srs_tab_->p;
+    srs_table_bytes_ = srs_tab_->bytes;
+    // the widest FK20 table that is already resident or still fits (another process may hold part of the HBM)
     static const int widths[] = {14, 13, 12, 10, 8, 4};
-    bool ok = false;
     for (int w : widths) {
         if (w > c_) continue;
-        if (build_table(w, d_fk_bases_, &d_fk_table_, &fk_table_bytes_, 128, 64, stream_)) { c_ = w; ok = true; break; }
+        if ((fk_tab_ = obtain(1, w, d_fk_bases_, 128))) { c_ = w; break; }
     }
-    if (!ok) throw std::runtime_error("not enough device memory for the FK20 window table");
+    if (!fk_tab_) throw std::runtime_error("not enough device memory for the FK20 window table");
+    d_fk_table_ = fk_tab_->p;
+    fk_table_bytes_ = fk_tab_->bytes;
 }
 
 void Engine::set_profiling(bool on) { std::lock_guard<std::recursive_mutex> lk(mu_); profiling_ = on; }

@@ -28,8 +28,10 @@ enum Status : int {
 
 class Engine {
 public:
-    // use_precomp: true -> width-8 window tables (the reference's RECOMMENDED_PRECOMP_WIDTH),
-    //              false -> width-4 tables (16x smaller, ~2x the additions).  Results identical.
+    struct SharedTable;  // engine.hip
+    // use_precomp: true -> the widest FK20 window table that fits in HBM (width 14 = 145 GB on an otherwise empty
+    //              MI355X; the reference's UsePrecomp::Yes uses width 8 on the CPU), false -> width-4 tables (0.7 GB,
+    //              ~3.4x the additions).  Results identical.  Tables are shared by the contexts of a device.
     Engine(bool use_precomp, int device);
     ~Engine();
     Engine(const Engine&) = delete;
@@ -140,6 +142,7 @@ private:
     Fp12w beta_;                  // cube root of unity in Fp: (beta x, y) = [lambda](x, y)
     void* d_srs_ = nullptr;       // G1Affine[4096] monomial SRS
     void* d_fk_bases_ = nullptr;  // G1Affine[128][64] FFT'd SRS vectors (batch_toeplitz.rs:46-61)
+    std::shared_ptr<SharedTable> fk_tab_, srs_tab_;  // owners of the two tables below (shared by the contexts of a device)
     void* d_fk_table_ = nullptr;  // window table over d_fk_bases_
     void* d_srs_table_ = nullptr; // window table over d_srs_ viewed as [64][64]
     size_t fk_table_bytes_ = 0, srs_table_bytes_ = 0;
