@@ -13,6 +13,8 @@ library built by `rust-eth-kzg_amd/csrc/Makefile` and a gfx950 device, and fails
     kzg = importlib.import_module("rust-eth-kzg_amd") )
 """
 import ctypes as C
+
+import numpy as np
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -128,6 +130,33 @@ def _ptr_array(bufs):
     return arr, keep
 
 
+def _flat_ptrs(items, size):
+    """(uint64 pointer table, keep-alive) over ONE contiguous copy of equal-length byte strings: marshalling thousands
+    of cells through per-item ctypes buffers costs more than the GPU work it feeds."""
+    n = len(items)
+    flat = np.frombuffer(b"".join(bytes(x) if not isinstance(x, bytes) else x for x in items), dtype=np.uint8) if n else np.zeros(1, np.uint8)
+    ptrs = np.uint64(flat.ctypes.data) + np.arange(max(1, n), dtype=np.uint64) * np.uint64(size)
+    return ptrs, flat
+
+
+def _out_ptrs(n_outer, n_inner, size):
+    """Caller-allocated outputs as one flat buffer: (flat uint8 array, inner pointer tables [n_outer][n_inner],
+    outer pointer table [n_outer]) in the layout the C ABI takes (arrays of n_inner pointers per blob)."""
+    flat = np.zeros(max(1, n_outer * n_inner * size), dtype=np.uint8)
+    inner = np.uint64(flat.ctypes.data) + np.arange(max(1, n_outer * n_inner), dtype=np.uint64) * np.uint64(size)
+    outer = np.uint64(inner.ctypes.data) + np.arange(max(1, n_outer), dtype=np.uint64) * np.uint64(n_inner * 8)
+    return flat, inner, outer
+
+
+def _split(flat, n_outer, n_inner, size):
+    raw = flat.tobytes()
+    return [[raw[(b * n_inner + k) * size:(b * n_inner + k + 1) * size] for k in range(n_inner)] for b in range(n_outer)]
+
+
+def _vp(arr):
+    return arr.ctypes.data_as(C.c_void_p)
+
+
 class DASContext:
     """Mirror of `rust_eth_kzg::DASContext` (crates/eip7594/src/lib.rs:41-87)."""
 
@@ -191,13 +220,14 @@ class DASContext:
         if any(len(c) != 48 for c in commitments) or any(len(p) != 48 for p in proofs) \
                 or any(len(c) != BYTES_PER_CELL for c in cells):
             raise KzgError("InvalidLength")
-        ca, _k1 = _ptr_array(commitments)
-        cla, _k2 = _ptr_array(cells)
-        pa, _k3 = _ptr_array(proofs)
-        idx = (C.c_uint64 * max(1, len(cell_indices)))(*cell_indices)
+        ca, _k1 = _flat_ptrs(commitments, 48)
+        cla, _k2 = _flat_ptrs(cells, BYTES_PER_CELL)
+        pa, _k3 = _flat_ptrs(proofs, 48)
+        idx = np.array(cell_indices, dtype=np.uint64) if len(cell_indices) else np.zeros(1, np.uint64)
         ok = C.c_bool(False)
         self._check(self._lib.eth_kzg_verify_cell_kzg_proof_batch(
-            self._ctx, len(commitments), ca, len(cell_indices), idx, len(cells), cla, len(proofs), pa, C.byref(ok)))
+            self._ctx, len(commitments), _vp(ca), len(cell_indices), _vp(idx), len(cells), _vp(cla), len(proofs), _vp(pa),
+            C.byref(ok)))
         return bool(ok.value)
 
     def verify_cell_kzg_proof_batch_partial(self, commitments, cell_indices, cells, proofs, shard_begin, shard_end):
@@ -206,13 +236,13 @@ class DASContext:
         if any(len(c) != 48 for c in commitments) or any(len(p) != 48 for p in proofs) \
                 or any(len(c) != BYTES_PER_CELL for c in cells):
             raise KzgError("InvalidLength")
-        ca, _k1 = _ptr_array(commitments)
-        cla, _k2 = _ptr_array(cells)
-        pa, _k3 = _ptr_array(proofs)
-        idx = (C.c_uint64 * max(1, len(cell_indices)))(*cell_indices)
+        ca, _k1 = _flat_ptrs(commitments, 48)
+        cla, _k2 = _flat_ptrs(cells, BYTES_PER_CELL)
+        pa, _k3 = _flat_ptrs(proofs, 48)
+        idx = np.array(cell_indices, dtype=np.uint64) if len(cell_indices) else np.zeros(1, np.uint64)
         out = C.create_string_buffer(VERIFY_PARTIAL_BYTES)
         self._check(self._lib.eth_kzg_amd_verify_cell_kzg_proof_batch_partial(
-            self._ctx, len(commitments), ca, len(cell_indices), idx, len(cells), cla, len(proofs), pa,
+            self._ctx, len(commitments), _vp(ca), len(cell_indices), _vp(idx), len(cells), _vp(cla), len(proofs), _vp(pa),
             int(shard_begin), int(shard_end), out))
         return out.raw
 
@@ -284,18 +314,14 @@ class DASContext:
     def compute_cells_and_kzg_proofs_batch(self, blobs):
         """List of blobs -> (status list, cells[b][128], proofs[b][128]); host buffers."""
         n = len(blobs)
-        ba, _kb = _ptr_array(blobs)
-        cells = [[C.create_string_buffer(BYTES_PER_CELL) for _ in range(128)] for _ in range(n)]
-        proofs = [[C.create_string_buffer(48) for _ in range(128)] for _ in range(n)]
-        keep, cpp, ppp = [], (C.c_void_p * max(1, n))(), (C.c_void_p * max(1, n))()
-        for b in range(n):
-            ca, k1 = _ptr_array(cells[b])
-            pa, k2 = _ptr_array(proofs[b])
-            keep += [ca, pa, k1, k2]
-            cpp[b], ppp[b] = C.addressof(ca), C.addressof(pa)
+        if any(len(b) != BYTES_PER_BLOB for b in blobs):
+            raise KzgError("InvalidLength")
+        ba, _kb = _flat_ptrs(blobs, BYTES_PER_BLOB)
+        cells, _ci, cpp = _out_ptrs(n, 128, BYTES_PER_CELL)
+        proofs, _pi, ppp = _out_ptrs(n, 128, 48)
         st = (C.c_int32 * max(1, n))()
-        self._check(self._lib.eth_kzg_amd_compute_cells_and_kzg_proofs_batch(self._ctx, n, ba, cpp, ppp, st))
-        return list(st)[:n], [[c.raw for c in cb] for cb in cells], [[p.raw for p in pb] for pb in proofs]
+        self._check(self._lib.eth_kzg_amd_compute_cells_and_kzg_proofs_batch(self._ctx, n, _vp(ba), _vp(cpp), _vp(ppp), st))
+        return list(st)[:n], _split(cells, n, 128, BYTES_PER_CELL), _split(proofs, n, 128, 48)
 
     def blob_to_kzg_commitment_batch(self, blobs):
         n = len(blobs)
@@ -310,27 +336,22 @@ class DASContext:
         """batch = [(cell_indices, cells), ...] -> (status list, cells[b][128], proofs[b][128])."""
         n = len(batch)
         keep = []
-        lens = (C.c_uint64 * max(1, n))(*[len(c) for _, c in batch])
-        ilens = (C.c_uint64 * max(1, n))(*[len(i) for i, _ in batch])
-        cpp, ipp = (C.c_void_p * max(1, n))(), (C.c_void_p * max(1, n))()
+        lens = np.array([len(c) for _, c in batch] or [0], dtype=np.uint64)
+        ilens = np.array([len(i) for i, _ in batch] or [0], dtype=np.uint64)
+        cpp, ipp = np.zeros(max(1, n), np.uint64), np.zeros(max(1, n), np.uint64)
         for b, (idx, cells) in enumerate(batch):
             if any(len(c) != BYTES_PER_CELL for c in cells):
                 raise KzgError("InvalidLength")
-            ca, k1 = _ptr_array(cells)
-            ia = (C.c_uint64 * max(1, len(idx)))(*idx)
+            ca, k1 = _flat_ptrs(cells, BYTES_PER_CELL)
+            ia = np.array(idx, dtype=np.uint64) if len(idx) else np.zeros(1, np.uint64)
             keep += [ca, k1, ia]
-            cpp[b], ipp[b] = C.addressof(ca), C.addressof(ia)
-        out_cells = [[C.create_string_buffer(BYTES_PER_CELL) for _ in range(128)] for _ in range(n)]
-        out_proofs = [[C.create_string_buffer(48) for _ in range(128)] for _ in range(n)]
-        ocp, opp = (C.c_void_p * max(1, n))(), (C.c_void_p * max(1, n))()
-        for b in range(n):
-            ca, k1 = _ptr_array(out_cells[b])
-            pa, k2 = _ptr_array(out_proofs[b])
-            keep += [ca, pa, k1, k2]
-            ocp[b], opp[b] = C.addressof(ca), C.addressof(pa)
+            cpp[b], ipp[b] = ca.ctypes.data, ia.ctypes.data
+        out_cells, _ci, ocp = _out_ptrs(n, 128, BYTES_PER_CELL)
+        out_proofs, _pi, opp = _out_ptrs(n, 128, 48)
         st = (C.c_int32 * max(1, n))()
-        self._check(self._lib.eth_kzg_amd_recover_cells_and_proofs_batch(self._ctx, n, lens, cpp, ilens, ipp, ocp, opp, st))
-        return list(st)[:n], [[c.raw for c in cb] for cb in out_cells], [[p.raw for p in pb] for pb in out_proofs]
+        self._check(self._lib.eth_kzg_amd_recover_cells_and_proofs_batch(
+            self._ctx, n, _vp(lens), _vp(cpp), _vp(ilens), _vp(ipp), _vp(ocp), _vp(opp), st))
+        return list(st)[:n], _split(out_cells, n, 128, BYTES_PER_CELL), _split(out_proofs, n, 128, 48)
 
     def compute_cells_and_kzg_proofs_device(self, n, d_blobs, d_cells, d_proofs, want_status=True, stream=None):
         """Device-resident flat buffers (integer device addresses, e.g. torch tensor .data_ptr())."""

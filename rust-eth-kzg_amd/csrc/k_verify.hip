@@ -249,6 +249,35 @@ __global__ void k_copy_affine(const G1Affine* __restrict__ src, G1Affine* __rest
 // (vanishing_poly, polynomial/src/poly_coeff.rs:109-115, built on the host: <= 64 roots).
 //   zeval[r][c] = Z'(omega_128^brp7(c))            (zero exactly on the missing cells)
 //   zcinv[r][c] = 1 / Z'(7^64 * omega_128^brp7(c)) (never zero: the coset has no roots of Z, reed_solomon.rs:356-357)
+// Z'_r(y) = prod over the missing cells of (y - omega_128^i), i the domain-order index (vanishing_poly,
+// polynomial/src/poly_coeff.rs:109-115; construct_vanishing_poly_from_block_erasures, reed_solomon.rs:220-262).
+// One wave per blob: lane k holds coefficient k of the monic running product (the leading 1 is implicit), and a factor
+// (y - root) is one multiply-add with the neighbour's coefficient: z[k] <- z[k] * (-root) + z[k-1].  <= 64 steps.
+// present: 128-bit mask per blob (bit i set = cell with domain index i is present).  zp: [R][65] Montgomery, deg: [R].
+__global__ __launch_bounds__(64) void k_rec_vanishing_poly(const uint32_t* __restrict__ present, const Fr* __restrict__ w8192,
+                                                           Fr* __restrict__ zp, int* __restrict__ deg, int R) {
+    const int r = blockIdx.x, k = threadIdx.x;
+    const Fr zero_ = zero<FrParams>(), one_ = one<FrParams>();
+    Fr z = zero_;
+    int d = 0;
+    for (int i = 0; i < N_CELLS; i++) {
+        if ((present[(size_t)r * 4 + (i >> 5)] >> (i & 31)) & 1) continue;  // wave-uniform
+        const Fr nr = neg(w8192[64 * i]);
+        const Fr cur = k < d ? z : (k == d ? one_ : zero_);
+        Fr prev;
+#pragma unroll
+        for (int w = 0; w < 8; w++) prev.v[w] = __shfl_up(cur.v[w], 1);
+        if (k == 0) prev = zero_;
+        z = add(mul(cur, nr), prev);
+        d++;
+    }
+    zp[(size_t)r * 65 + k] = k < d ? z : (k == d ? one_ : zero_);
+    if (k == 0) {
+        zp[(size_t)r * 65 + 64] = d == 64 ? one_ : zero_;
+        deg[r] = d;
+    }
+}
+
 __global__ void k_rec_vanishing(const Fr* __restrict__ zp, const int* __restrict__ deg, const Fr* __restrict__ w8192,
                                 Fr seven64, Fr* __restrict__ zeval, Fr* __restrict__ zcinv, int R) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -383,6 +412,9 @@ void msm_pippenger2(const void* points, const void* sc0, int n0, const void* sc1
     k_pip_buckets<<<dim3(PIP_W * PIP_B / 64, 2), 64, 0, st>>>(pts, idx, start, n_max, buckets);
     k_pip_window<<<dim3(PIP_W, 2), 256, 0, st>>>(buckets, wsum);
     k_pip_final<<<2, 64, 0, st>>>(wsum, (G1Affine*)out_affine2);
+}
+void rec_vanishing_poly(const uint32_t* present, const void* w8192, void* zp, int* deg, int R, hipStream_t st) {
+    k_rec_vanishing_poly<<<R, 64, 0, st>>>(present, (const Fr*)w8192, (Fr*)zp, deg, R);
 }
 void rec_vanishing(const void* zp, const int* deg, const void* w8192, const Fr8& seven64, void* zeval, void* zcinv, int R,
                    hipStream_t st) {

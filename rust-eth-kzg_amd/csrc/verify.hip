@@ -311,23 +311,9 @@ int Engine::recover_batch_to_coeffs(int R, const uint64_t* n_cells, const uint8_
                                     const uint64_t* const* cell_indices, int* st_out) {
     hipStream_t st = stream_;
     ensure_workspace(R);
-    // host: Z'_r coefficients (<= 64 roots each), flattened cell list
-    Fr w128 = one<FrParams>();
-    {   // omega_128 = 7^((r-1)/128)
-        uint32_t e[8];
-        for (int i = 0; i < 8; i++) e[i] = FrParams::MOD[i];
-        e[0] -= 1;
-        for (int s = 0; s < 7; s++)
-            for (int i = 0; i < 8; i++) e[i] = (e[i] >> 1) | (i < 7 ? (e[i + 1] << 31) : 0);
-        Fr acc = one<FrParams>(), base = fr_u64(7);
-        for (int i = 255; i >= 0; i--) { acc = sqr(acc); if ((e[i >> 5] >> (i & 31)) & 1) acc = mul(acc, base); }
-        w128 = acc;
-    }
-    std::vector<Fr> roots(N_CELLS);
-    roots[0] = one<FrParams>();
-    for (int i = 1; i < N_CELLS; i++) roots[i] = mul(roots[i - 1], w128);
-    std::vector<Fr> zp((size_t)R * 65, zero<FrParams>());
-    std::vector<int> deg(R, 0), slot, stof;
+    // host: presence masks (domain order) and the flattened cell list; the vanishing polynomials are built on the GPU
+    std::vector<uint32_t> present((size_t)R * 4, 0xffffffffu);  // a blob that failed validation has nothing missing
+    std::vector<int> slot, stof;
     size_t total_cells = 0;
     for (int r = 0; r < R; r++) total_cells += st_out[r] == OK ? n_cells[r] : 0;
     std::vector<uint8_t> hcells(total_cells * BYTES_PER_CELL);
@@ -335,22 +321,14 @@ int Engine::recover_batch_to_coeffs(int R, const uint64_t* n_cells, const uint8_
     stof.reserve(total_cells);
     size_t pos = 0;
     for (int r = 0; r < R; r++) {
-        Fr* z = &zp[(size_t)r * 65];
-        z[0] = one<FrParams>();
         if (st_out[r] != OK) continue;
         // domain-order index of a cell = bit-reversed cell index (cosets.rs:186-195); missing = complement (recovery.rs:69-75)
-        bool present[N_CELLS] = {false};
-        for (uint64_t k = 0; k < n_cells[r]; k++) present[brp7((int)cell_indices[r][k])] = true;
-        int d = 0;
-        for (int i = 0; i < N_CELLS; i++) {
-            if (present[i]) continue;
-            Fr nr = neg(roots[i]);  // multiply by (y - root): vanishing_poly, poly_coeff.rs:109-115
-            z[d + 1] = z[d];
-            for (int k = d; k >= 1; k--) z[k] = add(mul(z[k], nr), z[k - 1]);
-            z[0] = mul(z[0], nr);
-            d++;
+        uint32_t* m = &present[(size_t)r * 4];
+        m[0] = m[1] = m[2] = m[3] = 0;
+        for (uint64_t k = 0; k < n_cells[r]; k++) {
+            const int i = brp7((int)cell_indices[r][k]);
+            m[i >> 5] |= 1u << (i & 31);
         }
-        deg[r] = d;
         for (uint64_t k = 0; k < n_cells[r]; k++) {
             memcpy(&hcells[pos * BYTES_PER_CELL], cells[r][k], BYTES_PER_CELL);
             slot.push_back(r * N_CELLS + (int)cell_indices[r][k]);  // scatter into blob r's 128 cell slots (cosets.rs:170-175)
@@ -363,15 +341,15 @@ int Engine::recover_batch_to_coeffs(int R, const uint64_t* n_cells, const uint8_
     for (int i = 0; i < 6; i++) seven64 = sqr(seven64);
     DevBuf d_cellb(hcells.size()), d_slot((size_t)n * sizeof(int)), d_stof((size_t)n * sizeof(int));
     DevBuf d_E((size_t)R * N_EXT * sizeof(Fr)), d_T((size_t)R * N_EXT * sizeof(Fr)), d_U((size_t)R * N_EXT * sizeof(Fr));
-    DevBuf d_zp(zp.size() * sizeof(Fr)), d_deg(R * sizeof(int));
+    DevBuf d_zp((size_t)R * 65 * sizeof(Fr)), d_deg(R * sizeof(int)), d_present(present.size() * 4);
     DevBuf d_zeval((size_t)R * N_CELLS * sizeof(Fr)), d_zcinv((size_t)R * N_CELLS * sizeof(Fr)), d_st(R * sizeof(int));
     if (n) {
         HIPCK(hipMemcpyAsync(d_cellb.p, hcells.data(), hcells.size(), hipMemcpyHostToDevice, st));
         HIPCK(hipMemcpyAsync(d_slot.p, slot.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
         HIPCK(hipMemcpyAsync(d_stof.p, stof.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
     }
-    HIPCK(hipMemcpyAsync(d_zp.p, zp.data(), zp.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
-    HIPCK(hipMemcpyAsync(d_deg.p, deg.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCK(hipMemcpyAsync(d_present.p, present.data(), present.size() * 4, hipMemcpyHostToDevice, st));
+    launch::rec_vanishing_poly((const uint32_t*)d_present.p, d_w8192_, d_zp.p, (int*)d_deg.p, R, st);
     HIPCK(hipMemsetAsync(d_E.p, 0, (size_t)R * N_EXT * sizeof(Fr), st));
     HIPCK(hipMemsetAsync(d_st.p, 0, R * sizeof(int), st));
     if (n) launch::cells_to_fr((const uint8_t*)d_cellb.p, d_E.p, (const int*)d_slot.p, (int*)d_st.p, (const int*)d_stof.p, n, st);  // E in cell order
@@ -412,8 +390,17 @@ int Engine::recover_cells_and_kzg_proofs_batch_host(int R, const uint64_t* n_cel
     std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         HIPCK(hipSetDevice(dev_));
+        const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!trace) return;
+            auto t1 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[recover] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+            t0 = t1;
+        };
         int rc = recover_batch_to_coeffs(R, n_cells, cells, cell_indices, status);
         if (rc) return rc;
+        lap("stage in + RS decode");
         // compute_multi_opening_proofs(Input::PolyCoeff) = stages C..I (prover.rs:164-170) for the whole batch
         DevBuf d_c((size_t)R * N_CELLS * BYTES_PER_CELL), d_p((size_t)R * N_CELLS * 48);
         launch::coeffs_to_cells(R, d_coeffs_, (uint8_t*)d_c.p, d_w8192_, stream_);
@@ -422,6 +409,7 @@ int Engine::recover_cells_and_kzg_proofs_batch_host(int R, const uint64_t* n_cel
         HIPCK(hipMemcpyAsync(hc.data(), d_c.p, hc.size(), hipMemcpyDeviceToHost, stream_));
         HIPCK(hipMemcpyAsync(hp.data(), d_p.p, hp.size(), hipMemcpyDeviceToHost, stream_));
         HIPCK(hipStreamSynchronize(stream_));
+        lap("cells + proofs + D2H");
         for (int r = 0; r < R; r++) {
             if (status[r] != OK) continue;
             for (int k = 0; k < N_CELLS; k++) {
@@ -429,6 +417,7 @@ int Engine::recover_cells_and_kzg_proofs_batch_host(int R, const uint64_t* n_cel
                 memcpy(out_proofs[r][k], &hp[((size_t)r * N_CELLS + k) * 48], 48);
             }
         }
+        lap("scatter to caller buffers");
     } catch (const std::exception& e) {
         err_ = e.what();
         return ERR_DEVICE;
