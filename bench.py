@@ -232,7 +232,8 @@ def main():
         # valid only for the configuration they were collected on
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1c_pmc_b2048_w14.json")))["kernels"]
+            import glob
+            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_b2048_w14.json")))[-1]))["kernels"]  # newest round
             key = {"msm_fixed": "void kzg::k_msm_fixed<14>", "g1_ifft": "kzg::k_g1_twiddle_mul", "g1_fft": "kzg::k_g1_twiddle_mul"}.get(dom)
             if key in pm and B == 2048 and ctx.window_bits() == 14:
                 traffic = (pm[key]["FETCH_SIZE_per_launch_max"] + pm[key]["WRITE_SIZE_per_launch_max"]) * 1024.0

@@ -367,9 +367,32 @@ def test_eip4844_round_trip_on_synthetic_blobs(ctx, oracle):
     assert ctx.verify_kzg_proof(comms[1], z, y, p) is False
 
 
+@pytest.mark.parametrize("n", [2, 8, 9, 16, 17, 64, 65, 129, 200])
+def test_every_batch_size_regime_matches_oracle(ctx, oracle, n):
+    """The engine picks its G1 schedule by batch size (<= 8: flat MSM + circulant transforms, <= 16: circulant,
+    <= 128: direct 8 x 16 transforms, above: the radix-2 network).  Every regime and both sides of every threshold
+    must give the oracle's bytes; blobs not checked against the oracle are checked against the single-blob path."""
+    import numpy as np
+    rng = np.random.RandomState(1000 + n)
+    a = rng.randint(0, 256, size=(n, 4096, 32), dtype=np.uint8)
+    a[:, :, 0] &= 0x3F
+    blobs = [a[i].tobytes() for i in range(n)]
+    blobs[n // 2] = synth.dummy_blob()
+    st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs)
+    assert st == [0] * n
+    for b in sorted({0, n // 2, n - 1}):
+        ec, ep = oracle.compute_cells_and_kzg_proofs(blobs[b])
+        assert cells[b] == ec and proofs[b] == ep, (n, b)
+    for b in sorted({1 % n, n // 3, (2 * n) // 3}):
+        c1, p1 = ctx.compute_cells_and_kzg_proofs(blobs[b])
+        assert cells[b] == c1 and proofs[b] == p1, (n, b)
+    st2, comms = ctx.blob_to_kzg_commitment_batch(blobs)
+    assert st2 == [0] * n and comms[n - 1] == oracle.blob_to_kzg_commitment(blobs[n - 1])
+
+
 def test_batch_larger_than_one_lane_group(ctx, oracle):
-    """70 blobs: more than one 64-lane group, so the radix-2 G1-FFT network runs (batches <= 64 use the
-    direct 8x16 latency mode). Spot-check against the oracle and check the data-in-first-half invariant on all."""
+    """70 blobs: more than one 64-lane group (two groups in the direct 8 x 16 mode), with a duplicate blob and the
+    all-(r-1) fixture inside. Spot-check against the oracle and check the data-in-first-half invariant on all."""
     import numpy as np
     rng = np.random.RandomState(123)
     a = rng.randint(0, 256, size=(70, 4096, 32), dtype=np.uint8)

@@ -1,0 +1,20 @@
+"""Fold rocprofv3 --pmc counter_collection CSVs (one or more passes) into profiles/<name>.json:
+per kernel, the maximum over launches of every counter (a full-batch launch is the maximum) and the launch count.
+usage: python tools/pmc_summary.py OUT.json "note" DIR [DIR ...]"""
+import csv, glob, json, os, re, sys
+
+out, note, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
+kern = {}
+for d in dirs:
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        per_dispatch = {}
+        for r in csv.DictReader(open(f)):
+            name = re.sub(r"\(.*", "", r["Kernel_Name"]).strip()
+            key = (name, r["Dispatch_Id"], r["Counter_Name"])
+            per_dispatch[key] = per_dispatch.get(key, 0.0) + float(r["Counter_Value"])  # sum over XCDs / instances
+        for (name, _, ctr), v in per_dispatch.items():
+            k = kern.setdefault(name, {})
+            k[ctr + "_per_launch_max"] = max(k.get(ctr + "_per_launch_max", 0.0), v)
+            k[ctr + "_launches"] = k.get(ctr + "_launches", 0) + 1
+json.dump({"note": note, "kernels": kern}, open(out, "w"), indent=1)
+print(out, len(kern), "kernels")
