@@ -11,6 +11,9 @@
 #pragma once
 #include "field.hpp"
 #include "fp29_consts.hpp"
+#include "fp29_mac.hpp"
+#include <utility>
+
 
 namespace kzg {
 
@@ -142,10 +145,74 @@ HD Fq<pow2_at_least(2 * A) + pow2_at_least(2 * B)> signed_sub(bool negate, const
     normalise(r);
     return r;
 }
+// ---- device form with verbatim multiply-add chains (fp29_mac.hpp), enabled per translation unit with -DFQ_ASM_MAC ----
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FQ_ASM_MAC)
+namespace q29asm {
+template <int K>  // low half: column K < QL computes m[K]
+__device__ __forceinline__ void mul_lo(uint64_t& acc, const uint32_t* a, const uint32_t* b, uint32_t* m) {
+    MacRun<K + 1>::vv(acc, a, b + K);
+    if constexpr (K > 0) MacRun<K>::template vp<K>(acc, m);
+    m[K] = ((uint32_t)acc * q29::N0) & QMASK;
+    MacRun<1>::template vp<0>(acc, m + K);
+    acc >>= 29;
+}
+template <int K>  // high half: column K in [QL, 2 QL) emits limb K - QL
+__device__ __forceinline__ void mul_hi(uint64_t& acc, const uint32_t* a, const uint32_t* b, const uint32_t* m, uint32_t* r) {
+    constexpr int lo = K - QL + 1, n = QL - lo;
+    if constexpr (n > 0) {
+        MacRun<n>::vv(acc, a + lo, b + (K - lo));
+        MacRun<n>::template vp<K - lo>(acc, m + lo);
+    }
+    r[K - QL] = (uint32_t)acc & QMASK;
+    acc >>= 29;
+}
+template <int K>
+__device__ __forceinline__ void sqr_lo(uint64_t& acc, const uint32_t* a, const uint32_t* a2, uint32_t* m) {
+    constexpr int n = (K + 1) / 2;  // cross terms i < K - i
+    if constexpr (n > 0) MacRun<n>::vv(acc, a2, a + K);
+    if constexpr ((K & 1) == 0) MacRun<1>::vv(acc, a + K / 2, a + K / 2);
+    if constexpr (K > 0) MacRun<K>::template vp<K>(acc, m);
+    m[K] = ((uint32_t)acc * q29::N0) & QMASK;
+    MacRun<1>::template vp<0>(acc, m + K);
+    acc >>= 29;
+}
+template <int K>
+__device__ __forceinline__ void sqr_hi(uint64_t& acc, const uint32_t* a, const uint32_t* a2, const uint32_t* m, uint32_t* r) {
+    constexpr int lo = K - QL + 1, n = (K + 1) / 2 - lo, nm = QL - lo;
+    if constexpr (n > 0) MacRun<n>::vv(acc, a2 + lo, a + (K - lo));
+    if constexpr ((K & 1) == 0 && K / 2 < QL) MacRun<1>::vv(acc, a + K / 2, a + K / 2);
+    if constexpr (nm > 0) MacRun<nm>::template vp<K - lo>(acc, m + lo);
+    r[K - QL] = (uint32_t)acc & QMASK;
+    acc >>= 29;
+}
+template <int... Ks>
+__device__ __forceinline__ void mul_all(const uint32_t* a, const uint32_t* b, uint32_t* r, std::integer_sequence<int, Ks...>) {
+    uint32_t m[QL];
+    uint64_t acc = 0;
+    (mul_lo<Ks>(acc, a, b, m), ...);
+    (mul_hi<QL + Ks>(acc, a, b, m, r), ...);
+}
+template <int... Ks>
+__device__ __forceinline__ void sqr_all(const uint32_t* a, uint32_t* r, std::integer_sequence<int, Ks...>) {
+    uint32_t m[QL], a2[QL];
+#pragma unroll
+    for (int i = 0; i < QL; i++) a2[i] = a[i] << 1;
+    uint64_t acc = 0;
+    (sqr_lo<Ks>(acc, a, a2, m), ...);
+    (sqr_hi<QL + Ks>(acc, a, a2, m, r), ...);
+}
+}  // namespace q29asm
+#endif
+
 // Montgomery product scanning, single 64-bit accumulator per column.
 template <int A, int B>
 HD Fq<2> mul(const Fq<A>& a, const Fq<B>& b) {
     static_assert((long)A * B <= (1L << 24), "mul: operand bounds too large (result would exceed 2p)");
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FQ_ASM_MAC)
+    Fq<2> ra;
+    q29asm::mul_all(a.v, b.v, ra.v, std::make_integer_sequence<int, QL>{});
+    return ra;
+#endif
     uint32_t m[QL];
     Fq<2> r;
     uint64_t acc = 0;
@@ -174,6 +241,11 @@ HD Fq<2> mul(const Fq<A>& a, const Fq<B>& b) {
 template <int A>
 HD Fq<2> sqr(const Fq<A>& a) {
     static_assert((long)A * A <= (1L << 24), "sqr: operand bound too large");
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FQ_ASM_MAC)
+    Fq<2> ra;
+    q29asm::sqr_all(a.v, ra.v, std::make_integer_sequence<int, QL>{});
+    return ra;
+#endif
     uint32_t m[QL], a2[QL];
 #pragma unroll
     for (int i = 0; i < QL; i++) a2[i] = a.v[i] << 1;
