@@ -63,13 +63,13 @@ HD Fq<B> select(bool c, const Fq<B>& a, const Fq<B>& b) {
 
 // dbl-2009-l with D = 4 X Y^2 written as a product: 3M + 4S
 HD JacQ dbl(const JacQ& p) {
-    Fq<2> A = sqr(p.x), B = sqr(p.y), C = sqr(B);
+    Fq<2> A = sqr(p.x), B = sqr(p.y);
     Fq<8> D = dbl2(mul(p.x, B));
     Fq<6> E = add(dbl(A), A);
     Fq<2> F = sqr(E);
     JacQ r;
     auto x3 = sub2(F, D);                                       // F - 2D < 2 + 32
-    auto y3 = sub2(mul(E, sub(D, x3)), dbl2(C));                // E(D - x3) - 8C < 2 + 32
+    auto y3 = mul_add(E, sub(D, x3), neg2(B), dbl2(B));         // E(D - x3) - 8 B^2, one reduction: < 2
     r.x = relax<XB>(x3);
     r.y = relax<XB>(y3);
     r.z = dbl(mul(p.y, p.z));                                   // identity stays identity: z = 0 -> z3 = 0
@@ -93,11 +93,12 @@ HD JacQ add(const JacQ& p, const JacQ& q, bool negq = false) {
     Fq<2> v = mul(u1, i);
     JacQ r;
     auto x3 = sub_sub2(sqr(rr), j, v);                            // rr^2 - J - 2V < 2 + 4 + 8
-    auto y3 = sub2(mul(rr, sub(v, x3)), mul(s1, j));              // rr(V - X3) - 2 S1 J < 2 + 8
+    auto y3 = mul_add(rr, sub(v, x3), neg2(s1), j);               // rr(V - X3) - 2 S1 J, one reduction: < 2
     r.x = relax<XB>(x3);
     r.y = relax<XB>(y3);
-    r.z = dbl(mul(mul(p.z, q.z), h));
-    if (is_zero(r.z)) return add_slow(p, q, negq);
+    const Fq<2> zh = mul(mul(p.z, q.z), h);  // Z3 / 2: zero test on the product (two candidates) instead of on its double (four)
+    r.z = dbl(zh);
+    if (is_zero(zh)) return add_slow(p, q, negq);
     return r;
 }
 
@@ -115,11 +116,12 @@ HD JacQ add_mixed(const JacQ& p, const AffQ& q, bool negq = false) {
     Fq<2> v = mul(p.x, i);
     JacQ r;
     auto x3 = sub_sub2(sqr(rr), j, v);                            // rr^2 - J - 2V < 2 + 4 + 8
-    auto y3 = sub2(mul(rr, sub(v, x3)), mul(p.y, j));             // rr(V - X3) - 2 Y1 J < 2 + 8
+    auto y3 = mul_add(rr, sub(v, x3), neg2(p.y), j);              // rr(V - X3) - 2 Y1 J, one reduction: < 2
     r.x = relax<XB>(x3);
     r.y = relax<XB>(y3);
-    r.z = dbl(mul(p.z, h));
-        if (is_zero(r.z)) return add_mixed_slow(p, q, negq);
+    const Fq<2> zh = mul(p.z, h);
+    r.z = dbl(zh);
+    if (is_zero(zh)) return add_mixed_slow(p, q, negq);
     return r;
 }
 

@@ -96,6 +96,19 @@ HD Fq<pow2_at_least(2 * B)> neg(const Fq<B>& b) {
     return r;
 }
 
+// K*p - 2b, K = 2^e >= 4 * bound(b)
+template <int B>
+HD Fq<pow2_at_least(4 * B)> neg2(const Fq<B>& b) {
+    constexpr int K = pow2_at_least(4 * B);
+    constexpr int E = log2_exact(K);
+    static_assert(E >= 1 && E <= 12, "bound too large");
+    Fq<K> r;
+#pragma unroll
+    for (int i = 0; i < QL; i++) r.v[i] = q29::SUBK[E - 1][i] - (b.v[i] << 1);
+    normalise(r);
+    return r;
+}
+
 // ---- fused forms: several additive steps, ONE carry sweep (limbs have 3 spare bits: lazy sums stay below 8 * 2^29) ----
 // 4a
 template <int A>
@@ -185,6 +198,35 @@ __device__ __forceinline__ void sqr_hi(uint64_t& acc, const uint32_t* a, const u
     r[K - QL] = (uint32_t)acc & QMASK;
     acc >>= 29;
 }
+template <int K>
+__device__ __forceinline__ void mul2_lo(uint64_t& acc, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* m) {
+    MacRun<K + 1>::vv(acc, a, b + K);
+    MacRun<K + 1>::vv(acc, c, d + K);
+    if constexpr (K > 0) MacRun<K>::template vp<K>(acc, m);
+    m[K] = ((uint32_t)acc * q29::N0) & QMASK;
+    MacRun<1>::template vp<0>(acc, m + K);
+    acc >>= 29;
+}
+template <int K>
+__device__ __forceinline__ void mul2_hi(uint64_t& acc, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, const uint32_t* m,
+                                        uint32_t* r) {
+    constexpr int lo = K - QL + 1, n = QL - lo;
+    if constexpr (n > 0) {
+        MacRun<n>::vv(acc, a + lo, b + (K - lo));
+        MacRun<n>::vv(acc, c + lo, d + (K - lo));
+        MacRun<n>::template vp<K - lo>(acc, m + lo);
+    }
+    r[K - QL] = (uint32_t)acc & QMASK;
+    acc >>= 29;
+}
+template <int... Ks>
+__device__ __forceinline__ void mul2_all(const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* r,
+                                         std::integer_sequence<int, Ks...>) {
+    uint32_t m[QL];
+    uint64_t acc = 0;
+    (mul2_lo<Ks>(acc, a, b, c, d, m), ...);
+    (mul2_hi<QL + Ks>(acc, a, b, c, d, m, r), ...);
+}
 template <int... Ks>
 __device__ __forceinline__ void mul_all(const uint32_t* a, const uint32_t* b, uint32_t* r, std::integer_sequence<int, Ks...>) {
     uint32_t m[QL];
@@ -267,6 +309,45 @@ HD Fq<2> sqr(const Fq<A>& a) {
 #pragma unroll
         for (int i = k - QL + 1; 2 * i < k; i++) acc += (uint64_t)a2[i] * a.v[k - i];
         if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+#pragma unroll
+        for (int i = k - QL + 1; i < QL; i++) acc += (uint64_t)m[i] * q29::P[k - i];
+        r.v[k - QL] = (uint32_t)acc & QMASK;
+        acc >>= 29;
+    }
+    return r;
+}
+
+// a*b + c*d with ONE Montgomery reduction: the two products share the columns (42 terms < 2^58 each still fit 64 bits),
+// which saves the 196 m*p multiply-adds and the column bookkeeping of a second multiplication.
+template <int A, int B, int C, int D>
+HD Fq<2> mul_add(const Fq<A>& a, const Fq<B>& b, const Fq<C>& c, const Fq<D>& d) {
+    static_assert((long)A * B + (long)C * D <= (1L << 24), "mul_add: operand bounds too large (result would exceed 2p)");
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FQ_ASM_MAC)
+    Fq<2> ra;
+    q29asm::mul2_all(a.v, b.v, c.v, d.v, ra.v, std::make_integer_sequence<int, QL>{});
+    return ra;
+#endif
+    uint32_t m[QL];
+    Fq<2> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < QL; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)c.v[i] * d.v[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * q29::P[k - i];
+        m[k] = ((uint32_t)acc * q29::N0) & QMASK;
+        acc += (uint64_t)m[k] * q29::P[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = QL; k < 2 * QL; k++) {
+#pragma unroll
+        for (int i = k - QL + 1; i < QL; i++) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = k - QL + 1; i < QL; i++) acc += (uint64_t)c.v[i] * d.v[k - i];
 #pragma unroll
         for (int i = k - QL + 1; i < QL; i++) acc += (uint64_t)m[i] * q29::P[k - i];
         r.v[k - QL] = (uint32_t)acc & QMASK;

@@ -11,13 +11,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "rust-eth-kzg_amd", "csrc")
 
 
+def _build_and_run(tmp_path, name):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / name)
+    subprocess.check_call([hipcc, "-O2", "-std=c++17", "-x", "hip", "--cuda-host-only", "-I", CSRC,
+                           os.path.join(ROOT, "tests", "c", name + ".cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    return out.stdout
+
+
 @pytest.mark.timeout(600)
 def test_binary_gcd_inversion_matches_fermat(tmp_path):
     """csrc/inverse.hpp (used by the Jacobian -> affine step) against a^(p-2), 3000 values per field incl. edge cases."""
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    exe = str(tmp_path / "test_inverse")
-    subprocess.check_call([hipcc, "-O2", "-std=c++17", "-x", "hip", "--offload-arch=gfx950", "-I", CSRC,
-                           os.path.join(ROOT, "tests", "c", "test_inverse.cpp"), "-o", exe])
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stdout + out.stderr
-    assert "0 mismatches" in out.stdout
+    out = _build_and_run(tmp_path, "test_inverse")
+    assert "0 mismatches" in out
+
+
+@pytest.mark.timeout(600)
+def test_unsaturated_group_law_matches_saturated_formulas(tmp_path):
+    """csrc/curve29.hpp + fp29.hpp (14 x 29-bit field, fused a*b + c*d, Z3-based exceptional handling) against the
+    plain Jacobian formulas of csrc/curve.hpp: random points, P+P, P-P, identities, mixed chains."""
+    out = _build_and_run(tmp_path, "test_curve29")
+    assert "0 mismatches" in out
