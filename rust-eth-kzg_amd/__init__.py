@@ -66,11 +66,12 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("ETH_KZG_AMD_LIB", LIB_PATH)  # A/B builds of the same library (tools/); default: the in-tree build
+    if not os.path.exists(path):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C rust-eth-kzg_amd/csrc). There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     P, U8P, U64 = C.c_void_p, C.c_char_p, C.c_uint64
     lib.eth_kzg_das_context_new.restype = P
     lib.eth_kzg_das_context_new.argtypes = [C.c_bool]

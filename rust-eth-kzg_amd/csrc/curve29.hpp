@@ -148,6 +148,68 @@ HD JacQ add_mixed_slow(const JacQ& p, const AffQ& q, bool negq) {
     return jacq_inf();
 }
 
+// XYZZ accumulator for long runs of mixed additions (the fixed-base MSM): (X, Y, ZZ, ZZZ) stands for the affine point
+// (X / ZZ, Y / ZZZ), ZZ^3 = ZZZ^2; identity <=> ZZ == 0.  madd-2008-s costs 6M + 2S + one fused product pair against
+// 6M + 3S + one fused pair for the Jacobian form above, and needs none of its doublings of intermediate values.
+struct XyzzQ {
+    Fq<XB> x, y;
+    Fq<2> zz, zzz;
+};
+HD XyzzQ xyzz_inf() {
+    XyzzQ r;
+    r.x = relax<XB>(fq_one());
+    r.y = relax<XB>(fq_one());
+    r.zz = relax<2>(fq_zero());
+    r.zzz = relax<2>(fq_zero());
+    return r;
+}
+HD bool is_inf(const XyzzQ& p) { return is_zero(p.zz); }
+HD JacQ to_jacq(const XyzzQ& p) {  // (X ZZ, Y ZZZ, ZZ): X ZZ / ZZ^2 = X / ZZ and Y ZZZ / ZZ^3 = Y / ZZZ
+    JacQ r;
+    r.x = relax<XB>(mul(p.x, p.zz));
+    r.y = relax<XB>(mul(p.y, p.zzz));
+    r.z = relax<ZB>(p.zz);
+    return r;
+}
+HD XyzzQ add_mixed_slow(const XyzzQ& p, const AffQ& q, bool negq);
+HD XyzzQ add_mixed(const XyzzQ& p, const AffQ& q, bool negq = false) {
+    if (is_inf(q)) return p;
+    Fq<2> u2 = mul(q.x, p.zz), s2 = mul(q.y, p.zzz);
+    auto pp_ = sub(u2, p.x);                      // P  < 2 + 128
+    auto rr = signed_sub(negq, s2, p.y);          // R = +-S2 - Y1 < 4 + 128
+    Fq<2> pp = sqr(pp_);
+    Fq<2> ppp = mul(pp_, pp);
+    Fq<2> qq = mul(p.x, pp);
+    auto x3 = sub_sub2(sqr(rr), ppp, qq);         // R^2 - PPP - 2Q < 2 + 4 + 8
+    XyzzQ r;
+    r.x = relax<XB>(x3);
+    r.y = relax<XB>(mul_add(rr, sub(qq, x3), neg(p.y), ppp));  // R(Q - X3) - Y1 PPP, one reduction
+    r.zz = mul(p.zz, pp);
+    r.zzz = mul(p.zzz, ppp);
+    if (is_zero(r.zz)) return add_mixed_slow(p, q, negq);  // identity accumulator, or equal x: P + P / P - P
+    return r;
+}
+HD XyzzQ add_mixed_slow(const XyzzQ& p, const AffQ& q, bool negq) {
+    if (is_inf(q)) return p;
+    JacQ j;
+    if (is_inf(p)) {
+        j = to_jacq(q);
+        if (negq) j = neg(j);
+    } else {
+        Fq<2> s2p = mul(q.y, p.zzz);
+        Fq<4> s2 = select(negq, neg(s2p), relax<4>(s2p));
+        if (!is_zero_slow(sub(s2, p.y))) return xyzz_inf();  // opposite points
+        j = dbl(to_jacq(q));                                 // equal points: 2 q
+        if (negq) j = neg(j);
+    }
+    XyzzQ r;  // Jacobian (X, Y, Z) -> (X, Y, Z^2, Z^3)
+    r.x = j.x;
+    r.y = j.y;
+    r.zz = sqr(j.z);
+    r.zzz = mul(r.zz, j.z);
+    return r;
+}
+
 // conversions ------------------------------------------------------------------------------------------------
 HD AffQ affq_from_affine(const G1Affine& a) {  // a canonical Montgomery-384; identity (0,0) maps to (0,0)
     AffQ r;

@@ -5,6 +5,16 @@
 
 namespace kzg {
 
+#ifdef MSM_JACOBIAN_ACC  // A/B switch: the Jacobian accumulator the kernels used before the XYZZ form
+using MsmAcc = JacQ;
+__device__ __forceinline__ MsmAcc msm_acc_inf() { return jacq_inf(); }
+__device__ __forceinline__ JacQ msm_acc_to_jacq(const MsmAcc& a) { return a; }
+#else
+using MsmAcc = XyzzQ;
+__device__ __forceinline__ MsmAcc msm_acc_inf() { return xyzz_inf(); }
+__device__ __forceinline__ JacQ msm_acc_to_jacq(const MsmAcc& a) { return to_jacq(a); }
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Fixed-base MSM with window tables (replaces FixedBaseMSMPrecompWindow::msm,
 // fixed_base_msm_window.rs:102-168, and its batched affine adder batch_addition.rs:142-232).
@@ -44,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void k_msm_fixed(const Fr* __restrict__ sca
     const long m = (long)blockIdx.x * PER_BLOCK + local;  // MSM index = slice * n_groups + group
     const long total = (long)n_groups * n_slices;
     const bool active = local < PER_BLOCK && m < total;
-    JacQ acc = jacq_inf();
+    MsmAcc acc = msm_acc_inf();
     int group = 0, slice = 0;
     if (active) {
         slice = (int)(m / n_groups);
@@ -60,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void k_msm_fixed(const Fr* __restrict__ sca
             }
         }
     }
-    if (local < PER_BLOCK) red[local * W + w] = acc;
+    if (local < PER_BLOCK) red[local * W + w] = msm_acc_to_jacq(acc);
     __syncthreads();
     // fold the W window sums of each MSM (W is not a power of two in general)
     for (int span = 1; span < W; span <<= 1) {
@@ -88,16 +98,17 @@ __global__ __launch_bounds__(256) void k_msm_fixed_flat(const Fr* __restrict__ s
     const long m = blockIdx.x;  // MSM index = slice * n_groups + group
     const int slice = (int)(m / n_groups), group = (int)(m % n_groups);
     const Fr* sc = scalars + (size_t)m * nb;
-    JacQ acc = jacq_inf();
+    MsmAcc xacc = msm_acc_inf();
     for (int e = tid; e < W * nb; e += 256) {
         const int w = e / nb, i = e - w * nb;
         const int d = booth_digit(sc[i].v, w, C);
         if (d != 0) {
             const int ad = d < 0 ? -d : d;
             const AffQ p = table[((((size_t)group * W + w) * nb + i) << (C - 1)) + (ad - 1)];
-            acc = add_mixed(acc, p, d < 0);
+            xacc = add_mixed(xacc, p, d < 0);
         }
     }
+    JacQ acc = msm_acc_to_jacq(xacc);
 #pragma unroll 1
     for (int span = 128; span >= 1; span >>= 1) {
         red[tid] = acc;

@@ -50,6 +50,23 @@ int main() {
         expect(add_mixed(jacq_inf(), qa, true), neg(Q), "O-Q mixed");
         AffQ inf_a = affq_from_affine(aff_inf());
         expect(add_mixed(p, inf_a), P, "P+O mixed");
+        // XYZZ accumulator (the MSM's): sums of +-q onto p and the exceptional cases
+        {
+            XyzzQ xa = xyzz_inf();
+            xa = add_mixed(xa, affq_from_affine(to_affine(P)));           // O + P
+            expect(to_jacq(xa), P, "xyzz O+P");
+            expect(to_jacq(add_mixed(xa, qa)), add_mixed(P, Qaff), "xyzz madd");
+            expect(to_jacq(add_mixed(xa, qa, true)), add_mixed(P, neg(Qaff)), "xyzz msub");
+            XyzzQ xq = add_mixed(xyzz_inf(), qa, true);                   // O - Q
+            expect(to_jacq(xq), neg(Q), "xyzz O-Q");
+            expect(to_jacq(add_mixed(xq, qa)), jac_inf(), "xyzz -Q+Q");
+            expect(to_jacq(add_mixed(xq, qa, true)), dbl(neg(Q)), "xyzz -Q-Q");
+            expect(to_jacq(add_mixed(xa, inf_a)), P, "xyzz P+O");
+            XyzzQ run = xa;
+            G1Jac RUN = P;
+            for (int k = 0; k < 30; k++) { run = add_mixed(run, qa, k % 3 == 0); RUN = add_mixed(RUN, (k % 3 == 0) ? neg(Qaff) : Qaff); }
+            expect(to_jacq(run), RUN, "xyzz chain");
+        }
         // chains keep the stored bounds: 40 steps of mixed operations
         JacQ acc = p;
         G1Jac ACC = P;
