@@ -62,11 +62,10 @@ static Fr fr_root_of_unity(int log_n) {
     }
     return fr_pow_limbs(fr_from_u64(7), e, 8);
 }
-// GLV + joint sparse form of a public twiddle (host side, once per context).
+// GLV split of a public twiddle (host side, once per context).
 // phi(x, y) = (beta x, y) acts on G1 as multiplication by lambda = z^2 - 1 (z the BLS parameter), a 128-bit cube
-// root of unity mod r.  k = k1 + k2 lambda with k2 = floor(k / lambda), both < 2^128; the pair is then recoded
-// in Solinas' joint sparse form (digits in {-1,0,1}, about half of the <= 129 columns non-zero).
-// Table row per twiddle: 4 masks of 5 words: nz1, sg1, nz2, sg2 (bit i <-> column i).
+// root of unity mod r.  k = k1 + k2 lambda with k2 = floor(k / lambda), both < 2^128; each half is then recoded in
+// width-w non-adjacent form (init_constants; consumed by mul_by_twiddle in k_g1fft.hip and by k_g1circ.hip's term list).
 typedef unsigned __int128 u128;
 static const u128 GLV_LAMBDA = ((u128)0xac45a4010001a402ULL << 64) | 0x00000000ffffffffULL;
 static void glv_split(const Fr& canon, u128& k1, u128& k2) {
@@ -81,41 +80,6 @@ static void glv_split(const Fr& canon, u128& k1, u128& k2) {
     k1 = rem;
     k2 = q;
 }
-static void jsf_digits(u128 k0, u128 k1, uint32_t* row /*20 words*/) {
-    for (int i = 0; i < 20; i++) row[i] = 0;
-    int d0 = 0, d1 = 0, j = 0;
-    auto digit = [](u128 l, u128 lo) -> int {
-        if ((l & 1) == 0) return 0;
-        int u = 2 - (int)(l & 3);
-        int m8 = (int)(l & 7);
-        if ((m8 == 3 || m8 == 5) && ((int)(lo & 3) == 2)) u = -u;
-        return u;
-    };
-    while (k0 + d0 > 0 || k1 + d1 > 0) {
-        u128 l0 = k0 + d0, l1 = k1 + d1;
-        int a = digit(l0, l1), b = digit(l1, l0);
-        if (j >= 160) throw std::runtime_error("JSF too long");
-        if (a) { row[0 + (j >> 5)] |= 1u << (j & 31); if (a < 0) row[5 + (j >> 5)] |= 1u << (j & 31); }
-        if (b) { row[10 + (j >> 5)] |= 1u << (j & 31); if (b < 0) row[15 + (j >> 5)] |= 1u << (j & 31); }
-        if (2 * d0 == 1 + a) d0 = 1 - d0;
-        if (2 * d1 == 1 + b) d1 = 1 - d1;
-        k0 >>= 1;
-        k1 >>= 1;
-        j++;
-    }
-}
-// check a JSF row against (k1, k2)
-static bool jsf_check(const uint32_t* row, u128 k1, u128 k2) {
-    __int128 s1 = 0, s2 = 0;
-    for (int j = 159; j >= 0; j--) {
-        int a = (row[0 + (j >> 5)] >> (j & 31)) & 1, an = (row[5 + (j >> 5)] >> (j & 31)) & 1;
-        int b = (row[10 + (j >> 5)] >> (j & 31)) & 1, bn = (row[15 + (j >> 5)] >> (j & 31)) & 1;
-        s1 = s1 * 2 + (a ? (an ? -1 : 1) : 0);
-        s2 = s2 * 2 + (b ? (bn ? -1 : 1) : 0);
-    }
-    return s1 == (__int128)k1 && s2 == (__int128)k2;
-}
-
 // ---------------------------------------------------------------------------------------------
 Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14 : 4) {
     if (use_precomp) {
@@ -179,17 +143,34 @@ void Engine::init_constants() {
         for (int i = 0; i < 4; i++) lam.v[i] = (uint32_t)(GLV_LAMBDA >> (32 * i));
         Fr lm = to_mont(lam);
         if (!is_zero(add(add(sqr(lm), lm), one<FrParams>()))) throw std::runtime_error("GLV lambda is not a cube root of unity");
-        std::vector<uint32_t> jsf(128 * 20);
+        // width-w NAF of both GLV halves, one signed byte per digit (k_g1fft.hip: mul_by_twiddle)
+        constexpr int TWW = launch::TWIDDLE_WORDS, W = launch::TWIDDLE_WNAF_W;
+        std::vector<uint32_t> jsf((size_t)128 * 2 * TWW, 0u);
         for (int k = 0; k < 128; k++) {
             Fr canon = from_mont(w[64 * k]);
-            u128 k1, k2;
-            glv_split(canon, k1, k2);
+            u128 kk[2];
+            glv_split(canon, kk[0], kk[1]);
             // k1 + k2 * lambda == k (mod r), in Fr
             Fr a1 = zero<FrParams>(), a2 = zero<FrParams>();
-            for (int i = 0; i < 4; i++) { a1.v[i] = (uint32_t)(k1 >> (32 * i)); a2.v[i] = (uint32_t)(k2 >> (32 * i)); }
+            for (int i = 0; i < 4; i++) { a1.v[i] = (uint32_t)(kk[0] >> (32 * i)); a2.v[i] = (uint32_t)(kk[1] >> (32 * i)); }
             if (!eq(add(to_mont(a1), mul(to_mont(a2), lm)), w[64 * k])) throw std::runtime_error("GLV split failed");
-            jsf_digits(k1, k2, &jsf[k * 20]);
-            if (!jsf_check(&jsf[k * 20], k1, k2)) throw std::runtime_error("JSF recoding failed");
+            for (int h = 0; h < 2; h++) {
+                int8_t* dg = reinterpret_cast<int8_t*>(&jsf[((size_t)k * 2 + h) * TWW]);
+                u128 v = kk[h];
+                Fr back = zero<FrParams>(), pw = one<FrParams>();
+                for (int t = 0; v != 0; t++, v >>= 1, pw = add(pw, pw)) {
+                    if (t >= 4 * TWW) throw std::runtime_error("twiddle recoding too long");
+                    if (!(v & 1)) continue;
+                    int d = (int)(v & ((1u << W) - 1));        // v mods 2^w: odd residue in (-2^(w-1), 2^(w-1))
+                    if (d >= (1 << (W - 1))) d -= 1 << W;
+                    if (d < 0) v += (u128)(-d); else v -= (u128)d;
+                    dg[t] = (int8_t)d;
+                    Fr term = pw;
+                    for (int m = 1; m < (d < 0 ? -d : d); m++) term = add(term, pw);  // |d| * 2^t
+                    back = d < 0 ? sub(back, term) : add(back, term);
+                }
+                if (!eq(back, to_mont(h ? a2 : a1))) throw std::runtime_error("twiddle recoding failed");
+            }
         }
         HIPCK(hipMalloc(&d_naf_, jsf.size() * 4));
         HIPCK(hipMemcpy(d_naf_, jsf.data(), jsf.size() * 4, hipMemcpyHostToDevice));

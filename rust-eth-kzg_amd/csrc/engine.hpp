@@ -138,7 +138,7 @@ private:
 
     // constants in HBM
     void* d_w8192_ = nullptr;     // Fr[8192] omega_8192^k, Montgomery
-    void* d_naf_ = nullptr;       // u32[128][20] GLV + joint-sparse-form digits of omega_128^k
+    void* d_naf_ = nullptr;       // u32[128][2][33]: width-w NAF digits (signed bytes) of the GLV halves of omega_128^k
     Fp12w beta_;                  // cube root of unity in Fp: (beta x, y) = [lambda](x, y)
     void* d_srs_ = nullptr;       // G1Affine[4096] monomial SRS
     void* d_fk_bases_ = nullptr;  // G1Affine[128][64] FFT'd SRS vectors (batch_toeplitz.rs:46-61)

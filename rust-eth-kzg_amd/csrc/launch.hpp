@@ -51,6 +51,9 @@ void fk20_gather_bases(const void* X, void* bases, hipStream_t st);
 void test_load_points(const uint8_t* in, void* X, int n_lanes, int stride, hipStream_t st);
 void test_recompress(const void* pts, uint8_t* out, int n, hipStream_t st);
 
+// twiddle recoding shared by engine.hip (host) and k_g1fft.hip (device)
+constexpr int TWIDDLE_WNAF_W = 5;   // window width of the non-adjacent form (table of 2^(w-2) odd multiples)
+constexpr int TWIDDLE_WORDS = 33;   // 132 signed digit bytes per 128-bit half
 // k_g1circ.hip
 constexpr int CIRC_LANES = 256;
 size_t g1_circ_table_bytes(int n, int T);
