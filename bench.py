@@ -31,17 +31,21 @@ ALG_BYTES_PER_BLOB = BYTES_PER_BLOB + CELLS * BYTES_PER_CELL + CELLS * 48  # 399
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_INT_PEAK_GOPS = 34000.0     # measured on MI355X with tools/ubench.hip: integer VALU ops (v_mad_u64_u32,
                                  # v_addc_co_u32, ...) all issue at ~31-35 T lane-ops/s chip-wide
-FP_MUL_PEAK_G = 75.8             # measured ceiling of the 14x29-bit Montgomery multiplication (392 v_mad_u64_u32 + ~130
-                                 # shifts/masks), 8 waves/SIMD, profiles/r1_ubench_valu_rates.log
+FP_MUL_PEAK_G = 78.1             # measured ceiling of the 14x29-bit Montgomery multiplication (392 v_mad_u64_u32 + 68 shifts /
+                                 # masks as verbatim chains, fp29_mac.hpp) at 4 waves/SIMD: tools/ubench_fp29.hip,
+                                 # profiles/r1e_ubench_fp29.log (66.0 G/s at the 2 waves/SIMD the point kernels can hold)
 
 
 def fp_mul_eq_per_blob(window_bits):
-    """Fp multiplication equivalents this build spends per blob (S = 0.8 M):
-    stage D: 128 MSMs x 64 bases x W windows mixed additions (8M + 3S);
-    stages E+F: 642 twiddle multiplications x (129 doublings (3M+4S) + ~66 additions (12M+4S)) + 14 x 64 butterfly additions."""
+    """Fp multiplication equivalents this build spends per blob, counted in multiply-add passes of 392 MACs
+    (M = 1, squaring S = 301/392, fused pair a*b + c*d with one reduction F = 588/392):
+    stage D: 128 MSMs x 64 bases x W windows XYZZ mixed additions (6M + 2S + F);
+    stages E+F: 642 twiddle multiplications x (1 + 128 doublings (2M + 3S + F) + ~43 + 7 additions (10M + 4S + F) + 8 beta-muls)
+    + 14 x 64 butterfly additions."""
     w = (255 + window_bits) // window_bits
-    madd, dbl, add = 8 + 3 * 0.8, 3 + 4 * 0.8, 12 + 4 * 0.8
-    return 128 * 64 * w * madd + 642 * (129 * dbl + 66 * add) + 14 * 64 * 1.5 * add
+    S, F = 301 / 392, 588 / 392
+    madd, dbl, add = 6 + 2 * S + F, 2 + 3 * S + F, 10 + 4 * S + F
+    return 128 * 64 * w * madd + 642 * (129 * dbl + 50 * add + 8) + 14 * 64 * 1.5 * add
 
 
 def synth_blobs(n, seed):
