@@ -30,6 +30,14 @@ HD bool is_inf(const AffQ& p) {
     return d == 0;
 }
 HD bool is_inf(const JacQ& p) { return is_zero(p.z); }
+// "t == 0 mod p" for a fresh product t < 2p: only 0 and p qualify, so one look at the low limb settles almost every
+// case and the 28-word comparison runs only when that limb matches (hot paths: once per addition)
+HD bool product_is_zero(const Fq<2>& t) {
+    const uint32_t l0 = t.v[0];
+    if (l0 != 0 && l0 != q29::P[0]) return false;
+    return is_zero(t);
+}
+HD bool affine_is_inf(const AffQ& q) { return (q.x.v[0] | q.y.v[0]) == 0 && is_inf(q); }
 HD JacQ jacq_inf() {
     JacQ r;
     r.x = relax<XB>(fq_one());
@@ -98,13 +106,13 @@ HD JacQ add(const JacQ& p, const JacQ& q, bool negq = false) {
     r.y = relax<XB>(y3);
     const Fq<2> zh = mul(mul(p.z, q.z), h);  // Z3 / 2: zero test on the product (two candidates) instead of on its double (four)
     r.z = dbl(zh);
-    if (is_zero(zh)) return add_slow(p, q, negq);
+    if (product_is_zero(zh)) return add_slow(p, q, negq);
     return r;
 }
 
 // madd-2007-bl with Z3 = 2 Z1 H: 8M + 3S
 HD JacQ add_mixed(const JacQ& p, const AffQ& q, bool negq = false) {
-    if (is_inf(q)) return p;  // an affine identity (0,0) does not make Z3 vanish: test it up front (28 ORs)
+    if (affine_is_inf(q)) return p;  // an affine identity (0,0) does not make Z3 vanish: test it up front
     Fq<2> z1z1 = sqr(p.z);
     Fq<2> u2 = mul(q.x, z1z1);
     Fq<2> s2p = mul(mul(q.y, p.z), z1z1);
@@ -121,7 +129,7 @@ HD JacQ add_mixed(const JacQ& p, const AffQ& q, bool negq = false) {
     r.y = relax<XB>(y3);
     const Fq<2> zh = mul(p.z, h);
     r.z = dbl(zh);
-    if (is_zero(zh)) return add_mixed_slow(p, q, negq);
+    if (product_is_zero(zh)) return add_mixed_slow(p, q, negq);
     return r;
 }
 
@@ -173,7 +181,7 @@ HD JacQ to_jacq(const XyzzQ& p) {  // (X ZZ, Y ZZZ, ZZ): X ZZ / ZZ^2 = X / ZZ an
 }
 HD XyzzQ add_mixed_slow(const XyzzQ& p, const AffQ& q, bool negq);
 HD XyzzQ add_mixed(const XyzzQ& p, const AffQ& q, bool negq = false) {
-    if (is_inf(q)) return p;
+    if (affine_is_inf(q)) return p;
     Fq<2> u2 = mul(q.x, p.zz), s2 = mul(q.y, p.zzz);
     auto pp_ = sub(u2, p.x);                      // P  < 2 + 128
     auto rr = signed_sub(negq, s2, p.y);          // R = +-S2 - Y1 < 4 + 128
@@ -186,7 +194,7 @@ HD XyzzQ add_mixed(const XyzzQ& p, const AffQ& q, bool negq = false) {
     r.y = relax<XB>(mul_add(rr, sub(qq, x3), neg(p.y), ppp));  // R(Q - X3) - Y1 PPP, one reduction
     r.zz = mul(p.zz, pp);
     r.zzz = mul(p.zzz, ppp);
-    if (is_zero(r.zz)) return add_mixed_slow(p, q, negq);  // identity accumulator, or equal x: P + P / P - P
+    if (product_is_zero(r.zz)) return add_mixed_slow(p, q, negq);  // identity accumulator, or equal x: P + P / P - P
     return r;
 }
 HD XyzzQ add_mixed_slow(const XyzzQ& p, const AffQ& q, bool negq) {

@@ -137,7 +137,7 @@ void Engine::init_constants() {
     if (!eq(mul(w[N_EXT - 1], g), one<FrParams>())) throw std::runtime_error("omega_8192 has wrong order");
     HIPCK(hipMalloc(&d_w8192_, N_EXT * sizeof(Fr)));
     HIPCK(hipMemcpy(d_w8192_, w.data(), N_EXT * sizeof(Fr), hipMemcpyHostToDevice));
-    // GLV/JSF recoding of omega_128^k = w[64k] (the G1-FFT twiddles)
+    // GLV + width-w NAF recoding of omega_128^k = w[64k] (the G1-FFT twiddles)
     {
         Fr lam = zero<FrParams>();
         for (int i = 0; i < 4; i++) lam.v[i] = (uint32_t)(GLV_LAMBDA >> (32 * i));
@@ -145,7 +145,7 @@ void Engine::init_constants() {
         if (!is_zero(add(add(sqr(lm), lm), one<FrParams>()))) throw std::runtime_error("GLV lambda is not a cube root of unity");
         // width-w NAF of both GLV halves, one signed byte per digit (k_g1fft.hip: mul_by_twiddle)
         constexpr int TWW = launch::TWIDDLE_WORDS, W = launch::TWIDDLE_WNAF_W;
-        std::vector<uint32_t> jsf((size_t)128 * 2 * TWW, 0u);
+        std::vector<uint32_t> tw((size_t)128 * 2 * TWW, 0u);
         for (int k = 0; k < 128; k++) {
             Fr canon = from_mont(w[64 * k]);
             u128 kk[2];
@@ -155,7 +155,7 @@ void Engine::init_constants() {
             for (int i = 0; i < 4; i++) { a1.v[i] = (uint32_t)(kk[0] >> (32 * i)); a2.v[i] = (uint32_t)(kk[1] >> (32 * i)); }
             if (!eq(add(to_mont(a1), mul(to_mont(a2), lm)), w[64 * k])) throw std::runtime_error("GLV split failed");
             for (int h = 0; h < 2; h++) {
-                int8_t* dg = reinterpret_cast<int8_t*>(&jsf[((size_t)k * 2 + h) * TWW]);
+                int8_t* dg = reinterpret_cast<int8_t*>(&tw[((size_t)k * 2 + h) * TWW]);
                 u128 v = kk[h];
                 Fr back = zero<FrParams>(), pw = one<FrParams>();
                 for (int t = 0; v != 0; t++, v >>= 1, pw = add(pw, pw)) {
@@ -172,8 +172,8 @@ void Engine::init_constants() {
                 if (!eq(back, to_mont(h ? a2 : a1))) throw std::runtime_error("twiddle recoding failed");
             }
         }
-        HIPCK(hipMalloc(&d_naf_, jsf.size() * 4));
-        HIPCK(hipMemcpy(d_naf_, jsf.data(), jsf.size() * 4, hipMemcpyHostToDevice));
+        HIPCK(hipMalloc(&d_naf_, tw.size() * 4));
+        HIPCK(hipMemcpy(d_naf_, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
         // Small-batch circulant form (k_g1circ.hip): symbol c_d = sum_{t<64} omega_128^(d t); its non-zero entries,
         // GLV-split and NAF-recoded, become one flat list of +-D[k-d][half][t] terms dealt round-robin to 256 lanes.
         std::vector<uint32_t> plus, minus;

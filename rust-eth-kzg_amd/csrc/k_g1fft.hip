@@ -67,7 +67,7 @@ __device__ __forceinline__ JacQ mul_by_twiddle(const JacQ& p, const uint32_t* __
 // q = butterfly index; half = butterfly span; twiddle exponent = j * tw_step (128 - that when inverse).
 // grid = (n_bfly = 64, stride/64), block = 64 (one wave = one butterfly x 64 blobs).
 __global__ __launch_bounds__(64, 2) void k_g1_twiddle_mul(JacQ* __restrict__ X, int stride, int half, int tw_step, int inverse,
-                                                          int from_a, const uint32_t* __restrict__ jsf, Fq<1> beta) {
+                                                          int from_a, const uint32_t* __restrict__ tw, Fq<1> beta) {
     const int q = blockIdx.x, lane = blockIdx.y * 64 + threadIdx.x;
     const int j = q & (half - 1);
     const int i0 = ((q - j) << 1) + j, i1 = i0 + half;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64, 2) void k_g1_twiddle_mul(JacQ* __restrict__ X, 
     if (inverse) e = (128 - e) & 127;
     if (e == 0 && !from_a) return;  // multiplication by one, in place: nothing to do (wave-uniform)
     const JacQ src = X[(size_t)(from_a ? i0 : i1) * stride + lane];
-    X[(size_t)i1 * stride + lane] = mul_by_twiddle(src, jsf, beta, e);
+    X[(size_t)i1 * stride + lane] = mul_by_twiddle(src, tw, beta, e);
 }
 __global__ __launch_bounds__(64) void k_g1_butterfly(JacQ* __restrict__ X, int stride, int half, int want_diff) {
     const int q = blockIdx.x, lane = blockIdx.y * 64 + threadIdx.x;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64) void k_g1_butterfly(JacQ* __restrict__ X, int s
 //   stage 2:  X[k1+8 k2]  = sum_{n2 < 16} w^(n2 k1 + 8 n2 k2) A[k1][n2]
 // prod[(o * R + t) * stride + lane];  terms: number of non-zero input terms of the stage (forward FFT of (h || 0): 4).
 __global__ __launch_bounds__(64, 2) void k_g1_dft_products(const JacQ* __restrict__ in, JacQ* __restrict__ prod, int stride,
-                                                           int stage, int terms, int inverse, const uint32_t* __restrict__ jsf,
+                                                           int stage, int terms, int inverse, const uint32_t* __restrict__ tw,
                                                            Fq<1> beta) {
     const int R = stage == 1 ? 8 : 16;
     const int o = blockIdx.x / terms, t = blockIdx.x % terms, lane = blockIdx.y * 64 + threadIdx.x;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64, 2) void k_g1_dft_products(const JacQ* __restric
         e = (t * k1 + 8 * t * k2) & 127;
     }
     if (inverse) e = (128 - e) & 127;
-    prod[((size_t)o * R + t) * stride + lane] = mul_by_twiddle(in[(size_t)src * stride + lane], jsf, beta, e);
+    prod[((size_t)o * R + t) * stride + lane] = mul_by_twiddle(in[(size_t)src * stride + lane], tw, beta, e);
 }
 // out[perm(o)] = sum_{t < terms} prod[o][t]; block = 256 threads = 64 lanes x 4 partial sums
 __global__ __launch_bounds__(256) void k_g1_dft_sum(const JacQ* __restrict__ prod, JacQ* __restrict__ out, int stride, int R,
@@ -145,14 +145,14 @@ __global__ __launch_bounds__(256) void k_g1_dft_sum(const JacQ* __restrict__ pro
 namespace launch {
 // mode 0: DIT butterfly (a, b) -> (a + w b, a - w b);  mode 1: DIF butterfly (a, b) -> (a + b, (a - b) w);
 // mode 2: DIF first layer with b == identity: b <- a w;  mode 3: DIT last layer keeping only a <- a + w b.
-void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int mode, const void* jsf, const Fp12w& beta,
+void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int mode, const void* tw, const Fp12w& beta,
                   hipStream_t st) {
     Fp b384;
     for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
     const Fq<1> bt = fq_from_fp(b384);  // host-side conversion to the 14 x 29-bit Montgomery-406 form
     dim3 grid(64, stride / 64);
     JacQ* x = (JacQ*)X;
-    const uint32_t* js = (const uint32_t*)jsf;
+    const uint32_t* js = (const uint32_t*)tw;
     switch (mode) {
         case 0:
             k_g1_twiddle_mul<<<grid, 64, 0, st>>>(x, stride, half, tw_step, inverse, 0, js, bt);
@@ -175,11 +175,11 @@ void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int m
 // n_in: number of leading non-identity inputs (128, or 64 for (h || 0)); n_out: outputs wanted (128 or the first 64);
 // tmpA [128][stride], prod [128*16][stride].  Output goes back to X (natural order, or bit-reversed if brp_out).
 void g1_dft128_direct(void* X, void* tmpA, void* prod, int stride, int n_in, int n_out, int inverse, int brp_out,
-                      const void* jsf, const Fp12w& beta, hipStream_t st) {
+                      const void* tw, const Fp12w& beta, hipStream_t st) {
     Fp b384;
     for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
     const Fq<1> bt = fq_from_fp(b384);
-    const uint32_t* js = (const uint32_t*)jsf;
+    const uint32_t* js = (const uint32_t*)tw;
     const int terms1 = n_in / 16;   // n1 < n_in / 16
     const int outs2 = n_out;        // k < n_out  <=>  k2 < n_out / 8
     const int groups = stride / 64;

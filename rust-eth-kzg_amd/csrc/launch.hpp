@@ -33,11 +33,11 @@ void build_table(int c, const void* bases /*G1Affine*/, void* table /*G1Affine*/
                  int nb, hipStream_t st);
 
 // k_g1fft.hip
-void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int mode, const void* jsf, const Fp12w& beta,
+void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int mode, const void* tw, const Fp12w& beta,
                   hipStream_t st);
 
 void g1_dft128_direct(void* X, void* tmpA, void* prod, int stride, int n_in, int n_out, int inverse, int brp_out,
-                      const void* jsf, const Fp12w& beta, hipStream_t st);
+                      const void* tw, const Fp12w& beta, hipStream_t st);
 
 // k_g1misc.hip
 void g1_set_inf(void* X, size_t n, hipStream_t st);
