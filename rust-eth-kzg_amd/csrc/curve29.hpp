@@ -156,6 +156,39 @@ HD JacQ add_mixed_slow(const JacQ& p, const AffQ& q, bool negq) {
     return jacq_inf();
 }
 
+// Mixed addition with a table point whose coordinates are fresh products (< 2p, not canonical) and which is never the
+// identity: the twiddle multiplication's table after it has been brought to a common Z (k_g1fft.hip).
+struct AffQ2 {
+    Fq<2> x, y;
+};
+HD JacQ add_mixed_slow(const JacQ& p, const AffQ2& q, bool negq);
+HD JacQ add_mixed(const JacQ& p, const AffQ2& q, bool negq) {
+    Fq<2> z1z1 = sqr(p.z);
+    Fq<2> u2 = mul(q.x, z1z1);
+    Fq<2> s2p = mul(mul(q.y, p.z), z1z1);
+    auto h = sub(u2, p.x);
+    auto rr = dbl(signed_sub(negq, s2p, p.y));
+    Fq<2> hh = sqr(h);
+    Fq<8> i = dbl2(hh);
+    Fq<2> j = mul(h, i);
+    Fq<2> v = mul(p.x, i);
+    JacQ r;
+    auto x3 = sub_sub2(sqr(rr), j, v);
+    r.x = relax<XB>(x3);
+    r.y = relax<XB>(mul_add(rr, sub(v, x3), neg2(p.y), j));
+    const Fq<2> zh = mul(p.z, h);
+    r.z = dbl(zh);
+    if (product_is_zero(zh)) return add_mixed_slow(p, q, negq);
+    return r;
+}
+HD JacQ add_mixed_slow(const JacQ& p, const AffQ2& q, bool negq) {
+    JacQ qj;
+    qj.x = relax<XB>(q.x);
+    qj.y = relax<XB>(q.y);
+    qj.z = relax<ZB>(fq_one());
+    return add_slow(p, qj, negq);  // identity accumulator, P + P or P - P: the general slow path decides
+}
+
 // XYZZ accumulator for long runs of mixed additions (the fixed-base MSM): (X, Y, ZZ, ZZZ) stands for the affine point
 // (X / ZZ, Y / ZZZ), ZZ^3 = ZZZ^2; identity <=> ZZ == 0.  madd-2008-s costs 6M + 2S + one fused product pair against
 // 6M + 3S + one fused pair for the Jacobian form above, and needs none of its doublings of intermediate values.

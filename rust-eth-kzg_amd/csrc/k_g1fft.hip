@@ -23,15 +23,35 @@ __device__ __forceinline__ JacQ mul_by_twiddle(const JacQ& p, const uint32_t* __
     if (k == 0) return p;
     if (k == 64) return neg(p);
     constexpr int NT = 1 << (launch::TWIDDLE_WNAF_W - 2);  // odd multiples P, 3P, .., (2 NT - 1) P
-    JacQ T[NT];
-    Fq<XB> bx[NT];
+    // The table is brought to ONE common Z = prod z_j without an inversion: (X_j l_j^2, Y_j l_j^3) with l_j = Z / z_j are
+    // the affine coordinates of the same points on the isomorphic curve y^2 = x^3 + 4 Z^6.  The group law for a = 0
+    // never looks at b, and phi(x, y) = (beta x, y) is an endomorphism of that curve too, so the whole multiplication
+    // runs there with MIXED additions (6M + 3S + pair instead of 10M + 4S + pair) and one final Z <- Z * Z_common.
+    AffQ2 A[NT];
+    Fq<2> bx[NT];
+    Fq<ZB> zc;
     {
+        JacQ T[NT];
+        Fq<ZB> pre[NT];  // pre[j] = z_0 ... z_j
         const JacQ p2 = dbl(p);
         T[0] = p;
+        pre[0] = p.z;
 #pragma unroll 1
-        for (int j = 1; j < NT; j++) T[j] = add(T[j - 1], p2);
+        for (int j = 1; j < NT; j++) {
+            T[j] = add(T[j - 1], p2);
+            pre[j] = relax<ZB>(mul(pre[j - 1], T[j].z));
+        }
+        zc = pre[NT - 1];
+        Fq<ZB> suf = relax<ZB>(fq_one());  // z_(j+1) ... z_(NT-1)
 #pragma unroll 1
-        for (int j = 0; j < NT; j++) bx[j] = relax<XB>(mul(T[j].x, beta));  // phi(X : Y : Z) = (beta X : Y : Z)
+        for (int j = NT - 1; j >= 0; j--) {
+            const Fq<ZB> lam = j > 0 ? relax<ZB>(mul(pre[j > 0 ? j - 1 : 0], suf)) : suf;  // product of all the other z
+            const Fq<2> l2 = sqr(lam);
+            A[j].x = mul(T[j].x, l2);
+            A[j].y = mul(T[j].y, mul(l2, lam));
+            bx[j] = mul(A[j].x, beta);
+            suf = relax<ZB>(mul(suf, T[j].z));
+        }
     }
     const uint32_t* row = tab + (size_t)k * (2 * launch::TWIDDLE_WORDS);
     JacQ acc = jacq_inf();
@@ -49,13 +69,18 @@ __device__ __forceinline__ JacQ mul_by_twiddle(const JacQ& p, const uint32_t* __
                 const int d = (int)(int8_t)((h ? w2 : w1) >> (8 * q));
                 if (d == 0) continue;
                 const int idx = ((d < 0 ? -d : d) - 1) >> 1;
-                JacQ op = T[idx];
+                AffQ2 op = A[idx];
                 if (h) op.x = bx[idx];
-                if (!started) { acc = d < 0 ? neg(op) : op; started = true; }
-                else acc = add(acc, op, d < 0);
+                if (!started) {
+                    acc.x = relax<XB>(op.x);
+                    acc.y = d < 0 ? relax<XB>(neg(op.y)) : relax<XB>(op.y);
+                    acc.z = relax<ZB>(fq_one());
+                    started = true;
+                } else acc = add_mixed(acc, op, d < 0);
             }
         }
     }
+    acc.z = relax<ZB>(mul(acc.z, zc));  // back from the isomorphic curve
     return acc;
 }
 

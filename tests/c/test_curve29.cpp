@@ -50,6 +50,17 @@ int main() {
         expect(add_mixed(jacq_inf(), qa, true), neg(Q), "O-Q mixed");
         AffQ inf_a = affq_from_affine(aff_inf());
         expect(add_mixed(p, inf_a), P, "P+O mixed");
+        // mixed addition with a non-canonical affine operand (the twiddle table on the isomorphic curve with Z = 1)
+        {
+            AffQ2 q2;
+            q2.x = mul(qa.x, fq_one());  // same value, as a fresh product (< 2p)
+            q2.y = mul(qa.y, fq_one());
+            expect(add_mixed(p, q2, false), add_mixed(P, Qaff), "madd2");
+            expect(add_mixed(p, q2, true), add_mixed(P, neg(Qaff)), "msub2");
+            expect(add_mixed(qj, q2, false), dbl(Q), "Q+Q mixed2");
+            expect(add_mixed(qj, q2, true), jac_inf(), "Q-Q mixed2");
+            expect(add_mixed(jacq_inf(), q2, true), neg(Q), "O-Q mixed2");
+        }
         // XYZZ accumulator (the MSM's): sums of +-q onto p and the exceptional cases
         {
             XyzzQ xa = xyzz_inf();
