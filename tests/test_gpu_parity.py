@@ -378,8 +378,11 @@ def test_every_batch_size_regime_matches_oracle(ctx, oracle, n):
     a[:, :, 0] &= 0x3F
     blobs = [a[i].tobytes() for i in range(n)]
     blobs[n // 2] = synth.dummy_blob()
+    blobs[0] = bytes(131072)                                  # zero polynomial: every G1 intermediate is the identity
+    blobs[n - 1] = (b"\x00" * 31 + b"\x07") * 4096           # constant polynomial: identity proofs, non-trivial commitment
     st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs)
     assert st == [0] * n
+    assert proofs[0] == [b"\xc0" + bytes(47)] * 128 and proofs[n - 1] == [b"\xc0" + bytes(47)] * 128
     for b in sorted({0, n // 2, n - 1}):
         ec, ep = oracle.compute_cells_and_kzg_proofs(blobs[b])
         assert cells[b] == ec and proofs[b] == ep, (n, b)
