@@ -27,12 +27,6 @@ namespace kzg {
 
 static constexpr int N_BLOB = 4096, BYTES_PER_BLOB = 131072;
 
-struct DevBuf4 {
-    void* p = nullptr;
-    explicit DevBuf4(size_t bytes) { if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) throw std::runtime_error("hipMalloc failed"); }
-    ~DevBuf4() { if (p) hipFree(p); }
-    DevBuf4(const DevBuf4&) = delete;
-};
 
 static bool fr_from_be_canonical(Fr& out_mont, const uint8_t* b) {  // deserialize_bytes_to_scalar (serialization/src/lib.rs:50-63)
     Fr x;
@@ -81,7 +75,7 @@ int Engine::open_blobs_at(int n, const uint8_t* const* blobs, const Fr8* z_mont,
     hipStream_t st = stream_;
     ensure_workspace(n);
     const int bp = ((n + 63) / 64) * 64;
-    DevBuf4 d_blobs((size_t)n * BYTES_PER_BLOB), d_z((size_t)n * 32), d_y((size_t)n * 32), d_pr((size_t)n * 48);
+    PoolBuf d_blobs(*this, (size_t)n * BYTES_PER_BLOB), d_z(*this, (size_t)n * 32), d_y(*this, (size_t)n * 32), d_pr(*this, (size_t)n * 48);
     for (int b = 0; b < n; b++)
         HIPCK(hipMemcpyAsync((uint8_t*)d_blobs.p + (size_t)b * BYTES_PER_BLOB, blobs[b], BYTES_PER_BLOB, hipMemcpyHostToDevice, st));
     HIPCK(hipMemcpyAsync(d_z.p, z_mont, (size_t)n * 32, hipMemcpyHostToDevice, st));
@@ -129,12 +123,12 @@ int Engine::compute_kzg_proof_host(const uint8_t* blob, const uint8_t* z_bytes, 
 
 // decompress + subgroup-check a few points on the GPU; returns per-point status
 static void check_points(Engine* eng, const uint8_t* bytes, int n, void* d_out_affine, int* h_status, hipStream_t st, const Fp12w& beta) {
-    DevBuf4 d_b((size_t)n * 48), d_st((size_t)n * sizeof(int));
+    PoolBuf d_b(*eng, (size_t)n * 48), d_st(*eng, (size_t)n * sizeof(int));
     HIPCK(hipMemcpyAsync(d_b.p, bytes, (size_t)n * 48, hipMemcpyHostToDevice, st));
     launch::g1_decompress((const uint8_t*)d_b.p, d_out_affine, (int*)d_st.p, n, 1, beta, st);
     HIPCK(hipMemcpyAsync(h_status, d_st.p, n * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCK(hipStreamSynchronize(st));
-    (void)eng;
+
 }
 
 int Engine::compute_blob_kzg_proof_host(const uint8_t* blob, const uint8_t* commitment, uint8_t* out_proof) {
@@ -149,7 +143,7 @@ int Engine::compute_blob_kzg_proof_host(const uint8_t* blob, const uint8_t* comm
         const uint8_t* bl[1] = {blob};
         open_blobs_at(1, bl, &z8, true, proof, &y8, &st);
         if (st) return ERR_SCALAR;
-        DevBuf4 d_pt(sizeof(G1Affine));
+        PoolBuf d_pt(*this, sizeof(G1Affine));
         check_points(this, commitment, 1, d_pt.p, &cst, stream_, beta_);  // only validated (prover.rs:73-75)
         if (cst) return ERR_G1;
         memcpy(out_proof, proof, 48);
@@ -165,7 +159,7 @@ int Engine::compute_blob_kzg_proof_host(const uint8_t* blob, const uint8_t* comm
 int Engine::pairing_check_4844(const void* d_points, const std::vector<Fr8>& sc0, const std::vector<Fr8>& sc1) {
     hipStream_t st = stream_;
     const int n0 = (int)sc0.size(), n1 = (int)sc1.size();
-    DevBuf4 d_s0((size_t)n0 * 32), d_s1((size_t)n1 * 32), d_ws(launch::pip_workspace_bytes(n1 > n0 ? n1 : n0)), d_out(2 * sizeof(G1Affine));
+    PoolBuf d_s0(*this, (size_t)n0 * 32), d_s1(*this, (size_t)n1 * 32), d_ws(*this, launch::pip_workspace_bytes(n1 > n0 ? n1 : n0)), d_out(*this, 2 * sizeof(G1Affine));
     HIPCK(hipMemcpyAsync(d_s0.p, sc0.data(), (size_t)n0 * 32, hipMemcpyHostToDevice, st));
     HIPCK(hipMemcpyAsync(d_s1.p, sc1.data(), (size_t)n1 * 32, hipMemcpyHostToDevice, st));
     launch::msm_pippenger2(d_points, d_s0.p, n0, d_s1.p, n1, d_ws.p, d_out.p, st);
@@ -188,7 +182,7 @@ int Engine::verify_kzg_proof_host(const uint8_t* commitment, const uint8_t* z_by
     try {
         HIPCK(hipSetDevice(dev_));
         // point array [pi | C | G]
-        DevBuf4 d_pts(3 * sizeof(G1Affine));
+        PoolBuf d_pts(*this, 3 * sizeof(G1Affine));
         uint8_t two[96];
         memcpy(two, proof, 48);
         memcpy(two + 48, commitment, 48);
@@ -227,7 +221,7 @@ int Engine::verify_blob_kzg_proof_batch_host(uint64_t n_blobs, const uint8_t* co
         if (n) open_blobs_at(n, blobs, z8.data(), false, nullptr, y8.data(), bst.data());
         for (int i = 0; i < n; i++) if (bst[i]) return ERR_SCALAR;          // blobs first,
         // point array [proofs n | commitments n | G]
-        DevBuf4 d_pts((size_t)(2 * n + 1) * sizeof(G1Affine));
+        PoolBuf d_pts(*this, (size_t)(2 * n + 1) * sizeof(G1Affine));
         std::vector<uint8_t> pb((size_t)2 * n * 48 + 1);
         std::vector<int> pst(2 * n + 1);
         for (int i = 0; i < n; i++) { memcpy(&pb[(size_t)i * 48], proofs[i], 48); memcpy(&pb[(size_t)(n + i) * 48], commitments[i], 48); }

@@ -81,6 +81,54 @@ static void glv_split(const Fr& canon, u128& k1, u128& k2) {
     k2 = q;
 }
 // ---------------------------------------------------------------------------------------------
+BufferPool::~BufferPool() {
+    for (auto& f : free_) {
+        if (host_) (void)hipHostFree(f.second);
+        else (void)hipFree(f.second);
+    }
+}
+void* BufferPool::get(size_t bytes, size_t* cls) {
+    size_t c = 256;
+    while (c < bytes) c <<= 1;
+    *cls = c;
+    for (size_t i = 0; i < free_.size(); i++)
+        if (free_[i].first == c) {
+            void* p = free_[i].second;
+            free_[i] = free_.back();
+            free_.pop_back();
+            pooled_ -= c;
+            return p;
+        }
+    void* p = nullptr;
+    hipError_t e = host_ ? hipHostMalloc(&p, c, hipHostMallocDefault) : hipMalloc(&p, c);
+    if (e != hipSuccess) {  // give the cached blocks back and retry once
+        (void)hipGetLastError();
+        for (auto& f : free_) { if (host_) (void)hipHostFree(f.second); else (void)hipFree(f.second); }
+        free_.clear();
+        pooled_ = 0;
+        e = host_ ? hipHostMalloc(&p, c, hipHostMallocDefault) : hipMalloc(&p, c);
+        if (e != hipSuccess) throw std::runtime_error(host_ ? "hipHostMalloc failed" : "hipMalloc failed");
+    }
+    return p;
+}
+void BufferPool::put(void* p, size_t cls) {
+    constexpr size_t KEEP = 6ull << 30;  // cached bytes per pool; larger working sets fall back to plain free
+    if (pooled_ + cls > KEEP) {
+        if (host_) (void)hipHostFree(p); else (void)hipFree(p);
+        return;
+    }
+    free_.emplace_back(cls, p);
+    pooled_ += cls;
+}
+PoolBuf::PoolBuf(Engine& e, size_t bytes, bool pinned_host) : e_(e), host_(pinned_host) {
+    p = (host_ ? e_.pin_pool_ : e_.dev_pool_).get(bytes ? bytes : 1, &cls_);
+}
+PoolBuf::~PoolBuf() {
+    (void)hipStreamSynchronize(e_.stream_);  // nothing in flight may still use the block (free when the stream is idle)
+    (host_ ? e_.pin_pool_ : e_.dev_pool_).put(p, cls_);
+}
+
+// ---------------------------------------------------------------------------------------------
 Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14 : 4) {
     if (use_precomp) {
         // default width 14: 145 GB of window tables, 19 windows -> 1216 gathered additions per MSM (HBM is 288 GB).

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 #include <memory>
 
@@ -26,8 +27,36 @@ enum Status : int {
     ERR_DEVICE = 5,    // HIP failure
 };
 
+// Scoped scratch buffers of the host-pointer entry points come from per-context pools instead of hipMalloc / hipFree
+// (both cost 0.1 - 1 ms and hipFree drains the device): blocks are kept by power-of-two size class and reused; the pool
+// is emptied with the context.  Callers hold Engine::mu_, so no locking here.
+class BufferPool {
+public:
+    explicit BufferPool(bool pinned_host) : host_(pinned_host) {}
+    ~BufferPool();
+    void* get(size_t bytes, size_t* cls);
+    void put(void* p, size_t cls);
+private:
+    bool host_;
+    std::vector<std::pair<size_t, void*>> free_;
+    size_t pooled_ = 0;
+};
+class Engine;
+struct PoolBuf {  // RAII: a block of at least `bytes` from the context's device (or pinned-host) pool
+    void* p = nullptr;
+    PoolBuf(Engine& e, size_t bytes, bool pinned_host = false);
+    ~PoolBuf();
+    PoolBuf(const PoolBuf&) = delete;
+    PoolBuf& operator=(const PoolBuf&) = delete;
+private:
+    Engine& e_;
+    size_t cls_ = 0;
+    bool host_;
+};
+
 class Engine {
 public:
+    friend struct PoolBuf;
     struct SharedTable;  // engine.hip
     // use_precomp: true -> the widest FK20 window table that fits in HBM (width 14 = 145 GB on an otherwise empty
     //              MI355X; the reference's UsePrecomp::Yes uses width 8 on the CPU), false -> width-4 tables (0.7 GB,
@@ -142,6 +171,7 @@ private:
     Fp12w beta_;                  // cube root of unity in Fp: (beta x, y) = [lambda](x, y)
     void* d_srs_ = nullptr;       // G1Affine[4096] monomial SRS
     void* d_fk_bases_ = nullptr;  // G1Affine[128][64] FFT'd SRS vectors (batch_toeplitz.rs:46-61)
+    BufferPool dev_pool_{false}, pin_pool_{true};
     std::shared_ptr<SharedTable> fk_tab_, srs_tab_;  // owners of the two tables below (shared by the contexts of a device)
     void* d_fk_table_ = nullptr;  // window table over d_fk_bases_
     void* d_srs_table_ = nullptr; // window table over d_srs_ viewed as [64][64]

@@ -44,12 +44,6 @@ static Fr8 to8(const Fr& a) { Fr8 r; memcpy(&r, &a, 32); return r; }
 static Fr from8(const Fr8& a) { Fr r; memcpy(&r, &a, 32); return r; }
 static int brp7(int v) { int r = 0; for (int i = 0; i < 7; i++) r |= ((v >> i) & 1) << (6 - i); return r; }
 
-struct DevBuf {  // scoped device allocation
-    void* p = nullptr;
-    explicit DevBuf(size_t bytes) { if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) throw std::runtime_error("hipMalloc failed"); }
-    ~DevBuf() { if (p) hipFree(p); }
-    DevBuf(const DevBuf&) = delete;
-};
 
 void Engine::init_verifier() {
     launch::init_attributes_verify();
@@ -316,7 +310,9 @@ int Engine::recover_batch_to_coeffs(int R, const uint64_t* n_cells, const uint8_
     std::vector<int> slot, stof;
     size_t total_cells = 0;
     for (int r = 0; r < R; r++) total_cells += st_out[r] == OK ? n_cells[r] : 0;
-    std::vector<uint8_t> hcells(total_cells * BYTES_PER_CELL);
+    PoolBuf hcells_buf(*this, total_cells * BYTES_PER_CELL, true);  // pinned staging: the H2D copy below runs at link speed
+    uint8_t* hcells = (uint8_t*)hcells_buf.p;
+    const size_t hcells_bytes = total_cells * BYTES_PER_CELL;
     slot.reserve(total_cells);
     stof.reserve(total_cells);
     size_t pos = 0;
@@ -339,12 +335,12 @@ int Engine::recover_batch_to_coeffs(int R, const uint64_t* n_cells, const uint8_
     const int n = (int)total_cells;
     Fr seven64 = fr_u64(7);
     for (int i = 0; i < 6; i++) seven64 = sqr(seven64);
-    DevBuf d_cellb(hcells.size()), d_slot((size_t)n * sizeof(int)), d_stof((size_t)n * sizeof(int));
-    DevBuf d_E((size_t)R * N_EXT * sizeof(Fr)), d_T((size_t)R * N_EXT * sizeof(Fr)), d_U((size_t)R * N_EXT * sizeof(Fr));
-    DevBuf d_zp((size_t)R * 65 * sizeof(Fr)), d_deg(R * sizeof(int)), d_present(present.size() * 4);
-    DevBuf d_zeval((size_t)R * N_CELLS * sizeof(Fr)), d_zcinv((size_t)R * N_CELLS * sizeof(Fr)), d_st(R * sizeof(int));
+    PoolBuf d_cellb(*this, hcells_bytes), d_slot(*this, (size_t)n * sizeof(int)), d_stof(*this, (size_t)n * sizeof(int));
+    PoolBuf d_E(*this, (size_t)R * N_EXT * sizeof(Fr)), d_T(*this, (size_t)R * N_EXT * sizeof(Fr)), d_U(*this, (size_t)R * N_EXT * sizeof(Fr));
+    PoolBuf d_zp(*this, (size_t)R * 65 * sizeof(Fr)), d_deg(*this, R * sizeof(int)), d_present(*this, present.size() * 4);
+    PoolBuf d_zeval(*this, (size_t)R * N_CELLS * sizeof(Fr)), d_zcinv(*this, (size_t)R * N_CELLS * sizeof(Fr)), d_st(*this, R * sizeof(int));
     if (n) {
-        HIPCK(hipMemcpyAsync(d_cellb.p, hcells.data(), hcells.size(), hipMemcpyHostToDevice, st));
+        HIPCK(hipMemcpyAsync(d_cellb.p, hcells, hcells_bytes, hipMemcpyHostToDevice, st));
         HIPCK(hipMemcpyAsync(d_slot.p, slot.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
         HIPCK(hipMemcpyAsync(d_stof.p, stof.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
     }
@@ -402,12 +398,14 @@ int Engine::recover_cells_and_kzg_proofs_batch_host(int R, const uint64_t* n_cel
         if (rc) return rc;
         lap("stage in + RS decode");
         // compute_multi_opening_proofs(Input::PolyCoeff) = stages C..I (prover.rs:164-170) for the whole batch
-        DevBuf d_c((size_t)R * N_CELLS * BYTES_PER_CELL), d_p((size_t)R * N_CELLS * 48);
+        PoolBuf d_c(*this, (size_t)R * N_CELLS * BYTES_PER_CELL), d_p(*this, (size_t)R * N_CELLS * 48);
         launch::coeffs_to_cells(R, d_coeffs_, (uint8_t*)d_c.p, d_w8192_, stream_);
         run_proofs_from_coeffs(R, (uint8_t*)d_p.p, stream_);
-        std::vector<uint8_t> hc((size_t)R * N_CELLS * BYTES_PER_CELL), hp((size_t)R * N_CELLS * 48);
-        HIPCK(hipMemcpyAsync(hc.data(), d_c.p, hc.size(), hipMemcpyDeviceToHost, stream_));
-        HIPCK(hipMemcpyAsync(hp.data(), d_p.p, hp.size(), hipMemcpyDeviceToHost, stream_));
+        PoolBuf hc_buf(*this, (size_t)R * N_CELLS * BYTES_PER_CELL, true), hp_buf(*this, (size_t)R * N_CELLS * 48, true);
+        const uint8_t* hc = (const uint8_t*)hc_buf.p;
+        const uint8_t* hp = (const uint8_t*)hp_buf.p;
+        HIPCK(hipMemcpyAsync(hc_buf.p, d_c.p, (size_t)R * N_CELLS * BYTES_PER_CELL, hipMemcpyDeviceToHost, stream_));
+        HIPCK(hipMemcpyAsync(hp_buf.p, d_p.p, (size_t)R * N_CELLS * 48, hipMemcpyDeviceToHost, stream_));
         HIPCK(hipStreamSynchronize(stream_));
         lap("cells + proofs + D2H");
         for (int r = 0; r < R; r++) {
