@@ -321,38 +321,56 @@ static std::map<std::tuple<int, int, int>, std::weak_ptr<Engine::SharedTable>> g
 
 // returns false (and leaves *table null) if the device cannot hold the table + scratch
 static bool build_table(int c, const void* bases, void** table, size_t* bytes, int n_groups, int nb, hipStream_t st) {
-    // groups are built in chunks so that the Jacobian scratch (144 B per entry) stays below ~24 GB
+    // groups are built in chunks so that the scratch stays small: 56 B per entry for the wave-wide builder (widths >= 10),
+    // 144 B per entry (Jacobian) for the thread-per-window builder that serves widths 4 and 8
+    const bool fast = c >= 10;  // width 8 (128 entries per window = two wave steps) is quicker with the simple builder
     const size_t per_group = launch::table_entries(c, 1, nb);
-    int chunk = (int)((24ull << 30) / (per_group * sizeof(G1Jac)));
+    const size_t scratch_per_entry = fast ? 56 : sizeof(G1Jac);
+    int chunk = (int)((fast ? (9ull << 30) : (24ull << 30)) / (per_group * scratch_per_entry));
     if (chunk < 1) chunk = 1;
     if (chunk > n_groups) chunk = n_groups;
     const size_t entries = per_group * n_groups;
-    void* scratch = nullptr;
+    const size_t side_bytes = fast ? launch::table_fast_side_bytes(c, chunk, nb) : 0;
+    void *scratch = nullptr, *side = nullptr;
+    int* d_err = nullptr;
     *table = nullptr;
     size_t free_b = 0, total_b = 0;
     HIPCK(hipMemGetInfo(&free_b, &total_b));
-    const size_t need = entries * launch::SIZEOF_AFFQ + per_group * chunk * sizeof(G1Jac) + (8ull << 30);  // + head-room for batches
+    const size_t need = entries * launch::SIZEOF_AFFQ + per_group * chunk * scratch_per_entry + side_bytes + (8ull << 30);  // + head-room for batches
     if (need > free_b) return false;
     const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
+    auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     if (hipMalloc(table, entries * launch::SIZEOF_AFFQ) != hipSuccess) { (void)hipGetLastError(); *table = nullptr; return false; }
-    if (hipMalloc(&scratch, per_group * chunk * sizeof(G1Jac)) != hipSuccess) {
+    if (hipMalloc(&scratch, per_group * chunk * scratch_per_entry) != hipSuccess ||
+        (fast && (hipMalloc(&side, side_bytes) != hipSuccess || hipMalloc(&d_err, sizeof(int)) != hipSuccess))) {
         (void)hipGetLastError();
+        if (scratch) (void)hipFree(scratch);
+        if (side) (void)hipFree(side);
         HIPCK(hipFree(*table));
         *table = nullptr;
         return false;
     }
-    if (trace) fprintf(stderr, "[context]   table c=%d: hipMalloc %.1f GB  %8.1f ms\n", c, (entries * launch::SIZEOF_AFFQ + per_group * chunk * sizeof(G1Jac)) / 1e9,
-                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (trace) fprintf(stderr, "[context]   table c=%d: hipMalloc %.1f GB  %8.1f ms\n", c,
+                       (entries * launch::SIZEOF_AFFQ + per_group * chunk * scratch_per_entry + side_bytes) / 1e9, ms());
+    if (fast) HIPCK(hipMemsetAsync(d_err, 0, sizeof(int), st));
     for (int g0 = 0; g0 < n_groups; g0 += chunk) {
         int g = n_groups - g0 < chunk ? n_groups - g0 : chunk;
-        launch::build_table(c, (const char*)bases + (size_t)g0 * nb * sizeof(G1Affine),
-                            (char*)*table + (size_t)g0 * per_group * launch::SIZEOF_AFFQ, scratch, g, nb, st);
+        const char* b = (const char*)bases + (size_t)g0 * nb * sizeof(G1Affine);
+        char* t = (char*)*table + (size_t)g0 * per_group * launch::SIZEOF_AFFQ;
+        if (fast) launch::build_table_fast(c, b, t, scratch, side, g, nb, d_err, st);
+        else launch::build_table(c, b, t, scratch, g, nb, st);
         HIPCK(hipStreamSynchronize(st));
     }
-    if (trace) fprintf(stderr, "[context]   table c=%d: built            %8.1f ms\n", c, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (fast) {
+        int err = 0;
+        HIPCK(hipMemcpy(&err, d_err, sizeof(int), hipMemcpyDeviceToHost));
+        HIPCK(hipFree(d_err));
+        HIPCK(hipFree(side));
+        if (err) throw std::runtime_error("window table: a base point of small order");
+    }
+    if (trace) fprintf(stderr, "[context]   table c=%d: built            %8.1f ms\n", c, ms());
     HIPCK(hipFree(scratch));
-    if (trace) fprintf(stderr, "[context]   table c=%d: scratch freed    %8.1f ms\n", c, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     *bytes = entries * launch::SIZEOF_AFFQ;
     return true;
 }

@@ -53,7 +53,180 @@ __global__ __launch_bounds__(64) void k_build_table(const G1Affine* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast builder for widths >= 8 (2^(c-1) entries per (base, window) is a multiple of 64): two kernels in the unsaturated field.
+//  k_table_windows : thread per base: Q_w = 2^(c w) P and 64 Q_w for every window, normalised to affine with one inversion.
+//  k_table_fill    : ONE WAVE per (base, window).  Lane l starts at (l + 1) Q and steps by 64 Q, so at step k the wave
+//                    holds the 64 consecutive entries d = 64 k + l + 1: every load and store is a contiguous 7 KiB run
+//                    (the thread-per-(base, window) builder above strides each lane through its own 0.9 MB region and is
+//                    bound by address translation, not arithmetic).  Normalisation without a per-entry inversion: along a
+//                    lane Z_(k+1) = Z_k * f_k with f_k = 2 H_k from the mixed addition, so 1 / Z_k = (1 / Z_(k+1)) * f_k:
+//                    one binary-GCD inversion per lane per 2^(c-1) / 64 entries, one multiplication per entry on the way back.
+//                    X, Y wait in the destination slot (2 x 56 B = one table entry), f_k in a 56 B/entry scratch.
+__device__ __forceinline__ Fq<1> reduce_once(const Fq<2>& t) {  // t < 2p -> canonical
+    uint32_t d[QL];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < QL; i++) {
+        uint32_t x = t.v[i] - q29::P[i] - borrow;
+        borrow = x >> 31;
+        d[i] = x & QMASK;
+    }
+    Fq<1> r;
+#pragma unroll
+    for (int i = 0; i < QL; i++) r.v[i] = borrow ? t.v[i] : d[i];
+    return r;
+}
+template <int B>
+__device__ __forceinline__ Fq<1> fq_inv(const Fq<B>& z) {  // through the saturated form, where the binary-GCD inversion lives
+    return fq_from_fp(inv_fast(fp_from_fq(z)));
+}
+// p + q with the factor f = Z3 / Z1 (2 H in general; 2 Y1 when p == q and the sum is a doubling)
+__device__ __forceinline__ JacQ add_mixed_f(const JacQ& p, const AffQ& q, Fq<260>& f) {
+    Fq<2> z1z1 = sqr(p.z);
+    Fq<2> u2 = mul(q.x, z1z1);
+    Fq<2> s2p = mul(mul(q.y, p.z), z1z1);
+    auto h = sub(u2, p.x);
+    auto rr = dbl(signed_sub(false, s2p, p.y));
+    Fq<2> hh = sqr(h);
+    Fq<8> i = dbl2(hh);
+    Fq<2> j = mul(h, i);
+    Fq<2> v = mul(p.x, i);
+    JacQ r;
+    auto x3 = sub_sub2(sqr(rr), j, v);
+    r.x = relax<XB>(x3);
+    r.y = relax<XB>(mul_add(rr, sub(v, x3), neg2(p.y), j));
+    const Fq<2> zh = mul(p.z, h);
+    r.z = dbl(zh);
+    f = relax<260>(dbl(h));
+    if (product_is_zero(zh)) {  // same x: the table only ever meets p == q here (d Q + 64 Q with d = 64)
+        r = dbl(p);
+        f = relax<260>(dbl(p.y));
+    }
+    return r;
+}
+
+template <int C>
+__global__ void k_table_windows(const G1Affine* __restrict__ bases, AffQ* __restrict__ qw /*[n][2][W]*/, JacQ* __restrict__ tmp,
+                                Fq<2>* __restrict__ pre, int n_bases) {
+    constexpr int W = (255 + C) / C;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_bases) return;
+    AffQ* out = qw + (size_t)b * 2 * W;
+    const AffQ P = affq_from_affine(bases[b]);
+    if (is_inf(P)) {
+        for (int i = 0; i < 2 * W; i++) out[i] = P;
+        return;
+    }
+    JacQ* J = tmp + (size_t)b * 2 * W;
+    Fq<2>* pr = pre + (size_t)b * 2 * W;
+    JacQ cur = to_jacq(P);
+    for (int w = 0; w < W; w++) {
+        J[w] = cur;
+        for (int s = 0; s < C; s++) {
+            cur = dbl(cur);
+            if (s == 5) J[W + w] = cur;  // 64 Q_w
+        }
+    }
+    Fq<2> prod = relax<2>(fq_one());
+    for (int i = 0; i < 2 * W; i++) { pr[i] = prod; prod = mul(prod, J[i].z); }
+    Fq<2> inv = relax<2>(fq_inv(prod));
+    for (int i = 2 * W - 1; i >= 0; i--) {
+        const JacQ p = J[i];
+        const Fq<2> zi = mul(inv, pr[i]);
+        inv = mul(inv, p.z);
+        const Fq<2> zi2 = sqr(zi);
+        AffQ a;
+        a.x = reduce_once(mul(p.x, zi2));
+        a.y = reduce_once(mul(p.y, mul(zi2, zi)));
+        out[i] = a;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(64) void k_table_fill(const AffQ* __restrict__ qw, AffQ* __restrict__ table, Fq<260>* __restrict__ scratch,
+                                                   int nb, int* __restrict__ err) {
+    constexpr int W = (255 + C) / C;
+    constexpr int T = 1 << (C - 1), K = T / 64;
+    static_assert(T % 64 == 0, "wave-wide fill needs at least 64 entries per window");
+    const int lane = threadIdx.x;
+    const long blk = blockIdx.x;  // = (group * W + w) * nb + i : the table's own block order
+    const int i = (int)(blk % nb), w = (int)((blk / nb) % W);
+    const long group = blk / ((long)nb * W);
+    const long base = group * nb + i;
+    const AffQ Q = qw[(size_t)base * 2 * W + w], S = qw[(size_t)base * 2 * W + W + w];
+    AffQ* dst = table + ((size_t)blk << (C - 1));
+    Fq<260>* scr = scratch + ((size_t)blk << (C - 1));
+    if (is_inf(Q)) {  // identity base (wave-uniform): an all-identity block
+        for (int k = 0; k < K; k++) dst[k * 64 + lane] = Q;
+        return;
+    }
+    // (lane + 1) Q by double-and-add over 7 bits, branch-free across lanes
+    JacQ cur = jacq_inf();
+    const int n = lane + 1;
+#pragma unroll 1
+    for (int bit = 6; bit >= 0; bit--) {
+        cur = dbl(cur);
+        const JacQ t = add_mixed(cur, Q);
+        const bool take = (n >> bit) & 1;
+        cur.x = select(take, t.x, cur.x);
+        cur.y = select(take, t.y, cur.y);
+        cur.z = select(take, t.z, cur.z);
+    }
+    struct Raw { Fq<XB> x, y; };  // same 112 bytes as an AffQ
+    Raw* raw = reinterpret_cast<Raw*>(dst);
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {
+        raw[k * 64 + lane].x = cur.x;
+        raw[k * 64 + lane].y = cur.y;
+        if (k + 1 < K) {
+            Fq<260> f;
+            cur = add_mixed_f(cur, S, f);
+            scr[k * 64 + lane] = f;
+        }
+    }
+    if (is_inf(cur)) atomicOr(err, 1);  // cannot happen for a base of prime order
+    Fq<2> zinv = relax<2>(fq_inv(cur.z));
+#pragma unroll 1
+    for (int k = K - 1; k >= 0; k--) {
+        const Fq<XB> X = raw[k * 64 + lane].x, Y = raw[k * 64 + lane].y;
+        const Fq<2> zi2 = sqr(zinv);
+        AffQ a;
+        a.x = reduce_once(mul(X, zi2));
+        a.y = reduce_once(mul(Y, mul(zi2, zinv)));
+        dst[k * 64 + lane] = a;
+        if (k > 0) zinv = mul(zinv, scr[(k - 1) * 64 + lane]);
+    }
+}
+
 namespace launch {
+template <int C>
+static void table_fast_c(const void* bases, void* table, void* scratch, void* qw, void* tmp, void* pre, int n_groups, int nb, int* err,
+                         hipStream_t st) {
+    const int n_bases = n_groups * nb;
+    constexpr int W = (255 + C) / C;
+    k_table_windows<C><<<(n_bases + 63) / 64, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)qw, (JacQ*)tmp, (Fq<2>*)pre, n_bases);
+    k_table_fill<C><<<(unsigned)((long)n_bases * W), 64, 0, st>>>((const AffQ*)qw, (AffQ*)table, (Fq<260>*)scratch, nb, err);
+}
+// side buffers of the fast builder, in bytes, for a chunk of n_groups groups
+size_t table_fast_side_bytes(int c, int n_groups, int nb) {
+    const size_t W = (255 + c) / c, n = (size_t)n_groups * nb;
+    return n * 2 * W * (SIZEOF_AFFQ + SIZEOF_JACQ + 56) + 256;
+}
+bool build_table_fast(int c, const void* bases, void* table, void* scratch /*56 B per entry*/, void* side, int n_groups, int nb,
+                      int* err, hipStream_t st) {
+    const size_t W = (255 + c) / c, n = (size_t)n_groups * nb;
+    char* qw = (char*)side;
+    char* tmp = qw + n * 2 * W * SIZEOF_AFFQ;
+    char* pre = tmp + n * 2 * W * SIZEOF_JACQ;
+    if (c == 8) table_fast_c<8>(bases, table, scratch, qw, tmp, pre, n_groups, nb, err, st);
+    else if (c == 10) table_fast_c<10>(bases, table, scratch, qw, tmp, pre, n_groups, nb, err, st);
+    else if (c == 12) table_fast_c<12>(bases, table, scratch, qw, tmp, pre, n_groups, nb, err, st);
+    else if (c == 13) table_fast_c<13>(bases, table, scratch, qw, tmp, pre, n_groups, nb, err, st);
+    else if (c == 14) table_fast_c<14>(bases, table, scratch, qw, tmp, pre, n_groups, nb, err, st);
+    else return false;
+    return true;
+}
 size_t table_entries(int c, int n_groups, int nb) {
     int W = (255 + c) / c;
     return ((size_t)n_groups * nb * W) << (c - 1);

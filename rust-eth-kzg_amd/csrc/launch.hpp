@@ -29,6 +29,9 @@ void msm_fixed_flat(int c, const void* scalars, const void* table, void* out /*G
                int out_stride, int brp_bits, hipStream_t st);
 // k_table.hip
 size_t table_entries(int c, int n_groups, int nb);
+size_t table_fast_side_bytes(int c, int n_groups, int nb);
+// widths >= 8: wave-per-(base, window) builder; scratch = 56 B per entry of the chunk, side = table_fast_side_bytes; false if c unsupported
+bool build_table_fast(int c, const void* bases, void* table, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st);
 void build_table(int c, const void* bases /*G1Affine*/, void* table /*G1Affine*/, void* scratch /*G1Jac*/, int n_groups,
                  int nb, hipStream_t st);
 
