@@ -260,6 +260,12 @@ void Engine::init_constants() {
         HIPCK(hipMalloc(&d_circ_terms_, all.size() * 4));
         HIPCK(hipMemcpy(d_circ_terms_, all.data(), all.size() * 4, hipMemcpyHostToDevice));
     }
+    for (int sgi = 0; sgi < 3; sgi++) {  // Montgomery forms of 2^32, 2^64, 2^96 (k_fk20_scalars' segment copies)
+        Fr v = zero<FrParams>();
+        v.v[sgi + 1] = 1;
+        v = to_mont(v);
+        memcpy(&seg_shift_[sgi], &v, 32);
+    }
     Fr i4096 = inv(fr_from_u64(N_BLOB)), i128 = inv(fr_from_u64(128));
     memcpy(&n_inv4096_, &i4096, 32);
     memcpy(&inv128_, &i128, 32);
@@ -487,18 +493,22 @@ void Engine::g1_fft128_full(void* X, int stride, int inverse, hipStream_t st) {
 // stages C..G of SURVEY 3.2 from coefficients already in d_coeffs_
 void Engine::run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st) {
     const int bp = ((n + 63) / 64) * 64;
+    // one or two blobs: the MSM also delivers 2^32 u, 2^64 u, 2^96 u (scaled copies of the scalars, same tables), which
+    // cuts the doubling chain of the circulant form into four parallel quarters (needs 32 * 4 >= T - 1 doublings)
+    const int segs = (n > circ_max_ || circ_T_ > 129) ? 1 : n <= 2 ? 4 : n <= 4 ? 2 : 1;
+    const Fr8 two_segments[3] = {seg_shift_[1], seg_shift_[1], seg_shift_[1]};  // 2^64
     mark_begin(ST_FK20_SCALARS, st);
-    launch::fk20_scalars(n, d_coeffs_, d_scalars_, d_w8192_, inv128_, st);
+    launch::fk20_scalars(n, d_coeffs_, d_scalars_, d_w8192_, inv128_, segs, segs == 2 ? two_segments : seg_shift_, st);
     mark_end(1, st);
     launch::g1_set_inf(d_X_, (size_t)128 * bp, st);
     const bool latency_mode = bp <= LATENCY_MODE_MAX_LANES;  // few 64-blob groups: direct 8 x 16 transforms, 4 rounds instead of 14
     mark_begin(ST_MSM_FIXED, st);
-    launch_msm(d_scalars_, d_fk_table_, d_X_, 128, n, bp, latency_mode ? 0 : 7, st);
+    launch_msm(d_scalars_, d_fk_table_, d_X_, 128, segs * n, bp, latency_mode ? 0 : 7, st);
     mark_end(1, st);
     if (n <= circ_max_) {  // a handful of blobs: the two transforms as one circulant product (k_g1circ.hip)
         if (!d_circ_table_) HIPCK(hipMalloc(&d_circ_table_, launch::g1_circ_table_bytes(circ_max_, circ_T_)));
         mark_begin(ST_G1_IFFT, st);
-        launch::g1_circ128(d_X_, bp, n, d_circ_table_, circ_T_, d_circ_terms_, circ_per_lane_, beta_, st);
+        launch::g1_circ128(d_X_, bp, n, segs, d_circ_table_, circ_T_, d_circ_terms_, circ_per_lane_, beta_, st);
         mark_end(2, st);
     } else if (latency_mode) {
         if (!d_dft_tmp_) {

@@ -19,16 +19,22 @@
 namespace kzg {
 using launch::CIRC_LANES;
 
-__global__ __launch_bounds__(64) void k_g1_dbl_table(const JacQ* __restrict__ X, int stride, int n, JacQ* __restrict__ D,
+// segs > 1: the MSM stage has also produced 2^(32 s) u[j] in lane s * n + b (k_fk20_scalars scales the scalars), so the
+// chain of T doublings splits into `segs` independent chains of 128 / segs (the last takes the remainder): thread = (segment, blob, j).
+__global__ __launch_bounds__(64) void k_g1_dbl_table(const JacQ* __restrict__ X, int stride, int n, int segs, JacQ* __restrict__ D,
                                                      int T, Fq<1> beta) {
     const int tid = blockIdx.x * 64 + threadIdx.x;
-    if (tid >= n * N_CELLS) return;
-    const int b = tid >> 7, j = tid & 127;
-    JacQ p = X[(size_t)j * stride + b];
-    JacQ* d0 = D + (size_t)tid * 2 * T;
+    if (tid >= segs * n * N_CELLS) return;
+    const int seg = tid / (n * N_CELLS), bj = tid - seg * n * N_CELLS;
+    const int b = bj >> 7, j = bj & 127;
+    const int seg_len = 128 / segs;  // 32 (four segments) or 64 (two)
+    const int t0 = seg_len * seg;
+    const int t1 = seg + 1 < segs ? t0 + seg_len : T;
+    JacQ p = X[(size_t)j * stride + seg * n + b];
+    JacQ* d0 = D + (size_t)bj * 2 * T;
     JacQ* d1 = d0 + T;
 #pragma unroll 1
-    for (int t = 0; t < T; t++) {
+    for (int t = t0; t < t1; t++) {
         d0[t] = p;
         JacQ q = p;
         q.x = relax<XB>(mul(p.x, beta));  // phi(X : Y : Z) = (beta X : Y : Z)
@@ -77,11 +83,11 @@ __global__ __launch_bounds__(CIRC_LANES) void k_g1_circ_sum(const JacQ* __restri
 namespace launch {
 size_t g1_circ_table_bytes(int n, int T) { return (size_t)n * N_CELLS * 2 * T * sizeof(JacQ); }
 // X: [128][stride] MSM outputs (natural order) -> X: proofs (bit-reversed), for blobs 0 .. n-1
-void g1_circ128(void* X, int stride, int n, void* D, int T, const void* terms, int per_lane, const Fp12w& beta, hipStream_t st) {
+void g1_circ128(void* X, int stride, int n, int segs, void* D, int T, const void* terms, int per_lane, const Fp12w& beta, hipStream_t st) {
     Fp b384;
     for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
     const Fq<1> bt = fq_from_fp(b384);
-    k_g1_dbl_table<<<(n * N_CELLS + 63) / 64, 64, 0, st>>>((const JacQ*)X, stride, n, (JacQ*)D, T, bt);
+    k_g1_dbl_table<<<(segs * n * N_CELLS + 63) / 64, 64, 0, st>>>((const JacQ*)X, stride, n, segs, (JacQ*)D, T, bt);
     k_g1_circ_sum<<<dim3(N_CELLS, n), CIRC_LANES, 0, st>>>((const JacQ*)D, T, (const uint32_t*)terms, per_lane, (JacQ*)X, stride);
 }
 }  // namespace launch

@@ -112,8 +112,12 @@ __global__ __launch_bounds__(1024) void k_coeffs_to_cells(const Fr* __restrict__
 // scalars[b][j][i] = NTT_128(v)[j] * 128^-1  (the 128^-1 of the later G1 inverse FFT, domain.rs:189-191,
 // folded in here because everything downstream is linear), stored OUT of Montgomery form for the
 // MSM's window extraction.  grid = n_blobs * 16, block = 256 (4 vectors per block, one per wave).
+// segs > 1 (tiny batches only): copies of every scalar multiplied by 2^(128 seg / segs) are written as extra "blobs"
+// seg * n + b, so that the MSM stage also delivers 2^32 u, 2^64 u, 2^96 u (four segments; 2^64 u for two) and the
+// doubling chain of k_g1circ.hip splits into `segs` independent shorter chains.
+struct SegShifts { Fr p[3]; };  // Montgomery forms of the segment shifts, p[seg - 1]
 __global__ __launch_bounds__(256) void k_fk20_scalars(const Fr* __restrict__ coeffs, Fr* __restrict__ scalars,
-                                                      const Fr* __restrict__ w8192, Fr inv128) {
+                                                      const Fr* __restrict__ w8192, Fr inv128, int n, int segs, SegShifts sh) {
     __shared__ uint32_t s[4][8][128];
     const int b = blockIdx.x >> 4, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = ((blockIdx.x & 15) << 2) + wv;
@@ -148,6 +152,8 @@ __global__ __launch_bounds__(256) void k_fk20_scalars(const Fr* __restrict__ coe
         for (int l = 0; l < 8; l++) x.v[l] = sv[l][q];
         int j = __brev((unsigned)q) >> 25;
         scalars[((size_t)b * 128 + j) * 64 + i] = from_mont(x);
+        for (int sg = 1; sg < segs; sg++)
+            scalars[((size_t)(sg * n + b) * 128 + j) * 64 + i] = from_mont(mul(x, sh.p[sg - 1]));
     }
 }
 
@@ -201,8 +207,11 @@ void blob_to_coeffs(int n, const uint8_t* blobs, void* coeffs, void* canon, int*
 void coeffs_to_cells(int n, const void* coeffs, uint8_t* cells, const void* w8192, hipStream_t st) {
     k_coeffs_to_cells<<<dim3(n, 2), 1024, LDS_NTT, st>>>((const Fr*)coeffs, cells, (const Fr*)w8192);
 }
-void fk20_scalars(int n, const void* coeffs, void* scalars, const void* w8192, const Fr8& inv128, hipStream_t st) {
-    k_fk20_scalars<<<n * 16, 256, 0, st>>>((const Fr*)coeffs, (Fr*)scalars, (const Fr*)w8192, as_fr(inv128));
+void fk20_scalars(int n, const void* coeffs, void* scalars, const void* w8192, const Fr8& inv128, int segs, const Fr8* seg_shifts,
+                  hipStream_t st) {
+    SegShifts sh;
+    for (int i = 0; i < 3; i++) sh.p[i] = as_fr(seg_shifts[i]);
+    k_fk20_scalars<<<n * 16, 256, 0, st>>>((const Fr*)coeffs, (Fr*)scalars, (const Fr*)w8192, as_fr(inv128), n, segs, sh);
 }
 void test_ntt4096(const uint8_t* in, uint8_t* out, const void* w8192, const Fr8& n_inv, int inverse_dit, hipStream_t st) {
     k_test_ntt4096<<<1, 1024, LDS_NTT, st>>>(in, out, (const Fr*)w8192, as_fr(n_inv), inverse_dit);

@@ -16,7 +16,7 @@ void init_attributes();  // opt in to 128 KiB dynamic LDS for the NTT kernels
 void blob_to_coeffs(int n, const uint8_t* blobs, void* coeffs /*Fr*/, void* canon /*Fr or null*/, int* status,
                     const void* w8192, const Fr8& n_inv, hipStream_t st);
 void coeffs_to_cells(int n, const void* coeffs, uint8_t* cells, const void* w8192, hipStream_t st);
-void fk20_scalars(int n, const void* coeffs, void* scalars /*Fr canonical*/, const void* w8192, const Fr8& inv128,
+void fk20_scalars(int n, const void* coeffs, void* scalars, const void* w8192, const Fr8& inv128, int segs, const Fr8* seg_shifts,
                   hipStream_t st);
 void test_ntt4096(const uint8_t* in, uint8_t* out, const void* w8192, const Fr8& n_inv, int inverse_dit, hipStream_t st);
 void test_scalars_be(const uint8_t* in, void* out, size_t n, hipStream_t st);
@@ -60,7 +60,7 @@ constexpr int TWIDDLE_WORDS = 33;   // 132 signed digit bytes per 128-bit half
 // k_g1circ.hip
 constexpr int CIRC_LANES = 256;
 size_t g1_circ_table_bytes(int n, int T);
-void g1_circ128(void* X, int stride, int n, void* D, int T, const void* terms, int per_lane, const Fp12w& beta, hipStream_t st);
+void g1_circ128(void* X, int stride, int n, int segs, void* D, int T, const void* terms, int per_lane, const Fp12w& beta, hipStream_t st);
 // k_verify.hip
 void init_attributes_verify();
 // slot_of: destination cell slot per input cell (null = identity); status_of: status word per input cell (null = word 0)
