@@ -193,7 +193,7 @@ private:
 
     // small-batch circulant form of the two G1 transforms: term list, doubling tables (allocated on first use)
     void *d_circ_terms_ = nullptr, *d_circ_table_ = nullptr;
-    int circ_T_ = 0, circ_per_lane_ = 0, circ_max_ = 16;
+    int circ_T_ = 0, circ_per_lane_ = 0, circ_max_ = 32;  // measured cross-over with the direct 8 x 16 form: ~32 blobs
     Fr8 seg_shift_[3];  // 2^32, 2^64, 2^96 in Montgomery form
     void *d_dft_tmp_ = nullptr, *d_dft_prod_ = nullptr;  // latency-mode G1 transforms (one 64-blob group)
 

@@ -367,10 +367,11 @@ def test_eip4844_round_trip_on_synthetic_blobs(ctx, oracle):
     assert ctx.verify_kzg_proof(comms[1], z, y, p) is False
 
 
-@pytest.mark.parametrize("n", [2, 8, 9, 16, 17, 64, 65, 129, 200])
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 8, 9, 32, 33, 64, 65, 129, 200])
 def test_every_batch_size_regime_matches_oracle(ctx, oracle, n):
-    """The engine picks its G1 schedule by batch size (<= 8: flat MSM + circulant transforms, <= 16: circulant,
-    <= 128: direct 8 x 16 transforms, above: the radix-2 network).  Every regime and both sides of every threshold
+    """The engine picks its G1 schedule by batch size (<= 2 / <= 4: flat MSM over 4 / 2 scalar segments + segmented
+    doubling chains, <= 8: flat MSM + circulant transforms, <= 32: circulant, <= 128: direct 8 x 16 transforms, above:
+    the radix-2 network).  Every regime and both sides of every threshold
     must give the oracle's bytes; blobs not checked against the oracle are checked against the single-blob path."""
     import numpy as np
     rng = np.random.RandomState(1000 + n)
