@@ -247,12 +247,59 @@ HD Felt<P> mul_fips(const Felt<P>& a, const Felt<P>& b) {
     return r;
 }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host form: the same limbs read as N/2 64-bit words (little-endian host), CIOS with 128-bit products: ~3x fewer multiply
+// instructions than the 32-bit form above.  Backs the pairing check, SRS set-up and the transcript scalars.
+template <class P>
+inline Felt<P> mul_host64(const Felt<P>& a, const Felt<P>& b) {
+    constexpr int N = P::N / 2;
+    static_assert(P::N % 2 == 0, "even limb count");
+    typedef unsigned __int128 u128;
+    uint64_t A[N], B[N], M[N], t[N + 2];
+    for (int i = 0; i < N; i++) {
+        A[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+        B[i] = (uint64_t)b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
+        M[i] = (uint64_t)P::MOD[2 * i] | ((uint64_t)P::MOD[2 * i + 1] << 32);
+    }
+    uint64_t inv = M[0];  // Newton iteration for M[0]^-1 mod 2^64 (correct to 3 bits, doubling each round)
+    for (int i = 0; i < 6; i++) inv *= 2 - M[0] * inv;
+    const uint64_t n0 = 0 - inv;
+    for (int i = 0; i < N + 2; i++) t[i] = 0;
+    for (int i = 0; i < N; i++) {
+        u128 c = 0;
+        for (int j = 0; j < N; j++) {
+            c += (u128)A[j] * B[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[N];
+        t[N] = (uint64_t)c;
+        t[N + 1] = (uint64_t)(c >> 64);
+        const uint64_t m = t[0] * n0;
+        c = (u128)m * M[0] + t[0];
+        c >>= 64;
+        for (int j = 1; j < N; j++) {
+            c += (u128)m * M[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[N];
+        t[N - 1] = (uint64_t)c;
+        t[N] = t[N + 1] + (uint64_t)(c >> 64);
+    }
+    Felt<P> r;
+    for (int i = 0; i < N; i++) { r.v[2 * i] = (uint32_t)t[i]; r.v[2 * i + 1] = (uint32_t)(t[i] >> 32); }
+    reduce_once(r);
+    return r;
+}
+#endif
+
 template <class P>
 HD Felt<P> mul(const Felt<P>& a, const Felt<P>& b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return mul_fips(a, b);
 #else
-    return mul_cios(a, b);
+    return mul_host64(a, b);
 #endif
 }
 template <class P>

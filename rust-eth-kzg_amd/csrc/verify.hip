@@ -262,7 +262,11 @@ int Engine::verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8
     int st = verify_cells_partial(n_commitments, commitments, n_indices, cell_indices, n_cells, cells, n_proofs, proofs, 0,
                                   n_cells, pts, &empty);
     if (st) return st;
+    const auto t0 = std::chrono::steady_clock::now();
     *verified = (empty || verify_cells_pairing(pts)) ? 1 : 0;
+    if (getenv("ETH_KZG_AMD_TRACE"))
+        fprintf(stderr, "[verify] %-28s %8.3f ms\n", "pairing check (host)",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return OK;
 }
 

@@ -34,3 +34,10 @@ def test_unsaturated_group_law_matches_saturated_formulas(tmp_path):
     plain Jacobian formulas of csrc/curve.hpp: random points, P+P, P-P, identities, mixed chains."""
     out = _build_and_run(tmp_path, "test_curve29")
     assert "0 mismatches" in out
+
+
+@pytest.mark.timeout(600)
+def test_host_multiplication_64_bit_matches_32_bit(tmp_path):
+    """csrc/field.hpp: the host's 64-bit-limb Montgomery multiplication against the portable 32-bit CIOS form."""
+    out = _build_and_run(tmp_path, "test_host_mul")
+    assert "0 mismatches" in out
