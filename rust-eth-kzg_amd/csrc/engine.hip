@@ -31,7 +31,7 @@ namespace kzg {
 
 // batches up to this many lanes (blobs rounded up to 64) use the direct 8 x 16 G1 transforms (k_g1fft.hip)
 static constexpr int FLAT_MSM_MAX_SLICES = 8;  // measured: 1 blob 0.23 ms (vs 1.0), 16 blobs 1.6 ms (vs 1.06): one block per MSM pays while the chip is not full
-static constexpr int LATENCY_MODE_MAX_LANES = 128;  // measured: 64 -> 13.4 ms, 128 -> 22.3 ms, 192 -> 30.1 ms vs 26.5 ms for the radix-2 network
+static constexpr int LATENCY_MODE_MAX_LANES = 128;  // direct 8 x 16 transforms up to two 64-blob groups (128 blobs: 14.6 ms; the radix-2 network needs 17 ms at any batch below ~1000)
 static constexpr int N_BLOB = 4096, N_EXT = 8192, N_CELLS = 128, CELL_LEN = 64, BYTES_PER_BLOB = 131072, BYTES_PER_CELL = 2048;
 static_assert(sizeof(Fr) == launch::SIZEOF_FR && sizeof(G1Affine) == launch::SIZEOF_G1AFFINE && sizeof(G1Jac) == launch::SIZEOF_G1JAC, "layout");
 
