@@ -162,7 +162,7 @@ int Engine::pairing_check_4844(const void* d_points, const std::vector<Fr8>& sc0
     PoolBuf d_s0(*this, (size_t)n0 * 32), d_s1(*this, (size_t)n1 * 32), d_ws(*this, launch::pip_workspace_bytes(n1 > n0 ? n1 : n0)), d_out(*this, 2 * sizeof(G1Affine));
     HIPCK(hipMemcpyAsync(d_s0.p, sc0.data(), (size_t)n0 * 32, hipMemcpyHostToDevice, st));
     HIPCK(hipMemcpyAsync(d_s1.p, sc1.data(), (size_t)n1 * 32, hipMemcpyHostToDevice, st));
-    launch::msm_pippenger2(d_points, d_s0.p, n0, d_s1.p, n1, d_ws.p, d_out.p, st);
+    launch::msm_pippenger2(d_points, d_s0.p, n0, d_s1.p, n1, d_ws.p, d_out.p, beta_, st);
     G1Affine out[2];
     HIPCK(hipMemcpyAsync(out, d_out.p, sizeof out, hipMemcpyDeviceToHost, st));
     HIPCK(hipStreamSynchronize(st));

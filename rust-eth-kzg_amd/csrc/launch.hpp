@@ -76,7 +76,7 @@ void interp(const void* evals, const int* cell_idx, const void* rp_mont, const v
 size_t pip_workspace_bytes(int n_max);
 void copy_affine(const void* src, void* dst, int n, hipStream_t st);
 void msm_pippenger2(const void* points, const void* sc0, int n0, const void* sc1, int n1, void* workspace, void* out_affine2,
-                    hipStream_t st);
+                    const Fp12w& beta, hipStream_t st);
 void rec_dit_half(int R, const void* V, const void* fac, void* T, const void* w8192, hipStream_t st);
 void rec_dit_last(int R, const void* T, const void* shift, const Fr8& n_inv, void* U, void* coeffs, int* status,
                   const void* w8192, int final_pass, hipStream_t st);

@@ -236,7 +236,7 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
         // ---- the four lincombs (verifier.rs:186,200,224,235) as two bucket MSMs over the shared point array:
         //   out[0] = sum r^k pi_k;   out[1] = sum r^k h^64 pi_k + sum w_row C_row - commit(interpolation poly)
         View d_ws{db + off_ws}, d_out{db + off_out};
-        launch::msm_pippenger2(d_pts.p, d_s1.p, n, d_sB.p, n + m + 64, d_ws.p, d_out.p, st);
+        launch::msm_pippenger2(d_pts.p, d_s1.p, n, d_sB.p, n + m + 64, d_ws.p, d_out.p, beta_, st);
         HIPCK(hipMemcpyAsync(out, d_out.p, 2 * sizeof(G1Affine), hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
         lap("scalars+interp+lincombs (GPU)");
