@@ -137,7 +137,7 @@ Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14
             if (c == 8 || c == 10 || c == 12 || c == 13 || c == 14) c_ = c;
         }
     }
-    srs_c_ = use_precomp ? 8 : 4;
+    srs_c_ = use_precomp ? 13 : 4;  // commitment table over the monomial SRS: 37.6 GB at width 13 (20 windows instead of 32)
     if (const char* s = getenv("ETH_KZG_AMD_CIRC_MAX")) {  // tuning knob: largest batch served by the circulant form (0 disables it)
         int v = atoi(s);
         if (v >= 0 && v <= 64) circ_max_ = v;
@@ -401,7 +401,11 @@ void Engine::init_fk20() {
         g_tables[key] = t;
         return t;
     };
-    srs_tab_ = obtain(0, srs_c_, d_srs_, 64);  // SRS viewed as [64][64]
+    static const int srs_widths[] = {13, 12, 10, 8, 4};
+    for (int w : srs_widths) {  // SRS viewed as [64][64]; the widest table that is resident already or still fits
+        if (w > srs_c_) continue;
+        if ((srs_tab_ = obtain(0, w, d_srs_, 64))) { srs_c_ = w; break; }
+    }
     if (!srs_tab_) throw std::runtime_error("not enough device memory for the commitment window table");
     d_srs_table_ = srs_tab_->p;
     srs_table_bytes_ = srs_tab_->bytes;

@@ -160,7 +160,7 @@ private:
 
     int dev_ = 0;
     int c_ = 8;      // window width of the FK20 table
-    int srs_c_ = 8;  // window width of the commitment (monomial SRS) table
+    int srs_c_ = 13;  // window width of the commitment (monomial SRS) table (falls back like the FK20 table)
     hipStream_t stream_ = nullptr;
     std::recursive_mutex mu_;  // recursive: host-pointer entry points hold it across staging + the device call + read-back
     std::string err_;
