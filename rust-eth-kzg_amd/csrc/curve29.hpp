@@ -18,6 +18,13 @@ constexpr int ZB = 4;   // bound of stored z
 struct AffQ {  // canonical coordinates; identity = (0, 0)
     Fq<1> x, y;
 };
+// A window-table entry: the affine point padded to one 128-byte line.  At the natural 112-byte stride an entry straddles
+// 1.75 lines on average and the MSM's gathers fetch twice their algorithmic bytes (profiles/r1f_calib_fetch.log).
+struct alignas(16) TabQ {
+    AffQ a;
+    uint32_t pad[4];
+};
+static_assert(sizeof(TabQ) == 128, "table entries are one cache line");
 struct JacQ {  // identity <=> z == 0 mod p
     Fq<XB> x, y;
     Fq<ZB> z;

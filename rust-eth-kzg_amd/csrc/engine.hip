@@ -342,12 +342,12 @@ static bool build_table(int c, const void* bases, void** table, size_t* bytes, i
     *table = nullptr;
     size_t free_b = 0, total_b = 0;
     HIPCK(hipMemGetInfo(&free_b, &total_b));
-    const size_t need = entries * launch::SIZEOF_AFFQ + per_group * chunk * scratch_per_entry + side_bytes + (8ull << 30);  // + head-room for batches
+    const size_t need = entries * launch::SIZEOF_TABQ + per_group * chunk * scratch_per_entry + side_bytes + (8ull << 30);  // + head-room for batches
     if (need > free_b) return false;
     const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-    if (hipMalloc(table, entries * launch::SIZEOF_AFFQ) != hipSuccess) { (void)hipGetLastError(); *table = nullptr; return false; }
+    if (hipMalloc(table, entries * launch::SIZEOF_TABQ) != hipSuccess) { (void)hipGetLastError(); *table = nullptr; return false; }
     if (hipMalloc(&scratch, per_group * chunk * scratch_per_entry) != hipSuccess ||
         (fast && (hipMalloc(&side, side_bytes) != hipSuccess || hipMalloc(&d_err, sizeof(int)) != hipSuccess))) {
         (void)hipGetLastError();
@@ -358,12 +358,12 @@ static bool build_table(int c, const void* bases, void** table, size_t* bytes, i
         return false;
     }
     if (trace) fprintf(stderr, "[context]   table c=%d: hipMalloc %.1f GB  %8.1f ms\n", c,
-                       (entries * launch::SIZEOF_AFFQ + per_group * chunk * scratch_per_entry + side_bytes) / 1e9, ms());
+                       (entries * launch::SIZEOF_TABQ + per_group * chunk * scratch_per_entry + side_bytes) / 1e9, ms());
     if (fast) HIPCK(hipMemsetAsync(d_err, 0, sizeof(int), st));
     for (int g0 = 0; g0 < n_groups; g0 += chunk) {
         int g = n_groups - g0 < chunk ? n_groups - g0 : chunk;
         const char* b = (const char*)bases + (size_t)g0 * nb * sizeof(G1Affine);
-        char* t = (char*)*table + (size_t)g0 * per_group * launch::SIZEOF_AFFQ;
+        char* t = (char*)*table + (size_t)g0 * per_group * launch::SIZEOF_TABQ;
         if (fast) launch::build_table_fast(c, b, t, scratch, side, g, nb, d_err, st);
         else launch::build_table(c, b, t, scratch, g, nb, st);
         HIPCK(hipStreamSynchronize(st));
@@ -377,7 +377,7 @@ static bool build_table(int c, const void* bases, void** table, size_t* bytes, i
     }
     if (trace) fprintf(stderr, "[context]   table c=%d: built            %8.1f ms\n", c, ms());
     HIPCK(hipFree(scratch));
-    *bytes = entries * launch::SIZEOF_AFFQ;
+    *bytes = entries * launch::SIZEOF_TABQ;
     return true;
 }
 

@@ -21,7 +21,7 @@ __device__ __forceinline__ JacQ msm_acc_to_jacq(const MsmAcc& a) { return to_jac
 // Thread (m, w) accumulates the NB entries of MSM m = (slice, group) for window w; the W partial
 // sums of an MSM sit in adjacent lanes and are folded through LDS.
 // scalars: [msm][NB] canonical Fr.  out[(perm(group)) * out_stride + slice] Jacobian.
-// Arithmetic in the unsaturated 14 x 29-bit field (fp29.hpp): table entries are AffQ (112 B), running sums XyzzQ
+// Arithmetic in the unsaturated 14 x 29-bit field (fp29.hpp): table entries are AffQ padded to one 128-B line (TabQ), running sums XyzzQ
 // (224 B, registers only), folded and stored sums JacQ (168 B).
 __device__ __forceinline__ int booth_digit(const uint32_t* sc, int w, int c) {
     // (c+1)-bit window starting one bit below c*w; window 0 is padded with a zero bit
@@ -40,7 +40,7 @@ __device__ __forceinline__ int booth_digit(const uint32_t* sc, int w, int c) {
 }
 
 template <int C>
-__global__ __launch_bounds__(256, 2) void k_msm_fixed(const Fr* __restrict__ scalars, const AffQ* __restrict__ table,
+__global__ __launch_bounds__(256, 2) void k_msm_fixed(const Fr* __restrict__ scalars, const TabQ* __restrict__ table,
                                                    JacQ* __restrict__ out, int n_groups, int n_slices, int nb,
                                                    int out_stride, int brp_bits) {
     constexpr int W = (255 + C) / C;  // number of Booth windows
@@ -57,12 +57,12 @@ __global__ __launch_bounds__(256, 2) void k_msm_fixed(const Fr* __restrict__ sca
         slice = (int)(m / n_groups);
         group = (int)(m % n_groups);
         const Fr* sc = scalars + (size_t)m * nb;
-        const AffQ* tb = table + (((size_t)group * W + w) * nb << (C - 1));
+        const TabQ* tb = table + (((size_t)group * W + w) * nb << (C - 1));
         for (int i = 0; i < nb; i++) {
             int d = booth_digit(sc[i].v, w, C);
             if (d != 0) {
                 int ad = d < 0 ? -d : d;
-                AffQ p = tb[((size_t)i << (C - 1)) + (ad - 1)];
+                const AffQ p = tb[((size_t)i << (C - 1)) + (ad - 1)].a;
                 acc = add_mixed(acc, p, d < 0);
             }
         }
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void k_msm_fixed(const Fr* __restrict__ sca
 // to all 256 lanes (5 additions each for W = 19, nb = 64) and folded by an 8-level tree in LDS.  ~30 % more field
 // work than the kernel above, but the dependent chain drops from 64 + 5 additions to 5 + 8.
 template <int C>
-__global__ __launch_bounds__(256) void k_msm_fixed_flat(const Fr* __restrict__ scalars, const AffQ* __restrict__ table,
+__global__ __launch_bounds__(256) void k_msm_fixed_flat(const Fr* __restrict__ scalars, const TabQ* __restrict__ table,
                                                         JacQ* __restrict__ out, int n_groups, int nb, int out_stride,
                                                         int brp_bits) {
     constexpr int W = (255 + C) / C;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_msm_fixed_flat(const Fr* __restrict__ s
         const int d = booth_digit(sc[i].v, w, C);
         if (d != 0) {
             const int ad = d < 0 ? -d : d;
-            const AffQ p = table[((((size_t)group * W + w) * nb + i) << (C - 1)) + (ad - 1)];
+            const AffQ p = table[((((size_t)group * W + w) * nb + i) << (C - 1)) + (ad - 1)].a;
             xacc = add_mixed(xacc, p, d < 0);
         }
     }
@@ -123,7 +123,7 @@ namespace launch {
 template <int C>
 static void msm_flat_c(const void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,
                        int brp_bits, hipStream_t st) {
-    k_msm_fixed_flat<C><<<(unsigned)(n_groups * n_slices), 256, 0, st>>>((const Fr*)scalars, (const AffQ*)table, (JacQ*)out,
+    k_msm_fixed_flat<C><<<(unsigned)(n_groups * n_slices), 256, 0, st>>>((const Fr*)scalars, (const TabQ*)table, (JacQ*)out,
                                                                         n_groups, nb, out_stride, brp_bits);
 }
 void msm_fixed_flat(int c, const void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,
@@ -140,7 +140,7 @@ static void msm_c(const void* scalars, const void* table, void* out, int n_group
                   int brp_bits, hipStream_t st) {
     constexpr int PB = 256 / ((255 + C) / C);
     long total = (long)n_groups * n_slices;
-    k_msm_fixed<C><<<(unsigned)((total + PB - 1) / PB), 256, 0, st>>>((const Fr*)scalars, (const AffQ*)table, (JacQ*)out,
+    k_msm_fixed<C><<<(unsigned)((total + PB - 1) / PB), 256, 0, st>>>((const Fr*)scalars, (const TabQ*)table, (JacQ*)out,
                                                                      n_groups, n_slices, nb, out_stride, brp_bits);
 }
 void msm_fixed(int c, const void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,

@@ -9,7 +9,7 @@ namespace kzg {
 // normalised to affine with one inversion per thread (Montgomery's trick over the thread's entries).
 // bases: [n_groups][nb] affine.  scratch: one Fp per table entry (prefix products of the Z's).
 template <int C>
-__global__ __launch_bounds__(64) void k_build_table(const G1Affine* __restrict__ bases, AffQ* __restrict__ table,
+__global__ __launch_bounds__(64) void k_build_table(const G1Affine* __restrict__ bases, TabQ* __restrict__ table,
                                                     G1Jac* __restrict__ scratch, int n_groups, int nb) {
     constexpr int W = (255 + C) / C;
     constexpr int T = 1 << (C - 1);
@@ -20,10 +20,10 @@ __global__ __launch_bounds__(64) void k_build_table(const G1Affine* __restrict__
     long bi = t / W;
     int i = (int)(bi % nb), group = (int)(bi / nb);
     G1Affine P = bases[bi];
-    AffQ* dst = table + ((((size_t)group * W + w) * nb + i) << (C - 1));
+    TabQ* dst = table + ((((size_t)group * W + w) * nb + i) << (C - 1));
     G1Jac* scr = scratch + ((((size_t)group * W + w) * nb + i) << (C - 1));
     if (is_inf(P)) {
-        for (int d = 0; d < T; d++) dst[d] = affq_from_affine(aff_inf());
+        for (int d = 0; d < T; d++) dst[d].a = affq_from_affine(aff_inf());
         return;
     }
     G1Jac Q = to_jac(P);
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void k_build_table(const G1Affine* __restrict__
         G1Affine a;
         a.x = mul(scr[d].x, zi2);
         a.y = mul(scr[d].y, mul(zi2, zi));
-        dst[d] = affq_from_affine(a);  // canonical, Montgomery-406, 14 x 29-bit limbs
+        dst[d].a = affq_from_affine(a);  // canonical, Montgomery-406, 14 x 29-bit limbs
     }
 }
 
@@ -144,7 +144,7 @@ __global__ void k_table_windows(const G1Affine* __restrict__ bases, AffQ* __rest
 }
 
 template <int C>
-__global__ __launch_bounds__(64) void k_table_fill(const AffQ* __restrict__ qw, AffQ* __restrict__ table, Fq<260>* __restrict__ scratch,
+__global__ __launch_bounds__(64) void k_table_fill(const AffQ* __restrict__ qw, TabQ* __restrict__ table, Fq<260>* __restrict__ scratch,
                                                    int nb, int* __restrict__ err) {
     constexpr int W = (255 + C) / C;
     constexpr int T = 1 << (C - 1), K = T / 64;
@@ -155,10 +155,10 @@ __global__ __launch_bounds__(64) void k_table_fill(const AffQ* __restrict__ qw, 
     const long group = blk / ((long)nb * W);
     const long base = group * nb + i;
     const AffQ Q = qw[(size_t)base * 2 * W + w], S = qw[(size_t)base * 2 * W + W + w];
-    AffQ* dst = table + ((size_t)blk << (C - 1));
+    TabQ* dst = table + ((size_t)blk << (C - 1));
     Fq<260>* scr = scratch + ((size_t)blk << (C - 1));
     if (is_inf(Q)) {  // identity base (wave-uniform): an all-identity block
-        for (int k = 0; k < K; k++) dst[k * 64 + lane] = Q;
+        for (int k = 0; k < K; k++) dst[k * 64 + lane].a = Q;
         return;
     }
     // (lane + 1) Q by double-and-add over 7 bits, branch-free across lanes
@@ -173,7 +173,8 @@ __global__ __launch_bounds__(64) void k_table_fill(const AffQ* __restrict__ qw, 
         cur.y = select(take, t.y, cur.y);
         cur.z = select(take, t.z, cur.z);
     }
-    struct Raw { Fq<XB> x, y; };  // same 112 bytes as an AffQ
+    struct Raw { Fq<XB> x, y; uint32_t pad[4]; };  // X, Y wait in the entry they will become
+    static_assert(sizeof(Raw) == sizeof(TabQ), "in-place normalisation");
     Raw* raw = reinterpret_cast<Raw*>(dst);
 #pragma unroll 1
     for (int k = 0; k < K; k++) {
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(64) void k_table_fill(const AffQ* __restrict__ qw, 
         AffQ a;
         a.x = reduce_once(mul(X, zi2));
         a.y = reduce_once(mul(Y, mul(zi2, zinv)));
-        dst[k * 64 + lane] = a;
+        dst[k * 64 + lane].a = a;
         if (k > 0) zinv = mul(zinv, scr[(k - 1) * 64 + lane]);
     }
 }
@@ -206,7 +207,7 @@ static void table_fast_c(const void* bases, void* table, void* scratch, void* qw
     const int n_bases = n_groups * nb;
     constexpr int W = (255 + C) / C;
     k_table_windows<C><<<(n_bases + 63) / 64, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)qw, (JacQ*)tmp, (Fq<2>*)pre, n_bases);
-    k_table_fill<C><<<(unsigned)((long)n_bases * W), 64, 0, st>>>((const AffQ*)qw, (AffQ*)table, (Fq<260>*)scratch, nb, err);
+    k_table_fill<C><<<(unsigned)((long)n_bases * W), 64, 0, st>>>((const AffQ*)qw, (TabQ*)table, (Fq<260>*)scratch, nb, err);
 }
 // side buffers of the fast builder, in bytes, for a chunk of n_groups groups
 size_t table_fast_side_bytes(int c, int n_groups, int nb) {
@@ -235,12 +236,12 @@ void build_table(int c, const void* bases, void* table, void* scratch, int n_gro
     int W = (255 + c) / c;
     long threads = (long)n_groups * nb * W;
     unsigned blocks = (unsigned)((threads + 63) / 64);
-    if (c == 8) k_build_table<8><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)table, (G1Jac*)scratch, n_groups, nb);
-    else if (c == 12) k_build_table<12><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)table, (G1Jac*)scratch, n_groups, nb);
-    else if (c == 13) k_build_table<13><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)table, (G1Jac*)scratch, n_groups, nb);
-    else if (c == 14) k_build_table<14><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)table, (G1Jac*)scratch, n_groups, nb);
-    else if (c == 10) k_build_table<10><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)table, (G1Jac*)scratch, n_groups, nb);
-    else k_build_table<4><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)table, (G1Jac*)scratch, n_groups, nb);
+    if (c == 8) k_build_table<8><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (TabQ*)table, (G1Jac*)scratch, n_groups, nb);
+    else if (c == 12) k_build_table<12><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (TabQ*)table, (G1Jac*)scratch, n_groups, nb);
+    else if (c == 13) k_build_table<13><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (TabQ*)table, (G1Jac*)scratch, n_groups, nb);
+    else if (c == 14) k_build_table<14><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (TabQ*)table, (G1Jac*)scratch, n_groups, nb);
+    else if (c == 10) k_build_table<10><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (TabQ*)table, (G1Jac*)scratch, n_groups, nb);
+    else k_build_table<4><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (TabQ*)table, (G1Jac*)scratch, n_groups, nb);
 }
 }  // namespace launch
 }  // namespace kzg

@@ -86,7 +86,8 @@ void rec_dif_half(int R, const void* U, const void* fac, void* V, const void* w8
 void quotient_by_linear(int n, const void* coeffs, const void* z_mont, void* quotient, void* y_out, hipStream_t st);
 
 constexpr size_t SIZEOF_FR = 32, SIZEOF_G1AFFINE = 96, SIZEOF_G1JAC = 144;
-constexpr size_t SIZEOF_AFFQ = 112, SIZEOF_JACQ = 168;  // unsaturated 14 x 29-bit forms (curve29.hpp): table entries, FFT arrays
+constexpr size_t SIZEOF_AFFQ = 112, SIZEOF_JACQ = 168;  // unsaturated 14 x 29-bit forms (curve29.hpp): affine points, FFT arrays
+constexpr size_t SIZEOF_TABQ = 128;                     // a window-table entry: an AffQ padded to one 128-B line
 
 }  // namespace launch
 }  // namespace kzg
