@@ -57,7 +57,7 @@ def synth_blobs(n, seed):
     return a.reshape(n, BYTES_PER_BLOB)
 
 
-def cpu_baseline(blobs, budget_s=15.0):
+def cpu_baseline(blobs, budget_s=15.0, gpu_first=None):
     """Time the CPU oracle (C restatement of the reference algorithm: FK20, width-8 window tables, batched
     affine additions) on this box's host cores.  Two CPU configurations are timed on a bounded sample:
       * blob-parallel: one single-threaded prover per worker thread, distinct blobs, all host cores busy
@@ -99,8 +99,13 @@ def cpu_baseline(blobs, budget_s=15.0):
     # --- blob-parallel over all cores (ctypes releases the GIL; the context is read-only while computing)
     o = Oracle(use_precomp=True, threads=1)
     t1 = time.time()
-    o.compute_cells_and_kzg_proofs(blobs[0])
+    ref_cells, ref_proofs = o.compute_cells_and_kzg_proofs(blobs[0])
     single_thread = 1.0 / (time.time() - t1)
+    agrees = None
+    if gpu_first is not None:  # the oracle doubles as the checker here: the GPU's bytes for blob 0 of the timed batch
+        agrees = (b"".join(ref_cells) == gpu_first[0]) and (b"".join(ref_proofs) == gpu_first[1])
+        if not agrees:
+            raise SystemExit("bench.py: GPU cells/proofs of blob 0 differ from the CPU oracle")
     workers = cores
     per_worker = 2
     def work(w):
@@ -120,6 +125,7 @@ def cpu_baseline(blobs, budget_s=15.0):
                       f"{dt:.1f} s with one single-threaded prover per host thread ({workers} threads) = {par:.1f} blobs/s; "
                       f"(b) one blob at a time with OpenMP over the maybe_rayon axes = {rayon[best_th]:.1f} blobs/s at "
                       f"{best_th} threads; single thread = {single_thread:.2f} blobs/s",
+            "gpu_matches_oracle_on_blob0": agrees,
             "blob_parallel": {"value": par, "threads": workers},
             "single_thread": single_thread,
             "rayon_like": {"value": rayon[best_th], "threads": best_th, "all": {str(k): round(v, 2) for k, v in rayon.items()},
@@ -275,7 +281,8 @@ def main():
             "context_creation_s": round(t_ctx, 2),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline([bytes(blobs_h[i].tobytes()) for i in range(min(B, 16))])
+            gpu_first = (bytes(d_cells[:CELLS * BYTES_PER_CELL].cpu().numpy()), bytes(d_proofs[:CELLS * 48].cpu().numpy()))
+            out["cpu_baseline"] = cpu_baseline([bytes(blobs_h[i].tobytes()) for i in range(min(B, 16))], gpu_first=gpu_first)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if world > 1:
