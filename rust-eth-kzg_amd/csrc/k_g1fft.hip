@@ -93,12 +93,13 @@ __device__ __forceinline__ JacQ mul_by_twiddle(const JacQ& p, const uint32_t* __
 // grid = (n_bfly = 64, stride/64), block = 64 (one wave = one butterfly x 64 blobs).
 __global__ __launch_bounds__(64, 2) void k_g1_twiddle_mul(JacQ* __restrict__ X, int stride, int half, int tw_step, int inverse,
                                                           int from_a, const uint32_t* __restrict__ tw, Fq<1> beta) {
-    const int q = blockIdx.x, lane = blockIdx.y * 64 + threadIdx.x;
+    // in-place layers launch only the butterflies whose twiddle is not 1 (j != 0): compact index c -> q = c + c / (half - 1) + 1
+    const int c = blockIdx.x, lane = blockIdx.y * 64 + threadIdx.x;
+    const int q = from_a ? c : c + c / (half - 1) + 1;
     const int j = q & (half - 1);
     const int i0 = ((q - j) << 1) + j, i1 = i0 + half;
     int e = (j * tw_step) & 127;
     if (inverse) e = (128 - e) & 127;
-    if (e == 0 && !from_a) return;  // multiplication by one, in place: nothing to do (wave-uniform)
     const JacQ src = X[(size_t)(from_a ? i0 : i1) * stride + lane];
     X[(size_t)i1 * stride + lane] = mul_by_twiddle(src, tw, beta, e);
 }
@@ -176,22 +177,23 @@ void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int m
     for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
     const Fq<1> bt = fq_from_fp(b384);  // host-side conversion to the 14 x 29-bit Montgomery-406 form
     dim3 grid(64, stride / 64);
+    dim3 grid_tw(64 - 64 / half, stride / 64);  // butterflies with a twiddle other than 1 (none when half == 1)
     JacQ* x = (JacQ*)X;
     const uint32_t* js = (const uint32_t*)tw;
     switch (mode) {
         case 0:
-            k_g1_twiddle_mul<<<grid, 64, 0, st>>>(x, stride, half, tw_step, inverse, 0, js, bt);
+            if (grid_tw.x) k_g1_twiddle_mul<<<grid_tw, 64, 0, st>>>(x, stride, half, tw_step, inverse, 0, js, bt);
             k_g1_butterfly<<<grid, 64, 0, st>>>(x, stride, half, 1);
             break;
         case 1:
             k_g1_butterfly<<<grid, 64, 0, st>>>(x, stride, half, 1);
-            k_g1_twiddle_mul<<<grid, 64, 0, st>>>(x, stride, half, tw_step, inverse, 0, js, bt);
+            if (grid_tw.x) k_g1_twiddle_mul<<<grid_tw, 64, 0, st>>>(x, stride, half, tw_step, inverse, 0, js, bt);
             break;
         case 2:
             k_g1_twiddle_mul<<<grid, 64, 0, st>>>(x, stride, half, tw_step, inverse, 1, js, bt);
             break;
         default:
-            k_g1_twiddle_mul<<<grid, 64, 0, st>>>(x, stride, half, tw_step, inverse, 0, js, bt);
+            if (grid_tw.x) k_g1_twiddle_mul<<<grid_tw, 64, 0, st>>>(x, stride, half, tw_step, inverse, 0, js, bt);
             k_g1_butterfly<<<grid, 64, 0, st>>>(x, stride, half, 0);
             break;
     }
