@@ -125,6 +125,18 @@ CResult eth_kzg_amd_recover_cells_and_proofs_batch(const DASContext *ctx, uint64
                                                    const uint64_t *const *cell_indices, uint8_t *const *const *out_cells,
                                                    uint8_t *const *const *out_proofs, int32_t *status);
 
+/* Device-resident recovery (BASELINE.json config 5 for pipelines that hold extended blobs in HBM): d_cells is the flat
+ * [n][128][2048] layout on this GPU; present_masks (HOST memory) holds two 64-bit words per blob, bit (c % 64) of word
+ * (c / 64) set when cell c carries data - missing cells are never read.  Replaces the cell list + index list of
+ * eth_kzg_recover_cells_and_proofs (bindings/c/src/lib.rs:366): ascending unique indices hold by construction, a blob
+ * needs at least 64 present cells.  Outputs as in eth_kzg_amd_compute_cells_and_kzg_proofs_device (either may be NULL);
+ * status[b] (HOST, n entries) = 0 ok, 1 non-canonical field element, 3 fewer than 64 cells, 4 cells not consistent with
+ * a degree < 4096 polynomial; outputs of a failed blob are unspecified.  The decode runs and completes on the
+ * library's stream; the cells and proofs kernels are enqueued on hip_stream (NULL: library stream, synchronised). */
+CResult eth_kzg_amd_recover_cells_and_proofs_device(const DASContext *ctx, uint64_t n, const uint8_t *d_cells,
+                                                    const uint64_t *present_masks, uint8_t *d_out_cells,
+                                                    uint8_t *d_out_proofs, int32_t *status, void *hip_stream);
+
 /* verify_cell_kzg_proof_batch sharded over GPUs (BASELINE.json config 3).  The verification
  * equation of crates/cryptography/kzg_multi_open/src/fk20/verifier.rs:139-260 is linear in the cells once the
  * Fiat-Shamir challenge (taken over the WHOLE batch) is fixed, so each rank evaluates its slice

@@ -49,7 +49,7 @@ EXPORTED_SYMBOLS = [
     "eth_kzg_verify_blob_kzg_proof", "eth_kzg_verify_blob_kzg_proof_batch",
     "eth_kzg_amd_das_context_new_on_device",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_batch", "eth_kzg_amd_blob_to_kzg_commitment_batch",
-    "eth_kzg_amd_recover_cells_and_proofs_batch",
+    "eth_kzg_amd_recover_cells_and_proofs_batch", "eth_kzg_amd_recover_cells_and_proofs_device",
     "eth_kzg_amd_verify_cell_kzg_proof_batch_partial", "eth_kzg_amd_verify_cell_kzg_proof_batch_combine",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_device", "eth_kzg_amd_blob_to_kzg_commitment_device",
     "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits",
@@ -95,6 +95,7 @@ def load_library():
         "eth_kzg_amd_recover_cells_and_proofs_batch": [P, U64, P, P, P, P, P, P, P],
         "eth_kzg_amd_verify_cell_kzg_proof_batch_partial": [P, U64, P, U64, P, U64, P, U64, P, U64, U64, P],
         "eth_kzg_amd_verify_cell_kzg_proof_batch_combine": [P, U64, U8P, P],
+        "eth_kzg_amd_recover_cells_and_proofs_device": [P, U64, P, P, P, P, P, P],
         "eth_kzg_amd_compute_cells_and_kzg_proofs_device": [P, U64, P, P, P, P, P],
         "eth_kzg_amd_blob_to_kzg_commitment_device": [P, U64, P, P, P, P],
     }.items():
@@ -361,6 +362,21 @@ class DASContext:
             self._ctx, n, C.c_void_p(d_blobs), C.c_void_p(d_cells) if d_cells else None,
             C.c_void_p(d_proofs) if d_proofs else None, st, C.c_void_p(stream) if stream else None))
         return list(st)[:n] if want_status else None
+
+    def recover_cells_and_kzg_proofs_device(self, n, d_cells, present, d_out_cells, d_out_proofs, stream=None):
+        """Device-resident recovery: d_cells = flat [n][128][2048] buffer in HBM (integer address), present[b] = iterable
+        of the cell indices of blob b that hold data.  Returns the per-blob status list; outputs stay on the device."""
+        masks = np.zeros(2 * max(1, n), dtype=np.uint64)
+        for b in range(n):
+            for c in present[b]:
+                if not 0 <= c < CELLS_PER_EXT_BLOB:
+                    raise KzgError("InvalidCellIndex")
+                masks[2 * b + (c >> 6)] |= np.uint64(1) << np.uint64(c & 63)
+        st = (C.c_int32 * max(1, n))()
+        self._check(self._lib.eth_kzg_amd_recover_cells_and_proofs_device(
+            self._ctx, n, C.c_void_p(d_cells), _vp(masks), C.c_void_p(d_out_cells) if d_out_cells else None,
+            C.c_void_p(d_out_proofs) if d_out_proofs else None, st, C.c_void_p(stream) if stream else None))
+        return list(st)[:n]
 
     def blob_to_kzg_commitment_device(self, n, d_blobs, d_out, want_status=True, stream=None):
         st = (C.c_int32 * max(1, n))() if want_status else None

@@ -120,6 +120,17 @@ CResult eth_kzg_verify_cell_kzg_proof_batch(const DASContext* ctx, uint64_t comm
     return ok();
 }
 
+CResult eth_kzg_amd_recover_cells_and_proofs_device(const DASContext* ctx, uint64_t n, const uint8_t* d_cells,
+                                                    const uint64_t* present_masks, uint8_t* d_out_cells, uint8_t* d_out_proofs,
+                                                    int32_t* status, void* hip_stream) {
+    kzg::Engine* e = eng(ctx);
+    static_assert(sizeof(int32_t) == sizeof(int), "status array");
+    int st = e->recover_cells_and_kzg_proofs_device((int)n, d_cells, present_masks, d_out_cells, d_out_proofs, (int*)status,
+                                                    (hipStream_t)hip_stream);
+    if (st == kzg::ERR_DEVICE) return device_err(e);
+    return st ? err(status_text(st)) : ok();
+}
+
 // Sharded verification: per-rank partial, then one combine over the gathered records.
 CResult eth_kzg_amd_verify_cell_kzg_proof_batch_partial(const DASContext* ctx, uint64_t commitments_length,
                                                         const uint8_t* const* commitments, uint64_t cell_indices_length,

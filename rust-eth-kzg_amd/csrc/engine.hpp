@@ -107,6 +107,9 @@ public:
                                          const uint8_t* const* commitments, uint64_t n_proofs, const uint8_t* const* proofs,
                                          int* verified);
 
+    // device-resident recovery: flat [R][128][2048] cells in HBM + a 128-bit presence mask per blob (host); see verify.hip
+    int recover_cells_and_kzg_proofs_device(int R, const uint8_t* d_cells, const uint64_t* present_masks, uint8_t* d_out_cells,
+                                            uint8_t* d_out_proofs, int* status, hipStream_t stream);
     // batched form: R independent recoveries in one pass (ragged cell lists); status[r] per blob
     int recover_cells_and_kzg_proofs_batch_host(int R, const uint64_t* n_cells, const uint8_t* const* const* cells,
                                                 const uint64_t* n_indices, const uint64_t* const* cell_indices,
@@ -142,6 +145,8 @@ private:
                              const uint64_t* cell_indices, uint64_t n_cells, const uint8_t* const* cells, uint64_t n_proofs,
                              const uint8_t* const* proofs, uint64_t lo, uint64_t hi, G1Affine* out2, bool* empty);
     bool verify_cells_pairing(const G1Affine* pts2) const;
+    int rs_decode(int R, const uint8_t* d_cells, bool flat_source, const std::vector<int>& slot, const std::vector<int>& stof,
+                  const std::vector<uint32_t>& present, int* st_out);
     int recover_batch_to_coeffs(int R, const uint64_t* n_cells, const uint8_t* const* const* cells,
                                 const uint64_t* const* cell_indices, int* st_out);
     void ensure_workspace(int n);

@@ -54,12 +54,13 @@ __device__ __forceinline__ void v_dif_forward4096(uint32_t* s, const Fr* __restr
 // cells (n x 2048 B, big-endian) -> Fr Montgomery [slot][64]; status |= 1 on a non-canonical element.
 // slot_of == nullptr: slot = cell number (verify).  Otherwise the cell lands at slot_of[k] (recover scatter,
 // cosets.rs:170-175); evals must be zero-filled first.
+// src_of != nullptr: list entry k reads cell src_of[k] of the caller's buffer (flat device layout) instead of cell k.
 __global__ void k_cells_to_fr(const uint8_t* __restrict__ cells, Fr* __restrict__ evals, const int* __restrict__ slot_of,
-                              int* __restrict__ status, const int* __restrict__ status_of, int n) {
+                              int* __restrict__ status, const int* __restrict__ status_of, const int* __restrict__ src_of, int n) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * CELL_LEN) return;
     int k = idx >> 6, e = idx & 63;
-    Fr x = load_fr_be(cells + (size_t)idx * 32);
+    Fr x = load_fr_be(cells + ((size_t)(src_of ? src_of[k] : k) * CELL_LEN + e) * 32);
     if (geq_mod<FrParams>(x.v)) atomicOr(status + (status_of ? status_of[k] : 0), 1);
     int slot = slot_of ? slot_of[k] : k;
     evals[(size_t)slot * CELL_LEN + e] = to_mont(x);
@@ -478,8 +479,9 @@ void init_attributes_verify() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_rec_dit_half), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_NTT);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_rec_dif_half), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_NTT);
 }
-void cells_to_fr(const uint8_t* cells, void* evals, const int* slot_of, int* status, const int* status_of, int n, hipStream_t st) {
-    k_cells_to_fr<<<(n * CELL_LEN + 255) / 256, 256, 0, st>>>(cells, (Fr*)evals, slot_of, status, status_of, n);
+void cells_to_fr(const uint8_t* cells, void* evals, const int* slot_of, int* status, const int* status_of, const int* src_of, int n,
+                 hipStream_t st) {
+    k_cells_to_fr<<<(n * CELL_LEN + 255) / 256, 256, 0, st>>>(cells, (Fr*)evals, slot_of, status, status_of, src_of, n);
 }
 void verify_scalars(const Fr8* pow_table24, int k0, const int* cell_idx, const void* w8192, void* rp_mont, void* s1, void* s2,
                     int n, hipStream_t st) {

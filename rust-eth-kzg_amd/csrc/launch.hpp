@@ -64,7 +64,8 @@ void g1_circ128(void* X, int stride, int n, int segs, void* D, int T, const void
 // k_verify.hip
 void init_attributes_verify();
 // slot_of: destination cell slot per input cell (null = identity); status_of: status word per input cell (null = word 0)
-void cells_to_fr(const uint8_t* cells, void* evals, const int* slot_of, int* status, const int* status_of, int n, hipStream_t st);
+void cells_to_fr(const uint8_t* cells, void* evals, const int* slot_of, int* status, const int* status_of, const int* src_of, int n,
+                 hipStream_t st);
 void rec_vanishing_poly(const uint32_t* present, const void* w8192, void* zp, int* deg, int R, hipStream_t st);
 void rec_vanishing(const void* zp, const int* deg, const void* w8192, const Fr8& seven64, void* zeval, void* zcinv, int R,
                    hipStream_t st);

@@ -187,7 +187,7 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
         launch::g1_decompress((const uint8_t*)d_cb.p, d_comm_p, (int*)d_stc.p, m, 1, beta_, st);
         launch::g1_decompress((const uint8_t*)d_pb.p, d_prf_p, (int*)d_stp.p, n, 1, beta_, st);
         launch::copy_affine(d_srs_, d_comm_p + m, 64, st);  // vk.g1s: the first 64 SRS points (verification_key.rs:66-70)
-        launch::cells_to_fr((const uint8_t*)d_cellb.p, d_evals.p, nullptr, (int*)d_ste.p, nullptr, n, st);
+        launch::cells_to_fr((const uint8_t*)d_cellb.p, d_evals.p, nullptr, (int*)d_ste.p, nullptr, nullptr, n, st);
         int* stc = (int*)(hb + off_hst);  // pinned: the copies below do not block, so the host hashes meanwhile
         int* stp = stc + m;
         int* ste_p = stp + n;
@@ -336,15 +336,25 @@ int Engine::recover_batch_to_coeffs(int R, const uint64_t* n_cells, const uint8_
             pos++;
         }
     }
-    const int n = (int)total_cells;
+    PoolBuf d_cellb(*this, hcells_bytes);
+    if (total_cells) HIPCK(hipMemcpyAsync(d_cellb.p, hcells, hcells_bytes, hipMemcpyHostToDevice, st));
+    return rs_decode(R, (const uint8_t*)d_cellb.p, /*source index = list position*/ false, slot, stof, present, st_out);
+}
+
+// Reed-Solomon decode of R blobs whose present cells are listed in `slot` (blob * 128 + cell index), `stof` (blob of each
+// list entry) and `present` (domain-order masks); the cell bytes are read from d_cells at list position k, or at
+// slot[k] when the caller's buffer is the flat [R][128][2048] layout.  Leaves the coefficients in d_coeffs_.
+int Engine::rs_decode(int R, const uint8_t* d_cells, bool flat_source, const std::vector<int>& slot, const std::vector<int>& stof,
+                      const std::vector<uint32_t>& present, int* st_out) {
+    hipStream_t st = stream_;
+    const int n = (int)slot.size();
     Fr seven64 = fr_u64(7);
     for (int i = 0; i < 6; i++) seven64 = sqr(seven64);
-    PoolBuf d_cellb(*this, hcells_bytes), d_slot(*this, (size_t)n * sizeof(int)), d_stof(*this, (size_t)n * sizeof(int));
+    PoolBuf d_slot(*this, (size_t)n * sizeof(int)), d_stof(*this, (size_t)n * sizeof(int));
     PoolBuf d_E(*this, (size_t)R * N_EXT * sizeof(Fr)), d_T(*this, (size_t)R * N_EXT * sizeof(Fr)), d_U(*this, (size_t)R * N_EXT * sizeof(Fr));
     PoolBuf d_zp(*this, (size_t)R * 65 * sizeof(Fr)), d_deg(*this, R * sizeof(int)), d_present(*this, present.size() * 4);
     PoolBuf d_zeval(*this, (size_t)R * N_CELLS * sizeof(Fr)), d_zcinv(*this, (size_t)R * N_CELLS * sizeof(Fr)), d_st(*this, R * sizeof(int));
     if (n) {
-        HIPCK(hipMemcpyAsync(d_cellb.p, hcells, hcells_bytes, hipMemcpyHostToDevice, st));
         HIPCK(hipMemcpyAsync(d_slot.p, slot.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
         HIPCK(hipMemcpyAsync(d_stof.p, stof.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
     }
@@ -352,7 +362,8 @@ int Engine::recover_batch_to_coeffs(int R, const uint64_t* n_cells, const uint8_
     launch::rec_vanishing_poly((const uint32_t*)d_present.p, d_w8192_, d_zp.p, (int*)d_deg.p, R, st);
     HIPCK(hipMemsetAsync(d_E.p, 0, (size_t)R * N_EXT * sizeof(Fr), st));
     HIPCK(hipMemsetAsync(d_st.p, 0, R * sizeof(int), st));
-    if (n) launch::cells_to_fr((const uint8_t*)d_cellb.p, d_E.p, (const int*)d_slot.p, (int*)d_st.p, (const int*)d_stof.p, n, st);  // E in cell order
+    if (n) launch::cells_to_fr(d_cells, d_E.p, (const int*)d_slot.p, (int*)d_st.p, (const int*)d_stof.p,
+                               flat_source ? (const int*)d_slot.p : nullptr, n, st);  // E in cell order
     launch::rec_vanishing(d_zp.p, (const int*)d_deg.p, d_w8192_, to8(seven64), d_zeval.p, d_zcinv.p, R, st);
     launch::rec_dit_half(R, d_E.p, d_zeval.p, d_T.p, d_w8192_, st);                                      // (E*Z) -> IFFT ...
     launch::rec_dit_last(R, d_T.p, d_coset_, n_inv8192_, d_U.p, nullptr, nullptr, d_w8192_, 0, st);      // ... * 7^i
@@ -366,6 +377,47 @@ int Engine::recover_batch_to_coeffs(int R, const uint64_t* n_cells, const uint8_
         if (st_out[r] != OK) continue;
         if (hst[r] & 1) st_out[r] = ERR_SCALAR;
         else if (hst[r] & 4) st_out[r] = ERR_RECOVERY;
+    }
+    return OK;
+}
+
+// Device-resident form: d_cells is the flat [R][128][2048] extended-blob layout in HBM, present_masks[2 r .. 2 r + 1] the
+// 128-bit set of cells that hold data (bit c of word c / 64); missing cells are never read.  Outputs as in the
+// device-resident prover call; status[r] per blob, outputs of a failed blob are unspecified.
+int Engine::recover_cells_and_kzg_proofs_device(int R, const uint8_t* d_cells, const uint64_t* present_masks, uint8_t* d_out_cells,
+                                                uint8_t* d_out_proofs, int* status, hipStream_t user_stream) {
+    if (R <= 0) return OK;
+    std::lock_guard<std::recursive_mutex> lk(mu_);
+    try {
+        HIPCK(hipSetDevice(dev_));
+        ensure_workspace(R);
+        std::vector<uint32_t> present((size_t)R * 4, 0xffffffffu);
+        std::vector<int> slot, stof;
+        for (int r = 0; r < R; r++) {
+            const uint64_t m0 = present_masks[2 * r], m1 = present_masks[2 * r + 1];
+            const int cnt = __builtin_popcountll(m0) + __builtin_popcountll(m1);
+            status[r] = cnt < N_CELLS / 2 ? ERR_INPUT : OK;  // recovery.rs:90-146: at least half of the cells
+            if (status[r] != OK) continue;
+            uint32_t* m = &present[(size_t)r * 4];
+            m[0] = m[1] = m[2] = m[3] = 0;
+            for (int c = 0; c < N_CELLS; c++) {
+                if (!(((c < 64 ? m0 : m1) >> (c & 63)) & 1)) continue;
+                const int i = brp7(c);
+                m[i >> 5] |= 1u << (i & 31);
+                slot.push_back(r * N_CELLS + c);
+                stof.push_back(r);
+            }
+        }
+        int rc = rs_decode(R, d_cells, /*flat_source=*/true, slot, stof, present, status);
+        if (rc) return rc;
+        hipStream_t st = user_stream ? user_stream : stream_;
+        if (d_out_cells) launch::coeffs_to_cells(R, d_coeffs_, d_out_cells, d_w8192_, st);
+        if (d_out_proofs) run_proofs_from_coeffs(R, d_out_proofs, st);
+        HIPCK(hipGetLastError());
+        if (!user_stream) HIPCK(hipStreamSynchronize(st));
+    } catch (const std::exception& e) {
+        err_ = e.what();
+        return ERR_DEVICE;
     }
     return OK;
 }

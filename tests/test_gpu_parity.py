@@ -414,6 +414,48 @@ def test_batch_larger_than_one_lane_group(ctx, oracle):
         assert cells[b] == ec and proofs[b] == ep, b
 
 
+def test_recover_device_resident(ctx):
+    """eth_kzg_amd_recover_cells_and_proofs_device: extended blobs in HBM with cells knocked out (their bytes overwritten
+    with junk - missing cells must never be read), one presence mask per blob; every erasure pattern of the host API's
+    tests, a blob with too few cells and a blob with a non-canonical element, all in one call."""
+    import torch
+    import numpy as np
+    n = 6
+    blobs = [synth.seeded_blob(300 + i) for i in range(n)]
+    st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs)
+    rng = np.random.RandomState(5)
+    patterns = [list(range(0, 128, 2)), list(range(64)), list(range(64, 128)), sorted(rng.choice(128, 65, replace=False).tolist()),
+                list(range(128)), list(range(63))]
+    flat = bytearray()
+    for b in range(n):
+        for c in range(128):
+            flat += cells[b][c] if c in patterns[b] else b"\xff" * 2048  # junk (not even canonical) where the cell is missing
+    d_in = torch.frombuffer(flat, dtype=torch.uint8).cuda()
+    d_cells = torch.empty(n * 128 * 2048, dtype=torch.uint8, device="cuda")
+    d_proofs = torch.empty(n * 128 * 48, dtype=torch.uint8, device="cuda")
+    status = ctx.recover_cells_and_kzg_proofs_device(n, d_in.data_ptr(), patterns, d_cells.data_ptr(), d_proofs.data_ptr())
+    torch.cuda.synchronize()
+    assert status[:5] == [0] * 5 and status[5] == 3
+    out_c, out_p = bytes(d_cells.cpu().numpy()), bytes(d_proofs.cpu().numpy())
+    for b in range(5):
+        assert out_c[b * 128 * 2048:(b + 1) * 128 * 2048] == b"".join(cells[b]), b
+        assert out_p[b * 128 * 48:(b + 1) * 128 * 48] == b"".join(proofs[b]), b
+    # a present cell with an element >= r is reported for its blob only
+    bad = bytearray(flat)
+    bad[(1 * 128 + 3) * 2048:(1 * 128 + 3) * 2048 + 32] = synth.R.to_bytes(32, "big")
+    d_bad = torch.frombuffer(bad, dtype=torch.uint8).cuda()
+    status = ctx.recover_cells_and_kzg_proofs_device(n, d_bad.data_ptr(), patterns, d_cells.data_ptr(), d_proofs.data_ptr())
+    assert status == [0, 1, 0, 0, 0, 3]
+    # cells that are not evaluations of one degree < 4096 polynomial (needs redundancy: blob 4 has all 128 cells;
+    # exactly 64 cells, as in blob 2, always interpolate)
+    mixed = bytearray(flat)
+    mixed[(4 * 128 + 70) * 2048:(4 * 128 + 71) * 2048] = cells[0][70]
+    mixed[(2 * 128 + 70) * 2048:(2 * 128 + 71) * 2048] = cells[0][70]
+    d_mix = torch.frombuffer(mixed, dtype=torch.uint8).cuda()
+    status = ctx.recover_cells_and_kzg_proofs_device(n, d_mix.data_ptr(), patterns, d_cells.data_ptr(), d_proofs.data_ptr())
+    assert status == [0, 0, 0, 0, 4, 3]
+
+
 def test_second_context_shares_the_window_tables(ctx, oracle):
     """Several contexts in one process (the reference's Java test creates them freely): the second one must come up
     without another 145 GB of tables - it shares the first one's - and give identical results."""
