@@ -38,16 +38,104 @@ __global__ __launch_bounds__(64) void k_g1_sum_positions(JacQ* __restrict__ X, i
     X[slice] = acc;
 }
 
-// Unchecked decompression of the SRS (trusted_setup/src/lib.rs:80-86): thread per point.
-// subgroup_check: 0 none, 1 endomorphism test (production), 2 definitional [r]P == O (tests)
+// ------------------------------------------------------------------------------------------------
+// Decompression in the unsaturated field (the dependent chain of this kernel is what a single-proof verification waits
+// for): same decisions as curve.hpp's g1_decompress + g1_in_subgroup_endo, which stay as the host / reference forms.
+//   y = (x^3 + 4)^((p+1)/4) with fixed 4-bit windows: 380 squarings + <= 95 + 14 multiplications;
+//   subgroup test [z^2]P - P == phi(P) with mixed additions of the affine P: 126 doublings + 11 mixed additions.
+__device__ __forceinline__ Fq<2> fq_sqrt_candidate(const Fq<2>& a) {
+    constexpr uint32_t E[12] = {0xffffeaabu, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
+                                0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};  // (p + 1) / 4
+    Fq<2> tbl[16];
+    tbl[1] = a;
+#pragma unroll 1
+    for (int i = 2; i < 16; i++) tbl[i] = mul(tbl[i - 1], a);
+    Fq<2> acc = relax<2>(fq_one());
+    bool started = false;
+#pragma unroll 1
+    for (int nib = 95; nib >= 0; nib--) {
+        const int d = (E[nib >> 3] >> ((nib & 7) * 4)) & 15;  // wave-uniform: the exponent is a constant
+        if (started) {
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) acc = sqr(acc);
+        }
+        if (d) {
+            acc = started ? mul(acc, tbl[d]) : tbl[d];
+            started = true;
+        }
+    }
+    return acc;
+}
+// [|z|] P for a general Jacobian P (|z| = 0xd201000000010000: 63 doublings + 5 additions)
+__device__ __forceinline__ JacQ mul_by_z_abs_q(const JacQ& p) {
+    constexpr uint64_t Z = 0xd201000000010000ULL;
+    JacQ acc = p;
+#pragma unroll 1
+    for (int i = 62; i >= 0; i--) {
+        acc = dbl(acc);
+        if ((Z >> i) & 1) acc = add(acc, p);
+    }
+    return acc;
+}
+// rc 0 ok (out = affine Montgomery-384 point), 1 bad encoding / x >= p / not on the curve, 2 not in the subgroup
+__device__ __forceinline__ int g1_decompress_q(G1Affine& out, const uint8_t* in, bool subgroup_check, const Fq<1>& beta) {
+    const uint8_t b0 = in[0];
+    const bool compressed = (b0 >> 7) & 1, infinity = (b0 >> 6) & 1, sign = (b0 >> 5) & 1;
+    if (!compressed) return 1;
+    Fp x;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        uint32_t w = ((uint32_t)in[4 * i] << 24) | ((uint32_t)in[4 * i + 1] << 16) | ((uint32_t)in[4 * i + 2] << 8) | in[4 * i + 3];
+        if (i == 0) w &= 0x1fffffffu;
+        x.v[11 - i] = w;
+    }
+    if (infinity) {
+        if (sign || !is_zero(x)) return 1;
+        out = aff_inf();
+        return 0;
+    }
+    if (geq_mod<FpParams>(x.v)) return 1;
+    const Fp xm = to_mont(x);
+    const Fq<1> xq = fq_from_fp(xm);
+    Fq<1> four = fq_one();
+    four = canonical(dbl2(four));
+    const Fq<2> y2 = relax<2>(canonical(add(mul(sqr(xq), xq), four)));
+    const Fq<2> yc = fq_sqrt_candidate(y2);
+    if (!is_zero_slow(sub(sqr(yc), y2))) return 1;  // not a square: x is not the abscissa of a curve point
+    Fp ym = fp_from_fq(yc);
+    if (fp_is_lex_largest(ym) != sign) ym = neg(ym);
+    out.x = xm;
+    out.y = ym;
+    if (!subgroup_check) return 0;
+    // Scott's test: [z^2]P - P == phi(P) = (beta x, y)
+    AffQ pa;
+    pa.x = xq;
+    pa.y = fq_from_fp(ym);
+    const JacQ p = to_jacq(pa);
+    const JacQ q = mul_by_z_abs_q(mul_by_z_abs_q(p));
+    const JacQ r = add_mixed(q, pa, true);
+    if (is_inf(r)) return 2;
+    const Fq<2> zz = sqr(r.z);
+    if (!is_zero_slow(sub(r.x, mul(mul(pa.x, beta), zz)))) return 2;
+    if (!is_zero_slow(sub(r.y, mul(pa.y, mul(zz, r.z))))) return 2;
+    return 0;
+}
+
+// Decompression with validation: thread per point.
+// subgroup_check: 0 none (the embedded SRS, trusted_setup/src/lib.rs:80-86), 1 endomorphism test (production),
+// 2 definitional [r]P == O on the saturated reference forms (tests), 3 the saturated endomorphism test (tests)
 __global__ void k_g1_decompress(const uint8_t* __restrict__ in, G1Affine* __restrict__ out, int* __restrict__ status,
-                                int n, int subgroup_check, Fp beta) {
+                                int n, int subgroup_check, Fp beta, Fq<1> beta_q) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     G1Affine a;
-    int rc = g1_decompress(a, in + (size_t)i * 48);
-    if (rc == 0 && subgroup_check == 1 && !g1_in_subgroup_endo(a, beta)) rc = 2;
-    if (rc == 0 && subgroup_check == 2 && !g1_in_subgroup(a)) rc = 2;
+    int rc;
+    if (subgroup_check <= 1) rc = g1_decompress_q(a, in + (size_t)i * 48, subgroup_check == 1, beta_q);
+    else {
+        rc = g1_decompress(a, in + (size_t)i * 48);
+        if (rc == 0 && subgroup_check == 3 && !g1_in_subgroup_endo(a, beta)) rc = 2;
+        if (rc == 0 && subgroup_check == 2 && !g1_in_subgroup(a)) rc = 2;
+    }
     if (rc) { status[i] = rc; a = aff_inf(); } else status[i] = 0;
     out[i] = a;
 }
@@ -98,7 +186,8 @@ void g1_sum_positions(void* X, int n_pos, int stride, int n_slices, hipStream_t 
 void g1_decompress(const uint8_t* in, void* out, int* status, int n, int subgroup_check, const Fp12w& beta, hipStream_t st) {
     Fp b;
     for (int i = 0; i < 12; i++) b.v[i] = beta.v[i];
-    k_g1_decompress<<<(n + 63) / 64, 64, 0, st>>>(in, (G1Affine*)out, status, n, subgroup_check, b);
+    const Fq<1> bq = fq_from_fp(b);
+    k_g1_decompress<<<(n + 63) / 64, 64, 0, st>>>(in, (G1Affine*)out, status, n, subgroup_check, b, bq);
 }
 void fk20_srs_vectors(const void* srs, void* X, hipStream_t st) { k_fk20_srs_vectors<<<128 * 64 / 256, 256, 0, st>>>((const G1Affine*)srs, (JacQ*)X); }
 void fk20_gather_bases(const void* X, void* bases, hipStream_t st) { k_fk20_gather_bases<<<128 * 64 / 256, 256, 0, st>>>((const JacQ*)X, (G1Affine*)bases); }

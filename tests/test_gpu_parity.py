@@ -109,7 +109,9 @@ def test_g1_decompress_matches_oracle(ctx):
             bad.append(bytes(cand))
     allp = pts + bad
     n = len(allp)
-    for check in (0, 1, 2):
+    # modes: 0 = no subgroup test, 1 = production (unsaturated field, endomorphism test), 2 = definitional [r]P == O and
+    # 3 = endomorphism test on the saturated reference forms
+    for check in (0, 1, 2, 3):
         st = (C.c_int32 * n)()
         out = C.create_string_buffer(n * 48)
         assert lib.eth_kzg_amd_test_g1_decompress(ctx.handle, b"".join(allp), n, check, st, out) == 0
