@@ -416,6 +416,33 @@ def test_batch_larger_than_one_lane_group(ctx, oracle):
         assert cells[b] == ec and proofs[b] == ep, b
 
 
+def test_golden_vectors_through_the_batch_entry_points(ctx):
+    """The reference's vectors again, but as ONE batch per family through the eth_kzg_amd_*_batch entry points: valid
+    cases must reproduce the golden bytes, invalid ones must be flagged in their own status slot without disturbing
+    their neighbours (cases whose buffers have the wrong length cannot be expressed in the batch ABI and are skipped)."""
+    cases = [c for _, c in sorted(vectors.load("compute_cells_and_kzg_proofs").items()) if len(c["input"]["blob"]) == 131072]
+    st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch([c["input"]["blob"] for c in cases])
+    assert sum(1 for c in cases if c["output"] is None) >= 2 and sum(1 for c in cases if c["output"]) == 7
+    for b, c in enumerate(cases):
+        if c["output"] is None:
+            assert st[b] != 0
+        else:
+            assert st[b] == 0 and cells[b] == c["output"][0] and proofs[b] == c["output"][1]
+    cases = [c for _, c in sorted(vectors.load("blob_to_kzg_commitment").items()) if len(c["input"]["blob"]) == 131072]
+    st, comms = ctx.blob_to_kzg_commitment_batch([c["input"]["blob"] for c in cases])
+    for b, c in enumerate(cases):
+        assert (st[b] != 0) if c["output"] is None else (st[b] == 0 and comms[b] == c["output"])
+    cases = [c for _, c in sorted(vectors.load("recover_cells_and_kzg_proofs").items())
+             if all(len(x) == 2048 for x in c["input"]["cells"])]
+    st, rc, rp = ctx.recover_cells_and_kzg_proofs_batch([(c["input"]["cell_indices"], c["input"]["cells"]) for c in cases])
+    assert sum(1 for c in cases if c["output"]) == 4
+    for b, c in enumerate(cases):
+        if c["output"] is None:
+            assert st[b] != 0, b
+        else:
+            assert st[b] == 0 and rc[b] == c["output"][0] and rp[b] == c["output"][1]
+
+
 def test_recover_device_resident(ctx):
     """eth_kzg_amd_recover_cells_and_proofs_device: extended blobs in HBM with cells knocked out (their bytes overwritten
     with junk - missing cells must never be read), one presence mask per blob; every erasure pattern of the host API's
