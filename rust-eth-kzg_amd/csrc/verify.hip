@@ -19,6 +19,8 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <exception>
 
 extern "C" const unsigned char kzg_srs_begin[];
 
@@ -167,34 +169,43 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
         uint8_t *hc = hb + off_c, *hp = hb + off_p, *hcells = hb + off_cells;
         int* hidx = (int*)(hb + off_idx);
         int* hrow = (int*)(hb + off_row);
-        for (int i = 0; i < m; i++) memcpy(hc + (size_t)i * 48, uniq[i], 48);
-        for (int k = 0; k < n; k++) {
-            memcpy(hp + (size_t)k * 48, proofs[k0 + k], 48);
-            memcpy(hcells + (size_t)k * BYTES_PER_CELL, cells[k0 + k], BYTES_PER_CELL);
-            hidx[k] = (int)cell_indices[k0 + k];
-            hrow[k] = row[k0 + k];
-        }
-        lap("gather host inputs");
-        HIPCK(hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, st));
         struct View { void* p; };
         View d_cb{db + off_c}, d_pb{db + off_p}, d_cellb{db + off_cells}, d_idx{db + off_idx}, d_row{db + off_row};
         View d_pts{db + off_pts}, d_evals{db + off_evals}, d_stc{db + off_stc}, d_stp{db + off_stp}, d_ste{db + off_ste};
         // one point array [proofs n | commitments m | 64 SRS points] so that the second lincomb is a single MSM
         G1Affine* d_prf_p = (G1Affine*)d_pts.p;
         G1Affine* d_comm_p = d_prf_p + n;
-        HIPCK(hipMemsetAsync(d_ste.p, 0, sizeof(int), st));
-        // ---- deserialisation with on-curve + subgroup checks (serialization/src/lib.rs:69-99), on the GPU
-        launch::g1_decompress((const uint8_t*)d_cb.p, d_comm_p, (int*)d_stc.p, m, 1, beta_, st);
-        launch::g1_decompress((const uint8_t*)d_pb.p, d_prf_p, (int*)d_stp.p, n, 1, beta_, st);
-        launch::copy_affine(d_srs_, d_comm_p + m, 64, st);  // vk.g1s: the first 64 SRS points (verification_key.rs:66-70)
-        launch::cells_to_fr((const uint8_t*)d_cellb.p, d_evals.p, nullptr, (int*)d_ste.p, nullptr, nullptr, n, st);
-        int* stc = (int*)(hb + off_hst);  // pinned: the copies below do not block, so the host hashes meanwhile
+        int* stc = (int*)(hb + off_hst);  // pinned: the read-backs do not block
         int* stp = stc + m;
         int* ste_p = stp + n;
-        HIPCK(hipMemcpyAsync(stc, d_stc.p, m * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCK(hipMemcpyAsync(stp, d_stp.p, n * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCK(hipMemcpyAsync(ste_p, d_ste.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        lap("H2D + launch decompress");
+        // ---- staging, upload and deserialisation run on a helper thread while this one hashes the transcript straight from
+        // the caller's buffers (the hash is the longest sequential piece of a verification)
+        std::exception_ptr stage_error;
+        std::thread stager([&]() {
+            try {
+                HIPCK(hipSetDevice(dev_));
+                for (int i = 0; i < m; i++) memcpy(hc + (size_t)i * 48, uniq[i], 48);
+                for (int k = 0; k < n; k++) {
+                    memcpy(hp + (size_t)k * 48, proofs[k0 + k], 48);
+                    memcpy(hcells + (size_t)k * BYTES_PER_CELL, cells[k0 + k], BYTES_PER_CELL);
+                    hidx[k] = (int)cell_indices[k0 + k];
+                    hrow[k] = row[k0 + k];
+                }
+                HIPCK(hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, st));
+                HIPCK(hipMemsetAsync(d_ste.p, 0, sizeof(int), st));
+                // deserialisation with on-curve + subgroup checks (serialization/src/lib.rs:69-99), on the GPU
+                launch::g1_decompress((const uint8_t*)d_cb.p, d_comm_p, (int*)d_stc.p, m, 1, beta_, st);
+                launch::g1_decompress((const uint8_t*)d_pb.p, d_prf_p, (int*)d_stp.p, n, 1, beta_, st);
+                launch::copy_affine(d_srs_, d_comm_p + m, 64, st);  // vk.g1s: the first 64 SRS points (verification_key.rs:66-70)
+                launch::cells_to_fr((const uint8_t*)d_cellb.p, d_evals.p, nullptr, (int*)d_ste.p, nullptr, nullptr, n, st);
+                HIPCK(hipMemcpyAsync(stc, d_stc.p, m * sizeof(int), hipMemcpyDeviceToHost, st));
+                HIPCK(hipMemcpyAsync(stp, d_stp.p, n * sizeof(int), hipMemcpyDeviceToHost, st));
+                HIPCK(hipMemcpyAsync(ste_p, d_ste.p, sizeof(int), hipMemcpyDeviceToHost, st));
+            } catch (...) {
+                stage_error = std::current_exception();
+            }
+        });
+        struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{stager};
         // ---- Fiat-Shamir challenge on the host while the GPU decompresses (verifier.rs:269-328).
         // Valid inputs are canonical encodings, so the transcript is the input bytes themselves.
         Sha256 sh;
@@ -203,7 +214,7 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
         memcpy(hdr, "RCKZGCBATCH__V1_", 16);
         be64(N_BLOB, hdr + 16); be64(CELL_LEN, hdr + 24); be64((uint64_t)m, hdr + 32); be64((uint64_t)n_all, hdr + 40);
         sh.update(hdr, sizeof hdr);
-        sh.update(hc, sz_c);
+        for (int i = 0; i < m; i++) sh.update(uniq[i], 48);
         for (int k = 0; k < n_all; k++) {  // the transcript always covers the whole batch, whatever the shard
             uint8_t ix[16];
             be64((uint64_t)row[k], ix); be64(cell_indices[k], ix + 8);
@@ -215,6 +226,8 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
         sh.finish(dig);
         Fr r = reduce_be32(dig);
         lap("sha256 transcript (host)");
+        stager.join();
+        if (stage_error) std::rethrow_exception(stage_error);
         HIPCK(hipStreamSynchronize(st));
         lap("wait decompress/deserialise");
         for (int i = 0; i < m; i++) if (stc[i]) return ERR_G1;  // order of the reference: commitments, proofs, cells
