@@ -40,10 +40,11 @@ typedef struct CResult {
 /* bindings/c/src/lib.rs:50-52 (opaque) */
 typedef struct DASContext DASContext;
 
-/* bindings/c/src/lib.rs:79-92.  use_precomp = true selects width-8 window tables
- * (RECOMMENDED_PRECOMP_WIDTH); the embedded mainnet trusted setup is loaded; GPU 0
- * (or the ordinal in $ETH_KZG_AMD_DEVICE) is used. Aborts if no MI355X-class GPU is usable:
- * there is no CPU fallback. */
+/* bindings/c/src/lib.rs:79-92.  use_precomp = true selects precomputed window tables (the reference: width 8,
+ * RECOMMENDED_PRECOMP_WIDTH, on the CPU; here the widest tables that fit in HBM: width 14 for FK20 and 13 for
+ * commitments, 206 GB on an otherwise empty MI355X, narrower automatically when memory is short), false the
+ * 0.8 GB width-4 tables; results are identical.  The embedded mainnet trusted setup is loaded; GPU 0 (or the ordinal
+ * in $ETH_KZG_AMD_DEVICE) is used.  Aborts if no MI355X-class GPU is usable: there is no CPU fallback. */
 DASContext *eth_kzg_das_context_new(bool use_precomp);
 
 /* bindings/c/src/lib.rs:109-116.  NULL-safe. */

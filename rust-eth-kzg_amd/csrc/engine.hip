@@ -131,7 +131,7 @@ PoolBuf::~PoolBuf() {
 // ---------------------------------------------------------------------------------------------
 Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14 : 4) {
     if (use_precomp) {
-        // default width 14: 145 GB of window tables, 19 windows -> 1216 gathered additions per MSM (HBM is 288 GB).
+        // default width 14: 163 GB of window tables (128-B entries), 19 windows -> 1216 gathered additions per MSM (HBM is 288 GB).
         if (const char* s = getenv("ETH_KZG_AMD_WINDOW")) {  // tuning knob: FK20 table window width (8, 10, 12, 13, 14)
             int c = atoi(s);
             if (c == 8 || c == 10 || c == 12 || c == 13 || c == 14) c_ = c;
@@ -312,7 +312,7 @@ void Engine::init_srs() {
 }
 
 // Window tables are immutable once built and depend only on (device, which bases, width), so the contexts of one
-// process share them: the second DASContext on a GPU costs neither another 145 GB nor another build
+// process share them: the second DASContext on a GPU costs neither another 206 GB nor another build
 // (the reference's Java test creates several contexts, LibEthKZGTest.java:32).  The last context to go frees the table.
 struct Engine::SharedTable {
     void* p = nullptr;

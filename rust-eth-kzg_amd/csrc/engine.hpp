@@ -58,8 +58,8 @@ class Engine {
 public:
     friend struct PoolBuf;
     struct SharedTable;  // engine.hip
-    // use_precomp: true -> the widest FK20 window table that fits in HBM (width 14 = 145 GB on an otherwise empty
-    //              MI355X; the reference's UsePrecomp::Yes uses width 8 on the CPU), false -> width-4 tables (0.7 GB,
+    // use_precomp: true -> the widest FK20 window table that fits in HBM (width 14 = 163 GB on an otherwise empty
+    //              MI355X; the reference's UsePrecomp::Yes uses width 8 on the CPU), false -> width-4 tables (0.8 GB,
     //              ~3.4x the additions).  Results identical.  Tables are shared by the contexts of a device.
     Engine(bool use_precomp, int device);
     ~Engine();
