@@ -236,6 +236,9 @@ def main():
             "g1_ifft": B * 64 * 4 * 168,
             "g1_fft": B * 64 * 4 * 168,
             "compress": B * 128 * (168 + 48),
+            # compiled linear map: ~3.9 k point operations per blob (350 constant multiplications, 3.2 k additions, 0.4 k
+            # doubling runs), each reading one or two 168-B points and writing one, over its ~74 launches
+            "g1_linmap": B * 3900 * 3 * 168 // 74,
         }[dom]
         achieved = alg_bytes / per_launch_s / 1e9
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KB units),

@@ -384,7 +384,7 @@ class DASContext:
             self._ctx, n, C.c_void_p(d_blobs), C.c_void_p(d_out), st, C.c_void_p(stream) if stream else None))
         return list(st)[:n] if want_status else None
 
-    STAGES = ["blob_to_coeffs", "coeffs_to_cells", "fk20_scalars", "msm_fixed", "g1_ifft", "g1_fft", "compress"]
+    STAGES = ["blob_to_coeffs", "coeffs_to_cells", "fk20_scalars", "msm_fixed", "g1_ifft", "g1_fft", "compress", "g1_linmap"]
 
     def set_profiling(self, on):
         self._lib.eth_kzg_amd_set_profiling(self._ctx, int(bool(on)))

@@ -4,6 +4,7 @@
 // per-blob pipeline of compute_multi_opening_proofs (fk20/prover.rs:173-228) as a batch of kernels.
 #include "engine.hpp"
 #include "curve.hpp"
+#include "g1_linmap.hpp"
 #include "launch.hpp"
 
 #include <chrono>
@@ -80,6 +81,34 @@ static void glv_split(const Fr& canon, u128& k1, u128& k2) {
     k1 = rem;
     k2 = q;
 }
+// GLV split + width-w NAF of one public constant (Montgomery form): 2 x TWIDDLE_WORDS words, one signed byte per digit
+// (consumed by mul_by_recoded, g1_mulc.hpp).  Both steps are verified by recomputing the constant from its digits.
+static void recode_glv_wnaf(const Fr& k_mont, const Fr& lambda_mont, uint32_t* out) {
+    constexpr int TWW = launch::TWIDDLE_WORDS, W = launch::TWIDDLE_WNAF_W;
+    for (int i = 0; i < 2 * TWW; i++) out[i] = 0;
+    u128 kk[2];
+    glv_split(from_mont(k_mont), kk[0], kk[1]);
+    Fr a1 = zero<FrParams>(), a2 = zero<FrParams>();
+    for (int i = 0; i < 4; i++) { a1.v[i] = (uint32_t)(kk[0] >> (32 * i)); a2.v[i] = (uint32_t)(kk[1] >> (32 * i)); }
+    if (!eq(add(to_mont(a1), mul(to_mont(a2), lambda_mont)), k_mont)) throw std::runtime_error("GLV split failed");
+    for (int h = 0; h < 2; h++) {
+        int8_t* dg = reinterpret_cast<int8_t*>(out + (size_t)h * TWW);
+        u128 v = kk[h];
+        Fr back = zero<FrParams>(), pw = one<FrParams>();
+        for (int t = 0; v != 0; t++, v >>= 1, pw = add(pw, pw)) {
+            if (t >= 4 * TWW) throw std::runtime_error("constant recoding too long");
+            if (!(v & 1)) continue;
+            int d = (int)(v & ((1u << W) - 1));        // v mods 2^w: odd residue in (-2^(w-1), 2^(w-1))
+            if (d >= (1 << (W - 1))) d -= 1 << W;
+            if (d < 0) v += (u128)(-d); else v -= (u128)d;
+            dg[t] = (int8_t)d;
+            Fr term = pw;
+            for (int m = 1; m < (d < 0 ? -d : d); m++) term = add(term, pw);  // |d| * 2^t
+            back = d < 0 ? sub(back, term) : add(back, term);
+        }
+        if (!eq(back, to_mont(h ? a2 : a1))) throw std::runtime_error("constant recoding failed");
+    }
+}
 // ---------------------------------------------------------------------------------------------
 BufferPool::~BufferPool() {
     for (auto& f : free_) {
@@ -151,6 +180,15 @@ Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14
         t0 = t1;
     };
     HIPCK(hipSetDevice(dev_));
+    {
+        int cus = 0;
+        HIPCK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));
+        wave_slots_ = cus * 4 * 2;  // point kernels hold ~240 VGPRs: two waves per SIMD
+        if (const char* s = getenv("ETH_KZG_AMD_MSM_CHUNKS")) {
+            int v = atoi(s);
+            if (v == 0 || v == 1 || v == 2 || v == 4) msm_chunks_ = v;
+        }
+    }
     HIPCK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     launch::init_attributes();
     lap("HIP runtime + stream");
@@ -168,7 +206,7 @@ Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14
 Engine::~Engine() {
     hipSetDevice(dev_);
     void* ptrs[] = {d_w8192_, d_naf_, d_srs_, d_fk_bases_, d_coeffs_, d_canon_,
-                    d_scalars_, d_X_, d_status_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_dft_tmp_, d_dft_prod_, d_circ_terms_, d_circ_table_};
+                    d_scalars_, d_X_, d_status_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_dft_tmp_, d_dft_prod_, d_circ_terms_, d_circ_table_, d_slp_naf_, d_slp_words_, d_slp_arena_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (v_dev_) hipFree(v_dev_);
@@ -191,35 +229,10 @@ void Engine::init_constants() {
         for (int i = 0; i < 4; i++) lam.v[i] = (uint32_t)(GLV_LAMBDA >> (32 * i));
         Fr lm = to_mont(lam);
         if (!is_zero(add(add(sqr(lm), lm), one<FrParams>()))) throw std::runtime_error("GLV lambda is not a cube root of unity");
-        // width-w NAF of both GLV halves, one signed byte per digit (k_g1fft.hip: mul_by_twiddle)
-        constexpr int TWW = launch::TWIDDLE_WORDS, W = launch::TWIDDLE_WNAF_W;
+        // width-w NAF of both GLV halves of every twiddle omega_128^k = w[64 k] (k_g1fft.hip: mul_by_twiddle)
+        constexpr int TWW = launch::TWIDDLE_WORDS;
         std::vector<uint32_t> tw((size_t)128 * 2 * TWW, 0u);
-        for (int k = 0; k < 128; k++) {
-            Fr canon = from_mont(w[64 * k]);
-            u128 kk[2];
-            glv_split(canon, kk[0], kk[1]);
-            // k1 + k2 * lambda == k (mod r), in Fr
-            Fr a1 = zero<FrParams>(), a2 = zero<FrParams>();
-            for (int i = 0; i < 4; i++) { a1.v[i] = (uint32_t)(kk[0] >> (32 * i)); a2.v[i] = (uint32_t)(kk[1] >> (32 * i)); }
-            if (!eq(add(to_mont(a1), mul(to_mont(a2), lm)), w[64 * k])) throw std::runtime_error("GLV split failed");
-            for (int h = 0; h < 2; h++) {
-                int8_t* dg = reinterpret_cast<int8_t*>(&tw[((size_t)k * 2 + h) * TWW]);
-                u128 v = kk[h];
-                Fr back = zero<FrParams>(), pw = one<FrParams>();
-                for (int t = 0; v != 0; t++, v >>= 1, pw = add(pw, pw)) {
-                    if (t >= 4 * TWW) throw std::runtime_error("twiddle recoding too long");
-                    if (!(v & 1)) continue;
-                    int d = (int)(v & ((1u << W) - 1));        // v mods 2^w: odd residue in (-2^(w-1), 2^(w-1))
-                    if (d >= (1 << (W - 1))) d -= 1 << W;
-                    if (d < 0) v += (u128)(-d); else v -= (u128)d;
-                    dg[t] = (int8_t)d;
-                    Fr term = pw;
-                    for (int m = 1; m < (d < 0 ? -d : d); m++) term = add(term, pw);  // |d| * 2^t
-                    back = d < 0 ? sub(back, term) : add(back, term);
-                }
-                if (!eq(back, to_mont(h ? a2 : a1))) throw std::runtime_error("twiddle recoding failed");
-            }
-        }
+        for (int k = 0; k < 128; k++) recode_glv_wnaf(w[64 * k], lm, &tw[(size_t)k * 2 * TWW]);
         HIPCK(hipMalloc(&d_naf_, tw.size() * 4));
         HIPCK(hipMemcpy(d_naf_, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
         // Small-batch circulant form (k_g1circ.hip): symbol c_d = sum_{t<64} omega_128^(d t); its non-zero entries,
@@ -260,6 +273,7 @@ void Engine::init_constants() {
         HIPCK(hipMalloc(&d_circ_terms_, all.size() * 4));
         HIPCK(hipMemcpy(d_circ_terms_, all.data(), all.size() * 4, hipMemcpyHostToDevice));
     }
+    init_linmap(reinterpret_cast<const Fr8*>(w.data()));
     for (int sgi = 0; sgi < 3; sgi++) {  // Montgomery forms of 2^32, 2^64, 2^96 (k_fk20_scalars' segment copies)
         Fr v = zero<FrParams>();
         v.v[sgi + 1] = 1;
@@ -269,6 +283,64 @@ void Engine::init_constants() {
     Fr i4096 = inv(fr_from_u64(N_BLOB)), i128 = inv(fr_from_u64(128));
     memcpy(&n_inv4096_, &i4096, 32);
     memcpy(&inv128_, &i128, 32);
+}
+
+// The two G1 transforms of the prover as one straight-line program of point operations (g1_linmap.hpp): built, checked
+// against the definition of the map over Fr (plan and scheduled slot program), constants recoded, uploaded.
+void Engine::init_linmap(const Fr8* w8192_mont) {
+    static_assert(sizeof(Fr8) == sizeof(Fr), "layout");
+    const Fr* w8192 = reinterpret_cast<const Fr*>(w8192_mont);
+    if (const char* e = getenv("ETH_KZG_AMD_G1FFT")) {  // tuning knob: "radix2" keeps the butterfly network of k_g1fft.hip
+        if (!strcmp(e, "radix2")) { use_linmap_ = false; return; }
+    }
+    std::vector<Fr> w128(128);
+    for (int e = 0; e < 128; e++) w128[e] = w8192[64 * e];
+    const bool verbose = getenv("ETH_KZG_AMD_TRACE") != nullptr;
+    linmap::Plan plan = linmap::build_fk20_proofs_plan(w128, /*allow_toom8=*/getenv("ETH_KZG_AMD_NO_TOOM8") == nullptr, verbose);
+    {   // the executor leaves output p in arena slot 128 + p, and the proofs are wanted in bit-reversed FFT order
+        std::vector<linmap::Ref> perm(128);
+        for (int p = 0; p < 128; p++) {
+            int k = 0;
+            for (int b = 0; b < 7; b++) k |= ((p >> b) & 1) << (6 - b);
+            perm[p] = plan.outputs[k];
+        }
+        plan.outputs = perm;
+    }
+    const linmap::Schedule sched = linmap::make_schedule(plan);
+    // self-check: definition of the map vs the plan vs the scheduled slot program, over Fr
+    uint64_t st = 0x853c49e6748fea9bull;
+    for (int it = 0; it < 2; it++) {
+        std::vector<Fr> in(128);
+        for (auto& v : in) {
+            for (int i = 0; i < 8; i++) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; v.v[i] = (uint32_t)(st >> 16); }
+            v.v[7] &= 0x3fffffffu;
+        }
+        const auto want = linmap::fk20_proofs_map_by_definition(w128, in);
+        const auto got1 = linmap::run_over_fr(plan, in);
+        const auto got2 = linmap::run_schedule_over_fr(sched, plan.consts, 128, 128, in);
+        for (int p = 0; p < 128; p++) {
+            int k = 0;
+            for (int b = 0; b < 7; b++) k |= ((p >> b) & 1) << (6 - b);
+            if (!eq(want[k], got1[p]) || !eq(want[k], got2[p])) throw std::runtime_error("FK20 proofs map: compiled program differs from its definition");
+        }
+    }
+    Fr lam = zero<FrParams>();
+    for (int i = 0; i < 4; i++) lam.v[i] = (uint32_t)(GLV_LAMBDA >> (32 * i));
+    const Fr lm = to_mont(lam);
+    constexpr int TWW = launch::TWIDDLE_WORDS;
+    std::vector<uint32_t> naf(plan.consts.size() * 2 * TWW);
+    for (size_t c = 0; c < plan.consts.size(); c++) recode_glv_wnaf(plan.consts[c], lm, &naf[c * 2 * TWW]);
+    HIPCK(hipMalloc(&d_slp_naf_, naf.size() * 4));
+    HIPCK(hipMemcpy(d_slp_naf_, naf.data(), naf.size() * 4, hipMemcpyHostToDevice));
+    HIPCK(hipMalloc(&d_slp_words_, sched.words.size() * 4));
+    HIPCK(hipMemcpy(d_slp_words_, sched.words.data(), sched.words.size() * 4, hipMemcpyHostToDevice));
+    slp_launches_.clear();
+    for (auto& L : sched.launches) slp_launches_.push_back(SlpLaunch{(int)L.kind, L.first, L.count});
+    slp_slots_ = sched.n_slots;
+    slp_mulc_ = (int)sched.mulc_total;
+    const Fr h = inv(fr_from_u64(2));
+    memcpy(&half_, &h, 32);
+    use_linmap_ = true;
 }
 
 void Engine::init_srs() {
@@ -466,7 +538,19 @@ void Engine::ensure_workspace(int n) {
 void Engine::launch_msm(const void* scalars, const void* table, void* out, int n_groups, int n_slices, int out_stride,
                         int brp_bits, hipStream_t st) {
     const int c = table == d_srs_table_ ? srs_c_ : c_;
-    if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) launch::msm_fixed_flat(c, scalars, table, out, n_groups, n_slices, 64, out_stride, brp_bits, st);
+    if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) {
+        launch::msm_fixed_flat(c, scalars, table, out, n_groups, n_slices, 64, out_stride, brp_bits, st);
+        return;
+    }
+    // Large batches: threads own a chunk of the windows of an MSM (S = 4 chunks: the fold is two additions per ~300, and
+    // the waves are short enough for the tail of a launch not to matter; measured equal or better than S = 1, 2 at every
+    // batch that fills the chip).  Below one round of the chip's 2-per-SIMD wave slots the windowed kernel (one thread
+    // per window) has more parallelism.
+    const long msms = (long)n_groups * n_slices;
+    int S = 0;
+    if (msm_chunks_ >= 0) S = msm_chunks_;  // tuning knob ETH_KZG_AMD_MSM_CHUNKS: 0 = windowed kernel, 1/2/4 = chunked
+    else if ((msms * 4 + 63) / 64 >= (long)wave_slots_) S = 4;
+    if (S) launch::msm_fixed_chunked(c, scalars, table, out, n_groups, n_slices, 64, out_stride, brp_bits, S, st);
     else launch::msm_fixed(c, scalars, table, out, n_groups, n_slices, 64, out_stride, brp_bits, st);
 }
 
@@ -501,14 +585,37 @@ void Engine::run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st) {
     // cuts the doubling chain of the circulant form into four parallel quarters (needs 32 * 4 >= T - 1 doublings)
     const int segs = (n > circ_max_ || circ_T_ > 129) ? 1 : n <= 2 ? 4 : n <= 4 ? 2 : 1;
     const Fr8 two_segments[3] = {seg_shift_[1], seg_shift_[1], seg_shift_[1]};  // 2^64
+    // beyond the small-batch circulant kernel the two transforms run as one compiled linear map (g1_linmap.hpp), which wants
+    // the MSM outputs halved instead of divided by 128 and in natural Fourier order in the first 128 arena slots
+    const bool linmap_mode = use_linmap_ && n > circ_max_;
+    void* X = d_X_;
+    if (linmap_mode) {
+        const size_t need = (size_t)slp_slots_ * bp * launch::SIZEOF_JACQ;
+        if (need > slp_arena_bytes_) {
+            if (d_slp_arena_) { HIPCK(hipStreamSynchronize(st)); HIPCK(hipFree(d_slp_arena_)); d_slp_arena_ = nullptr; }
+            HIPCK(hipMalloc(&d_slp_arena_, need));
+            slp_arena_bytes_ = need;
+        }
+        X = d_slp_arena_;
+    }
     mark_begin(ST_FK20_SCALARS, st);
-    launch::fk20_scalars(n, d_coeffs_, d_scalars_, d_w8192_, inv128_, segs, segs == 2 ? two_segments : seg_shift_, st);
+    launch::fk20_scalars(n, d_coeffs_, d_scalars_, d_w8192_, linmap_mode ? half_ : inv128_, segs, segs == 2 ? two_segments : seg_shift_, st);
     mark_end(1, st);
-    launch::g1_set_inf(d_X_, (size_t)128 * bp, st);
+    launch::g1_set_inf(X, (size_t)128 * bp, st);
     const bool latency_mode = bp <= LATENCY_MODE_MAX_LANES;  // few 64-blob groups: direct 8 x 16 transforms, 4 rounds instead of 14
     mark_begin(ST_MSM_FIXED, st);
-    launch_msm(d_scalars_, d_fk_table_, d_X_, 128, segs * n, bp, latency_mode ? 0 : 7, st);
+    launch_msm(d_scalars_, d_fk_table_, X, 128, segs * n, bp, (latency_mode || linmap_mode) ? 0 : 7, st);
     mark_end(1, st);
+    if (linmap_mode) {
+        mark_begin(ST_G1_LINMAP, st);
+        for (auto& L : slp_launches_)
+            launch::g1_slp_launch(L.kind, d_slp_arena_, bp, (const uint32_t*)d_slp_words_ + (size_t)L.first * 4, L.count, d_slp_naf_, beta_, st);
+        mark_end((int)slp_launches_.size(), st);
+        mark_begin(ST_COMPRESS, st);
+        launch::g1_compress((const char*)d_slp_arena_ + (size_t)128 * bp * launch::SIZEOF_JACQ, d_proofs, 128, bp, n, st);
+        mark_end(1, st);
+        return;
+    }
     if (n <= circ_max_) {  // a handful of blobs: the two transforms as one circulant product (k_g1circ.hip)
         if (!d_circ_table_) HIPCK(hipMalloc(&d_circ_table_, launch::g1_circ_table_bytes(circ_max_, circ_T_)));
         mark_begin(ST_G1_IFFT, st);

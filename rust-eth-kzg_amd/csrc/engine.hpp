@@ -125,7 +125,7 @@ public:
 
     // ---- per-stage HIP-event timing (bench.py's roofline leg) ----
     enum Stage { ST_BLOB_TO_COEFFS = 0, ST_COEFFS_TO_CELLS, ST_FK20_SCALARS, ST_MSM_FIXED, ST_G1_IFFT, ST_G1_FFT,
-                 ST_COMPRESS, ST_COUNT };
+                 ST_COMPRESS, ST_G1_LINMAP, ST_COUNT };
     void set_profiling(bool on);
     // sums since the last call: ms[ST_COUNT], launches[ST_COUNT]; synchronises the device
     void get_stage_times(double* ms, uint64_t* launches);
@@ -135,6 +135,7 @@ public:
 
 private:
     void init_constants();
+    void init_linmap(const Fr8* w8192_mont);  // host copy of omega_8192^k
     void init_srs();
     void init_fk20();
     void init_verifier();
@@ -166,6 +167,8 @@ private:
     int dev_ = 0;
     int c_ = 8;      // window width of the FK20 table
     int srs_c_ = 13;  // window width of the commitment (monomial SRS) table (falls back like the FK20 table)
+    int wave_slots_ = 2048;  // CUs x 4 SIMDs x 2 waves: what one round of a ~240-VGPR point kernel occupies
+    int msm_chunks_ = -1;    // -1: pick per launch (launch_msm); otherwise forced by ETH_KZG_AMD_MSM_CHUNKS
     hipStream_t stream_ = nullptr;
     std::recursive_mutex mu_;  // recursive: host-pointer entry points hold it across staging + the device call + read-back
     std::string err_;
@@ -201,6 +204,14 @@ private:
     int circ_T_ = 0, circ_per_lane_ = 0, circ_max_ = 32;  // measured cross-over with the direct 8 x 16 form: ~32 blobs
     Fr8 seg_shift_[3];  // 2^32, 2^64, 2^96 in Montgomery form
     void *d_dft_tmp_ = nullptr, *d_dft_prod_ = nullptr;  // latency-mode G1 transforms (one 64-blob group)
+    // the two G1 transforms as one compiled linear map (g1_linmap.hpp, k_g1slp.hip): launches, constants, slot arena
+    struct SlpLaunch { int kind, first, count; };
+    std::vector<SlpLaunch> slp_launches_;
+    void *d_slp_words_ = nullptr, *d_slp_naf_ = nullptr, *d_slp_arena_ = nullptr;
+    size_t slp_arena_bytes_ = 0;
+    int slp_slots_ = 0, slp_mulc_ = 0;
+    bool use_linmap_ = false;
+    Fr8 half_;  // 1/2 in Montgomery form: the scaling folded into the MSM scalars in linear-map mode
 
     // workspace (grown on demand, guarded by mu_)
     int cap_ = 0;

@@ -5,84 +5,9 @@
 #include "kcommon.hpp"
 #include "curve29.hpp"
 #include "launch.hpp"
+#include "g1_mulc.hpp"
 
 namespace kzg {
-
-// Data layout: X[pos * stride + lane], lane = blob index inside the batch (stride = batch padded to a
-// multiple of 64), so all 64 lanes of a wave run the SAME butterfly and the twiddle is wave-uniform.
-// `b * twiddle` (fft.rs:164-177) is a 255-bit scalar multiplication by a PUBLIC constant, so the scalar is
-// recoded once on the host: GLV split k = k1 + k2*lambda (phi(x,y) = (beta x, y) = [lambda](x,y)), then each
-// 128-bit half in width-w non-adjacent form (odd digits |d| < 2^(w-1), one non-zero digit in w+1 on average).
-// The two digit streams share the <= 129 doublings; the additions take (2j+1) P from a small table built with
-// one doubling and 2^(w-2) - 1 additions (phi of a table entry only swaps in beta x).  w = 5: ~43 additions + 8
-// for the table, against ~66 for the joint sparse form and 255 doublings + ~85 additions for a plain NAF.
-// Every digit test is a scalar branch on wave-uniform data: no lane divergence.
-// tab[k][2][33] words = 2 x 132 signed bytes: digit t of half h is byte t of tab[k][h].
-__device__ __forceinline__ JacQ mul_by_twiddle(const JacQ& p, const uint32_t* __restrict__ tab, const Fq<1>& beta, int k) {
-    // k is wave-uniform; 0 -> identity map, 64 -> negation (omega_128^64 = -1)
-    if (k == 0) return p;
-    if (k == 64) return neg(p);
-    constexpr int NT = 1 << (launch::TWIDDLE_WNAF_W - 2);  // odd multiples P, 3P, .., (2 NT - 1) P
-    // The table is brought to ONE common Z = prod z_j without an inversion: (X_j l_j^2, Y_j l_j^3) with l_j = Z / z_j are
-    // the affine coordinates of the same points on the isomorphic curve y^2 = x^3 + 4 Z^6.  The group law for a = 0
-    // never looks at b, and phi(x, y) = (beta x, y) is an endomorphism of that curve too, so the whole multiplication
-    // runs there with MIXED additions (6M + 3S + pair instead of 10M + 4S + pair) and one final Z <- Z * Z_common.
-    AffQ2 A[NT];
-    Fq<2> bx[NT];
-    Fq<ZB> zc;
-    {
-        JacQ T[NT];
-        Fq<ZB> pre[NT];  // pre[j] = z_0 ... z_j
-        const JacQ p2 = dbl(p);
-        T[0] = p;
-        pre[0] = p.z;
-#pragma unroll 1
-        for (int j = 1; j < NT; j++) {
-            T[j] = add(T[j - 1], p2);
-            pre[j] = relax<ZB>(mul(pre[j - 1], T[j].z));
-        }
-        zc = pre[NT - 1];
-        Fq<ZB> suf = relax<ZB>(fq_one());  // z_(j+1) ... z_(NT-1)
-#pragma unroll 1
-        for (int j = NT - 1; j >= 0; j--) {
-            const Fq<ZB> lam = j > 0 ? relax<ZB>(mul(pre[j > 0 ? j - 1 : 0], suf)) : suf;  // product of all the other z
-            const Fq<2> l2 = sqr(lam);
-            A[j].x = mul(T[j].x, l2);
-            A[j].y = mul(T[j].y, mul(l2, lam));
-            bx[j] = mul(A[j].x, beta);
-            suf = relax<ZB>(mul(suf, T[j].z));
-        }
-    }
-    const uint32_t* row = tab + (size_t)k * (2 * launch::TWIDDLE_WORDS);
-    JacQ acc = jacq_inf();
-    bool started = false;
-#pragma unroll 1
-    for (int wd = launch::TWIDDLE_WORDS - 1; wd >= 0; wd--) {
-        const uint32_t w1 = __builtin_amdgcn_readfirstlane(row[wd]);
-        const uint32_t w2 = __builtin_amdgcn_readfirstlane(row[launch::TWIDDLE_WORDS + wd]);
-        if (!started && (w1 | w2) == 0) continue;
-#pragma unroll 1
-        for (int q = 3; q >= 0; q--) {
-            if (started) acc = dbl(acc);
-#pragma unroll 1
-            for (int h = 0; h < 2; h++) {
-                const int d = (int)(int8_t)((h ? w2 : w1) >> (8 * q));
-                if (d == 0) continue;
-                const int idx = ((d < 0 ? -d : d) - 1) >> 1;
-                AffQ2 op = A[idx];
-                if (h) op.x = bx[idx];
-                if (!started) {
-                    acc.x = relax<XB>(op.x);
-                    acc.y = d < 0 ? relax<XB>(neg(op.y)) : relax<XB>(op.y);
-                    acc.z = relax<ZB>(fq_one());
-                    started = true;
-                } else acc = add_mixed(acc, op, d < 0);
-            }
-        }
-    }
-    acc.z = relax<ZB>(mul(acc.z, zc));  // back from the isomorphic curve
-    return acc;
-}
 
 // One radix-2 layer = two small kernels, so that each heavy primitive (Jacobian add / double) is inlined once:
 //   k_g1_twiddle_mul : X[i1] <- w^e * X[src]      (src = i1, or i0 for the (h || 0) first DIF layer)

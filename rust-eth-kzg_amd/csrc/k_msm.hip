@@ -82,6 +82,122 @@ __global__ __launch_bounds__(256, 2) void k_msm_fixed(const Fr* __restrict__ sca
     }
 }
 
+// Large-batch variant: a thread runs a CHUNK of the windows of one MSM -- windows [s * Wc, (s+1) * Wc) of all nb bases,
+// Wc = ceil(W / S) -- into one running sum; S = 1, 2 or 4 adjacent lanes share an MSM and fold through LDS.
+// The windowed kernel above (S = W) folds the W window sums of every MSM with a five-level tree in which most lanes
+// idle: five full Jacobian additions per wave on top of 64 mixed ones (12 % of its instructions), plus a conversion
+// per window sum.  With S = 4 the fold is two additions per 304 (1 %), with S = 1 there is none; the price is fewer,
+// longer-running threads, so the engine picks the smallest S that still fills the chip (engine.hip: launch_msm).
+// The next table entry is requested one addition ahead (128 B into registers), so the random gathers from the
+// 160 GB table are in flight during the ~4.5 k instructions of the current addition.
+struct TabLine { uint4 q[7]; };
+__device__ __forceinline__ TabLine load_line(const TabQ* p) {
+    TabLine l;
+    const uint4* s = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < 7; i++) l.q[i] = s[i];
+    return l;
+}
+__device__ __forceinline__ AffQ line_to_affq(const TabLine& l) {
+    AffQ a;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const uint32_t w[4] = {l.q[i].x, l.q[i].y, l.q[i].z, l.q[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int t = 4 * i + j;
+            if (t < QL) a.x.v[t] = w[j];
+            else a.y.v[t - QL] = w[j];
+        }
+    }
+    return a;
+}
+__device__ __forceinline__ Fr shl1(const Fr& a) {
+    Fr r;
+#pragma unroll
+    for (int k = 7; k > 0; k--) r.v[k] = (a.v[k] << 1) | (a.v[k - 1] >> 31);
+    r.v[0] = a.v[0] << 1;
+    return r;
+}
+// signed Booth digit of the c+1 low bits; then s >>= c
+template <int C>
+__device__ __forceinline__ int take_booth(Fr& s) {
+    const uint32_t x = s.v[0] & ((1u << (C + 1)) - 1);
+#pragma unroll
+    for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> C) | (s.v[k + 1] << (32 - C));
+    s.v[7] >>= C;
+    const int t = (int)((x + 1) >> 1);
+    return (x >> C) ? t - (1 << C) : t;
+}
+template <int C>
+__global__ __launch_bounds__(256, 2) void k_msm_fixed_chunked(const Fr* __restrict__ scalars, const TabQ* __restrict__ table,
+                                                              JacQ* __restrict__ out, int n_groups, int n_slices, int nb,
+                                                              int out_stride, int brp_bits, int S) {
+    constexpr int W = (255 + C) / C;
+    __shared__ JacQ red[256];
+    const int tid = threadIdx.x;
+    const int chunk = tid & (S - 1);                                      // S is a power of two
+    const long m = ((long)blockIdx.x * 256 + tid) / S;                    // MSM index = slice * n_groups + group
+    const bool active = m < (long)n_groups * n_slices;
+    const int Wc = (W + S - 1) / S;
+    const int w0 = chunk * Wc, nw = (w0 + Wc <= W ? Wc : W - w0);        // this thread's windows [w0, w0 + nw); nw may be <= 0
+    int slice = 0, group = 0;
+    MsmAcc acc = msm_acc_inf();
+    if (active && nw > 0) {
+        slice = (int)(m / n_groups);
+        group = (int)(m % n_groups);
+        const Fr* sc = scalars + (size_t)m * nb;
+        const TabQ* tb = table + ((((size_t)group * W + w0) * nb) << (C - 1));  // entry (w, i, a): tb[(((w - w0) * nb + i) << (C-1)) + a]
+        // The scalar sits in registers shifted left by one bit (window 0 is padded with a zero bit,
+        // booth_encoding.rs:4-46; r < 2^255 so nothing is lost); each window reads its c+1 low bits and shifts the
+        // scalar right by c: static register indexing only.
+        auto fetch = [&](int i) {
+            Fr t = shl1(sc[i]);
+            for (int k = 0; k < w0; k++) (void)take_booth<C>(t);
+            return t;
+        };
+        Fr s = fetch(0);
+        int i = 0, w = 0;
+        int d = take_booth<C>(s);
+        TabLine cur = load_line(tb + (d ? (d < 0 ? -d : d) - 1 : 0));
+        const int total = nw * nb;
+#pragma unroll 1
+        for (int e = 0; e < total; e++) {
+            // address of the next entry, requested before the current addition
+            int w2 = w + 1, i2 = i;
+            if (w2 == nw) {
+                w2 = 0;
+                i2 = i + 1;
+                s = fetch(i2 < nb ? i2 : 0);
+            }
+            const int d2 = i2 < nb ? take_booth<C>(s) : 0;
+            const int a2 = d2 ? (d2 < 0 ? -d2 : d2) - 1 : 0;
+            const TabLine nxt = load_line(tb + ((((size_t)w2 * nb + (i2 < nb ? i2 : 0)) << (C - 1)) + a2));
+            if (d != 0) acc = add_mixed(acc, line_to_affq(cur), d < 0);
+            cur = nxt;
+            d = d2;
+            w = w2;
+            i = i2;
+        }
+    } else if (active) {
+        slice = (int)(m / n_groups);
+        group = (int)(m % n_groups);
+    }
+    JacQ sum = msm_acc_to_jacq(acc);
+    if (S > 1) {  // fold the S chunk sums of each MSM (adjacent lanes)
+        for (int span = 1; span < S; span <<= 1) {
+            red[tid] = sum;
+            __syncthreads();
+            if ((chunk & (2 * span - 1)) == 0) sum = add(sum, red[tid + span]);
+            __syncthreads();
+        }
+    }
+    if (active && chunk == 0) {
+        const int pos = brp_bits ? (int)(__brev((unsigned)group) >> (32 - brp_bits)) : group;
+        out[(size_t)pos * out_stride + slice] = sum;
+    }
+}
+
 // Small-batch variant (a handful of blobs): one block per MSM, the W * nb table entries of the sum dealt round-robin
 // to all 256 lanes (5 additions each for W = 19, nb = 64) and folded by an 8-level tree in LDS.  ~30 % more field
 // work than the kernel above, but the dependent chain drops from 64 + 5 additions to 5 + 8.
@@ -134,6 +250,22 @@ void msm_fixed_flat(int c, const void* scalars, const void* table, void* out, in
     else if (c == 14) msm_flat_c<14>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
     else if (c == 10) msm_flat_c<10>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
     else msm_flat_c<4>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
+}
+template <int C>
+static void msm_chunked_c(const void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,
+                          int brp_bits, int S, hipStream_t st) {
+    const long threads = (long)n_groups * n_slices * S;
+    k_msm_fixed_chunked<C><<<(unsigned)((threads + 255) / 256), 256, 0, st>>>((const Fr*)scalars, (const TabQ*)table, (JacQ*)out,
+                                                                               n_groups, n_slices, nb, out_stride, brp_bits, S);
+}
+void msm_fixed_chunked(int c, const void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,
+                       int brp_bits, int S, hipStream_t st) {
+    if (c == 8) msm_chunked_c<8>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, S, st);
+    else if (c == 12) msm_chunked_c<12>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, S, st);
+    else if (c == 13) msm_chunked_c<13>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, S, st);
+    else if (c == 14) msm_chunked_c<14>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, S, st);
+    else if (c == 10) msm_chunked_c<10>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, S, st);
+    else msm_chunked_c<4>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, S, st);
 }
 template <int C>
 static void msm_c(const void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,

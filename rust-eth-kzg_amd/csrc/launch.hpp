@@ -25,6 +25,9 @@ void test_field_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, int n, int
 // k_msm.hip
 void msm_fixed(int c, const void* scalars, const void* table, void* out /*G1Jac*/, int n_groups, int n_slices, int nb,
                int out_stride, int brp_bits, hipStream_t st);
+// S = 1, 2 or 4 threads per MSM, each summing a chunk of the windows (large batches: no window-sum fold to speak of)
+void msm_fixed_chunked(int c, const void* scalars, const void* table, void* out /*JacQ*/, int n_groups, int n_slices, int nb,
+                       int out_stride, int brp_bits, int S, hipStream_t st);
 void msm_fixed_flat(int c, const void* scalars, const void* table, void* out /*G1Jac*/, int n_groups, int n_slices, int nb,
                int out_stride, int brp_bits, hipStream_t st);
 // k_table.hip
@@ -41,6 +44,10 @@ void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int m
 
 void g1_dft128_direct(void* X, void* tmpA, void* prod, int stride, int n_in, int n_out, int inverse, int brp_out,
                       const void* tw, const Fp12w& beta, hipStream_t st);
+
+// k_g1slp.hip: one launch of the straight-line program of the FK20 proofs map (g1_linmap.hpp); kind = linmap::OpKind
+void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int count, const void* naf, const Fp12w& beta,
+                   hipStream_t st);
 
 // k_g1misc.hip
 void g1_set_inf(void* X, size_t n, hipStream_t st);

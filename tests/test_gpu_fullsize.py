@@ -1,0 +1,258 @@
+"""GPU parity at BASELINE.json's FULL sizes (the oracle cannot run these whole in seconds, so: every blob is held to the
+size-independent invariants, a seeded sample of blobs is compared byte-for-byte with the CPU oracle).
+
+  config 3  verify_cell_kzg_proof_batch, 64 blobs x 128 cells = 8192 cells   (crates/eip7594/tests/verify_cell_kzg_proof_batch.rs)
+  config 4  compute_cells_and_kzg_proofs, 512-blob batch                      (crates/eip7594/tests/compute_cells_and_kzg_proofs.rs)
+  config 5  recover_cells_and_kzg_proofs, 256 blobs at 50 % erasure           (crates/eip7594/tests/recover_cells_and_kzg_proofs.rs)
+  bench     compute_cells_and_kzg_proofs, 2048 device-resident blobs (bench.py's step)
+  widths    FK20 window tables of width 8 and 12 + the stage-level fixed-base MSM against oracle_g1_msm
+            (crates/cryptography/bls12_381/src/fixed_base_msm_window.rs:178-321 tests widths 2..14)
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import synth
+
+pytestmark = pytest.mark.gpu
+kzg = importlib.import_module("rust-eth-kzg_amd")
+
+INF = b"\xc0" + bytes(47)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = kzg.DASContext(use_precomp=True)
+    yield c
+    c.close()
+
+
+def _random_blobs(n, seed):
+    """n blobs of uniformly random canonical field elements (top two bits cleared: < 2^254 < r)."""
+    rng = np.random.RandomState(seed)
+    a = rng.randint(0, 256, size=(n, 4096, 32), dtype=np.uint8)
+    a[:, :, 0] &= 0x3F
+    return a
+
+
+def _compute_on_device(ctx, blobs_np):
+    """blobs [n][4096][32] u8 -> (status, cells [n][128*2048] u8, proofs [n][128*48] u8) through the device entry point."""
+    import torch
+    n = blobs_np.shape[0]
+    d_blobs = torch.from_numpy(blobs_np.reshape(-1)).cuda()
+    d_cells = torch.empty(n * 128 * 2048, dtype=torch.uint8, device="cuda")
+    d_proofs = torch.empty(n * 128 * 48, dtype=torch.uint8, device="cuda")
+    st = ctx.compute_cells_and_kzg_proofs_device(n, d_blobs.data_ptr(), d_cells.data_ptr(), d_proofs.data_ptr())
+    torch.cuda.synchronize()
+    return st, d_cells.cpu().numpy().reshape(n, 128 * 2048), d_proofs.cpu().numpy().reshape(n, 128 * 48)
+
+
+def _check_sample_against_oracle(oracle, blobs_np, cells, proofs, sample):
+    for b in sample:
+        ec, ep = oracle.compute_cells_and_kzg_proofs(blobs_np[b].tobytes())
+        assert cells[b].tobytes() == b"".join(ec), f"blob {b}: cells differ from the oracle"
+        assert proofs[b].tobytes() == b"".join(ep), f"blob {b}: proofs differ from the oracle"
+
+
+@pytest.mark.parametrize("n", [512, 2048])
+def test_compute_full_batches_device_resident(ctx, oracle, n):
+    """The bench step (2048 blobs) and config 4's whole batch (512) through the device entry point: data-in-first-half
+    invariant (prover.rs:251-275) on EVERY blob, 16 sampled blobs (first, last, both sides of every 64-lane group
+    boundary that the sample hits, the planted edge cases) byte-for-byte against the oracle."""
+    blobs = _random_blobs(n, 7000 + n)
+    blobs[3] = 0                                                        # zero polynomial: identity proofs
+    blobs[n - 2] = np.frombuffer(synth.dummy_blob(), dtype=np.uint8).reshape(4096, 32)
+    blobs[65] = np.frombuffer((b"\x00" * 31 + b"\x07") * 4096, dtype=np.uint8).reshape(4096, 32)  # constant polynomial
+    st, cells, proofs = _compute_on_device(ctx, blobs)
+    assert st == [0] * n
+    flat_in = blobs.reshape(n, 131072)
+    assert np.array_equal(cells[:, :131072], flat_in), "cells 0..63 must be the blob itself"
+    assert proofs[3].tobytes() == INF * 128 and proofs[65].tobytes() == INF * 128
+    rng = np.random.RandomState(n)
+    sample = {0, 3, 63, 64, 65, n // 2 - 1, n // 2, n - 2, n - 1}
+    while len(sample) < 16:
+        sample.add(int(rng.randint(n)))
+    sample = sorted(sample)
+    _check_sample_against_oracle(oracle, blobs, cells, proofs, sample)
+    # identical blobs in different lanes give identical results (lane independence across the whole batch)
+    blobs2 = blobs.copy()
+    blobs2[n - 1] = blobs2[0]
+    st2, cells2, proofs2 = _compute_on_device(ctx, blobs2)
+    assert st2 == [0] * n and np.array_equal(cells2[n - 1], cells[0]) and np.array_equal(proofs2[n - 1], proofs[0])
+    assert np.array_equal(proofs2[: n - 1], proofs[: n - 1])
+
+
+def test_compute_512_through_the_host_batch_abi(ctx, oracle):
+    """Config 4's 512 blobs through the host-pointer batch entry point (what a C / Go / Java caller uses):
+    same bytes as the device-resident form."""
+    n = 512
+    blobs = _random_blobs(n, 7000 + n)
+    st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch([blobs[b].tobytes() for b in range(n)])
+    assert st == [0] * n
+    _, dcells, dproofs = _compute_on_device(ctx, blobs)
+    for b in range(n):
+        assert b"".join(cells[b]) == dcells[b].tobytes() and b"".join(proofs[b]) == dproofs[b].tobytes(), b
+
+
+def _config3_inputs(ctx, n_blobs=64):
+    blobs = _random_blobs(n_blobs, 3003)
+    st, cells, proofs = _compute_on_device(ctx, blobs)
+    assert st == [0] * n_blobs
+    st2, comms = ctx.blob_to_kzg_commitment_batch([blobs[b].tobytes() for b in range(n_blobs)])
+    assert st2 == [0] * n_blobs
+    C, I, L, P = [], [], [], []
+    for b in range(n_blobs):
+        cb, pb = cells[b].tobytes(), proofs[b].tobytes()
+        for k in range(128):
+            C.append(comms[b]); I.append(k); L.append(cb[2048 * k:2048 * (k + 1)]); P.append(pb[48 * k:48 * (k + 1)])
+    return blobs, comms, C, I, L, P
+
+
+def test_verify_config3_full_size(ctx, oracle):
+    """64 blobs x 128 cells in ONE call (8192 cells, 64 distinct commitments, 17.6 MB of input): true; one tampered
+    proof, one tampered cell, one swapped commitment: false each (not an error); verdicts equal the oracle's;
+    the sharded form (partial + combine) at world 8 agrees."""
+    blobs, comms, C, I, L, P = _config3_inputs(ctx)
+    assert len(L) == 8192
+    assert ctx.verify_cell_kzg_proof_batch(C, I, L, P) is True
+    assert oracle.verify_cell_kzg_proof_batch(C, I, L, P) is True
+    P2 = list(P); P2[4097] = P[4098]
+    L2 = list(L); L2[8191] = L[0]
+    C2 = list(C); C2[700] = comms[63]
+    for (c_, l_, p_) in ((C, L, P2), (C, L2, P), (C2, L, P)):
+        assert ctx.verify_cell_kzg_proof_batch(c_, I, l_, p_) is False
+    assert oracle.verify_cell_kzg_proof_batch(C, I, L, P2) is False
+    # sharded over 8 ranks' worth of cell ranges
+    world = 8
+    bounds = [(r * 8192 // world, (r + 1) * 8192 // world) for r in range(world)]
+    parts = [ctx.verify_cell_kzg_proof_batch_partial(C, I, L, P, lo, hi) for lo, hi in bounds]
+    assert ctx.verify_cell_kzg_proof_batch_combine(parts) is True
+    parts_bad = [ctx.verify_cell_kzg_proof_batch_partial(C, I, L, P2, lo, hi) for lo, hi in bounds]
+    assert ctx.verify_cell_kzg_proof_batch_combine(parts_bad) is False
+    # a malformed proof (not in G1) anywhere in the 8192 is an error, not "false"
+    P3 = list(P); P3[5000] = b"\x80" + bytes(46) + b"\x05"
+    if oracle_lib.g1_validate(P3[5000], True) != 0:
+        with pytest.raises(kzg.KzgError):
+            ctx.verify_cell_kzg_proof_batch(C, I, L, P3)
+
+
+@pytest.mark.parametrize("pattern", ["even", "first_half"])
+def test_recover_config5_full_size(ctx, oracle, pattern):
+    """256 blobs at 50 % erasure, host-batch and device-resident forms: recovered cells and proofs == what the prover
+    produced for the whole blob; 8 sampled blobs against the oracle's recovery."""
+    import torch
+    n = 256
+    blobs = _random_blobs(n, 5005)
+    st, cells, proofs = _compute_on_device(ctx, blobs)
+    assert st == [0] * n
+    idx = list(range(0, 128, 2)) if pattern == "even" else list(range(64))
+    # device-resident form: extended blobs in HBM with the missing cells overwritten by junk
+    flat = cells.reshape(n, 128, 2048).copy()
+    missing = [k for k in range(128) if k not in idx]
+    flat[:, missing, :] = 0xFF
+    d_in = torch.from_numpy(flat.reshape(-1)).cuda()
+    d_cells = torch.empty(n * 128 * 2048, dtype=torch.uint8, device="cuda")
+    d_proofs = torch.empty(n * 128 * 48, dtype=torch.uint8, device="cuda")
+    status = ctx.recover_cells_and_kzg_proofs_device(n, d_in.data_ptr(), [idx] * n, d_cells.data_ptr(), d_proofs.data_ptr())
+    torch.cuda.synchronize()
+    assert status == [0] * n
+    assert np.array_equal(d_cells.cpu().numpy().reshape(n, -1), cells)
+    assert np.array_equal(d_proofs.cpu().numpy().reshape(n, -1), proofs)
+    # host-batch form
+    cell_bytes = [cells[b].tobytes() for b in range(n)]
+    batch = [(idx, [cell_bytes[b][2048 * k:2048 * (k + 1)] for k in idx]) for b in range(n)]
+    st2, rc, rp = ctx.recover_cells_and_kzg_proofs_batch(batch)
+    assert st2 == [0] * n
+    for b in range(n):
+        assert b"".join(rc[b]) == cell_bytes[b] and b"".join(rp[b]) == proofs[b].tobytes(), b
+    for b in sorted(np.random.RandomState(5).choice(n, 8, replace=False).tolist()):
+        oc, op = oracle.recover_cells_and_kzg_proofs(batch[b][0], batch[b][1])
+        assert rc[b] == oc and rp[b] == op, b
+
+
+@pytest.mark.parametrize("width", [8, 12])
+def test_fallback_window_widths_match_oracle(oracle, monkeypatch, width):
+    """The table widths the engine falls back to when HBM is short (14 -> 13 -> 12 -> 10 -> 8): identical bytes."""
+    monkeypatch.setenv("ETH_KZG_AMD_WINDOW", str(width))
+    c2 = kzg.DASContext(use_precomp=True)
+    try:
+        assert c2.window_bits() == width
+        blobs = _random_blobs(70, 800 + width)
+        blobs[1] = 0
+        st, cells, proofs = _compute_on_device(c2, blobs)
+        assert st == [0] * 70
+        _check_sample_against_oracle(oracle, blobs, cells, proofs, [0, 1, 63, 64, 69])
+        # large-batch MSM schedule (threads own chunks of windows) at this width
+        blobs = _random_blobs(1024, 900 + width)
+        st, cells, proofs = _compute_on_device(c2, blobs)
+        assert st == [0] * 1024
+        _check_sample_against_oracle(oracle, blobs, cells, proofs, [0, 511, 1023])
+    finally:
+        c2.close()
+
+
+_FK20_BASES = {}
+
+
+def _fk20_base_column(i):
+    """S^[.][i]: FFT_128 of SRS vector i (batch_toeplitz.rs:46-61), compressed, computed by the oracle (cached)."""
+    if i not in _FK20_BASES:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        raw = open(os.path.join(root, "rust-eth-kzg_amd", "data", "trusted_setup_4096.bin"), "rb").read()
+        srs = [raw[16 + 48 * k:16 + 48 * (k + 1)] for k in range(4096)]
+        vec = [srs[4096 - 1 - 64 - (i + 64 * pos)] if pos < 63 else INF for pos in range(128)]
+        out = oracle_lib.g1_fft(b"".join(vec), inverse=False)
+        _FK20_BASES[i] = [out[48 * j:48 * (j + 1)] for j in range(128)]
+    return _FK20_BASES[i]
+
+
+@pytest.mark.parametrize("chunks", ["auto", "0", "1", "2", "4"])
+def test_fixed_base_msm_stage_matches_oracle(oracle, monkeypatch, chunks):
+    """Stage D alone (128 fixed-base MSM_64 per scalar set over the FK20 window tables) against oracle_g1_msm, for
+    every MSM schedule: the windowed kernel (0) and threads owning 1 / 2 / 4 chunks of windows.  Scalars include 0,
+    1, r-1 and values whose Booth digits hit the table ends (2^(c-1) and its negative)."""
+    import ctypes as C
+    if chunks != "auto":
+        monkeypatch.setenv("ETH_KZG_AMD_MSM_CHUNKS", chunks)
+    c2 = kzg.DASContext(use_precomp=True)
+    try:
+        lib = kzg.load_library()
+        n_msm = 9  # > FLAT_MSM_MAX_SLICES so that the batch kernels run, not the one-block-per-MSM form
+        sc = [synth.seeded_scalars(128 * 64, b"msm%d" % m) for m in range(n_msm)]
+        w = c2.window_bits()
+        edge = [0, 1, synth.R - 1, 1 << (w - 1), (1 << (w - 1)) + 1, (1 << w) - 1, (1 << 254), (1 << (w * 3)) - (1 << (w - 1))]
+        for k, v in enumerate(edge):
+            sc[0][k] = (v % synth.R).to_bytes(32, "big")
+        sc[1] = [bytes(32)] * (128 * 64)  # all-zero scalars: identity everywhere
+        flat = b"".join(b"".join(s) for s in sc)
+        out = C.create_string_buffer(n_msm * 128 * 48)
+        assert lib.eth_kzg_amd_test_fixed_msm(c2.handle, flat, n_msm, out) == 0
+        got = lambda m, j: out.raw[(m * 128 + j) * 48:(m * 128 + j + 1) * 48]
+        assert all(got(1, j) == INF for j in range(128))
+        for (m, j) in [(0, 0), (0, 1), (2, 64), (5, 127), (8, 77)]:
+            pts = b"".join(_fk20_base_column(i)[j] for i in range(64))
+            scal = b"".join(sc[m][j * 64:(j + 1) * 64])
+            assert got(m, j) == oracle_lib.g1_msm(pts, scal), (chunks, m, j)
+    finally:
+        c2.close()
+
+
+def test_radix2_transform_schedule_still_matches_oracle(oracle, monkeypatch):
+    """ETH_KZG_AMD_G1FFT=radix2 keeps the butterfly network (and the direct 8 x 16 form below 129 blobs) instead of the
+    compiled linear map: same bytes."""
+    monkeypatch.setenv("ETH_KZG_AMD_G1FFT", "radix2")
+    c2 = kzg.DASContext(use_precomp=True)
+    try:
+        for n in (70, 200):
+            blobs = _random_blobs(n, 400 + n)
+            blobs[2] = 0
+            st, cells, proofs = _compute_on_device(c2, blobs)
+            assert st == [0] * n
+            _check_sample_against_oracle(oracle, blobs, cells, proofs, [0, 2, 63, 64, n - 1])
+    finally:
+        c2.close()

@@ -41,3 +41,13 @@ def test_host_multiplication_64_bit_matches_32_bit(tmp_path):
     """csrc/field.hpp: the host's 64-bit-limb Montgomery multiplication against the portable 32-bit CIOS form."""
     out = _build_and_run(tmp_path, "test_host_mul")
     assert "0 mismatches" in out
+
+
+@pytest.mark.timeout(600)
+def test_fk20_proofs_map_compiles_to_its_definition(tmp_path):
+    """csrc/g1_linmap.hpp: the two G1 transforms of the prover compiled into a straight-line program of point operations
+    (free cyclotomic splits + Karatsuba / Toom-Cook Toeplitz products with the interpolation on the fixed side). Run over
+    Fr, the plan and its scheduled slot program must equal IDFT_128 -> keep 64 -> DFT_128; the Hankel building blocks
+    are checked for every size and split."""
+    out = _build_and_run(tmp_path, "test_linmap")
+    assert "0 mismatches" in out and "fk20 plan" in out
