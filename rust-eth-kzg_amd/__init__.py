@@ -325,8 +325,29 @@ class DASContext:
         self._check(self._lib.eth_kzg_amd_compute_cells_and_kzg_proofs_batch(self._ctx, n, _vp(ba), _vp(cpp), _vp(ppp), st))
         return list(st)[:n], _split(cells, n, 128, BYTES_PER_CELL), _split(proofs, n, 128, 48)
 
+    def host_batch_buffers(self, n):
+        """Caller-side buffers of the host-pointer batch ABI, allocated and touched once so that repeated calls measure
+        the library and not the page faults of fresh output memory: (cells [n,128,2048] u8, proofs [n,128,48] u8,
+        cell pointer tables, proof pointer tables)."""
+        cells, ci, cpp = _out_ptrs(n, 128, BYTES_PER_CELL)
+        proofs, pi, ppp = _out_ptrs(n, 128, 48)
+        return {"cells": cells.reshape(n, 128, BYTES_PER_CELL), "proofs": proofs.reshape(n, 128, 48), "_ci": ci, "_pi": pi,
+                "cpp": cpp, "ppp": ppp, "status": (C.c_int32 * max(1, n))()}
+
+    def compute_cells_and_kzg_proofs_batch_np(self, blobs_np, bufs, want_proofs=True):
+        """eth_kzg_amd_compute_cells_and_kzg_proofs_batch on a contiguous [n,131072] uint8 array (one pointer per blob, as
+        a C caller would pass) into `bufs` from host_batch_buffers; returns the status list.  Only the C call happens here."""
+        n = blobs_np.shape[0]
+        assert blobs_np.dtype == np.uint8 and blobs_np.flags["C_CONTIGUOUS"] and blobs_np.size == n * BYTES_PER_BLOB
+        ba = np.uint64(blobs_np.ctypes.data) + np.arange(max(1, n), dtype=np.uint64) * np.uint64(BYTES_PER_BLOB)
+        self._check(self._lib.eth_kzg_amd_compute_cells_and_kzg_proofs_batch(
+            self._ctx, n, _vp(ba), _vp(bufs["cpp"]), _vp(bufs["ppp"]) if want_proofs else None, bufs["status"]))
+        return list(bufs["status"])[:n]
+
     def blob_to_kzg_commitment_batch(self, blobs):
         n = len(blobs)
+        if any(len(b) != BYTES_PER_BLOB for b in blobs):
+            raise KzgError("InvalidLength")
         ba, _kb = _ptr_array(blobs)
         outs = [C.create_string_buffer(48) for _ in range(n)]
         oa, _ko = _ptr_array(outs)

@@ -115,7 +115,7 @@ int Engine::compute_kzg_proof_host(const uint8_t* blob, const uint8_t* z_bytes, 
         memcpy(&y, &y8, 32);
         fr_to_be(out_y, y);
     } catch (const std::exception& e) {
-        err_ = e.what();
+        set_error(e);
         return ERR_DEVICE;
     }
     return OK;
@@ -148,7 +148,7 @@ int Engine::compute_blob_kzg_proof_host(const uint8_t* blob, const uint8_t* comm
         if (cst) return ERR_G1;
         memcpy(out_proof, proof, 48);
     } catch (const std::exception& e) {
-        err_ = e.what();
+        set_error(e);
         return ERR_DEVICE;
     }
     return OK;
@@ -198,7 +198,7 @@ int Engine::verify_kzg_proof_host(const uint8_t* commitment, const uint8_t* z_by
         std::vector<Fr8> s1 = {canon8(z), canon8(one<FrParams>()), canon8(neg(y))};
         *verified = pairing_check_4844(d_pts.p, s0, s1);
     } catch (const std::exception& e) {
-        err_ = e.what();
+        set_error(e);
         return ERR_DEVICE;
     }
     return OK;
@@ -263,7 +263,7 @@ int Engine::verify_blob_kzg_proof_batch_host(uint64_t n_blobs, const uint8_t* co
         s1[2 * n] = canon8(neg(ysum));
         *verified = pairing_check_4844(d_pts.p, s0, s1);
     } catch (const std::exception& e) {
-        err_ = e.what();
+        set_error(e);
         return ERR_DEVICE;
     }
     return OK;
@@ -288,7 +288,7 @@ int Engine::verify_blob_kzg_proof_host(const uint8_t* blob, const uint8_t* commi
             if (bst) return ERR_SCALAR;
             memcpy(&y, &y8, 32);
         } catch (const std::exception& e) {
-            err_ = e.what();
+            set_error(e);
             return ERR_DEVICE;
         }
     }

@@ -7,6 +7,7 @@
 #include "g1_linmap.hpp"
 #include "launch.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -109,6 +110,44 @@ static void recode_glv_wnaf(const Fr& k_mont, const Fr& lambda_mont, uint32_t* o
         if (!eq(back, to_mont(h ? a2 : a1))) throw std::runtime_error("constant recoding failed");
     }
 }
+// The text of a device error belongs to the call that failed, and calls run concurrently: keep it per thread.
+static thread_local std::string t_last_error;
+const std::string& Engine::last_error() const { return t_last_error; }
+void Engine::set_error(const std::exception& e) { t_last_error = e.what(); }
+
+HostPool::HostPool(int threads, int device) {
+    for (int i = 0; i < threads; i++) th_.emplace_back([this, device] { run(device); });
+}
+HostPool::~HostPool() {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+}
+void HostPool::submit(std::function<void()> fn) {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        q_.push_back(std::move(fn));
+    }
+    cv_.notify_one();
+}
+void HostPool::run(int device) {
+    (void)hipSetDevice(device);
+    for (;;) {
+        std::function<void()> fn;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+            if (q_.empty()) return;
+            fn = std::move(q_.front());
+            q_.pop_front();
+        }
+        fn();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 BufferPool::~BufferPool() {
     for (auto& f : free_) {
@@ -190,6 +229,21 @@ Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14
         }
     }
     HIPCK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    for (Work& w : work_) {
+        HIPCK(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&w.ev_in, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&w.ev_cells, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&w.ev_cells_host, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
+        if (&w == &work_[0]) continue;  // the paths under mu_ run on stream_
+        // ROCm multiplexes streams onto a few hardware queues per priority level and a queue runs in order: a copy stream
+        // that shares its queue with a compute stream delivers the cells only after the MSMs.  Copy streams get the high
+        // priority level, i.e. queues of their own.
+        int prio_low = 0, prio_high = 0;
+        HIPCK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        HIPCK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+        HIPCK(hipStreamCreateWithPriority(&w.copy, hipStreamNonBlocking, prio_high));
+    }
     launch::init_attributes();
     lap("HIP runtime + stream");
     init_constants();
@@ -205,10 +259,25 @@ Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14
 
 Engine::~Engine() {
     hipSetDevice(dev_);
-    void* ptrs[] = {d_w8192_, d_naf_, d_srs_, d_fk_bases_, d_coeffs_, d_canon_,
-                    d_scalars_, d_X_, d_status_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_dft_tmp_, d_dft_prod_, d_circ_terms_, d_circ_table_, d_slp_naf_, d_slp_words_, d_slp_arena_};
+    host_pool_.reset();  // joins the helper threads before anything they might touch goes away
+    void* ptrs[] = {d_w8192_, d_naf_, d_srs_, d_fk_bases_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_circ_terms_,
+                    d_slp_naf_, d_slp_words_};
     for (void* p : ptrs)
         if (p) hipFree(p);
+    for (Work& w : work_) {
+        void* dev[] = {w.coeffs, w.canon, w.scalars, w.X, w.status, w.dft_tmp, w.dft_prod, w.circ_table, w.slp_arena, w.d_in, w.d_cells, w.d_proofs};
+        for (void* p : dev)
+            if (p) hipFree(p);
+        void* pin[] = {w.h_in, w.h_cells, w.h_proofs, w.h_status};
+        for (void* p : pin)
+            if (p) hipHostFree(p);
+        hipEvent_t evs[] = {w.done, w.ev_in, w.ev_cells, w.ev_cells_host, w.ev_done};
+        for (hipEvent_t e : evs)
+            if (e) hipEventDestroy(e);
+        for (hipEvent_t e : w.sub_events) hipEventDestroy(e);
+        if (w.stream) hipStreamDestroy(w.stream);
+        if (w.copy) hipStreamDestroy(w.copy);
+    }
     if (v_dev_) hipFree(v_dev_);
     if (v_pin_) hipHostFree(v_pin_);
     if (stream_) hipStreamDestroy(stream_);
@@ -492,9 +561,11 @@ void Engine::init_fk20() {
     fk_table_bytes_ = fk_tab_->bytes;
 }
 
-void Engine::set_profiling(bool on) { std::lock_guard<std::recursive_mutex> lk(mu_); profiling_ = on; }
+// Per-stage HIP events (bench.py's roofline leg).  Meant for one caller at a time: marks of concurrent calls would interleave.
+void Engine::set_profiling(bool on) { std::lock_guard<std::mutex> lk(marks_mu_); profiling_ = on; }
 void Engine::mark_begin(int stage, hipStream_t st) {
     if (!profiling_) return;
+    std::lock_guard<std::mutex> lk(marks_mu_);
     StageMark m{stage, 0, nullptr, nullptr};
     HIPCK(hipEventCreate(&m.a));
     HIPCK(hipEventCreate(&m.b));
@@ -503,11 +574,12 @@ void Engine::mark_begin(int stage, hipStream_t st) {
 }
 void Engine::mark_end(int launches, hipStream_t st) {
     if (!profiling_) return;
+    std::lock_guard<std::mutex> lk(marks_mu_);
     marks_.back().launches = launches;
     HIPCK(hipEventRecord(marks_.back().b, st));
 }
 void Engine::get_stage_times(double* ms, uint64_t* launches) {
-    std::lock_guard<std::recursive_mutex> lk(mu_);
+    std::lock_guard<std::mutex> lk(marks_mu_);
     for (int i = 0; i < ST_COUNT; i++) { ms[i] = 0; launches[i] = 0; }
     hipSetDevice(dev_);
     hipDeviceSynchronize();
@@ -520,18 +592,47 @@ void Engine::get_stage_times(double* ms, uint64_t* launches) {
     marks_.clear();
 }
 
-void Engine::ensure_workspace(int n) {
-    if (n <= cap_) return;
+void Engine::ensure_workspace(Work& w, int n) {
+    if (n <= w.cap) return;
     int cap = ((n + 63) / 64) * 64;
-    void** ptrs[] = {&d_coeffs_, &d_canon_, &d_scalars_, &d_X_, (void**)&d_status_};
+    void** ptrs[] = {&w.coeffs, &w.canon, &w.scalars, &w.X, (void**)&w.status};
     for (void** p : ptrs)
         if (*p) { HIPCK(hipFree(*p)); *p = nullptr; }
-    HIPCK(hipMalloc(&d_coeffs_, (size_t)cap * N_BLOB * sizeof(Fr)));
-    HIPCK(hipMalloc(&d_canon_, (size_t)cap * N_BLOB * sizeof(Fr)));
-    HIPCK(hipMalloc(&d_scalars_, (size_t)cap * 128 * 64 * sizeof(Fr)));
-    HIPCK(hipMalloc(&d_X_, (size_t)cap * 128 * launch::SIZEOF_JACQ));
-    HIPCK(hipMalloc(&d_status_, (size_t)cap * sizeof(int)));
-    cap_ = cap;
+    w.cap = 0;
+    HIPCK(hipMalloc(&w.coeffs, (size_t)cap * N_BLOB * sizeof(Fr)));
+    HIPCK(hipMalloc(&w.canon, (size_t)cap * N_BLOB * sizeof(Fr)));
+    HIPCK(hipMalloc(&w.scalars, (size_t)cap * 128 * 64 * sizeof(Fr)));
+    HIPCK(hipMalloc(&w.X, (size_t)cap * 128 * launch::SIZEOF_JACQ));
+    HIPCK(hipMalloc(&w.status, (size_t)cap * sizeof(int)));
+    w.cap = cap;
+}
+// staging of the host-pointer prover entry point: one chunk of blobs in, its cells and proofs out (device + pinned host)
+void Engine::ensure_staging(Work& w, int n) {
+    if (n <= w.stage_cap) return;
+    void* dev[] = {w.d_in, w.d_cells, w.d_proofs};
+    for (void* p : dev)
+        if (p) HIPCK(hipFree(p));
+    void* pin[] = {w.h_in, w.h_cells, w.h_proofs, w.h_status};
+    for (void* p : pin)
+        if (p) HIPCK(hipHostFree(p));
+    w.d_in = w.d_cells = w.d_proofs = w.h_in = w.h_cells = w.h_proofs = nullptr;
+    w.h_status = nullptr;
+    w.stage_cap = 0;
+    HIPCK(hipMalloc(&w.d_in, (size_t)n * BYTES_PER_BLOB));
+    HIPCK(hipMalloc(&w.d_cells, (size_t)n * N_CELLS * BYTES_PER_CELL));
+    HIPCK(hipMalloc(&w.d_proofs, (size_t)n * N_CELLS * 48));
+    HIPCK(hipHostMalloc(&w.h_in, (size_t)n * BYTES_PER_BLOB, hipHostMallocDefault));
+    HIPCK(hipHostMalloc(&w.h_cells, (size_t)n * N_CELLS * BYTES_PER_CELL, hipHostMallocDefault));
+    HIPCK(hipHostMalloc(&w.h_proofs, (size_t)n * N_CELLS * 48, hipHostMallocDefault));
+    HIPCK(hipHostMalloc(&w.h_status, (size_t)n * sizeof(int), hipHostMallocDefault));
+    w.stage_cap = n;
+}
+// a free set among work_[first..last]: the first one whose lock is free, else wait for `first`
+Work& Engine::lease_work(int first, int last) {
+    for (int i = first; i <= last; i++)
+        if (work_[i].mu.try_lock()) return work_[i];
+    work_[first].mu.lock();
+    return work_[first];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -578,8 +679,8 @@ void Engine::g1_fft128_full(void* X, int stride, int inverse, hipStream_t st) {
     }
 }
 
-// stages C..G of SURVEY 3.2 from coefficients already in d_coeffs_
-void Engine::run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st) {
+// stages C..G of SURVEY 3.2 from coefficients already in w.coeffs
+void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream_t st) {
     const int bp = ((n + 63) / 64) * 64;
     // one or two blobs: the MSM also delivers 2^32 u, 2^64 u, 2^96 u (scaled copies of the scalars, same tables), which
     // cuts the doubling chain of the circulant form into four parallel quarters (needs 32 * 4 >= T - 1 doublings)
@@ -588,86 +689,100 @@ void Engine::run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st) {
     // beyond the small-batch circulant kernel the two transforms run as one compiled linear map (g1_linmap.hpp), which wants
     // the MSM outputs halved instead of divided by 128 and in natural Fourier order in the first 128 arena slots
     const bool linmap_mode = use_linmap_ && n > circ_max_;
-    void* X = d_X_;
+    void* X = w.X;
     if (linmap_mode) {
         const size_t need = (size_t)slp_slots_ * bp * launch::SIZEOF_JACQ;
-        if (need > slp_arena_bytes_) {
-            if (d_slp_arena_) { HIPCK(hipStreamSynchronize(st)); HIPCK(hipFree(d_slp_arena_)); d_slp_arena_ = nullptr; }
-            HIPCK(hipMalloc(&d_slp_arena_, need));
-            slp_arena_bytes_ = need;
+        if (need > w.slp_arena_bytes) {
+            if (w.slp_arena) { HIPCK(hipStreamSynchronize(st)); HIPCK(hipFree(w.slp_arena)); w.slp_arena = nullptr; }
+            HIPCK(hipMalloc(&w.slp_arena, need));
+            w.slp_arena_bytes = need;
         }
-        X = d_slp_arena_;
+        X = w.slp_arena;
     }
     mark_begin(ST_FK20_SCALARS, st);
-    launch::fk20_scalars(n, d_coeffs_, d_scalars_, d_w8192_, linmap_mode ? half_ : inv128_, segs, segs == 2 ? two_segments : seg_shift_, st);
+    launch::fk20_scalars(n, w.coeffs, w.scalars, d_w8192_, linmap_mode ? half_ : inv128_, segs, segs == 2 ? two_segments : seg_shift_, st);
     mark_end(1, st);
     launch::g1_set_inf(X, (size_t)128 * bp, st);
     const bool latency_mode = bp <= LATENCY_MODE_MAX_LANES;  // few 64-blob groups: direct 8 x 16 transforms, 4 rounds instead of 14
     mark_begin(ST_MSM_FIXED, st);
-    launch_msm(d_scalars_, d_fk_table_, X, 128, segs * n, bp, (latency_mode || linmap_mode) ? 0 : 7, st);
+    launch_msm(w.scalars, d_fk_table_, X, 128, segs * n, bp, (latency_mode || linmap_mode) ? 0 : 7, st);
     mark_end(1, st);
     if (linmap_mode) {
         mark_begin(ST_G1_LINMAP, st);
         for (auto& L : slp_launches_)
-            launch::g1_slp_launch(L.kind, d_slp_arena_, bp, (const uint32_t*)d_slp_words_ + (size_t)L.first * 4, L.count, d_slp_naf_, beta_, st);
+            launch::g1_slp_launch(L.kind, w.slp_arena, bp, (const uint32_t*)d_slp_words_ + (size_t)L.first * 4, L.count, d_slp_naf_, beta_, st);
         mark_end((int)slp_launches_.size(), st);
         mark_begin(ST_COMPRESS, st);
-        launch::g1_compress((const char*)d_slp_arena_ + (size_t)128 * bp * launch::SIZEOF_JACQ, d_proofs, 128, bp, n, st);
+        launch::g1_compress((const char*)w.slp_arena + (size_t)128 * bp * launch::SIZEOF_JACQ, d_proofs, 128, bp, n, st);
         mark_end(1, st);
         return;
     }
     if (n <= circ_max_) {  // a handful of blobs: the two transforms as one circulant product (k_g1circ.hip)
-        if (!d_circ_table_) HIPCK(hipMalloc(&d_circ_table_, launch::g1_circ_table_bytes(circ_max_, circ_T_)));
+        if (!w.circ_table) HIPCK(hipMalloc(&w.circ_table, launch::g1_circ_table_bytes(circ_max_, circ_T_)));
         mark_begin(ST_G1_IFFT, st);
-        launch::g1_circ128(d_X_, bp, n, segs, d_circ_table_, circ_T_, d_circ_terms_, circ_per_lane_, beta_, st);
+        launch::g1_circ128(w.X, bp, n, segs, w.circ_table, circ_T_, d_circ_terms_, circ_per_lane_, beta_, st);
         mark_end(2, st);
     } else if (latency_mode) {
-        if (!d_dft_tmp_) {
-            HIPCK(hipMalloc(&d_dft_tmp_, (size_t)128 * LATENCY_MODE_MAX_LANES * launch::SIZEOF_JACQ));
-            HIPCK(hipMalloc(&d_dft_prod_, (size_t)128 * 16 * LATENCY_MODE_MAX_LANES * launch::SIZEOF_JACQ));
+        if (!w.dft_tmp) {
+            HIPCK(hipMalloc(&w.dft_tmp, (size_t)128 * LATENCY_MODE_MAX_LANES * launch::SIZEOF_JACQ));
+            HIPCK(hipMalloc(&w.dft_prod, (size_t)128 * 16 * LATENCY_MODE_MAX_LANES * launch::SIZEOF_JACQ));
         }
         mark_begin(ST_G1_IFFT, st);
-        launch::g1_dft128_direct(d_X_, d_dft_tmp_, d_dft_prod_, bp, 128, 64, 1, 0, d_naf_, beta_, st);  // h = first 64 outputs
+        launch::g1_dft128_direct(w.X, w.dft_tmp, w.dft_prod, bp, 128, 64, 1, 0, d_naf_, beta_, st);  // h = first 64 outputs
         mark_end(2, st);
         mark_begin(ST_G1_FFT, st);
-        launch::g1_dft128_direct(d_X_, d_dft_tmp_, d_dft_prod_, bp, 64, 128, 0, 1, d_naf_, beta_, st);  // proofs, bit-reversed
+        launch::g1_dft128_direct(w.X, w.dft_tmp, w.dft_prod, bp, 64, 128, 0, 1, d_naf_, beta_, st);  // proofs, bit-reversed
         mark_end(2, st);
     } else {
         mark_begin(ST_G1_IFFT, st);
-        g1_ifft128_take64(d_X_, bp, st);
+        g1_ifft128_take64(w.X, bp, st);
         mark_end(7, st);  // 7 layers (each = one twiddle-multiplication launch + one butterfly launch)
         mark_begin(ST_G1_FFT, st);
-        g1_fft128_from64(d_X_, bp, st);
+        g1_fft128_from64(w.X, bp, st);
         mark_end(7, st);
     }
     mark_begin(ST_COMPRESS, st);
-    launch::g1_compress(d_X_, d_proofs, 128, bp, n, st);
+    launch::g1_compress(w.X, d_proofs, 128, bp, n, st);
     mark_end(1, st);
+}
+
+// the kernels of one prover call on `st`, scratch from `w`; optionally records `after_cells` once the cells are written
+void Engine::enqueue_compute(Work& w, int n, const uint8_t* d_blobs, uint8_t* d_cells, uint8_t* d_proofs, hipStream_t st,
+                             hipEvent_t after_cells) {
+    ensure_workspace(w, n);
+    HIPCK(hipStreamWaitEvent(st, w.done, 0));  // an earlier call may still be using this set on another stream
+    HIPCK(hipMemsetAsync(w.status, 0, n * sizeof(int), st));
+    mark_begin(ST_BLOB_TO_COEFFS, st);
+    launch::blob_to_coeffs(n, d_blobs, w.coeffs, nullptr, w.status, d_w8192_, n_inv4096_, st);
+    mark_end(1, st);
+    if (d_cells) {
+        mark_begin(ST_COEFFS_TO_CELLS, st);
+        launch::coeffs_to_cells(n, w.coeffs, d_cells, d_w8192_, st);
+        mark_end(1, st);
+    }
+    if (after_cells) HIPCK(hipEventRecord(after_cells, st));
+    if (d_proofs) run_proofs_from_coeffs(w, n, d_proofs, st);
 }
 
 int Engine::compute_cells_and_kzg_proofs_device(int n, const uint8_t* d_blobs, uint8_t* d_cells, uint8_t* d_proofs,
                                                 int* h_status, hipStream_t st, bool sync) {
     if (n <= 0) return OK;
-    std::lock_guard<std::recursive_mutex> lk(mu_);
+    Work* held = nullptr;
     try {
         HIPCK(hipSetDevice(dev_));
-        if (!st) st = stream_;
-        ensure_workspace(n);
-        HIPCK(hipMemsetAsync(d_status_, 0, n * sizeof(int), st));
-        mark_begin(ST_BLOB_TO_COEFFS, st);
-        launch::blob_to_coeffs(n, d_blobs, d_coeffs_, nullptr, d_status_, d_w8192_, n_inv4096_, st);
-        mark_end(1, st);
-        if (d_cells) {
-            mark_begin(ST_COEFFS_TO_CELLS, st);
-            launch::coeffs_to_cells(n, d_coeffs_, d_cells, d_w8192_, st);
-            mark_end(1, st);
-        }
-        if (d_proofs) run_proofs_from_coeffs(n, d_proofs, st);
-        if (h_status) HIPCK(hipMemcpyAsync(h_status, d_status_, n * sizeof(int), hipMemcpyDeviceToHost, st));
+        Work& w = lease_work(1, NW - 1);
+        held = &w;
+        if (!st) st = w.stream;
+        enqueue_compute(w, n, d_blobs, d_cells, d_proofs, st, nullptr);
+        if (h_status) HIPCK(hipMemcpyAsync(h_status, w.status, n * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCK(hipEventRecord(w.done, st));
         HIPCK(hipGetLastError());
+        w.mu.unlock();
+        held = nullptr;
         if (sync || h_status) HIPCK(hipStreamSynchronize(st));
     } catch (const std::exception& e) {
-        err_ = e.what();
+        if (held) held->mu.unlock();
+        set_error(e);
         return ERR_DEVICE;
     }
     return OK;
@@ -694,7 +809,7 @@ int Engine::blob_to_kzg_commitment_device(int n, const uint8_t* d_blobs, uint8_t
         HIPCK(hipGetLastError());
         if (sync || h_status) HIPCK(hipStreamSynchronize(st));
     } catch (const std::exception& e) {
-        err_ = e.what();
+        set_error(e);
         return ERR_DEVICE;
     }
     return OK;
@@ -702,53 +817,161 @@ int Engine::blob_to_kzg_commitment_device(int n, const uint8_t* d_blobs, uint8_t
 
 // ---------------------------------------------------------------------------------------------
 // host-buffer entry points: stage through device buffers owned by the engine
+// The reference's entry point (bindings/c/src/lib.rs:226-236) and its batched form: host pointers in, 256 caller
+// buffers per blob out.  The light per-blob stages run per sub-batch as the blobs arrive -- helper threads gather them
+// into pinned memory, the upload, blob_to_coeffs and coeffs_to_cells follow on the compute stream, and the cells (95 %
+// of the output bytes) go back on a copy stream and are scattered to the caller's buffers by the helper threads --
+// while the heavy stages (fixed-base MSMs, the G1 linear map) run ONCE over the whole batch at its saturated rate.
 int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs, uint8_t* const* const* cells,
                                               uint8_t* const* const* proofs, int* h_status) {
     if (n <= 0) return OK;
-    std::lock_guard<std::recursive_mutex> whole_call(mu_);  // staging buffers are shared: one host call at a time
-    {
-        std::lock_guard<std::recursive_mutex> lk(mu_);
-        try {
-            HIPCK(hipSetDevice(dev_));
-            if (n > stage_cap_) {
-                if (d_in_) { HIPCK(hipFree(d_in_)); HIPCK(hipFree(d_cells_)); HIPCK(hipFree(d_proofs_)); }
-                HIPCK(hipMalloc(&d_in_, (size_t)n * BYTES_PER_BLOB));
-                HIPCK(hipMalloc(&d_cells_, (size_t)n * N_CELLS * BYTES_PER_CELL));
-                HIPCK(hipMalloc(&d_proofs_, (size_t)n * N_CELLS * 48));
-                stage_cap_ = n;
-            }
-            for (int b = 0; b < n; b++)
-                HIPCK(hipMemcpyAsync(d_in_ + (size_t)b * BYTES_PER_BLOB, blobs[b], BYTES_PER_BLOB, hipMemcpyHostToDevice, stream_));
-        } catch (const std::exception& e) {
-            err_ = e.what();
-            return ERR_DEVICE;
-        }
-    }
-    std::vector<int> st(n);
-    int rc = compute_cells_and_kzg_proofs_device(n, d_in_, cells ? d_cells_ : nullptr, proofs ? d_proofs_ : nullptr,
-                                                 st.data(), stream_, true);
-    if (rc) return rc;
-    std::lock_guard<std::recursive_mutex> lk(mu_);
+    constexpr int SUPER = 4096, SUB = 256, PART = 64;
+    const bool threaded = n >= 32;  // small calls: everything on the calling thread (latency)
+    const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    Work* held = nullptr;
+    std::atomic<int> failed{0};
+    std::mutex err_mu;
+    std::string err_text;
+    auto fail = [&](const std::exception& e) {
+        std::lock_guard<std::mutex> lk(err_mu);
+        if (!failed.exchange(1)) err_text = e.what();
+    };
+    std::atomic<int> outstanding{0};  // helper-thread tasks of this call still running or queued
+    auto drain = [&]() { while (outstanding.load(std::memory_order_acquire) > 0) std::this_thread::yield(); };
     try {
-        std::vector<uint8_t> hc, hp;
-        if (cells) {
-            hc.resize((size_t)n * N_CELLS * BYTES_PER_CELL);
-            HIPCK(hipMemcpy(hc.data(), d_cells_, hc.size(), hipMemcpyDeviceToHost));
-        }
-        if (proofs) {
-            hp.resize((size_t)n * N_CELLS * 48);
-            HIPCK(hipMemcpy(hp.data(), d_proofs_, hp.size(), hipMemcpyDeviceToHost));
-        }
-        for (int b = 0; b < n; b++) {
-            if (h_status) h_status[b] = st[b] ? ERR_SCALAR : OK;
-            if (st[b]) continue;
-            for (int k = 0; k < N_CELLS; k++) {
-                if (cells) memcpy(cells[b][k], hc.data() + ((size_t)b * N_CELLS + k) * BYTES_PER_CELL, BYTES_PER_CELL);
-                if (proofs) memcpy(proofs[b][k], hp.data() + ((size_t)b * N_CELLS + k) * 48, 48);
+        HIPCK(hipSetDevice(dev_));
+        if (threaded) std::call_once(host_pool_once_, [this] { host_pool_.reset(new HostPool(4, dev_)); });
+        Work& w = lease_work(1, NW - 1);
+        held = &w;
+        for (int s0 = 0; s0 < n && !failed.load(); s0 += SUPER) {
+            const int ns = std::min(SUPER, n - s0), n_sub = (ns + SUB - 1) / SUB;
+            ensure_workspace(w, ns);
+            ensure_staging(w, ns);
+            while ((int)w.sub_events.size() < 2 * n_sub) {
+                hipEvent_t e;
+                HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                w.sub_events.push_back(e);
             }
+            HIPCK(hipStreamWaitEvent(w.stream, w.done, 0));
+            HIPCK(hipMemsetAsync(w.status, 0, ns * sizeof(int), w.stream));
+            // gather tasks for the whole super-batch, in order; gathered[i] counts the parts of sub-batch i still to copy
+            std::vector<std::atomic<int>> gathered(n_sub);
+            for (int i = 0; i < n_sub; i++) {
+                const int lo = i * SUB, hi = std::min(ns, lo + SUB), parts = (hi - lo + PART - 1) / PART;
+                gathered[i].store(threaded ? parts : 0, std::memory_order_relaxed);
+                if (!threaded) {
+                    for (int b = lo; b < hi; b++) memcpy(w.h_in + (size_t)b * BYTES_PER_BLOB, blobs[s0 + b], BYTES_PER_BLOB);
+                    continue;
+                }
+                for (int p0 = lo; p0 < hi; p0 += PART) {
+                    const int p1 = std::min(hi, p0 + PART);
+                    outstanding.fetch_add(1, std::memory_order_relaxed);
+                    host_pool_->submit([&, i, p0, p1, s0] {
+                        for (int b = p0; b < p1; b++) memcpy(w.h_in + (size_t)b * BYTES_PER_BLOB, blobs[s0 + b], BYTES_PER_BLOB);
+                        gathered[i].fetch_sub(1, std::memory_order_release);
+                        outstanding.fetch_sub(1, std::memory_order_release);
+                    });
+                }
+            }
+            // scatter of one sub-batch's status words and cells once its copy-stream event has fired; a task that finds the
+            // event pending goes back to the end of the queue instead of blocking a helper thread
+            std::function<void(int, int, int)> scatter_cells = [&](int i, int lo, int hi) {
+                const hipError_t q = hipEventQuery(w.sub_events[2 * i + 1]);
+                if (q == hipErrorNotReady) {
+                    std::this_thread::yield();
+                    host_pool_->submit([&, i, lo, hi] { scatter_cells(i, lo, hi); });
+                    return;
+                }
+                try {
+                    HIPCK(q);
+                    for (int b = lo; b < hi; b++) {
+                        if (h_status) h_status[s0 + b] = w.h_status[b] ? ERR_SCALAR : OK;
+                        if (w.h_status[b] || !cells) continue;
+                        const uint8_t* src = w.h_cells + (size_t)b * N_CELLS * BYTES_PER_CELL;
+                        for (int k = 0; k < N_CELLS; k++) memcpy(cells[s0 + b][k], src + (size_t)k * BYTES_PER_CELL, BYTES_PER_CELL);
+                    }
+                } catch (const std::exception& e) { fail(e); }
+                outstanding.fetch_sub(1, std::memory_order_release);
+            };
+            for (int i = 0; i < n_sub; i++) {
+                const int lo = i * SUB, hi = std::min(ns, lo + SUB), nb = hi - lo;
+                while (gathered[i].load(std::memory_order_acquire) > 0) std::this_thread::yield();
+                HIPCK(hipMemcpyAsync(w.d_in + (size_t)lo * BYTES_PER_BLOB, w.h_in + (size_t)lo * BYTES_PER_BLOB, (size_t)nb * BYTES_PER_BLOB,
+                                     hipMemcpyHostToDevice, w.stream));
+                launch::blob_to_coeffs(nb, w.d_in + (size_t)lo * BYTES_PER_BLOB, (char*)w.coeffs + (size_t)lo * N_BLOB * sizeof(Fr), nullptr,
+                                       w.status + lo, d_w8192_, n_inv4096_, w.stream);
+                if (cells)
+                    launch::coeffs_to_cells(nb, (char*)w.coeffs + (size_t)lo * N_BLOB * sizeof(Fr),
+                                            w.d_cells + (size_t)lo * N_CELLS * BYTES_PER_CELL, d_w8192_, w.stream);
+                HIPCK(hipEventRecord(w.sub_events[2 * i], w.stream));
+                HIPCK(hipStreamWaitEvent(w.copy, w.sub_events[2 * i], 0));
+                HIPCK(hipMemcpyAsync(w.h_status + lo, w.status + lo, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, w.copy));
+                if (cells)
+                    HIPCK(hipMemcpyAsync(w.h_cells + (size_t)lo * N_CELLS * BYTES_PER_CELL, w.d_cells + (size_t)lo * N_CELLS * BYTES_PER_CELL,
+                                         (size_t)nb * N_CELLS * BYTES_PER_CELL, hipMemcpyDeviceToHost, w.copy));
+                HIPCK(hipEventRecord(w.sub_events[2 * i + 1], w.copy));
+                if (threaded) {
+                    for (int p0 = lo; p0 < hi; p0 += PART) {
+                        const int p1 = std::min(hi, p0 + PART);
+                        outstanding.fetch_add(1, std::memory_order_relaxed);
+                        host_pool_->submit([&, i, p0, p1] { scatter_cells(i, p0, p1); });
+                    }
+                }
+                if (trace) fprintf(stderr, "[host-batch] sub-batch %d (%d blobs) enqueued at %.2f ms\n", i, nb, now_ms());
+            }
+            if (proofs) {
+                run_proofs_from_coeffs(w, ns, w.d_proofs, w.stream);
+                HIPCK(hipMemcpyAsync(w.h_proofs, w.d_proofs, (size_t)ns * N_CELLS * 48, hipMemcpyDeviceToHost, w.stream));
+            }
+            HIPCK(hipEventRecord(w.ev_done, w.stream));
+            HIPCK(hipEventRecord(w.done, w.stream));
+            HIPCK(hipGetLastError());
+            if (!threaded) {  // small call: status and cells as soon as they are back, proofs at the end, all on this thread
+                HIPCK(hipEventSynchronize(w.sub_events[1]));
+                for (int b = 0; b < ns; b++) {
+                    if (h_status) h_status[s0 + b] = w.h_status[b] ? ERR_SCALAR : OK;
+                    if (w.h_status[b] || !cells) continue;
+                    const uint8_t* src = w.h_cells + (size_t)b * N_CELLS * BYTES_PER_CELL;
+                    for (int k = 0; k < N_CELLS; k++) memcpy(cells[s0 + b][k], src + (size_t)k * BYTES_PER_CELL, BYTES_PER_CELL);
+                }
+            }
+            HIPCK(hipEventSynchronize(w.ev_done));
+            HIPCK(hipStreamSynchronize(w.copy));
+            if (trace) fprintf(stderr, "[host-batch] proofs of %d blobs back at %.2f ms\n", ns, now_ms());
+            if (proofs) {
+                auto scatter_proofs = [&, s0](int lo, int hi) {
+                    for (int b = lo; b < hi; b++) {
+                        if (w.h_status[b]) continue;
+                        const uint8_t* src = w.h_proofs + (size_t)b * N_CELLS * 48;
+                        for (int k = 0; k < N_CELLS; k++) memcpy(proofs[s0 + b][k], src + (size_t)k * 48, 48);
+                    }
+                };
+                if (threaded && ns >= 256) {
+                    const int parts = 4;
+                    for (int t = 1; t < parts; t++) {
+                        outstanding.fetch_add(1, std::memory_order_relaxed);
+                        host_pool_->submit([&, t] { scatter_proofs(t * ns / parts, (t + 1) * ns / parts); outstanding.fetch_sub(1, std::memory_order_release); });
+                    }
+                    scatter_proofs(0, ns / parts);
+                } else scatter_proofs(0, ns);
+            }
+            drain();  // the pinned buffers are reused by the next super-batch
         }
+        drain();
+        w.mu.unlock();
+        held = nullptr;
+        if (trace) fprintf(stderr, "[host-batch] %d blobs delivered at %.2f ms\n", n, now_ms());
+        if (failed.load()) throw std::runtime_error(err_text);
     } catch (const std::exception& e) {
-        err_ = e.what();
+        if (held) {  // let the streams drain and the helper tasks finish before the set is handed back, whatever happened
+            (void)hipStreamSynchronize(held->stream);
+            (void)hipStreamSynchronize(held->copy);
+            drain();
+            held->mu.unlock();
+        }
+        set_error(e);
         return ERR_DEVICE;
     }
     return OK;
@@ -773,7 +996,7 @@ int Engine::blob_to_kzg_commitment_host(int n, const uint8_t* const* blobs, uint
                 HIPCK(hipMemcpyAsync(d_in_ + (size_t)b * BYTES_PER_BLOB, blobs[b], BYTES_PER_BLOB, hipMemcpyHostToDevice, stream_));
             d_out = d_proofs_;  // reuse staging
         } catch (const std::exception& e) {
-            err_ = e.what();
+            set_error(e);
             return ERR_DEVICE;
         }
     }
@@ -789,7 +1012,7 @@ int Engine::blob_to_kzg_commitment_host(int n, const uint8_t* const* blobs, uint
             if (!st[b]) memcpy(out[b], h.data() + (size_t)b * 48, 48);
         }
     } catch (const std::exception& e) {
-        err_ = e.what();
+        set_error(e);
         return ERR_DEVICE;
     }
     return OK;
@@ -811,7 +1034,7 @@ int Engine::test_fr_ntt4096(const uint8_t* in_be, uint8_t* out_be, int inverse_d
         HIPCK(hipFree(di));
         HIPCK(hipFree(dout));
     } catch (const std::exception& e) {
-        err_ = e.what();
+        set_error(e);
         return ERR_DEVICE;
     }
     return OK;
@@ -851,7 +1074,7 @@ int Engine::test_g1_fft128(const uint8_t* in, uint8_t* out, int n_lanes, int inv
         HIPCK(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
         HIPCK(hipFree(di)); HIPCK(hipFree(dout)); HIPCK(hipFree(X));
     } catch (const std::exception& e) {
-        err_ = e.what();
+        set_error(e);
         return ERR_DEVICE;
     }
     return OK;
@@ -879,7 +1102,7 @@ int Engine::test_fixed_msm(const uint8_t* scalars_be, int n_msm, uint8_t* out) {
         HIPCK(hipMemcpy(out, dout, (size_t)n_msm * 128 * 48, hipMemcpyDeviceToHost));
         HIPCK(hipFree(di)); HIPCK(hipFree(sc)); HIPCK(hipFree(X)); HIPCK(hipFree(dout));
     } catch (const std::exception& e) {
-        err_ = e.what();
+        set_error(e);
         return ERR_DEVICE;
     }
     return OK;
@@ -902,7 +1125,7 @@ int Engine::test_g1_decompress(const uint8_t* in, int n, int subgroup_check, int
         HIPCK(hipMemcpy(out, dout, (size_t)n * 48, hipMemcpyDeviceToHost));
         HIPCK(hipFree(di)); HIPCK(hipFree(dout)); HIPCK(hipFree(pts)); HIPCK(hipFree(st));
     } catch (const std::exception& e) {
-        err_ = e.what();
+        set_error(e);
         return ERR_DEVICE;
     }
     return OK;
@@ -922,7 +1145,7 @@ int Engine::test_field_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, int
         HIPCK(hipMemcpy(out, dout, nb, hipMemcpyDeviceToHost));
         HIPCK(hipFree(da)); HIPCK(hipFree(db)); HIPCK(hipFree(dout));
     } catch (const std::exception& e) {
-        err_ = e.what();
+        set_error(e);
         return ERR_DEVICE;
     }
     return OK;

@@ -5,7 +5,12 @@
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <cstdint>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <utility>
 #include <vector>
@@ -54,6 +59,42 @@ private:
     bool host_;
 };
 
+// One set of device scratch for a prover call: coefficients, MSM scalars, G1 arrays, status words, the staging buffers of
+// the host-pointer entry point and the streams / events that order its use.  The engine owns a few of them, so that
+// independent calls (and the chunks of one large host-pointer call) overlap on the GPU instead of queueing on one lock.
+struct Work {
+    std::mutex mu;  // held while a call enqueues on / owns this set
+    int cap = 0;    // blobs the arrays below hold
+    void *coeffs = nullptr, *canon = nullptr, *scalars = nullptr, *X = nullptr;
+    int* status = nullptr;
+    void *dft_tmp = nullptr, *dft_prod = nullptr, *circ_table = nullptr, *slp_arena = nullptr;
+    size_t slp_arena_bytes = 0;
+    hipEvent_t done = nullptr;  // recorded after the last kernel that touches the set; the next user's stream waits on it
+    // host-pointer path: device and pinned-host staging for one chunk, a compute stream, a copy stream, events
+    int stage_cap = 0;
+    uint8_t *d_in = nullptr, *d_cells = nullptr, *d_proofs = nullptr;
+    uint8_t *h_in = nullptr, *h_cells = nullptr, *h_proofs = nullptr;
+    int* h_status = nullptr;
+    hipStream_t stream = nullptr, copy = nullptr;
+    hipEvent_t ev_in = nullptr, ev_cells = nullptr, ev_cells_host = nullptr, ev_done = nullptr;
+    std::vector<hipEvent_t> sub_events;  // per sub-batch of a host-pointer call: [2i] cells computed, [2i+1] cells on the host
+};
+// A few helper threads for the host-side memcpy work of the host-pointer entry points (gathering blobs into pinned
+// memory, scattering cells / proofs to the caller's 256 buffers per blob), so that it overlaps the GPU.
+class HostPool {
+public:
+    explicit HostPool(int threads, int device);
+    ~HostPool();
+    void submit(std::function<void()> fn);
+private:
+    void run(int device);
+    std::vector<std::thread> th_;
+    std::deque<std::function<void()>> q_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+};
+
 class Engine {
 public:
     friend struct PoolBuf;
@@ -67,7 +108,7 @@ public:
 
     int device() const { return dev_; }
     hipStream_t stream() const { return stream_; }
-    const std::string& last_error() const { return err_; }
+    const std::string& last_error() const;  // of the calling thread's last failed call
 
     // ---- device-resident batch entry points (flat buffers in HBM, launched on `stream`) ----
     // d_blobs: n * 131072 B.  d_cells: n * 128 * 2048 B.  d_proofs: n * 128 * 48 B.  d_commitments: n * 48 B.
@@ -150,8 +191,15 @@ private:
                   const std::vector<uint32_t>& present, int* st_out);
     int recover_batch_to_coeffs(int R, const uint64_t* n_cells, const uint8_t* const* const* cells,
                                 const uint64_t* const* cell_indices, int* st_out);
-    void ensure_workspace(int n);
-    void run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st);
+    void ensure_workspace(int n) { ensure_workspace(work_[0], n); }
+    void ensure_workspace(Work& w, int n);
+    void ensure_staging(Work& w, int n);
+    void run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st) { run_proofs_from_coeffs(work_[0], n, d_proofs, st); }
+    void run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream_t st);
+    void enqueue_compute(Work& w, int n, const uint8_t* d_blobs, uint8_t* d_cells, uint8_t* d_proofs, hipStream_t st,
+                         hipEvent_t after_cells);
+    Work& lease_work(int first, int last);  // locks and returns a free set among work_[first..last] (blocks if none)
+    void set_error(const std::exception& e);
     void launch_msm(const void* scalars, const void* table, void* out, int n_groups, int n_slices, int out_stride,
                     int brp_bits, hipStream_t st);
     void g1_ifft128_take64(void* X, int stride, hipStream_t st);
@@ -163,6 +211,7 @@ private:
     void mark_end(int launches, hipStream_t st);
     bool profiling_ = false;
     std::vector<StageMark> marks_;
+    std::mutex marks_mu_;
 
     int dev_ = 0;
     int c_ = 8;      // window width of the FK20 table
@@ -170,8 +219,11 @@ private:
     int wave_slots_ = 2048;  // CUs x 4 SIMDs x 2 waves: what one round of a ~240-VGPR point kernel occupies
     int msm_chunks_ = -1;    // -1: pick per launch (launch_msm); otherwise forced by ETH_KZG_AMD_MSM_CHUNKS
     hipStream_t stream_ = nullptr;
-    std::recursive_mutex mu_;  // recursive: host-pointer entry points hold it across staging + the device call + read-back
-    std::string err_;
+    std::recursive_mutex mu_;  // the verification / recovery / EIP-4844 / commitment paths and work_[0]: one call at a time
+    static constexpr int NW = 4;  // work_[0]: the paths under mu_; work_[1..3]: compute_cells(_and_kzg_proofs) calls, concurrently
+    Work work_[NW];
+    std::unique_ptr<HostPool> host_pool_;
+    std::once_flag host_pool_once_;
 
     // constants in HBM
     void* d_w8192_ = nullptr;     // Fr[8192] omega_8192^k, Montgomery
@@ -200,23 +252,21 @@ private:
     size_t v_pin_cap_ = 0;
 
     // small-batch circulant form of the two G1 transforms: term list, doubling tables (allocated on first use)
-    void *d_circ_terms_ = nullptr, *d_circ_table_ = nullptr;
+    void *d_circ_terms_ = nullptr;
     int circ_T_ = 0, circ_per_lane_ = 0, circ_max_ = 32;  // measured cross-over with the direct 8 x 16 form: ~32 blobs
     Fr8 seg_shift_[3];  // 2^32, 2^64, 2^96 in Montgomery form
-    void *d_dft_tmp_ = nullptr, *d_dft_prod_ = nullptr;  // latency-mode G1 transforms (one 64-blob group)
     // the two G1 transforms as one compiled linear map (g1_linmap.hpp, k_g1slp.hip): launches, constants, slot arena
     struct SlpLaunch { int kind, first, count; };
     std::vector<SlpLaunch> slp_launches_;
-    void *d_slp_words_ = nullptr, *d_slp_naf_ = nullptr, *d_slp_arena_ = nullptr;
-    size_t slp_arena_bytes_ = 0;
+    void *d_slp_words_ = nullptr, *d_slp_naf_ = nullptr;
     int slp_slots_ = 0, slp_mulc_ = 0;
     bool use_linmap_ = false;
     Fr8 half_;  // 1/2 in Montgomery form: the scaling folded into the MSM scalars in linear-map mode
 
-    // workspace (grown on demand, guarded by mu_)
-    int cap_ = 0;
-    void *d_coeffs_ = nullptr, *d_canon_ = nullptr, *d_scalars_ = nullptr, *d_X_ = nullptr;
-    int* d_status_ = nullptr;
+    // work_[0] under its historical names (grown on demand, guarded by mu_)
+    int& cap_ = work_[0].cap;
+    void *&d_coeffs_ = work_[0].coeffs, *&d_canon_ = work_[0].canon, *&d_scalars_ = work_[0].scalars, *&d_X_ = work_[0].X;
+    int*& d_status_ = work_[0].status;
     uint8_t *d_in_ = nullptr, *d_cells_ = nullptr, *d_proofs_ = nullptr;  // staging for host API
     int stage_cap_ = 0;
 };

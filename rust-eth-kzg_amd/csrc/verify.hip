@@ -254,7 +254,7 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
         HIPCK(hipStreamSynchronize(st));
         lap("scalars+interp+lincombs (GPU)");
     } catch (const std::exception& e) {
-        err_ = e.what();
+        set_error(e);
         return ERR_DEVICE;
     }
     return OK;
@@ -429,7 +429,7 @@ int Engine::recover_cells_and_kzg_proofs_device(int R, const uint8_t* d_cells, c
         HIPCK(hipGetLastError());
         if (!user_stream) HIPCK(hipStreamSynchronize(st));
     } catch (const std::exception& e) {
-        err_ = e.what();
+        set_error(e);
         return ERR_DEVICE;
     }
     return OK;
@@ -486,7 +486,7 @@ int Engine::recover_cells_and_kzg_proofs_batch_host(int R, const uint64_t* n_cel
         }
         lap("scatter to caller buffers");
     } catch (const std::exception& e) {
-        err_ = e.what();
+        set_error(e);
         return ERR_DEVICE;
     }
     return OK;
