@@ -8,11 +8,13 @@ A step = one pass of the hot path (blob bytes -> 128 cells + 128 proofs per blob
 synthetic blobs that is already resident in HBM, through the device-pointer C ABI
 (eth_kzg_amd_compute_cells_and_kzg_proofs_device).  One process per GPU; the batch is sharded by
 contiguous blob index with no data-path collective; with N > 1 each step ends with one RCCL
-all-gather of the proof vectors (48 B x 128 per blob), which is the only exchange north_star names.
-Weak scaling: the per-GPU batch is fixed (default 2048 blobs: the batch that fills all 1024 SIMDs of the chip in
-the wave-per-butterfly G1-FFT stage; BASELINE.json's config-4 and config-2 sizes are reported alongside).
+all-gather of the proof vectors (48 B x 128 per blob) on the library's own communicator
+(eth_kzg_amd_all_gather), which is the only exchange north_star names.
+Weak scaling: the per-GPU batch is fixed (default 2048 blobs, batch-saturated as BASELINE.md section 3 asks).
 
-Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`, `cpu_baseline` and, at N = 1, a
+`configs` block: BASELINE.json's other configurations and the reference's own bench set
+(crates/eip7594/benches/benchmark-mt.rs:36-113) measured in the same process, outside the headline region.
 """
 import argparse
 import importlib
@@ -36,16 +38,17 @@ FP_MUL_PEAK_G = 78.1             # measured ceiling of the 14x29-bit Montgomery 
                                  # profiles/r1e_ubench_fp29.log (66.0 G/s at the 2 waves/SIMD the point kernels can hold)
 
 
-def fp_mul_eq_per_blob(window_bits):
+def fp_mul_eq_per_blob(window_bits, linmap):
     """Fp multiplication equivalents this build spends per blob, counted in multiply-add passes of 392 MACs
     (M = 1, squaring S = 301/392, fused pair a*b + c*d with one reduction F = 588/392):
     stage D: 128 MSMs x 64 bases x W windows XYZZ mixed additions (6M + 2S + F);
-    stages E+F: 642 twiddle multiplications x (1 + 128 doublings (2M + 3S + F) + ~43 + 7 additions (10M + 4S + F) + 8 beta-muls)
-    + 14 x 64 butterfly additions."""
+    stages E+F as one compiled linear map (g1_linmap.hpp): `mulc` constant multiplications x (1 + 128 doublings
+    (2M + 3S + F) + ~43 + 7 additions (10M + 4S + F) + 8 beta-muls) + its additions and doublings."""
     w = (255 + window_bits) // window_bits
     S, F = 301 / 392, 588 / 392
     madd, dbl, add = 6 + 2 * S + F, 2 + 3 * S + F, 10 + 4 * S + F
-    return 128 * 64 * w * madd + 642 * (129 * dbl + 50 * add + 8) + 14 * 64 * 1.5 * add
+    mulc, adds, dbls = linmap
+    return 128 * 64 * w * madd + mulc * (129 * dbl + 50 * add + 8) + adds * add + dbls * dbl
 
 
 def synth_blobs(n, seed):
@@ -57,15 +60,7 @@ def synth_blobs(n, seed):
     return a.reshape(n, BYTES_PER_BLOB)
 
 
-def cpu_baseline(blobs, budget_s=15.0, gpu_first=None):
-    """Time the CPU oracle (C restatement of the reference algorithm: FK20, width-8 window tables, batched
-    affine additions) on this box's host cores.  Two CPU configurations are timed on a bounded sample:
-      * blob-parallel: one single-threaded prover per worker thread, distinct blobs, all host cores busy
-        (the strongest CPU arrangement for a throughput metric) -> cpu_baseline.value
-      * rayon-like: one blob at a time with OpenMP threads over the axes maybe_rayon parallelises
-        (fk20/batch_toeplitz.rs:50,68,95,104,114; polynomial/src/fft.rs:72,119) -> cpu_baseline.rayon_like
-    """
-    import concurrent.futures as cf
+def _host_cores():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:  # a cgroup CPU quota caps the usable cores below the visible count (the GPU boxes: 256 visible, quota 16)
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -73,6 +68,49 @@ def cpu_baseline(blobs, budget_s=15.0, gpu_first=None):
             cores = max(1, min(cores, int(int(q) / int(per))))
     except Exception:
         pass
+    return cores
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def _criterion(fn, warmup_s, samples, max_s):
+    """criterion-like: warm up for warmup_s, then `samples` timed iterations (cut short at max_s); returns the sample times."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < warmup_s:
+        fn()
+    ts, t0 = [], time.perf_counter()
+    while len(ts) < samples and (time.perf_counter() - t0 < max_s or len(ts) < 3):
+        t1 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t1)
+    return ts
+
+
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
+
+
+def cpu_baseline(blobs, gpu_first=None, extra=None):
+    """Time the CPU oracle (C restatement of the reference algorithm: FK20, width-8 window tables, batched affine
+    additions; portable unsigned __int128 field arithmetic, NOT blst's assembly) on this box's host cores with the
+    criterion-like protocol of BASELINE.md section 3 (3 s warm-up, 30 samples, median and min), in two arrangements:
+      * blob-parallel: one single-threaded prover per host core, distinct blobs (the strongest CPU arrangement for a
+        throughput metric); a sample = one round of `cores` blobs                       -> cpu_baseline.value
+      * rayon-like: one blob at a time with OpenMP threads over the axes maybe_rayon parallelises
+        (fk20/batch_toeplitz.rs:50,68,95,104,114; polynomial/src/fft.rs:72,119)        -> cpu_baseline.rayon_like
+    plus the single-threaded rate (8 samples: a blob takes ~0.3 s) and, if `extra` is given, one CPU sample each of
+    BASELINE configs 3 and 5."""
+    import concurrent.futures as cf
+    cores = _host_cores()
     import oracle_lib
     try:
         # a native build of the same sources for this host (the prebuilt liboracle.so is generic x86-64)
@@ -84,52 +122,176 @@ def cpu_baseline(blobs, budget_s=15.0, gpu_first=None):
     except Exception:
         pass
     from oracle_lib import Oracle
-    # --- rayon-like (intra-blob parallel), best of a few thread counts
-    rayon = {}
-    for th in sorted({min(cores, t) for t in (8, 16, 32)}):
-        o = Oracle(use_precomp=True, threads=th)
-        o.compute_cells_and_kzg_proofs(blobs[0])
-        n, t0 = 0, time.time()
-        while time.time() - t0 < budget_s / 6 and n < 200:
-            o.compute_cells_and_kzg_proofs(blobs[n % len(blobs)])
-            n += 1
-        rayon[th] = n / (time.time() - t0)
-        o.close()
-    best_th = max(rayon, key=rayon.get)
+    # --- rayon-like (intra-blob parallel) at all usable cores
+    o = Oracle(use_precomp=True, threads=cores)
+    k = [0]
+
+    def one_rayon():
+        o.compute_cells_and_kzg_proofs(blobs[k[0] % len(blobs)])
+        k[0] += 1
+    ts = _criterion(one_rayon, 3.0, 30, 6.0)
+    rayon = {"value": 1.0 / _median(ts), "best": 1.0 / min(ts), "threads": cores, "samples": len(ts),
+             "note": "one blob at a time, OpenMP over the maybe_rayon axes; median of the samples"}
+    o.close()
     # --- blob-parallel over all cores (ctypes releases the GIL; the context is read-only while computing)
     o = Oracle(use_precomp=True, threads=1)
-    t1 = time.time()
     ref_cells, ref_proofs = o.compute_cells_and_kzg_proofs(blobs[0])
-    single_thread = 1.0 / (time.time() - t1)
     agrees = None
     if gpu_first is not None:  # the oracle doubles as the checker here: the GPU's bytes for blob 0 of the timed batch
         agrees = (b"".join(ref_cells) == gpu_first[0]) and (b"".join(ref_proofs) == gpu_first[1])
         if not agrees:
             raise SystemExit("bench.py: GPU cells/proofs of blob 0 differ from the CPU oracle")
-    workers = cores
-    per_worker = 2
-    def work(w):
-        for k in range(per_worker):
-            o.compute_cells_and_kzg_proofs(blobs[(w * per_worker + k) % len(blobs)])
-        return per_worker
-    t0 = time.time()
-    with cf.ThreadPoolExecutor(max_workers=workers) as ex:
-        done = sum(ex.map(work, range(workers)))
-    dt = time.time() - t0
+    ts1 = _criterion(lambda: o.compute_cells_and_kzg_proofs(blobs[1 % len(blobs)]), 1.0, 8, 4.0)
+    single_thread = 1.0 / _median(ts1)
+    ex = cf.ThreadPoolExecutor(max_workers=cores)
+
+    def one_round():
+        list(ex.map(lambda w: o.compute_cells_and_kzg_proofs(blobs[w % len(blobs)]), range(cores)))
+    tsp = _criterion(one_round, 3.0, 30, 12.0)
+    par, par_best = cores / _median(tsp), cores / min(tsp)
+    out_extra = {}
+    if extra is not None:  # one CPU sample each of configs 3 and 5 (seconds each: stated deviation from the 30-sample protocol)
+        try:
+            C_, I_, L_, P_ = extra["verify"]
+            ov = Oracle(use_precomp=True, threads=cores)
+            t0 = time.perf_counter()
+            ok = ov.verify_cell_kzg_proof_batch(C_, I_, L_, P_)
+            out_extra["config3_verify_8192_cells_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+            out_extra["config3_verified"] = bool(ok)
+            ov.close()
+            idx, cells = extra["recover"]
+            t0 = time.perf_counter()
+            list(ex.map(lambda w: o.recover_cells_and_kzg_proofs(idx, cells), range(cores)))
+            out_extra["config5_recover_blobs_per_s"] = round(cores / (time.perf_counter() - t0), 2)
+            out_extra["note"] = "one sample each (a verification of 8192 cells and a round of recoveries take seconds on the CPU)"
+        except Exception as e:  # the baseline of the side configs must never sink the headline record
+            out_extra["error"] = repr(e)
+    ex.shutdown()
     o.close()
-    par = done / dt
-    best_value, best_cores = (par, workers) if par >= rayon[best_th] else (rayon[best_th], best_th)
-    return {"value": best_value, "unit": "blobs/s", "cores": best_cores, "kind": "port",
-            "sample": f"best of two CPU arrangements of the C oracle (width-8 tables, portable __int128 field arithmetic -- not "
-                      f"blst assembly): (a) {done} x compute_cells_and_kzg_proofs over {len(blobs)} distinct synthetic blobs in "
-                      f"{dt:.1f} s with one single-threaded prover per host thread ({workers} threads) = {par:.1f} blobs/s; "
-                      f"(b) one blob at a time with OpenMP over the maybe_rayon axes = {rayon[best_th]:.1f} blobs/s at "
-                      f"{best_th} threads; single thread = {single_thread:.2f} blobs/s",
+    best_value, best_cores = (par, cores) if par >= rayon["value"] else (rayon["value"], cores)
+    return {"value": best_value, "unit": "blobs/s", "cores": best_cores, "kind": "port", "cpu_model": _cpu_model(),
+            "protocol": "criterion-like (BASELINE.md section 3): 3 s warm-up, 30 timed samples, median; context built once outside",
+            "sample": f"C oracle (width-8 tables, portable __int128 field arithmetic -- not blst assembly) on {cores} usable host "
+                      f"cores: (a) blob-parallel, one single-threaded prover per core, {len(tsp)} rounds of {cores} distinct "
+                      f"synthetic blobs, median {_median(tsp):.3f} s per round = {par:.1f} blobs/s (best {par_best:.1f}); (b) one blob "
+                      f"at a time with OpenMP over the maybe_rayon axes, {rayon['samples']} samples = {rayon['value']:.1f} blobs/s; "
+                      f"single thread ({len(ts1)} samples) = {single_thread:.2f} blobs/s",
             "gpu_matches_oracle_on_blob0": agrees,
-            "blob_parallel": {"value": par, "threads": workers},
+            "blob_parallel": {"value": par, "best": par_best, "threads": cores, "samples": len(tsp)},
             "single_thread": single_thread,
-            "rayon_like": {"value": rayon[best_th], "threads": best_th, "all": {str(k): round(v, 2) for k, v in rayon.items()},
-                           "note": "one blob at a time, OpenMP over the maybe_rayon axes"}}
+            "rayon_like": rayon,
+            "other_configs_cpu": out_extra}
+
+
+def side_configs(ctx, kzg, torch, dev, blobs_h, t_ctx_cold):
+    """BASELINE.json's other configurations and the reference's own bench set (benchmark-mt.rs:36-113), on this GPU, after
+    the headline region: medians of a few runs each, inputs resident where the entry point is device-resident."""
+    import numpy as np
+    out = {}
+    stream = torch.cuda.Stream(device=dev)
+
+    def dev_rate(nb, fn_name="compute"):
+        d_b = torch.from_numpy(blobs_h[:nb]).to(dev)
+        d_c = torch.empty(nb * CELLS * BYTES_PER_CELL, dtype=torch.uint8, device=dev)
+        d_p = torch.empty(nb * CELLS * 48, dtype=torch.uint8, device=dev)
+        ts = []
+        for it in range(7):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            with torch.cuda.stream(stream):
+                if fn_name == "compute":
+                    ctx.compute_cells_and_kzg_proofs_device(nb, d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), want_status=False, stream=stream.cuda_stream)
+                elif fn_name == "cells":
+                    ctx.compute_cells_and_kzg_proofs_device(nb, d_b.data_ptr(), d_c.data_ptr(), 0, want_status=False, stream=stream.cuda_stream)
+                else:
+                    ctx.blob_to_kzg_commitment_device(nb, d_b.data_ptr(), d_p.data_ptr(), want_status=False, stream=stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            if it >= 2:
+                ts.append(time.perf_counter() - t0)
+        return nb / _median(ts), _median(ts) * 1e3, (d_b, d_c, d_p)
+
+    B = blobs_h.shape[0]
+    r64, ms64, _ = dev_rate(min(64, B))
+    out["config4_per_gpu_share_64_blobs"] = {"blobs_per_s": round(r64), "ms": round(ms64, 2), "form": "device-resident"}
+    r512, ms512, _ = dev_rate(min(512, B))
+    out["config4_512_blobs_on_one_gpu"] = {"blobs_per_s": round(r512), "ms": round(ms512, 2), "form": "device-resident"}
+    rc, msc, _ = dev_rate(B, "cells")
+    out["compute_cells_only"] = {"blobs_per_s": round(rc), "ms": round(msc, 2), "blobs": B, "form": "device-resident"}
+    rk, msk, _ = dev_rate(B, "commit")
+    out["blob_to_kzg_commitment"] = {"commitments_per_s": round(rk), "ms": round(msk, 2), "blobs": B, "form": "device-resident"}
+    # the reference's ABI: host pointers (pageable memory in, 256 caller buffers per blob out)
+    bufs = ctx.host_batch_buffers(B)
+    ctx.compute_cells_and_kzg_proofs_batch_np(blobs_h, bufs)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        ctx.compute_cells_and_kzg_proofs_batch_np(blobs_h, bufs)
+        ts.append(time.perf_counter() - t0)
+    out["abi_host_pointer_batch"] = {"blobs_per_s": round(B / _median(ts)), "ms": round(_median(ts) * 1e3, 2), "blobs": B,
+                                     "entry": "eth_kzg_amd_compute_cells_and_kzg_proofs_batch (PCIe both ways, gather and scatter included)"}
+    one = blobs_h[0].tobytes()
+    ctx.compute_cells_and_kzg_proofs(one)
+    ts = []
+    for _ in range(9):
+        t0 = time.perf_counter()
+        ctx.compute_cells_and_kzg_proofs(one)
+        ts.append(time.perf_counter() - t0)
+    out["abi_single_call_latency_ms"] = {"ms": round(_median(ts) * 1e3, 3), "entry": "eth_kzg_compute_cells_and_kzg_proofs (ctypes wrapper included)"}
+    # config 3: verify 64 blobs x 128 cells (host-pointer ABI; its transcript hash needs the bytes on the host anyway)
+    nb = 64
+    d_b = torch.from_numpy(blobs_h[:nb]).to(dev)
+    d_c = torch.empty(nb * CELLS * BYTES_PER_CELL, dtype=torch.uint8, device=dev)
+    d_p = torch.empty(nb * CELLS * 48, dtype=torch.uint8, device=dev)
+    ctx.compute_cells_and_kzg_proofs_device(nb, d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr())
+    cells = d_c.cpu().numpy().tobytes()
+    proofs = d_p.cpu().numpy().tobytes()
+    _, comms = ctx.blob_to_kzg_commitment_batch([blobs_h[b].tobytes() for b in range(nb)])
+    C_, I_, L_, P_ = [], [], [], []
+    for b in range(nb):
+        for k in range(CELLS):
+            j = b * CELLS + k
+            C_.append(comms[b]); I_.append(k); L_.append(cells[BYTES_PER_CELL * j:BYTES_PER_CELL * (j + 1)]); P_.append(proofs[48 * j:48 * (j + 1)])
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        ok = ctx.verify_cell_kzg_proof_batch(C_, I_, L_, P_)
+        ts.append(time.perf_counter() - t0)
+        assert ok
+    P2 = list(P_)
+    P2[77] = P_[78]
+    assert ctx.verify_cell_kzg_proof_batch(C_, I_, L_, P2) is False
+    out["config3_verify_64x128_cells"] = {"ms": round(_median(ts) * 1e3, 2), "cells": len(L_), "cells_per_s": round(len(L_) / _median(ts)),
+                                          "entry": "eth_kzg_verify_cell_kzg_proof_batch (host pointers; tampered proof -> false checked)"}
+    # config 5: recover 256 blobs at 50 % erasure, device-resident form; and its per-GPU share on 8 GPUs (32 blobs)
+    for nb, key in ((min(256, B), "config5_recover_256_blobs_half_erased"), (32, "config5_per_gpu_share_32_blobs")):
+        d_b = torch.from_numpy(blobs_h[:nb]).to(dev)
+        d_c = torch.empty(nb * CELLS * BYTES_PER_CELL, dtype=torch.uint8, device=dev)
+        d_p = torch.empty(nb * CELLS * 48, dtype=torch.uint8, device=dev)
+        ctx.compute_cells_and_kzg_proofs_device(nb, d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr())
+        erased = d_c.view(nb, CELLS, BYTES_PER_CELL).clone()
+        erased[:, 1::2, :] = 0xFF
+        d_oc, d_op = torch.empty_like(d_c), torch.empty_like(d_p)
+        idx = list(range(0, CELLS, 2))
+        ts = []
+        for it in range(5):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            st = ctx.recover_cells_and_kzg_proofs_device(nb, erased.data_ptr(), [idx] * nb, d_oc.data_ptr(), d_op.data_ptr())
+            torch.cuda.synchronize(dev)
+            if it >= 1:
+                ts.append(time.perf_counter() - t0)
+        assert st == [0] * nb and torch.equal(d_oc, d_c) and torch.equal(d_op, d_p), "recovery does not reproduce the prover's output"
+        out[key] = {"ms": round(_median(ts) * 1e3, 2), "blobs_per_s": round(nb / _median(ts)), "blobs": nb, "form": "device-resident"}
+    recover_one = (list(range(0, CELLS, 2)), [cells[BYTES_PER_CELL * k:BYTES_PER_CELL * (k + 1)] for k in range(0, CELLS, 2)])
+    # context creation (the reference's "Initialize context" bench): cold = first context of the process (measured by the
+    # caller), warm = another context while one is alive (tables shared), fresh = after every context was closed
+    t0 = time.perf_counter()
+    c2 = kzg.DASContext(use_precomp=True, device=ctx.device_index)
+    warm = time.perf_counter() - t0
+    c2.close()
+    out["context_creation_s"] = {"cold_first_in_process": round(t_ctx_cold, 2), "warm_tables_shared": round(warm, 3),
+                                 "note": "cold = HIP runtime start + hipMalloc of the window tables (the driver maps ~206 GB: seconds) + 0.5 s of table build"}
+    return out, {"verify": (C_, I_, L_, P_), "recover": recover_one}
 
 
 def main():
@@ -139,6 +301,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--blobs-per-gpu", type=int, default=int(os.environ.get("KZG_BENCH_BLOBS", "2048")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the side configurations (BASELINE configs 3-5, ABI, context creation)")
     ap.add_argument("--no-latency-probe", action="store_true",
                     help="skip the 1-blob latency launches (profiling runs: keeps rocprofv3's per-kernel averages to full-batch launches)")
     args = ap.parse_args()
@@ -168,13 +331,19 @@ def main():
     d_proofs = torch.empty(B * CELLS * 48, dtype=torch.uint8, device=dev)
     d_all_proofs = torch.empty(world * B * CELLS * 48, dtype=torch.uint8, device=dev) if world > 1 else None
     stream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream: kernels are enqueued on it without host syncs
+    # the exchange runs on the library's own RCCL communicator (what a C / Go / Java host would use); torch.distributed
+    # carries the 128-byte id and stays the fallback if the library cannot build its communicator
+    lib_comm = world > 1 and sharding.attach_library_comm(ctx, dist)
 
     def step():
         with torch.cuda.stream(stream):
             ctx.compute_cells_and_kzg_proofs_device(B, d_blobs.data_ptr(), d_cells.data_ptr(), d_proofs.data_ptr(),
                                                     want_status=False, stream=stream.cuda_stream)
-            if world > 1:
-                sharding.all_gather_flat(d_proofs, d_all_proofs, dist)  # the only exchange: proof vectors over RCCL/xGMI
+            if world > 1:  # the only exchange: proof vectors over RCCL/xGMI
+                if lib_comm:
+                    sharding.all_gather_proofs(ctx, d_proofs, d_all_proofs, stream)
+                else:
+                    sharding.all_gather_flat(d_proofs, d_all_proofs, dist)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -238,39 +407,45 @@ def main():
             "compress": B * 128 * (168 + 48),
             # compiled linear map: ~3.9 k point operations per blob (350 constant multiplications, 3.2 k additions, 0.4 k
             # doubling runs), each reading one or two 168-B points and writing one, over its ~74 launches
-            "g1_linmap": B * 3900 * 3 * 168 // 74,
+            "g1_linmap": B * (sum(ctx.linmap_info()[:2]) + 400) * 3 * 168 // max(1, ctx.linmap_info()[3]),
         }[dom]
         achieved = alg_bytes / per_launch_s / 1e9
-        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KB units),
-        # valid only for the configuration they were collected on
-        traffic = None
+        # HBM traffic of the dominant kernel: NOT measured in this run (PMC passes need rocprofv3) -- taken from the newest
+        # committed profile of this round and labelled with its file name; valid only for the configuration it was collected on
+        traffic, traffic_source = None, None
         try:
             import glob
-            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_b2048_w14.json")))[-1]))["kernels"]  # newest round
-            key = {"msm_fixed": "void kzg::k_msm_fixed<14>", "g1_ifft": "kzg::k_g1_twiddle_mul", "g1_fft": "kzg::k_g1_twiddle_mul"}.get(dom)
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r2*_pmc_b2048_w14.json")))
+            pm = json.load(open(files[-1]))["kernels"]
+            key = {"msm_fixed": "void kzg::k_msm_fixed_chunked<14>", "g1_linmap": "kzg::k_slp_mulc"}.get(dom)
             if key in pm and B == 2048 and ctx.window_bits() == 14:
                 # gfx950 correction (MI355X_MICROARCH.md, calibrated for this kernel's 16-B-per-lane gathers in
                 # profiles/r1f_calib_fetch.log): FETCH_SIZE tallies every 128-B line request at 64 B -> double it; WRITE_SIZE is exact
                 traffic = (2.0 * pm[key]["FETCH_SIZE_per_launch_max"] + pm[key]["WRITE_SIZE_per_launch_max"]) * 1024.0
+                traffic_source = os.path.relpath(files[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command; not re-measured here)"
         except Exception:
             pass
         stage_ms_per_step = {s: round(stages[s][0] / args.steps, 3) for s in stages}
         # integer-VALU view (the bound that actually binds)
         mac_rate = value * 1.0e9 / 1e9  # reference-algorithm count: ~1.0e9 32x32 MACs per blob
-        mul_eq = fp_mul_eq_per_blob(ctx.window_bits())
+        li = ctx.linmap_info()
+        mul_eq = fp_mul_eq_per_blob(ctx.window_bits(), li[:3] if li[0] else (642, 14 * 64 * 1.5, 0))
         mul_rate = value * mul_eq / 1e9
         out = {
             "metric": "blobs/sec compute_cells_and_kzg_proofs (4096-pt blob)",
             "value": value, "unit": "blobs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "dtype_note": "381-bit Fp as 14x29-bit / 12x32-bit limbs, 255-bit Fr as 8x32-bit limbs, Montgomery integers; exact arithmetic", "data": "synthetic",
-            "config": {"workload": f"compute_cells_and_kzg_proofs, batch-saturated: {B} synthetic blobs per GPU per step "
-                                   f"(config 2's single blob is reported as single_blob_latency_ms)",
+            "config": {"workload": f"compute_cells_and_kzg_proofs on DEVICE-RESIDENT blobs (inputs and outputs stay in HBM; the "
+                                   f"host-pointer ABI rate is configs.abi_host_pointer_batch), batch-saturated: {B} synthetic blobs "
+                                   f"per GPU per step (config 2's single blob is reported as single_blob_latency_ms)",
                        "blobs_per_gpu": B, "use_precomp": True, "window_bits": ctx.window_bits(),
                        "table_GB": round(ctx.table_bytes() / 1e9, 2),
-                       "exchange": "RCCL all-gather of proofs per step" if world > 1 else "none"},
+                       "g1_transforms": f"compiled linear map: {li[0]} constant multiplications, {li[1]} additions, {li[2]} doublings per blob, {li[3]} launches" if li[0] else "radix-2 network",
+                       "exchange": ("ncclAllGather of the proof vectors per step inside libc_eth_kzg.so (eth_kzg_amd_all_gather)" if lib_comm
+                                    else "RCCL all-gather of proofs per step (torch.distributed)") if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": per_launch_s * 1e3, "launches_per_step": dom_launches // max(1, args.steps),
                          "note": "the path is integer-VALU bound, not HBM bound (SURVEY.md 8d); see roofline_valu"},
             "roofline_valu": {"bound": "valu-int", "achieved": mul_rate, "peak": FP_MUL_PEAK_G, "unit": "G Fp-mul/s",
@@ -283,9 +458,13 @@ def main():
             "single_blob_latency_ms": (min(lat) * 1e3) if lat else None,
             "context_creation_s": round(t_ctx, 2),
         }
+        extra = None
+        if not args.no_configs and world == 1:
+            out["configs"], extra = side_configs(ctx, kzg, torch, dev, blobs_h, t_ctx)
+            out["context_creation_s"] = out["configs"]["context_creation_s"]["cold_first_in_process"]
         if not args.no_cpu_baseline and world == 1:
             gpu_first = (bytes(d_cells[:CELLS * BYTES_PER_CELL].cpu().numpy()), bytes(d_proofs[:CELLS * 48].cpu().numpy()))
-            out["cpu_baseline"] = cpu_baseline([bytes(blobs_h[i].tobytes()) for i in range(min(B, 16))], gpu_first=gpu_first)
+            out["cpu_baseline"] = cpu_baseline([bytes(blobs_h[i].tobytes()) for i in range(min(B, 32))], gpu_first=gpu_first, extra=extra)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -164,8 +164,9 @@ CResult eth_kzg_amd_verify_cell_kzg_proof_batch_combine(const DASContext *ctx, u
  *   status         n ints in HOST memory, or NULL: then nothing is copied back and, if
  *                  `hip_stream` is non-NULL, the call returns without synchronising (work is
  *                  enqueued on that hipStream_t; NULL = the context's own stream, synchronised).
- * A context owns ONE set of intermediate buffers: asynchronous calls on the same context must use the same
- * stream (they are then ordered); use one context per stream for concurrent pipelines. */
+ * Calls on one stream are ordered.  The context owns a few sets of intermediate buffers; a call takes a free one and
+ * makes its stream wait for the previous user of that set, so asynchronous calls on different streams are safe too
+ * (they overlap while sets are free, otherwise they queue). */
 CResult eth_kzg_amd_compute_cells_and_kzg_proofs_device(const DASContext *ctx, uint64_t n, const uint8_t *d_blobs,
                                                         uint8_t *d_out_cells, uint8_t *d_out_proofs, int32_t *status,
                                                         void *hip_stream);
@@ -175,23 +176,38 @@ CResult eth_kzg_amd_blob_to_kzg_commitment_device(const DASContext *ctx, uint64_
 /* Introspection used by bench.py / DESIGN.md: bytes of window tables resident in HBM, window width. */
 uint64_t eth_kzg_amd_table_bytes(const DASContext *ctx);
 int eth_kzg_amd_window_bits(const DASContext *ctx);
+/* The compiled linear map that replaces the two G1 transforms of the prover: out4 = constant multiplications, point
+ * additions, point doublings per blob, kernel launches per call (all 0 when ETH_KZG_AMD_G1FFT=radix2 keeps the butterfly network). */
+void eth_kzg_amd_linmap_info(const DASContext *ctx, int32_t *out4);
 
 /* Per-stage HIP-event timing for bench.py's roofline leg.  Stages, in order: blob_to_coeffs,
- * coeffs_to_cells, fk20_scalars, msm_fixed, g1_ifft, g1_fft, compress.  get_stage_times writes the
+ * coeffs_to_cells, fk20_scalars, msm_fixed, g1_ifft, g1_fft, compress, g1_linmap.  get_stage_times writes the
  * milliseconds and kernel-launch counts accumulated since the previous call (it synchronises the
  * device) and returns the number of stages. */
 void eth_kzg_amd_set_profiling(const DASContext *ctx, int on);
 int eth_kzg_amd_get_stage_times(const DASContext *ctx, double *ms, uint64_t *launches, int n);
 
-/* Stage-level hooks for the kernel parity tests (tests/ only; canonical big-endian encodings).
- * Return 0 on success. */
-int eth_kzg_amd_test_fr_ntt4096(const DASContext *ctx, const uint8_t *in, uint8_t *out, int inverse_dit);
-int eth_kzg_amd_test_g1_fft128(const DASContext *ctx, const uint8_t *in, uint8_t *out, int n_lanes, int inverse);
-int eth_kzg_amd_test_fixed_msm(const DASContext *ctx, const uint8_t *scalars, int n_msm, uint8_t *out);
-int eth_kzg_amd_test_g1_decompress(const DASContext *ctx, const uint8_t *in, int n, int subgroup_check, int32_t *status,
-                                   uint8_t *out);
-int eth_kzg_amd_test_field_mul(const DASContext *ctx, const uint8_t *a, const uint8_t *b, uint8_t *out, int n,
-                               int is_fp);
+/* ---- multi-GPU (north_star: blob batches shard across the GPUs of a node; one all-gather of the proof vectors) ----
+ *
+ * (1) One process per GPU (torchrun / MPI style).  The library owns the RCCL communicator: rank 0 obtains an id,
+ *     the caller distributes its 128 bytes by whatever it already has (MPI_Bcast, torch.distributed, a file), every
+ *     rank attaches its context, and eth_kzg_amd_all_gather is one ncclAllGather over xGMI on the given stream:
+ *     d_recv receives world * bytes_per_rank bytes, rank r's slab at offset r * bytes_per_rank.  RCCL is loaded with
+ *     dlopen when the first of these functions is called, so the library itself does not depend on it. */
+CResult eth_kzg_amd_comm_unique_id(uint8_t *out_id /* 128 */);
+CResult eth_kzg_amd_comm_init(DASContext *ctx, const uint8_t *id /* 128 */, int rank, int world);
+CResult eth_kzg_amd_all_gather(const DASContext *ctx, const void *d_send, void *d_recv, uint64_t bytes_per_rank,
+                               void *hip_stream);
+void eth_kzg_amd_comm_destroy(DASContext *ctx);
+/* (2) One process, several GPUs: contexts[d] created with eth_kzg_amd_das_context_new_on_device(.., d).  The batch
+ *     is cut into contiguous slices, one per context, each served by its own host thread through the host-pointer
+ *     path above; the caller's buffers are the gather target, so there is no collective.  status as in the batch call. */
+CResult eth_kzg_amd_compute_cells_and_kzg_proofs_batch_multi(const DASContext *const *contexts, uint64_t n_contexts,
+                                                             uint64_t n, const uint8_t *const *blobs,
+                                                             uint8_t *const *const *out_cells,
+                                                             uint8_t *const *const *out_proofs, int32_t *status);
+/* number of GPUs visible to the library (hipGetDeviceCount) */
+int eth_kzg_amd_device_count(void);
 
 #ifdef __cplusplus
 }

@@ -52,8 +52,13 @@ EXPORTED_SYMBOLS = [
     "eth_kzg_amd_recover_cells_and_proofs_batch", "eth_kzg_amd_recover_cells_and_proofs_device",
     "eth_kzg_amd_verify_cell_kzg_proof_batch_partial", "eth_kzg_amd_verify_cell_kzg_proof_batch_combine",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_device", "eth_kzg_amd_blob_to_kzg_commitment_device",
-    "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits",
+    "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits", "eth_kzg_amd_linmap_info",
     "eth_kzg_amd_set_profiling", "eth_kzg_amd_get_stage_times",
+    "eth_kzg_amd_comm_unique_id", "eth_kzg_amd_comm_init", "eth_kzg_amd_all_gather", "eth_kzg_amd_comm_destroy",
+    "eth_kzg_amd_compute_cells_and_kzg_proofs_batch_multi", "eth_kzg_amd_device_count",
+]
+# include/c_eth_kzg_test_hooks.h: stage-level hooks for tests/, not part of the drop-in ABI
+TEST_HOOK_SYMBOLS = [
     "eth_kzg_amd_test_fr_ntt4096", "eth_kzg_amd_test_g1_fft128", "eth_kzg_amd_test_fixed_msm",
     "eth_kzg_amd_test_g1_decompress", "eth_kzg_amd_test_field_mul",
 ]
@@ -98,6 +103,10 @@ def load_library():
         "eth_kzg_amd_recover_cells_and_proofs_device": [P, U64, P, P, P, P, P, P],
         "eth_kzg_amd_compute_cells_and_kzg_proofs_device": [P, U64, P, P, P, P, P],
         "eth_kzg_amd_blob_to_kzg_commitment_device": [P, U64, P, P, P, P],
+        "eth_kzg_amd_comm_unique_id": [P],
+        "eth_kzg_amd_comm_init": [P, U8P, C.c_int, C.c_int],
+        "eth_kzg_amd_all_gather": [P, P, P, U64, P],
+        "eth_kzg_amd_compute_cells_and_kzg_proofs_batch_multi": [P, U64, U64, P, P, P, P],
     }.items():
         fn = getattr(lib, name)
         fn.restype = CResult
@@ -105,9 +114,14 @@ def load_library():
     for name in ("eth_kzg_constant_bytes_per_cell", "eth_kzg_constant_bytes_per_proof",
                  "eth_kzg_constant_cells_per_ext_blob"):
         getattr(lib, name).restype = U64
+    lib.eth_kzg_amd_comm_destroy.argtypes = [P]
+    lib.eth_kzg_amd_comm_destroy.restype = None
+    lib.eth_kzg_amd_device_count.restype = C.c_int
     lib.eth_kzg_amd_table_bytes.restype = U64
     lib.eth_kzg_amd_table_bytes.argtypes = [P]
     lib.eth_kzg_amd_window_bits.argtypes = [P]
+    lib.eth_kzg_amd_linmap_info.argtypes = [P, P]
+    lib.eth_kzg_amd_linmap_info.restype = None
     lib.eth_kzg_amd_set_profiling.argtypes = [P, C.c_int]
     lib.eth_kzg_amd_set_profiling.restype = None
     lib.eth_kzg_amd_get_stage_times.argtypes = [P, P, P, C.c_int]
@@ -162,7 +176,10 @@ def _vp(arr):
 class DASContext:
     """Mirror of `rust_eth_kzg::DASContext` (crates/eip7594/src/lib.rs:41-87)."""
 
+    device_index = 0
+
     def __init__(self, use_precomp=True, device=None):
+        self.device_index = int(device) if device is not None else int(os.environ.get("ETH_KZG_AMD_DEVICE", "0"))
         self._lib = load_library()
         if device is None:
             self._ctx = C.c_void_p(self._lib.eth_kzg_das_context_new(bool(use_precomp)))
@@ -399,6 +416,42 @@ class DASContext:
             C.c_void_p(d_out_proofs) if d_out_proofs else None, st, C.c_void_p(stream) if stream else None))
         return list(st)[:n]
 
+    # ---- multi-GPU (include/c_eth_kzg.h): the library's own RCCL communicator and the single-process fan-out
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes from ncclGetUniqueId (rank 0 calls this and distributes them)."""
+        out = C.create_string_buffer(128)
+        res = load_library().eth_kzg_amd_comm_unique_id(out)
+        if res.status != 0:
+            msg = C.cast(res.error_msg, C.c_char_p).value.decode() if res.error_msg else "error"
+            load_library().eth_kzg_free_error_message(res.error_msg)
+            raise KzgError(msg)
+        return out.raw
+
+    def comm_init(self, unique_id, rank, world):
+        self._check(self._lib.eth_kzg_amd_comm_init(self._ctx, unique_id, int(rank), int(world)))
+
+    def all_gather(self, d_send, d_recv, bytes_per_rank, stream=None):
+        """ncclAllGather of bytes_per_rank bytes from every rank's d_send into d_recv (device addresses), on `stream`
+        (None: the context's stream, synchronised)."""
+        self._check(self._lib.eth_kzg_amd_all_gather(self._ctx, C.c_void_p(d_send), C.c_void_p(d_recv), int(bytes_per_rank),
+                                                     C.c_void_p(stream) if stream else None))
+
+    def comm_destroy(self):
+        self._lib.eth_kzg_amd_comm_destroy(self._ctx)
+
+    @staticmethod
+    def compute_cells_and_kzg_proofs_batch_multi(contexts, blobs_np, bufs):
+        """eth_kzg_amd_compute_cells_and_kzg_proofs_batch_multi: one host-pointer batch cut into contiguous slices over
+        `contexts` (one per GPU), buffers as in compute_cells_and_kzg_proofs_batch_np."""
+        lib = load_library()
+        n = blobs_np.shape[0]
+        ba = np.uint64(blobs_np.ctypes.data) + np.arange(max(1, n), dtype=np.uint64) * np.uint64(BYTES_PER_BLOB)
+        ctxs = (C.c_void_p * len(contexts))(*[c.handle for c in contexts])
+        contexts[0]._check(lib.eth_kzg_amd_compute_cells_and_kzg_proofs_batch_multi(
+            ctxs, len(contexts), n, _vp(ba), _vp(bufs["cpp"]), _vp(bufs["ppp"]), bufs["status"]))
+        return list(bufs["status"])[:n]
+
     def blob_to_kzg_commitment_device(self, n, d_blobs, d_out, want_status=True, stream=None):
         st = (C.c_int32 * max(1, n))() if want_status else None
         self._check(self._lib.eth_kzg_amd_blob_to_kzg_commitment_device(
@@ -423,3 +476,9 @@ class DASContext:
 
     def window_bits(self):
         return int(self._lib.eth_kzg_amd_window_bits(self._ctx))
+
+    def linmap_info(self):
+        """(constant multiplications, additions, doublings per blob, launches per call) of the compiled G1 linear map."""
+        out = (C.c_int32 * 4)()
+        self._lib.eth_kzg_amd_linmap_info(self._ctx, out)
+        return tuple(out)

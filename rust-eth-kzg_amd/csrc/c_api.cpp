@@ -1,6 +1,7 @@
 // C ABI of the MI355X KZG engine: the reference's `eth_kzg_*` symbols (bindings/c/src/lib.rs) over
 // kzg::Engine, plus the batched / device-resident `eth_kzg_amd_*` additions.  See include/c_eth_kzg.h.
 #include "../../include/c_eth_kzg.h"
+#include "../../include/c_eth_kzg_test_hooks.h"
 #include "engine.hpp"
 
 #include <cstdio>
@@ -69,6 +70,7 @@ DASContext* eth_kzg_amd_das_context_new_on_device(bool use_precomp, int device_o
 }
 void eth_kzg_das_context_free(DASContext* ctx) {
     if (!ctx) return;
+    eth_kzg_amd_comm_destroy(ctx);
     delete ctx->engine;
     delete ctx;
 }
@@ -266,6 +268,9 @@ int eth_kzg_amd_get_stage_times(const DASContext* ctx, double* ms, uint64_t* lau
 }
 uint64_t eth_kzg_amd_table_bytes(const DASContext* ctx) { return eng(ctx)->table_bytes(); }
 int eth_kzg_amd_window_bits(const DASContext* ctx) { return eng(ctx)->window_bits(); }
+void eth_kzg_amd_linmap_info(const DASContext* ctx, int32_t* out4) {
+    for (int i = 0; i < 4; i++) out4[i] = eng(ctx)->linmap_info()[i];
+}
 
 int eth_kzg_amd_test_fr_ntt4096(const DASContext* ctx, const uint8_t* in, uint8_t* out, int inverse_dit) {
     return eng(ctx)->test_fr_ntt4096(in, out, inverse_dit);

@@ -24,6 +24,14 @@ namespace kzg {
             throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " + __FILE__ + ":" + \
                                      std::to_string(__LINE__));                                               \
     } while (0)
+// Kernel launches report failures only through the thread's last-error slot: look at it before trusting anything that
+// is read back after the synchronisation (a stale status word or result point must never pass for a fresh one).
+#define SYNC_CHECKED(stream)                 \
+    do {                                     \
+        HIPCK(hipGetLastError());            \
+        HIPCK(hipStreamSynchronize(stream)); \
+        HIPCK(hipGetLastError());            \
+    } while (0)
 
 static constexpr int N_BLOB = 4096, BYTES_PER_BLOB = 131072;
 
@@ -92,7 +100,7 @@ int Engine::open_blobs_at(int n, const uint8_t* const* blobs, const Fr8* z_mont,
     }
     HIPCK(hipMemcpyAsync(h_y_canon, d_y.p, (size_t)n * 32, hipMemcpyDeviceToHost, st));
     HIPCK(hipMemcpyAsync(h_status, d_status_, n * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCK(hipStreamSynchronize(st));
+    SYNC_CHECKED(st);
     return OK;
 }
 
@@ -127,7 +135,7 @@ static void check_points(Engine* eng, const uint8_t* bytes, int n, void* d_out_a
     HIPCK(hipMemcpyAsync(d_b.p, bytes, (size_t)n * 48, hipMemcpyHostToDevice, st));
     launch::g1_decompress((const uint8_t*)d_b.p, d_out_affine, (int*)d_st.p, n, 1, beta, st);
     HIPCK(hipMemcpyAsync(h_status, d_st.p, n * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCK(hipStreamSynchronize(st));
+    SYNC_CHECKED(st);
 
 }
 
@@ -165,7 +173,7 @@ int Engine::pairing_check_4844(const void* d_points, const std::vector<Fr8>& sc0
     launch::msm_pippenger2(d_points, d_s0.p, n0, d_s1.p, n1, d_ws.p, d_out.p, beta_, st);
     G1Affine out[2];
     HIPCK(hipMemcpyAsync(out, d_out.p, sizeof out, hipMemcpyDeviceToHost, st));
-    HIPCK(hipStreamSynchronize(st));
+    SYNC_CHECKED(st);
     // out[0] = rhs (pairs with [tau]_2), out[1] = lhs (pairs with -[1]_2)
     const pairing::G2Prepared* q[2] = {g2_tau1_.get(), g2_neg_gen_.get()};
     return pairing::product_is_one(out, q, 2) ? 1 : 0;

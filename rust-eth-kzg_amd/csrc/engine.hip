@@ -407,6 +407,10 @@ void Engine::init_linmap(const Fr8* w8192_mont) {
     for (auto& L : sched.launches) slp_launches_.push_back(SlpLaunch{(int)L.kind, L.first, L.count});
     slp_slots_ = sched.n_slots;
     slp_mulc_ = (int)sched.mulc_total;
+    slp_info_[0] = (int)plan.count(linmap::OP_MULC);
+    slp_info_[1] = (int)(plan.count(linmap::OP_ADD) + plan.count(linmap::OP_SUB));
+    slp_info_[2] = (int)plan.doublings();
+    slp_info_[3] = (int)sched.launches.size();
     const Fr h = inv(fr_from_u64(2));
     memcpy(&half_, &h, 32);
     use_linmap_ = true;
@@ -592,6 +596,10 @@ void Engine::get_stage_times(double* ms, uint64_t* launches) {
     marks_.clear();
 }
 
+void Engine::ensure_workspace(int n) {
+    ensure_workspace(work_[0], n);
+    HIPCK(hipStreamWaitEvent(stream_, work_[0].done, 0));
+}
 void Engine::ensure_workspace(Work& w, int n) {
     if (n <= w.cap) return;
     int cap = ((n + 63) / 64) * 64;
@@ -796,6 +804,7 @@ int Engine::blob_to_kzg_commitment_device(int n, const uint8_t* d_blobs, uint8_t
         HIPCK(hipSetDevice(dev_));
         if (!st) st = stream_;
         ensure_workspace(n);
+        HIPCK(hipStreamWaitEvent(st, work_[0].done, 0));  // an earlier asynchronous call on another stream may still use the workspace
         const int bp = ((n + 63) / 64) * 64;
         HIPCK(hipMemsetAsync(d_status_, 0, n * sizeof(int), st));
         // commit = MSM_4096(coeffs, g1_monomial)  (fk20/prover.rs:128-145, commit_key.rs:38-44):
@@ -806,6 +815,7 @@ int Engine::blob_to_kzg_commitment_device(int n, const uint8_t* d_blobs, uint8_t
         launch::g1_sum_positions(d_X_, 64, bp, n, st);
         launch::g1_compress(d_X_, d_commitments, 1, bp, n, st);
         if (h_status) HIPCK(hipMemcpyAsync(h_status, d_status_, n * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCK(hipEventRecord(work_[0].done, st));
         HIPCK(hipGetLastError());
         if (sync || h_status) HIPCK(hipStreamSynchronize(st));
     } catch (const std::exception& e) {

@@ -19,6 +19,7 @@
 namespace kzg {
 
 namespace pairing { struct G2Prepared; }
+struct Comm;  // multi_gpu.cpp
 struct G1Affine;  // curve.hpp
 struct Fr8 { uint32_t v[8]; };
 struct Fp12w { uint32_t v[12]; };
@@ -107,6 +108,8 @@ public:
     Engine(const Engine&) = delete;
 
     int device() const { return dev_; }
+    Comm* comm() const { return comm_; }       // RCCL communicator attached by eth_kzg_amd_comm_init (multi_gpu.cpp)
+    void set_comm(Comm* c) { comm_ = c; }
     hipStream_t stream() const { return stream_; }
     const std::string& last_error() const;  // of the calling thread's last failed call
 
@@ -173,6 +176,7 @@ public:
 
     size_t table_bytes() const { return fk_table_bytes_ + srs_table_bytes_; }
     int window_bits() const { return c_; }
+    const int* linmap_info() const { return slp_info_; }
 
 private:
     void init_constants();
@@ -191,7 +195,7 @@ private:
                   const std::vector<uint32_t>& present, int* st_out);
     int recover_batch_to_coeffs(int R, const uint64_t* n_cells, const uint8_t* const* const* cells,
                                 const uint64_t* const* cell_indices, int* st_out);
-    void ensure_workspace(int n) { ensure_workspace(work_[0], n); }
+    void ensure_workspace(int n);  // work_[0]; also makes stream_ wait for the last asynchronous call that used it
     void ensure_workspace(Work& w, int n);
     void ensure_staging(Work& w, int n);
     void run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st) { run_proofs_from_coeffs(work_[0], n, d_proofs, st); }
@@ -214,6 +218,7 @@ private:
     std::mutex marks_mu_;
 
     int dev_ = 0;
+    Comm* comm_ = nullptr;
     int c_ = 8;      // window width of the FK20 table
     int srs_c_ = 13;  // window width of the commitment (monomial SRS) table (falls back like the FK20 table)
     int wave_slots_ = 2048;  // CUs x 4 SIMDs x 2 waves: what one round of a ~240-VGPR point kernel occupies
@@ -260,6 +265,7 @@ private:
     std::vector<SlpLaunch> slp_launches_;
     void *d_slp_words_ = nullptr, *d_slp_naf_ = nullptr;
     int slp_slots_ = 0, slp_mulc_ = 0;
+    int slp_info_[4] = {0, 0, 0, 0};  // constant multiplications, additions, doublings, launches of the compiled map
     bool use_linmap_ = false;
     Fr8 half_;  // 1/2 in Montgomery form: the scaling folded into the MSM scalars in linear-map mode
 

@@ -121,21 +121,36 @@ __device__ __forceinline__ int g1_decompress_q(G1Affine& out, const uint8_t* in,
     return 0;
 }
 
-// Decompression with validation: thread per point.
-// subgroup_check: 0 none (the embedded SRS, trusted_setup/src/lib.rs:80-86), 1 endomorphism test (production),
-// 2 definitional [r]P == O on the saturated reference forms (tests), 3 the saturated endomorphism test (tests)
-__global__ void k_g1_decompress(const uint8_t* __restrict__ in, G1Affine* __restrict__ out, int* __restrict__ status,
-                                int n, int subgroup_check, Fp beta, Fq<1> beta_q) {
+// Decompression with validation: thread per point, one wave per block (launch bounds tell the compiler it may use the
+// whole register file: without them it budgets for 1024-thread blocks and spills several hundred VGPRs).
+// subgroup_check: 0 none (the embedded SRS, trusted_setup/src/lib.rs:80-86), 1 endomorphism test (production)
+// Two independent (input, output, status) segments per launch: a verification decodes its proofs and its commitments in one
+// go (a launch of 64 points costs the same ~1 ms of dependent doublings as one of 8192).
+__global__ __launch_bounds__(64) void k_g1_decompress(const uint8_t* __restrict__ in0, G1Affine* __restrict__ out0,
+                                                      int* __restrict__ status0, int n0, const uint8_t* __restrict__ in1,
+                                                      G1Affine* __restrict__ out1, int* __restrict__ status1, int n1,
+                                                      int subgroup_check, Fq<1> beta_q) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n0 + n1) return;
+    const bool second = i >= n0;
+    if (second) i -= n0;
+    const uint8_t* in = second ? in1 : in0;
+    G1Affine a;
+    const int rc = g1_decompress_q(a, in + (size_t)i * 48, subgroup_check == 1, beta_q);
+    if (rc) a = aff_inf();
+    (second ? status1 : status0)[i] = rc;
+    (second ? out1 : out0)[i] = a;
+}
+// The same decoding on the saturated reference forms, for the parity tests only: mode 2 = definitional [r]P == O,
+// mode 3 = the saturated endomorphism test.
+__global__ __launch_bounds__(64) void k_g1_decompress_reference(const uint8_t* __restrict__ in, G1Affine* __restrict__ out,
+                                                                int* __restrict__ status, int n, int mode, Fp beta) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     G1Affine a;
-    int rc;
-    if (subgroup_check <= 1) rc = g1_decompress_q(a, in + (size_t)i * 48, subgroup_check == 1, beta_q);
-    else {
-        rc = g1_decompress(a, in + (size_t)i * 48);
-        if (rc == 0 && subgroup_check == 3 && !g1_in_subgroup_endo(a, beta)) rc = 2;
-        if (rc == 0 && subgroup_check == 2 && !g1_in_subgroup(a)) rc = 2;
-    }
+    int rc = g1_decompress(a, in + (size_t)i * 48);
+    if (rc == 0 && mode == 3 && !g1_in_subgroup_endo(a, beta)) rc = 2;
+    if (rc == 0 && mode == 2 && !g1_in_subgroup(a)) rc = 2;
     if (rc) { status[i] = rc; a = aff_inf(); } else status[i] = 0;
     out[i] = a;
 }
@@ -186,8 +201,14 @@ void g1_sum_positions(void* X, int n_pos, int stride, int n_slices, hipStream_t 
 void g1_decompress(const uint8_t* in, void* out, int* status, int n, int subgroup_check, const Fp12w& beta, hipStream_t st) {
     Fp b;
     for (int i = 0; i < 12; i++) b.v[i] = beta.v[i];
-    const Fq<1> bq = fq_from_fp(b);
-    k_g1_decompress<<<(n + 63) / 64, 64, 0, st>>>(in, (G1Affine*)out, status, n, subgroup_check, b, bq);
+    if (subgroup_check >= 2) k_g1_decompress_reference<<<(n + 63) / 64, 64, 0, st>>>(in, (G1Affine*)out, status, n, subgroup_check, b);
+    else k_g1_decompress<<<(n + 63) / 64, 64, 0, st>>>(in, (G1Affine*)out, status, n, nullptr, nullptr, nullptr, 0, subgroup_check, fq_from_fp(b));
+}
+void g1_decompress2(const uint8_t* in0, void* out0, int* status0, int n0, const uint8_t* in1, void* out1, int* status1, int n1,
+                    const Fp12w& beta, hipStream_t st) {
+    Fp b;
+    for (int i = 0; i < 12; i++) b.v[i] = beta.v[i];
+    k_g1_decompress<<<(n0 + n1 + 63) / 64, 64, 0, st>>>(in0, (G1Affine*)out0, status0, n0, in1, (G1Affine*)out1, status1, n1, 1, fq_from_fp(b));
 }
 void fk20_srs_vectors(const void* srs, void* X, hipStream_t st) { k_fk20_srs_vectors<<<128 * 64 / 256, 256, 0, st>>>((const G1Affine*)srs, (JacQ*)X); }
 void fk20_gather_bases(const void* X, void* bases, hipStream_t st) { k_fk20_gather_bases<<<128 * 64 / 256, 256, 0, st>>>((const JacQ*)X, (G1Affine*)bases); }

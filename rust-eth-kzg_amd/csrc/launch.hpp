@@ -56,6 +56,9 @@ void g1_sum_positions(void* X, int n_pos, int stride, int n_slices, hipStream_t 
 // subgroup_check: 0 none, 1 endomorphism test, 2 definitional [r]P == O
 void g1_decompress(const uint8_t* in, void* out /*G1Affine*/, int* status, int n, int subgroup_check, const Fp12w& beta,
                    hipStream_t st);
+// two segments in one launch, production checks (on curve + subgroup)
+void g1_decompress2(const uint8_t* in0, void* out0, int* status0, int n0, const uint8_t* in1, void* out1, int* status1, int n1,
+                    const Fp12w& beta, hipStream_t st);
 void fk20_srs_vectors(const void* srs, void* X, hipStream_t st);
 void fk20_gather_bases(const void* X, void* bases, hipStream_t st);
 void test_load_points(const uint8_t* in, void* X, int n_lanes, int stride, hipStream_t st);

@@ -1,0 +1,173 @@
+// Multi-GPU entry points of the C ABI (include/c_eth_kzg.h, "multi-GPU"): blob batches shard across the GPUs of a node
+// with no data-path collective; the only exchange north_star names is one all-gather of the proof vectors, done here by
+// RCCL (ncclAllGather over xGMI) on a communicator the library owns.  RCCL is dlopen'ed on first use, so loading
+// libc_eth_kzg.so never depends on it.  The single-process form fans a host-pointer batch out over one context per GPU
+// with one host thread each; the caller's buffers are the gather target.
+// Reference analogue: the per-blob independence that maybe_rayon's par_iter exploits (crates/eip7594/src/prover.rs,
+// crates/maybe_rayon), stretched over devices.
+#include "../../include/c_eth_kzg.h"
+#include "engine.hpp"
+
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct DASContext {
+    kzg::Engine* engine;
+};
+
+namespace {
+
+CResult ok() { return CResult{Ok, nullptr}; }
+CResult err(const std::string& m) {
+    char* s = (char*)malloc(m.size() + 1);
+    memcpy(s, m.c_str(), m.size() + 1);
+    return CResult{Err, s};
+}
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) { r.why = "RCCL not found (librccl.so)"; return; }
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
+        r.AllGather = (decltype(r.AllGather))dlsym(r.handle, "ncclAllGather");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
+        if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { r.why = "RCCL symbols missing"; r.handle = nullptr; }
+    });
+    return r;
+}
+std::string nccl_text(ncclResult_t e) {
+    Rccl& r = rccl();
+    return std::string("RCCL: ") + (r.GetErrorString ? r.GetErrorString(e) : "error") + " (" + std::to_string((int)e) + ")";
+}
+
+}  // namespace
+
+namespace kzg {
+// the communicator a context owns (Engine keeps it as an opaque pointer so that engine.hpp stays free of RCCL types)
+struct Comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+};
+}  // namespace kzg
+
+extern "C" {
+
+static_assert(sizeof(ncclUniqueId) == 128, "the ABI passes the id as 128 bytes");
+
+CResult eth_kzg_amd_comm_unique_id(uint8_t* out_id) {
+    Rccl& r = rccl();
+    if (!r.handle) return err(r.why);
+    ncclUniqueId id;
+    ncclResult_t e = r.GetUniqueId(&id);
+    if (e != ncclSuccess) return err(nccl_text(e));
+    memcpy(out_id, &id, 128);
+    return ok();
+}
+
+CResult eth_kzg_amd_comm_init(DASContext* ctx, const uint8_t* id_bytes, int rank, int world) {
+    if (!ctx || !ctx->engine) abort();
+    Rccl& r = rccl();
+    if (!r.handle) return err(r.why);
+    if (world < 1 || rank < 0 || rank >= world) return err("InvalidInput");
+    kzg::Engine* e = ctx->engine;
+    if (e->comm()) return err("communicator already attached to this context");
+    if (hipSetDevice(e->device()) != hipSuccess) return err("DeviceError(hipSetDevice)");
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, 128);
+    auto* c = new kzg::Comm;
+    c->rank = rank;
+    c->world = world;
+    ncclResult_t rc = r.CommInitRank(&c->comm, world, id, rank);
+    if (rc != ncclSuccess) { delete c; return err(nccl_text(rc)); }
+    e->set_comm(c);
+    return ok();
+}
+
+CResult eth_kzg_amd_all_gather(const DASContext* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* hip_stream) {
+    if (!ctx || !ctx->engine) abort();
+    Rccl& r = rccl();
+    kzg::Comm* c = ctx->engine->comm();
+    if (!r.handle || !c) return err("no communicator: call eth_kzg_amd_comm_init first");
+    if (hipSetDevice(ctx->engine->device()) != hipSuccess) return err("DeviceError(hipSetDevice)");
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->engine->stream();
+    ncclResult_t rc = r.AllGather(d_send, d_recv, (size_t)bytes_per_rank, ncclUint8, c->comm, st);
+    if (rc != ncclSuccess) return err(nccl_text(rc));
+    if (!hip_stream && hipStreamSynchronize(st) != hipSuccess) return err("DeviceError(hipStreamSynchronize)");
+    return ok();
+}
+
+void eth_kzg_amd_comm_destroy(DASContext* ctx) {
+    if (!ctx || !ctx->engine) return;
+    kzg::Comm* c = ctx->engine->comm();
+    if (!c) return;
+    (void)hipSetDevice(ctx->engine->device());
+    if (rccl().handle) (void)rccl().CommDestroy(c->comm);
+    delete c;
+    ctx->engine->set_comm(nullptr);
+}
+
+int eth_kzg_amd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+CResult eth_kzg_amd_compute_cells_and_kzg_proofs_batch_multi(const DASContext* const* contexts, uint64_t n_contexts, uint64_t n,
+                                                             const uint8_t* const* blobs, uint8_t* const* const* out_cells,
+                                                             uint8_t* const* const* out_proofs, int32_t* status) {
+    if (n_contexts == 0 || !contexts) return err("InvalidInput");
+    for (uint64_t d = 0; d < n_contexts; d++)
+        if (!contexts[d] || !contexts[d]->engine) abort();
+    if (n == 0) return ok();
+    // contiguous slices, sizes differing by at most one blob (rust-eth-kzg_amd/sharding.py: shard_bounds)
+    std::vector<uint64_t> lo(n_contexts + 1);
+    for (uint64_t d = 0; d <= n_contexts; d++) lo[d] = d * n / n_contexts;
+    std::vector<int> rc(n_contexts, 0);
+    std::vector<std::string> why(n_contexts);
+    std::vector<std::vector<int>> st(n_contexts);
+    std::vector<std::thread> th;
+    for (uint64_t d = 0; d < n_contexts; d++) {
+        const uint64_t b0 = lo[d], nb = lo[d + 1] - lo[d];
+        if (!nb) continue;
+        st[d].assign(nb, 0);
+        th.emplace_back([&, d, b0, nb] {
+            kzg::Engine* e = contexts[d]->engine;
+            rc[d] = e->compute_cells_and_kzg_proofs_host((int)nb, blobs + b0, out_cells ? out_cells + b0 : nullptr,
+                                                         out_proofs ? out_proofs + b0 : nullptr, st[d].data());
+            if (rc[d]) why[d] = e->last_error();
+        });
+    }
+    for (auto& t : th) t.join();
+    for (uint64_t d = 0; d < n_contexts; d++)
+        if (rc[d]) return err("DeviceError(device " + std::to_string(contexts[d]->engine->device()) + ": " + why[d] + ")");
+    if (status)
+        for (uint64_t d = 0; d < n_contexts; d++)
+            for (size_t i = 0; i < st[d].size(); i++) status[lo[d] + i] = st[d][i];
+    return ok();
+}
+
+}  // extern "C"

@@ -33,6 +33,14 @@ namespace kzg {
             throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " + __FILE__ + ":" + \
                                      std::to_string(__LINE__));                                               \
     } while (0)
+// Kernel launches report failures only through the thread's last-error slot: look at it before trusting anything that
+// is read back after the synchronisation (a stale status word or result point must never pass for a fresh one).
+#define SYNC_CHECKED(stream)                 \
+    do {                                     \
+        HIPCK(hipGetLastError());            \
+        HIPCK(hipStreamSynchronize(stream)); \
+        HIPCK(hipGetLastError());            \
+    } while (0)
 
 static constexpr int N_BLOB = 4096, N_EXT = 8192, N_CELLS = 128, CELL_LEN = 64, BYTES_PER_CELL = 2048;
 
@@ -191,16 +199,22 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
                     hidx[k] = (int)cell_indices[k0 + k];
                     hrow[k] = row[k0 + k];
                 }
+                // stale contents of the persistent arena must fail closed: poison every status word and the result slot
+                // (device side and pinned read-back side) before anything is launched
+                memset(stc, 0xff, ((size_t)m + n + 1) * sizeof(int));
+                HIPCK(hipMemsetAsync(d_stc.p, 0xff, (size_t)m * sizeof(int), st));
+                HIPCK(hipMemsetAsync(d_stp.p, 0xff, (size_t)n * sizeof(int), st));
+                HIPCK(hipMemsetAsync(db + off_out, 0xff, 2 * sizeof(G1Affine), st));
                 HIPCK(hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, st));
                 HIPCK(hipMemsetAsync(d_ste.p, 0, sizeof(int), st));
                 // deserialisation with on-curve + subgroup checks (serialization/src/lib.rs:69-99), on the GPU
-                launch::g1_decompress((const uint8_t*)d_cb.p, d_comm_p, (int*)d_stc.p, m, 1, beta_, st);
-                launch::g1_decompress((const uint8_t*)d_pb.p, d_prf_p, (int*)d_stp.p, n, 1, beta_, st);
+                launch::g1_decompress2((const uint8_t*)d_pb.p, d_prf_p, (int*)d_stp.p, n, (const uint8_t*)d_cb.p, d_comm_p, (int*)d_stc.p, m, beta_, st);
                 launch::copy_affine(d_srs_, d_comm_p + m, 64, st);  // vk.g1s: the first 64 SRS points (verification_key.rs:66-70)
                 launch::cells_to_fr((const uint8_t*)d_cellb.p, d_evals.p, nullptr, (int*)d_ste.p, nullptr, nullptr, n, st);
                 HIPCK(hipMemcpyAsync(stc, d_stc.p, m * sizeof(int), hipMemcpyDeviceToHost, st));
                 HIPCK(hipMemcpyAsync(stp, d_stp.p, n * sizeof(int), hipMemcpyDeviceToHost, st));
                 HIPCK(hipMemcpyAsync(ste_p, d_ste.p, sizeof(int), hipMemcpyDeviceToHost, st));
+                HIPCK(hipGetLastError());  // launch failures are per thread: this thread's would be lost with it
             } catch (...) {
                 stage_error = std::current_exception();
             }
@@ -228,7 +242,7 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
         lap("sha256 transcript (host)");
         stager.join();
         if (stage_error) std::rethrow_exception(stage_error);
-        HIPCK(hipStreamSynchronize(st));
+        SYNC_CHECKED(st);
         lap("wait decompress/deserialise");
         for (int i = 0; i < m; i++) if (stc[i]) return ERR_G1;  // order of the reference: commitments, proofs, cells
         for (int i = 0; i < n; i++) if (stp[i]) return ERR_G1;
@@ -251,7 +265,9 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
         View d_ws{db + off_ws}, d_out{db + off_out};
         launch::msm_pippenger2(d_pts.p, d_s1.p, n, d_sB.p, n + m + 64, d_ws.p, d_out.p, beta_, st);
         HIPCK(hipMemcpyAsync(out, d_out.p, 2 * sizeof(G1Affine), hipMemcpyDeviceToHost, st));
-        HIPCK(hipStreamSynchronize(st));
+        SYNC_CHECKED(st);
+        for (int i = 0; i < 2; i++)  // the poison pattern (or anything else that is not a reduced coordinate) is a device failure
+            if (out[i].x.v[11] > FpParams::MOD[11] || out[i].y.v[11] > FpParams::MOD[11]) throw std::runtime_error("verification MSM left no result");
         lap("scalars+interp+lincombs (GPU)");
     } catch (const std::exception& e) {
         set_error(e);
@@ -385,7 +401,7 @@ int Engine::rs_decode(int R, const uint8_t* d_cells, bool flat_source, const std
     launch::rec_dit_last(R, d_T.p, d_coset_inv_, n_inv8192_, nullptr, d_coeffs_, (int*)d_st.p, d_w8192_, 1, st);  // ... * 7^-i
     std::vector<int> hst(R);
     HIPCK(hipMemcpyAsync(hst.data(), d_st.p, R * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCK(hipStreamSynchronize(st));
+    SYNC_CHECKED(st);
     for (int r = 0; r < R; r++) {
         if (st_out[r] != OK) continue;
         if (hst[r] & 1) st_out[r] = ERR_SCALAR;
@@ -403,7 +419,11 @@ int Engine::recover_cells_and_kzg_proofs_device(int R, const uint8_t* d_cells, c
     std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         HIPCK(hipSetDevice(dev_));
-        ensure_workspace(R);
+        ensure_workspace(R);  // also orders stream_ behind the previous asynchronous call that used the workspace
+        if (user_stream) {    // the decode runs on the library's stream: it must see what the caller's stream wrote into d_cells
+            HIPCK(hipEventRecord(work_[0].ev_in, user_stream));
+            HIPCK(hipStreamWaitEvent(stream_, work_[0].ev_in, 0));
+        }
         std::vector<uint32_t> present((size_t)R * 4, 0xffffffffu);
         std::vector<int> slot, stof;
         for (int r = 0; r < R; r++) {
@@ -426,8 +446,9 @@ int Engine::recover_cells_and_kzg_proofs_device(int R, const uint8_t* d_cells, c
         hipStream_t st = user_stream ? user_stream : stream_;
         if (d_out_cells) launch::coeffs_to_cells(R, d_coeffs_, d_out_cells, d_w8192_, st);
         if (d_out_proofs) run_proofs_from_coeffs(R, d_out_proofs, st);
+        HIPCK(hipEventRecord(work_[0].done, st));  // the next user of the workspace waits for these kernels (ensure_workspace)
         HIPCK(hipGetLastError());
-        if (!user_stream) HIPCK(hipStreamSynchronize(st));
+        if (!user_stream) SYNC_CHECKED(st);
     } catch (const std::exception& e) {
         set_error(e);
         return ERR_DEVICE;
@@ -475,7 +496,7 @@ int Engine::recover_cells_and_kzg_proofs_batch_host(int R, const uint64_t* n_cel
         const uint8_t* hp = (const uint8_t*)hp_buf.p;
         HIPCK(hipMemcpyAsync(hc_buf.p, d_c.p, (size_t)R * N_CELLS * BYTES_PER_CELL, hipMemcpyDeviceToHost, stream_));
         HIPCK(hipMemcpyAsync(hp_buf.p, d_p.p, (size_t)R * N_CELLS * 48, hipMemcpyDeviceToHost, stream_));
-        HIPCK(hipStreamSynchronize(stream_));
+        SYNC_CHECKED(stream_);
         lap("cells + proofs + D2H");
         for (int r = 0; r < R; r++) {
             if (status[r] != OK) continue;

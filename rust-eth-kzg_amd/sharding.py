@@ -27,6 +27,45 @@ def all_gather_flat(local, out=None, dist=None):
     return out
 
 
+def attach_library_comm(ctx, dist) -> bool:
+    """Give `ctx` the library's own RCCL communicator (eth_kzg_amd_comm_init): rank 0 draws the id, torch.distributed
+    only carries its 128 bytes to the other ranks.  After this, all_gather_proofs runs ncclAllGather inside
+    libc_eth_kzg.so, which is also what a C / Go / Java host would call.  Returns False (and leaves the torch path in
+    charge) if RCCL cannot be loaded or the communicator cannot be built."""
+    if dist is None or not dist.is_initialized():
+        return False
+    world, rank = dist.get_world_size(), dist.get_rank()
+    box = [None]
+    try:
+        if rank == 0:
+            box[0] = ctx.comm_unique_id()
+    except Exception:
+        box[0] = None
+    dist.broadcast_object_list(box, src=0)
+    if box[0] is None:
+        return False
+    ok = True
+    try:
+        ctx.comm_init(box[0], rank, world)
+    except Exception:
+        ok = False
+    import torch
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks or none
+    if not int(flag.item()):
+        if ok:
+            ctx.comm_destroy()
+        return False
+    return True
+
+
+def all_gather_proofs(ctx, local, out, stream=None):
+    """The one exchange of the sharded prover path through the library's communicator: equal-size per-rank proof slabs
+    (torch uint8 tensors on the GPU) into out[world * local.numel()], enqueued on `stream` (a torch stream or None)."""
+    ctx.all_gather(local.data_ptr(), out.data_ptr(), local.numel(), stream.cuda_stream if stream is not None else None)
+    return out
+
+
 def gather_slabs(local: bytes, item_bytes: int, n_total: int, dist=None) -> bytes:
     """All-gather variable-length per-rank slabs (len(local) = items_on_rank * item_bytes) into the
     full [n_total * item_bytes] byte string on every rank.  Slabs are padded to the largest shard so a

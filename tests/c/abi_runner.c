@@ -3,6 +3,8 @@
  * the reference's c_eth_kzg library (bindings/golang/prover.go:4-10).  Used by tests/test_c_abi_runner.py:
  *   abi_runner compute <blob file> <out file>      out = 128*2048 cell bytes | 128*48 proof bytes | 48 commitment bytes
  *   abi_runner verify  <blob file>                 computes, then verifies all 128 cells; prints "verified=1"
+ *   abi_runner multi   <blob file>                 the same blob 5 times through eth_kzg_amd_compute_cells_and_kzg_proofs_batch_multi
+ *                                                  over every visible GPU (one context each); prints "multi=1 devices=N"
  * Exit code 0 on success, 2 when the library reports Err (message on stderr).
  */
 #include <stdio.h>
@@ -46,6 +48,33 @@ int main(int argc, char **argv) {
         fwrite(proofs, 1, sizeof proofs, o);
         fwrite(commitment, 1, sizeof commitment, o);
         fclose(o);
+    } else if (!strcmp(argv[1], "multi")) {
+        /* single-process fan-out: one context per visible GPU, a 5-blob batch (blob 3 invalid) cut into slices */
+        enum { NB = 5 };
+        int ndev = eth_kzg_amd_device_count();
+        if (ndev < 1) return 1;
+        if (ndev > 8) ndev = 8;
+        const DASContext *ctxs[8];
+        ctxs[0] = ctx;
+        for (int d = 1; d < ndev; d++) ctxs[d] = eth_kzg_amd_das_context_new_on_device(true, d);
+        static uint8_t bad[BLOB], mc[NB][CELLS][CELL], mp[NB][CELLS][48];
+        memset(bad, 0xff, sizeof bad);
+        const uint8_t *blobs[NB] = {blob, blob, blob, bad, blob};
+        uint8_t *cp[NB][CELLS], *pp[NB][CELLS];
+        uint8_t *const *cpp[NB];
+        uint8_t *const *ppp[NB];
+        int32_t st[NB];
+        for (int b = 0; b < NB; b++) {
+            for (int i = 0; i < CELLS; i++) { cp[b][i] = mc[b][i]; pp[b][i] = mp[b][i]; }
+            cpp[b] = cp[b]; ppp[b] = pp[b];
+        }
+        r = eth_kzg_amd_compute_cells_and_kzg_proofs_batch_multi(ctxs, (uint64_t)ndev, NB, blobs, cpp, ppp, st);
+        if (r.status != Ok) return fail(r, "compute_cells_and_kzg_proofs_batch_multi");
+        int good = st[3] != 0;
+        for (int b = 0; b < NB; b++)
+            if (b != 3) good = good && st[b] == 0 && !memcmp(mc[b], cells, sizeof cells) && !memcmp(mp[b], proofs, sizeof proofs);
+        printf("multi=%d devices=%d\n", good, ndev);
+        for (int d = 1; d < ndev; d++) eth_kzg_das_context_free((DASContext *)ctxs[d]);
     } else {
         const uint8_t *comm_ptrs[CELLS], *ccell[CELLS], *cproof[CELLS];
         uint64_t idx[CELLS];

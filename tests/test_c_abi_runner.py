@@ -19,6 +19,21 @@ def _build(tmp_path):
     return exe
 
 
+def _build_static(tmp_path):
+    """The same consumer linked against the static archive, the way bindings/golang/prover.go links libc_eth_kzg.a;
+    the HIP runtime and the C++ runtime come from the consumer's link line."""
+    exe = str(tmp_path / "abi_runner_static")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), SRC,
+                           os.path.join(LIBDIR, "libc_eth_kzg.a"), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib",
+                           "-lamdhip64", "-lstdc++", "-ldl", "-lpthread", "-lm", "-o", exe])
+    return exe
+
+
+def test_c_program_links_against_the_static_archive(tmp_path):
+    assert os.path.exists(os.path.join(LIBDIR, "libc_eth_kzg.a")), "build the HIP extension first"
+    _build_static(tmp_path)
+
+
 def test_header_is_plain_c():
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c",
                            os.path.join(ROOT, "include", "c_eth_kzg.h")])
@@ -47,6 +62,14 @@ def test_c_program_reproduces_the_golden_vector(tmp_path):
         assert out[-48:] == expected_commitment[0]
     res = subprocess.run([exe, "verify", str(blob_path)], check=True, capture_output=True, text=True).stdout
     assert "verified=1" in res and "recovered=1" in res
+    # the single-process multi-GPU fan-out (one context per visible GPU; one GPU on the test box) from plain C
+    res = subprocess.run([exe, "multi", str(blob_path)], check=True, capture_output=True, text=True).stdout
+    assert "multi=1" in res
+    # the statically linked consumer computes the same bytes
+    exe_s = _build_static(tmp_path)
+    out2 = tmp_path / "out_static.bin"
+    subprocess.check_call([exe_s, "compute", str(blob_path), str(out2)])
+    assert out2.read_bytes() == out
     # an invalid blob (all 0xff) must come back as Err with a message, exit code 2
     bad = tmp_path / "bad.bin"
     bad.write_bytes(b"\xff" * 131072)

@@ -256,3 +256,92 @@ def test_radix2_transform_schedule_still_matches_oracle(oracle, monkeypatch):
             _check_sample_against_oracle(oracle, blobs, cells, proofs, [0, 2, 63, 64, n - 1])
     finally:
         c2.close()
+
+
+def test_pipelined_async_recoveries_on_a_user_stream(ctx):
+    """Two back-to-back asynchronous device-resident recoveries on ONE user stream, the first one's input still being
+    produced on that stream when the call is made (a device-to-device copy queued just before): the header promises
+    stream order.  Results must equal the synchronous ones.  Then an asynchronous prover call and an asynchronous
+    commitment call interleaved with them on the same stream."""
+    import torch
+    n = 48
+    blobs = _random_blobs(2 * n, 6006)
+    st, cells, proofs = _compute_on_device(ctx, blobs)
+    assert st == [0] * (2 * n)
+    idx = list(range(1, 128, 2))
+    flat = cells.reshape(2 * n, 128, 2048).copy()
+    flat[:, [k for k in range(128) if k not in idx], :] = 0xEE
+    src = torch.from_numpy(flat.reshape(-1)).cuda()
+    stream = torch.cuda.Stream()
+    d_in = [torch.zeros(n * 128 * 2048, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    d_c = [torch.empty(n * 128 * 2048, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    d_p = [torch.empty(n * 128 * 48, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    d_cc = torch.empty(n * 128 * 2048, dtype=torch.uint8, device="cuda")
+    d_pp = torch.empty(n * 128 * 48, dtype=torch.uint8, device="cuda")
+    d_blobs = torch.from_numpy(blobs[:n].reshape(-1)).cuda()
+    d_comm = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        for h in range(2):
+            d_in[h].copy_(src[h * n * 128 * 2048:(h + 1) * n * 128 * 2048], non_blocking=True)  # input produced on the stream
+            status = ctx.recover_cells_and_kzg_proofs_device(n, d_in[h].data_ptr(), [idx] * n, d_c[h].data_ptr(), d_p[h].data_ptr(),
+                                                             stream=stream.cuda_stream)
+            assert status == [0] * n
+            if h == 0:
+                ctx.compute_cells_and_kzg_proofs_device(n, d_blobs.data_ptr(), d_cc.data_ptr(), d_pp.data_ptr(), want_status=False,
+                                                        stream=stream.cuda_stream)
+                ctx.blob_to_kzg_commitment_device(n, d_blobs.data_ptr(), d_comm.data_ptr(), want_status=False, stream=stream.cuda_stream)
+    torch.cuda.synchronize()
+    for h in range(2):
+        assert np.array_equal(d_c[h].cpu().numpy().reshape(n, -1), cells[h * n:(h + 1) * n]), h
+        assert np.array_equal(d_p[h].cpu().numpy().reshape(n, -1), proofs[h * n:(h + 1) * n]), h
+    assert np.array_equal(d_cc.cpu().numpy().reshape(n, -1), cells[:n]) and np.array_equal(d_pp.cpu().numpy().reshape(n, -1), proofs[:n])
+    _, comms = ctx.blob_to_kzg_commitment_batch([blobs[b].tobytes() for b in range(n)])
+    assert d_comm.cpu().numpy().tobytes() == b"".join(comms)
+
+
+def test_library_rccl_all_gather_at_world_one(ctx):
+    """The library's own RCCL communicator (eth_kzg_amd_comm_unique_id / _comm_init / _all_gather), as far as a one-GPU
+    box can take it: world = 1, ncclAllGather of the proof slab on a user stream must reproduce the slab."""
+    import torch
+    uid = kzg.DASContext.comm_unique_id()
+    assert len(uid) == 128
+    c2 = kzg.DASContext(use_precomp=True)
+    try:
+        c2.comm_init(uid, 0, 1)
+        with pytest.raises(kzg.KzgError):
+            c2.comm_init(uid, 0, 1)  # one communicator per context
+        n = 8
+        blobs = _random_blobs(n, 77)
+        st, cells, proofs = _compute_on_device(c2, blobs)
+        d_p = torch.from_numpy(proofs.reshape(-1)).cuda()
+        d_all = torch.zeros_like(d_p)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            c2.all_gather(d_p.data_ptr(), d_all.data_ptr(), d_p.numel(), stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(d_all, d_p)
+        c2.comm_destroy()
+        with pytest.raises(kzg.KzgError):
+            c2.all_gather(d_p.data_ptr(), d_all.data_ptr(), d_p.numel())
+    finally:
+        c2.close()
+
+
+def test_single_process_fan_out_over_contexts(ctx):
+    """eth_kzg_amd_compute_cells_and_kzg_proofs_batch_multi with two contexts on the one GPU of the test box (they share
+    the window tables): slices 0..k and k..n run on two host threads concurrently; results equal the plain batch call."""
+    n = 150
+    blobs = np.ascontiguousarray(_random_blobs(n, 88).reshape(n, 131072))
+    blobs[7] = 0xFF  # invalid blob in the first slice
+    c2 = kzg.DASContext(use_precomp=True)
+    try:
+        bufs = ctx.host_batch_buffers(n)
+        st = kzg.DASContext.compute_cells_and_kzg_proofs_batch_multi([ctx, c2], blobs, bufs)
+        ref = ctx.host_batch_buffers(n)
+        st_ref = ctx.compute_cells_and_kzg_proofs_batch_np(blobs, ref)
+        assert st == st_ref and st[7] != 0 and sum(1 for x in st if x) == 1
+        keep = [b for b in range(n) if b != 7]
+        assert np.array_equal(bufs["cells"][keep], ref["cells"][keep]) and np.array_equal(bufs["proofs"][keep], ref["proofs"][keep])
+    finally:
+        c2.close()

@@ -61,6 +61,27 @@ def _worker(rank, world, port, n_blobs, q):
     except Exception:
         raised = True
     assert raised
+    # the hand-over of the library's RCCL id (bench.py: attach_library_comm): rank 0 draws it, every rank attaches with the
+    # same 128 bytes; if any rank cannot attach, all ranks fall back together
+    class FakeComm:
+        def __init__(self, fail_on=None):
+            self.fail_on, self.attached, self.destroyed = fail_on, None, False
+
+        def comm_unique_id(self):
+            return bytes(range(128))
+
+        def comm_init(self, uid, r, w):
+            if self.fail_on == r:
+                raise RuntimeError("no RCCL here")
+            self.attached = (uid, r, w)
+
+        def comm_destroy(self):
+            self.destroyed = True
+
+    fc = FakeComm()
+    assert sh.attach_library_comm(fc, dist) is True and fc.attached == (bytes(range(128)), rank, world)
+    fc = FakeComm(fail_on=1)
+    assert sh.attach_library_comm(fc, dist) is False and (fc.destroyed if rank == 0 else fc.attached is None)
     if rank == 0:
         q.put(res)
     dist.barrier()
