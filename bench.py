@@ -38,13 +38,13 @@ FP_MUL_PEAK_G = 78.1             # measured ceiling of the 14x29-bit Montgomery 
                                  # profiles/r1e_ubench_fp29.log (66.0 G/s at the 2 waves/SIMD the point kernels can hold)
 
 
-def fp_mul_eq_per_blob(window_bits, linmap):
+def fp_mul_eq_per_blob(window_bits, linmap, glv=False):
     """Fp multiplication equivalents this build spends per blob, counted in multiply-add passes of 392 MACs
     (M = 1, squaring S = 301/392, fused pair a*b + c*d with one reduction F = 588/392):
     stage D: 128 MSMs x 64 bases x W windows XYZZ mixed additions (6M + 2S + F);
     stages E+F as one compiled linear map (g1_linmap.hpp): `mulc` constant multiplications x (1 + 128 doublings
     (2M + 3S + F) + ~43 + 7 additions (10M + 4S + F) + 8 beta-muls) + its additions and doublings."""
-    w = (255 + window_bits) // window_bits
+    w = 16 if glv else (255 + window_bits) // window_bits  # gathered additions per (scalar, base)
     S, F = 301 / 392, 588 / 392
     madd, dbl, add = 6 + 2 * S + F, 2 + 3 * S + F, 10 + 4 * S + F
     mulc, adds, dbls = linmap
@@ -400,7 +400,8 @@ def main():
             "coeffs_to_cells": B * (4096 * 32 * 2 + 8192 * 32),
             "fk20_scalars": B * (4096 * 32 + 128 * 64 * 32),
             # scalars in + one 96-B table entry per (scalar, window) + 128 Jacobian sums out
-            "msm_fixed": B * (128 * 64 * 32 + 128 * 64 * ((255 + ctx.window_bits()) // ctx.window_bits()) * 112 + 128 * 168),
+            # (GLV table: 16 packed 96-B entries per scalar; plain table of width c: ceil(256/c) entries of 112 B)
+            "msm_fixed": B * (128 * 64 * 32 + 128 * 64 * (16 * 96 if ctx.glv_table() else ((255 + ctx.window_bits()) // ctx.window_bits()) * 112) + 128 * 168),
             # one radix-2 layer: 64 butterflies x (2 points in, 2 points out) x 168 B per blob
             "g1_ifft": B * 64 * 4 * 168,
             "g1_fft": B * 64 * 4 * 168,
@@ -415,10 +416,10 @@ def main():
         traffic, traffic_source = None, None
         try:
             import glob
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r2*_pmc_b2048_w14.json")))
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r2*_pmc_b2048*.json")))
             pm = json.load(open(files[-1]))["kernels"]
-            key = {"msm_fixed": "void kzg::k_msm_fixed_chunked<14>", "g1_linmap": "kzg::k_slp_mulc"}.get(dom)
-            if key in pm and B == 2048 and ctx.window_bits() == 14:
+            key = {"msm_fixed": "kzg::k_msm_glv_chunked" if ctx.glv_table() else "void kzg::k_msm_fixed_chunked<14>", "g1_linmap": "kzg::k_slp_mulc"}.get(dom)
+            if key in pm and B == 2048:
                 # gfx950 correction (MI355X_MICROARCH.md, calibrated for this kernel's 16-B-per-lane gathers in
                 # profiles/r1f_calib_fetch.log): FETCH_SIZE tallies every 128-B line request at 64 B -> double it; WRITE_SIZE is exact
                 traffic = (2.0 * pm[key]["FETCH_SIZE_per_launch_max"] + pm[key]["WRITE_SIZE_per_launch_max"]) * 1024.0
@@ -429,7 +430,7 @@ def main():
         # integer-VALU view (the bound that actually binds)
         mac_rate = value * 1.0e9 / 1e9  # reference-algorithm count: ~1.0e9 32x32 MACs per blob
         li = ctx.linmap_info()
-        mul_eq = fp_mul_eq_per_blob(ctx.window_bits(), li[:3] if li[0] else (642, 14 * 64 * 1.5, 0))
+        mul_eq = fp_mul_eq_per_blob(ctx.window_bits(), li[:3] if li[0] else (642, 14 * 64 * 1.5, 0), ctx.glv_table())
         mul_rate = value * mul_eq / 1e9
         out = {
             "metric": "blobs/sec compute_cells_and_kzg_proofs (4096-pt blob)",
@@ -440,6 +441,8 @@ def main():
                                    f"host-pointer ABI rate is configs.abi_host_pointer_batch), batch-saturated: {B} synthetic blobs "
                                    f"per GPU per step (config 2's single blob is reported as single_blob_latency_ms)",
                        "blobs_per_gpu": B, "use_precomp": True, "window_bits": ctx.window_bits(),
+                       "fk20_table": "GLV: 8 windows of 16 bits per 128-bit half scalar, packed 96-B entries, 16 gathered additions per base" if ctx.glv_table()
+                                     else f"plain: width {ctx.window_bits()}, {(255 + ctx.window_bits()) // ctx.window_bits()} gathered additions per base",
                        "table_GB": round(ctx.table_bytes() / 1e9, 2),
                        "g1_transforms": f"compiled linear map: {li[0]} constant multiplications, {li[1]} additions, {li[2]} doublings per blob, {li[3]} launches" if li[0] else "radix-2 network",
                        "exchange": ("ncclAllGather of the proof vectors per step inside libc_eth_kzg.so (eth_kzg_amd_all_gather)" if lib_comm

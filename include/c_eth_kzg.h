@@ -176,6 +176,9 @@ CResult eth_kzg_amd_blob_to_kzg_commitment_device(const DASContext *ctx, uint64_
 /* Introspection used by bench.py / DESIGN.md: bytes of window tables resident in HBM, window width. */
 uint64_t eth_kzg_amd_table_bytes(const DASContext *ctx);
 int eth_kzg_amd_window_bits(const DASContext *ctx);
+/* 1 if the FK20 window table is the GLV table (8 windows of 16 bits over the two 128-bit halves of each scalar, packed
+ * 96-byte entries, 16 gathered additions per base), 0 for a plain table of eth_kzg_amd_window_bits bits. */
+int eth_kzg_amd_glv_table(const DASContext *ctx);
 /* The compiled linear map that replaces the two G1 transforms of the prover: out4 = constant multiplications, point
  * additions, point doublings per blob, kernel launches per call (all 0 when ETH_KZG_AMD_G1FFT=radix2 keeps the butterfly network). */
 void eth_kzg_amd_linmap_info(const DASContext *ctx, int32_t *out4);

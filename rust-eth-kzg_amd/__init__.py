@@ -52,7 +52,7 @@ EXPORTED_SYMBOLS = [
     "eth_kzg_amd_recover_cells_and_proofs_batch", "eth_kzg_amd_recover_cells_and_proofs_device",
     "eth_kzg_amd_verify_cell_kzg_proof_batch_partial", "eth_kzg_amd_verify_cell_kzg_proof_batch_combine",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_device", "eth_kzg_amd_blob_to_kzg_commitment_device",
-    "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits", "eth_kzg_amd_linmap_info",
+    "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits", "eth_kzg_amd_glv_table", "eth_kzg_amd_linmap_info",
     "eth_kzg_amd_set_profiling", "eth_kzg_amd_get_stage_times",
     "eth_kzg_amd_comm_unique_id", "eth_kzg_amd_comm_init", "eth_kzg_amd_all_gather", "eth_kzg_amd_comm_destroy",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_batch_multi", "eth_kzg_amd_device_count",
@@ -120,6 +120,7 @@ def load_library():
     lib.eth_kzg_amd_table_bytes.restype = U64
     lib.eth_kzg_amd_table_bytes.argtypes = [P]
     lib.eth_kzg_amd_window_bits.argtypes = [P]
+    lib.eth_kzg_amd_glv_table.argtypes = [P]
     lib.eth_kzg_amd_linmap_info.argtypes = [P, P]
     lib.eth_kzg_amd_linmap_info.restype = None
     lib.eth_kzg_amd_set_profiling.argtypes = [P, C.c_int]
@@ -476,6 +477,9 @@ class DASContext:
 
     def window_bits(self):
         return int(self._lib.eth_kzg_amd_window_bits(self._ctx))
+
+    def glv_table(self):
+        return bool(self._lib.eth_kzg_amd_glv_table(self._ctx))
 
     def linmap_info(self):
         """(constant multiplications, additions, doublings per blob, launches per call) of the compiled G1 linear map."""

@@ -25,6 +25,12 @@ struct alignas(16) TabQ {
     uint32_t pad[4];
 };
 static_assert(sizeof(TabQ) == 128, "table entries are one cache line");
+// A GLV window-table entry: both coordinates canonical (Montgomery-406 values < p), packed 12 x 32 bits each
+// (k_table.hip: k_table_fill_packed).  Identity = all zero.
+struct alignas(16) TabP {
+    uint32_t w[24];
+};
+static_assert(sizeof(TabP) == 96, "packed table entries");
 struct JacQ {  // identity <=> z == 0 mod p
     Fq<XB> x, y;
     Fq<ZB> z;

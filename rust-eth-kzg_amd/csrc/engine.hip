@@ -199,10 +199,12 @@ PoolBuf::~PoolBuf() {
 // ---------------------------------------------------------------------------------------------
 Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14 : 4) {
     if (use_precomp) {
-        // default width 14: 163 GB of window tables (128-B entries), 19 windows -> 1216 gathered additions per MSM (HBM is 288 GB).
-        if (const char* s = getenv("ETH_KZG_AMD_WINDOW")) {  // tuning knob: FK20 table window width (8, 10, 12, 13, 14)
+        // default: the GLV table (8 windows of 16 bits per 128-bit half scalar, packed 96-B entries, 206 GB: 1024 gathered
+        // additions per MSM); if HBM is short, plain tables of width 14 (163 GB, 19 windows -> 1216 additions), 13, 12, 10, 8, 4.
+        want_glv_ = true;
+        if (const char* s = getenv("ETH_KZG_AMD_WINDOW")) {  // tuning knob: plain FK20 table of this window width (8, 10, 12, 13, 14)
             int c = atoi(s);
-            if (c == 8 || c == 10 || c == 12 || c == 13 || c == 14) c_ = c;
+            if (c == 8 || c == 10 || c == 12 || c == 13 || c == 14) { c_ = c; want_glv_ = false; }
         }
     }
     srs_c_ = use_precomp ? 13 : 4;  // commitment table over the monomial SRS: 37.6 GB at width 13 (20 windows instead of 32)
@@ -526,6 +528,53 @@ static bool build_table(int c, const void* bases, void** table, size_t* bytes, i
     return true;
 }
 
+// the GLV table (k_table.hip: build_table_glv16): packed 96-B entries, built in chunks of groups with 168 B of scratch per entry
+static bool build_table_glv(const void* bases, void** table, size_t* bytes, int n_groups, int nb, hipStream_t st) {
+    const size_t per_group = launch::table_glv16_entries(1, nb), entries = per_group * n_groups;
+    int chunk = (int)((9ull << 30) / (per_group * 168));
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_groups) chunk = n_groups;
+    const size_t side_bytes = launch::table_glv16_side_bytes(chunk, nb);
+    *table = nullptr;
+    size_t free_b = 0, total_b = 0;
+    HIPCK(hipMemGetInfo(&free_b, &total_b));
+    const size_t need = entries * launch::SIZEOF_TABP + per_group * chunk * 168 + side_bytes + (8ull << 30);  // + head-room for batches
+    if (need > free_b) return false;
+    const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    void *scratch = nullptr, *side = nullptr;
+    int* d_err = nullptr;
+    if (hipMalloc(table, entries * launch::SIZEOF_TABP) != hipSuccess) { (void)hipGetLastError(); *table = nullptr; return false; }
+    if (hipMalloc(&scratch, per_group * chunk * 168) != hipSuccess || hipMalloc(&side, side_bytes) != hipSuccess ||
+        hipMalloc(&d_err, sizeof(int)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (scratch) (void)hipFree(scratch);
+        if (side) (void)hipFree(side);
+        HIPCK(hipFree(*table));
+        *table = nullptr;
+        return false;
+    }
+    if (trace) fprintf(stderr, "[context]   GLV table (8 x 16-bit windows): hipMalloc %.1f GB  %8.1f ms\n",
+                       (entries * launch::SIZEOF_TABP + per_group * chunk * 168 + side_bytes) / 1e9, ms());
+    HIPCK(hipMemsetAsync(d_err, 0, sizeof(int), st));
+    for (int g0 = 0; g0 < n_groups; g0 += chunk) {
+        const int g = n_groups - g0 < chunk ? n_groups - g0 : chunk;
+        launch::build_table_glv16((const char*)bases + (size_t)g0 * nb * sizeof(G1Affine),
+                                  (char*)*table + (size_t)g0 * per_group * launch::SIZEOF_TABP, scratch, side, g, nb, d_err, st);
+        HIPCK(hipStreamSynchronize(st));
+    }
+    int err = 0;
+    HIPCK(hipMemcpy(&err, d_err, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCK(hipFree(d_err));
+    HIPCK(hipFree(side));
+    HIPCK(hipFree(scratch));
+    if (err) throw std::runtime_error("window table: a base point of small order");
+    if (trace) fprintf(stderr, "[context]   GLV table: built            %8.1f ms\n", ms());
+    *bytes = entries * launch::SIZEOF_TABP;
+    return true;
+}
+
 void Engine::init_fk20() {
     // 64 G1-FFT_128 of the SRS vectors: the 64 vectors ride on the 64 lanes of the FFT kernel.
     void* X;
@@ -554,9 +603,21 @@ void Engine::init_fk20() {
     if (!srs_tab_) throw std::runtime_error("not enough device memory for the commitment window table");
     d_srs_table_ = srs_tab_->p;
     srs_table_bytes_ = srs_tab_->bytes;
-    // the widest FK20 table that is already resident or still fits (another process may hold part of the HBM)
+    // the FK20 table: the GLV table if wanted and it is resident already or still fits, else the widest plain table that does
+    // (another process may hold part of the HBM)
+    if (want_glv_) {
+        auto key = std::make_tuple(dev_, 2, launch::GLV_C);
+        if (auto live = g_tables[key].lock()) fk_tab_ = live;
+        else {
+            auto t = std::make_shared<SharedTable>();
+            t->dev = dev_;
+            if (build_table_glv(d_fk_bases_, &t->p, &t->bytes, 128, 64, stream_)) { g_tables[key] = t; fk_tab_ = t; }
+        }
+        if (fk_tab_) { fk_glv_ = true; c_ = launch::GLV_C; }
+    }
     static const int widths[] = {14, 13, 12, 10, 8, 4};
     for (int w : widths) {
+        if (fk_tab_) break;
         if (w > c_) continue;
         if ((fk_tab_ = obtain(1, w, d_fk_bases_, 128))) { c_ = w; break; }
     }
@@ -647,6 +708,14 @@ Work& Engine::lease_work(int first, int last) {
 void Engine::launch_msm(const void* scalars, const void* table, void* out, int n_groups, int n_slices, int out_stride,
                         int brp_bits, hipStream_t st) {
     const int c = table == d_srs_table_ ? srs_c_ : c_;
+    if (table == d_fk_table_ && fk_glv_) {  // GLV table: the scalars are split in place by the launcher (they feed nothing else)
+        const long msms = (long)n_groups * n_slices;
+        int mode = 1;
+        if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) mode = 0;
+        else if (msm_chunks_ >= 0 ? msm_chunks_ > 0 : (msms * 4 + 63) / 64 >= (long)wave_slots_) mode = 2;
+        launch::msm_glv16(mode, const_cast<void*>(scalars), table, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st);
+        return;
+    }
     if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) {
         launch::msm_fixed_flat(c, scalars, table, out, n_groups, n_slices, 64, out_stride, brp_bits, st);
         return;

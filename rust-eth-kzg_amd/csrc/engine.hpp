@@ -175,7 +175,8 @@ public:
     void get_stage_times(double* ms, uint64_t* launches);
 
     size_t table_bytes() const { return fk_table_bytes_ + srs_table_bytes_; }
-    int window_bits() const { return c_; }
+    int window_bits() const { return c_; }          // 16 for the GLV table
+    bool glv_table() const { return fk_glv_; }
     const int* linmap_info() const { return slp_info_; }
 
 private:
@@ -221,6 +222,7 @@ private:
     Comm* comm_ = nullptr;
     int c_ = 8;      // window width of the FK20 table
     int srs_c_ = 13;  // window width of the commitment (monomial SRS) table (falls back like the FK20 table)
+    bool want_glv_ = false, fk_glv_ = false;  // FK20 table kind: GLV (8 x 16-bit windows over the half scalars, packed entries) or plain
     int wave_slots_ = 2048;  // CUs x 4 SIMDs x 2 waves: what one round of a ~240-VGPR point kernel occupies
     int msm_chunks_ = -1;    // -1: pick per launch (launch_msm); otherwise forced by ETH_KZG_AMD_MSM_CHUNKS
     hipStream_t stream_ = nullptr;

@@ -106,10 +106,9 @@ __device__ __forceinline__ JacQ add_mixed_f(const JacQ& p, const AffQ& q, Fq<260
     return r;
 }
 
-template <int C>
+template <int C, int W = (255 + C) / C>
 __global__ void k_table_windows(const G1Affine* __restrict__ bases, AffQ* __restrict__ qw /*[n][2][W]*/, JacQ* __restrict__ tmp,
                                 Fq<2>* __restrict__ pre, int n_bases) {
-    constexpr int W = (255 + C) / C;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_bases) return;
     AffQ* out = qw + (size_t)b * 2 * W;
@@ -200,6 +199,67 @@ __global__ __launch_bounds__(64) void k_table_fill(const AffQ* __restrict__ qw, 
     }
 }
 
+// GLV table (curve29.hpp: TabP): the scalars are split k = k1 + k2 lambda with |k1|, |k2| < 2^127 and phi is applied to the
+// SUM of the k2 terms (phi is a homomorphism), so one table over W = 8 windows of c = 16 bits serves both halves: 16
+// gathered additions per base instead of 19 at width 14 -- and half the memory per window, which is what lets the
+// window be 16 bits wide at all.  Entries are packed canonical coordinates (2 x 48 B): at 128 B they would not fit in HBM.
+// Same wave-per-(base, window) walk as k_table_fill; the un-normalised X, Y wait in a scratch (the 96-B entry cannot hold them).
+template <int C, int W>
+__global__ __launch_bounds__(64) void k_table_fill_packed(const AffQ* __restrict__ qw, TabP* __restrict__ table,
+                                                          Fq<260>* __restrict__ scratch_f, Fq<XB>* __restrict__ scratch_xy,
+                                                          int nb, int* __restrict__ err) {
+    constexpr int T = 1 << (C - 1), K = T / 64;
+    const int lane = threadIdx.x;
+    const long blk = blockIdx.x;  // = (group * W + w) * nb + i : the table's own block order
+    const int i = (int)(blk % nb), w = (int)((blk / nb) % W);
+    const long group = blk / ((long)nb * W);
+    const long base = group * nb + i;
+    const AffQ Q = qw[(size_t)base * 2 * W + w], S = qw[(size_t)base * 2 * W + W + w];
+    TabP* dst = table + ((size_t)blk << (C - 1));
+    Fq<260>* scr = scratch_f + ((size_t)blk << (C - 1));
+    Fq<XB>* raw = scratch_xy + ((size_t)blk << C);  // 2 per entry
+    if (is_inf(Q)) {  // identity base (wave-uniform): an all-identity block
+        TabP z;
+        for (int t = 0; t < 24; t++) z.w[t] = 0;
+        for (int k = 0; k < K; k++) dst[k * 64 + lane] = z;
+        return;
+    }
+    JacQ cur = jacq_inf();
+    const int n = lane + 1;
+#pragma unroll 1
+    for (int bit = 6; bit >= 0; bit--) {
+        cur = dbl(cur);
+        const JacQ t = add_mixed(cur, Q);
+        const bool take = (n >> bit) & 1;
+        cur.x = select(take, t.x, cur.x);
+        cur.y = select(take, t.y, cur.y);
+        cur.z = select(take, t.z, cur.z);
+    }
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {
+        raw[2 * (size_t)(k * 64 + lane)] = cur.x;
+        raw[2 * (size_t)(k * 64 + lane) + 1] = cur.y;
+        if (k + 1 < K) {
+            Fq<260> f;
+            cur = add_mixed_f(cur, S, f);
+            scr[k * 64 + lane] = f;
+        }
+    }
+    if (is_inf(cur)) atomicOr(err, 1);  // cannot happen for a base of prime order
+    Fq<2> zinv = relax<2>(fq_inv(cur.z));
+#pragma unroll 1
+    for (int k = K - 1; k >= 0; k--) {
+        const Fq<XB> X = raw[2 * (size_t)(k * 64 + lane)], Y = raw[2 * (size_t)(k * 64 + lane) + 1];
+        const Fq<2> zi2 = sqr(zinv);
+        const Fq<1> ax = reduce_once(mul(X, zi2)), ay = reduce_once(mul(Y, mul(zi2, zinv)));
+        TabP e;
+        regroup_29_to_32(e.w, ax.v);
+        regroup_29_to_32(e.w + 12, ay.v);
+        dst[k * 64 + lane] = e;
+        if (k > 0) zinv = mul(zinv, scr[(k - 1) * 64 + lane]);
+    }
+}
+
 namespace launch {
 template <int C>
 static void table_fast_c(const void* bases, void* table, void* scratch, void* qw, void* tmp, void* pre, int n_groups, int nb, int* err,
@@ -227,6 +287,23 @@ bool build_table_fast(int c, const void* bases, void* table, void* scratch /*56 
     else if (c == 14) table_fast_c<14>(bases, table, scratch, qw, tmp, pre, n_groups, nb, err, st);
     else return false;
     return true;
+}
+// GLV table of width 16 over 8 windows: packed 96-B entries; scratch = 168 B per entry of the chunk (56 for the Z factors,
+// 112 for the waiting X, Y); side as for the plain builder with W = 8
+size_t table_glv16_entries(int n_groups, int nb) { return ((size_t)n_groups * nb * GLV_W) << (GLV_C - 1); }
+size_t table_glv16_side_bytes(int n_groups, int nb) {
+    const size_t n = (size_t)n_groups * nb;
+    return n * 2 * GLV_W * (SIZEOF_AFFQ + SIZEOF_JACQ + 56) + 256;
+}
+void build_table_glv16(const void* bases, void* table, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st) {
+    const size_t n = (size_t)n_groups * nb, entries = table_glv16_entries(n_groups, nb);
+    char* qw = (char*)side;
+    char* tmp = qw + n * 2 * GLV_W * SIZEOF_AFFQ;
+    char* pre = tmp + n * 2 * GLV_W * SIZEOF_JACQ;
+    char* scr_f = (char*)scratch;
+    char* scr_xy = scr_f + entries * 56;
+    k_table_windows<GLV_C, GLV_W><<<((int)n + 63) / 64, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)qw, (JacQ*)tmp, (Fq<2>*)pre, (int)n);
+    k_table_fill_packed<GLV_C, GLV_W><<<(unsigned)(n * GLV_W), 64, 0, st>>>((const AffQ*)qw, (TabP*)table, (Fq<260>*)scr_f, (Fq<XB>*)scr_xy, nb, err);
 }
 size_t table_entries(int c, int n_groups, int nb) {
     int W = (255 + c) / c;

@@ -28,9 +28,18 @@ void msm_fixed(int c, const void* scalars, const void* table, void* out /*G1Jac*
 // S = 1, 2 or 4 threads per MSM, each summing a chunk of the windows (large batches: no window-sum fold to speak of)
 void msm_fixed_chunked(int c, const void* scalars, const void* table, void* out /*JacQ*/, int n_groups, int n_slices, int nb,
                        int out_stride, int brp_bits, int S, hipStream_t st);
+// GLV table of width 16 (packed entries): mode 0 flat, 1 windowed, 2 chunked; splits the scalars in place
+void msm_glv16(int mode, void* scalars, const void* table, void* out /*JacQ*/, int n_groups, int n_slices, int nb, int out_stride,
+               int brp_bits, const Fp12w& beta, hipStream_t st);
 void msm_fixed_flat(int c, const void* scalars, const void* table, void* out /*G1Jac*/, int n_groups, int n_slices, int nb,
                int out_stride, int brp_bits, hipStream_t st);
 // k_table.hip
+constexpr int GLV_C = 16, GLV_W = 8;  // the GLV table: 8 windows of 16 bits cover a 128-bit half scalar
+constexpr size_t SIZEOF_TABP = 96;    // its packed entries
+size_t table_glv16_entries(int n_groups, int nb);
+size_t table_glv16_side_bytes(int n_groups, int nb);
+// scratch: 168 B per entry of the chunk; side: table_glv16_side_bytes
+void build_table_glv16(const void* bases, void* table, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st);
 size_t table_entries(int c, int n_groups, int nb);
 size_t table_fast_side_bytes(int c, int n_groups, int nb);
 // widths >= 8: wave-per-(base, window) builder; scratch = 56 B per entry of the chunk, side = table_fast_side_bytes; false if c unsupported

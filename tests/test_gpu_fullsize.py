@@ -59,6 +59,28 @@ def _check_sample_against_oracle(oracle, blobs_np, cells, proofs, sample):
         assert proofs[b].tobytes() == b"".join(ep), f"blob {b}: proofs differ from the oracle"
 
 
+@pytest.mark.parametrize("width", [8, 12])
+def test_fallback_window_widths_match_oracle(oracle, monkeypatch, width):
+    """The plain table widths the engine falls back to when HBM is short (GLV -> 14 -> 13 -> 12 -> 10 -> 8): identical
+    bytes.  Runs before the module's default context exists: a width-12 table (47 GB) does not fit next to the GLV one."""
+    monkeypatch.setenv("ETH_KZG_AMD_WINDOW", str(width))
+    c2 = kzg.DASContext(use_precomp=True)
+    try:
+        assert c2.window_bits() == width
+        blobs = _random_blobs(70, 800 + width)
+        blobs[1] = 0
+        st, cells, proofs = _compute_on_device(c2, blobs)
+        assert st == [0] * 70
+        _check_sample_against_oracle(oracle, blobs, cells, proofs, [0, 1, 63, 64, 69])
+        # large-batch MSM schedule (threads own chunks of windows) at this width
+        blobs = _random_blobs(1024, 900 + width)
+        st, cells, proofs = _compute_on_device(c2, blobs)
+        assert st == [0] * 1024
+        _check_sample_against_oracle(oracle, blobs, cells, proofs, [0, 511, 1023])
+    finally:
+        c2.close()
+
+
 @pytest.mark.parametrize("n", [512, 2048])
 def test_compute_full_batches_device_resident(ctx, oracle, n):
     """The bench step (2048 blobs) and config 4's whole batch (512) through the device entry point: data-in-first-half
@@ -175,27 +197,6 @@ def test_recover_config5_full_size(ctx, oracle, pattern):
         assert rc[b] == oc and rp[b] == op, b
 
 
-@pytest.mark.parametrize("width", [8, 12])
-def test_fallback_window_widths_match_oracle(oracle, monkeypatch, width):
-    """The table widths the engine falls back to when HBM is short (14 -> 13 -> 12 -> 10 -> 8): identical bytes."""
-    monkeypatch.setenv("ETH_KZG_AMD_WINDOW", str(width))
-    c2 = kzg.DASContext(use_precomp=True)
-    try:
-        assert c2.window_bits() == width
-        blobs = _random_blobs(70, 800 + width)
-        blobs[1] = 0
-        st, cells, proofs = _compute_on_device(c2, blobs)
-        assert st == [0] * 70
-        _check_sample_against_oracle(oracle, blobs, cells, proofs, [0, 1, 63, 64, 69])
-        # large-batch MSM schedule (threads own chunks of windows) at this width
-        blobs = _random_blobs(1024, 900 + width)
-        st, cells, proofs = _compute_on_device(c2, blobs)
-        assert st == [0] * 1024
-        _check_sample_against_oracle(oracle, blobs, cells, proofs, [0, 511, 1023])
-    finally:
-        c2.close()
-
-
 _FK20_BASES = {}
 
 
@@ -211,21 +212,28 @@ def _fk20_base_column(i):
     return _FK20_BASES[i]
 
 
+@pytest.mark.parametrize("table", ["glv", "plain"])
 @pytest.mark.parametrize("chunks", ["auto", "0", "1", "2", "4"])
-def test_fixed_base_msm_stage_matches_oracle(oracle, monkeypatch, chunks):
+def test_fixed_base_msm_stage_matches_oracle(oracle, monkeypatch, chunks, table):
     """Stage D alone (128 fixed-base MSM_64 per scalar set over the FK20 window tables) against oracle_g1_msm, for
     every MSM schedule: the windowed kernel (0) and threads owning 1 / 2 / 4 chunks of windows.  Scalars include 0,
     1, r-1 and values whose Booth digits hit the table ends (2^(c-1) and its negative)."""
     import ctypes as C
     if chunks != "auto":
         monkeypatch.setenv("ETH_KZG_AMD_MSM_CHUNKS", chunks)
+    if table == "plain":
+        monkeypatch.setenv("ETH_KZG_AMD_WINDOW", "12")  # a plain table (whichever width <= 12 still fits next to the default context)
     c2 = kzg.DASContext(use_precomp=True)
     try:
+        assert c2.glv_table() == (table == "glv")
         lib = kzg.load_library()
         n_msm = 9  # > FLAT_MSM_MAX_SLICES so that the batch kernels run, not the one-block-per-MSM form
         sc = [synth.seeded_scalars(128 * 64, b"msm%d" % m) for m in range(n_msm)]
         w = c2.window_bits()
-        edge = [0, 1, synth.R - 1, 1 << (w - 1), (1 << (w - 1)) + 1, (1 << w) - 1, (1 << 254), (1 << (w * 3)) - (1 << (w - 1))]
+        lam = 0xac45a4010001a40200000000ffffffff  # the GLV eigenvalue: scalars around its multiples sit on the split's branch points
+        edge = [0, 1, synth.R - 1, 1 << (w - 1), (1 << (w - 1)) + 1, (1 << w) - 1, (1 << 254), (1 << (w * 3)) - (1 << (w - 1)),
+                lam, lam - 1, lam + 1, (lam - 1) // 2, (lam + 1) // 2, (lam + 1) // 2 + 1, lam * ((lam + 1) // 2), lam * ((lam + 1) // 2 + 1),
+                lam * ((lam + 1) // 2) + (lam - 1) // 2, lam * ((lam + 1) // 2) + (lam + 1) // 2, synth.R - lam, (1 << 127), (1 << 128) - 1]
         for k, v in enumerate(edge):
             sc[0][k] = (v % synth.R).to_bytes(32, "big")
         sc[1] = [bytes(32)] * (128 * 64)  # all-zero scalars: identity everywhere
