@@ -104,8 +104,8 @@ HD void modinv_limbs(uint32_t* out, const uint32_t* y) {
             xb = tb;
             f0 = tf0 - (odd ? tf1 : 0);
             g0 = tg0 - (odd ? tg1 : 0);
-            f1 = tf1 << 1;
-            g1 = tg1 << 1;
+            f1 = (int64_t)((uint64_t)tf1 << 1);  // doubling of a possibly negative entry: shift the bit pattern (|entries| <= 2^31)
+            g1 = (int64_t)((uint64_t)tg1 << 1);
         }
         // ---- apply the matrix
         uint32_t na[N], nb[N];
