@@ -918,7 +918,8 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
         if (!failed.exchange(1)) err_text = e.what();
     };
     std::atomic<int> outstanding{0};  // helper-thread tasks of this call still running or queued
-    auto drain = [&]() { while (outstanding.load(std::memory_order_acquire) > 0) std::this_thread::yield(); };
+    auto nap = [] { std::this_thread::sleep_for(std::chrono::microseconds(30)); };  // waits below are tens of microseconds to milliseconds long
+    auto drain = [&]() { while (outstanding.load(std::memory_order_acquire) > 0) nap(); };
     try {
         HIPCK(hipSetDevice(dev_));
         if (threaded) std::call_once(host_pool_once_, [this] { host_pool_.reset(new HostPool(4, dev_)); });
@@ -959,7 +960,7 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
             std::function<void(int, int, int)> scatter_cells = [&](int i, int lo, int hi) {
                 const hipError_t q = hipEventQuery(w.sub_events[2 * i + 1]);
                 if (q == hipErrorNotReady) {
-                    std::this_thread::yield();
+                    nap();
                     host_pool_->submit([&, i, lo, hi] { scatter_cells(i, lo, hi); });
                     return;
                 }
@@ -976,7 +977,7 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
             };
             for (int i = 0; i < n_sub; i++) {
                 const int lo = i * SUB, hi = std::min(ns, lo + SUB), nb = hi - lo;
-                while (gathered[i].load(std::memory_order_acquire) > 0) std::this_thread::yield();
+                while (gathered[i].load(std::memory_order_acquire) > 0) std::this_thread::yield();  // a few hundred microseconds: the gather of 32 MB
                 HIPCK(hipMemcpyAsync(w.d_in + (size_t)lo * BYTES_PER_BLOB, w.h_in + (size_t)lo * BYTES_PER_BLOB, (size_t)nb * BYTES_PER_BLOB,
                                      hipMemcpyHostToDevice, w.stream));
                 launch::blob_to_coeffs(nb, w.d_in + (size_t)lo * BYTES_PER_BLOB, (char*)w.coeffs + (size_t)lo * N_BLOB * sizeof(Fr), nullptr,
@@ -1034,6 +1035,7 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
                         host_pool_->submit([&, t] { scatter_proofs(t * ns / parts, (t + 1) * ns / parts); outstanding.fetch_sub(1, std::memory_order_release); });
                     }
                     scatter_proofs(0, ns / parts);
+                    drain();  // the helper tasks call scatter_proofs through a reference: it must outlive them
                 } else scatter_proofs(0, ns);
             }
             drain();  // the pinned buffers are reused by the next super-batch

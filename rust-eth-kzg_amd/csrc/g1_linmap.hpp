@@ -491,12 +491,12 @@ inline std::vector<Fr> fk20_proofs_map_by_definition(const std::vector<Fr>& w128
 // independent.  All constant multiplications of equal "multiplication depth" share ONE launch (they are the expensive,
 // chip-filling part); the cheap operations between them are levelled by dependency.
 struct Launch {
-    OpKind kind;     // OP_ADD stands for a mixed add / sub launch
+    OpKind kind;     // OP_MULC, or OP_ADD for a mixed launch of additions, subtractions and doubling runs
     int first, count;  // range in Schedule::words (4 words per operation)
 };
 struct Schedule {
     int n_slots = 0;             // arena slots; inputs occupy 0 .. n_in-1, outputs n_in .. n_in+n_out-1
-    std::vector<uint32_t> words;  // per operation: dst slot, a slot, b (slot | doublings | constant id), flags (1 = subtract)
+    std::vector<uint32_t> words;  // per operation: dst slot, a slot, b (slot | doublings | constant id), flags (1 = subtract, 2 = doubling run)
     std::vector<Launch> launches;
     long mulc_total = 0;
 };
@@ -571,17 +571,18 @@ inline Schedule make_schedule(const Plan& p) {
             else slot[v] = next_slot++;
         }
         for (int v : expire[s]) free_list.push_back(slot[v]);
-        // emit the launches of this step, one per kind present
-        for (int pass = 0; pass < 3; pass++) {
-            Launch L{pass == 0 ? OP_MULC : pass == 1 ? OP_DBL : OP_ADD, (int)S.words.size() / 4, 0};
+        // emit the launches of this step: the constant multiplications, then ONE launch for the additions, subtractions
+        // and doubling runs together (they are independent of each other within a step; half as many small launches)
+        for (int pass = 0; pass < 2; pass++) {
+            Launch L{pass == 0 ? OP_MULC : OP_ADD, (int)S.words.size() / 4, 0};
             for (int i : step_ops[s]) {
                 const Op& o = p.ops[i];
                 const bool two = o.kind == OP_ADD || o.kind == OP_SUB;
-                if ((pass == 0) != (o.kind == OP_MULC) || (pass == 1) != (o.kind == OP_DBL)) continue;
+                if ((pass == 0) != (o.kind == OP_MULC)) continue;
                 S.words.push_back((uint32_t)slot[o.dst]);
                 S.words.push_back((uint32_t)slot[o.a]);
                 S.words.push_back(two ? (uint32_t)slot[o.b] : (uint32_t)o.b);
-                S.words.push_back(o.kind == OP_SUB ? 1u : 0u);
+                S.words.push_back(o.kind == OP_SUB ? 1u : o.kind == OP_DBL ? 2u : 0u);
                 L.count++;
             }
             if (L.count) S.launches.push_back(L);
@@ -603,8 +604,8 @@ inline std::vector<Fr> run_schedule_over_fr(const Schedule& S, const std::vector
             const uint32_t* w = &S.words[(size_t)(L.first + i) * 4];
             const Fr a = arena[w[1]];
             if (L.kind == OP_MULC) res[i] = mul(a, consts[w[2]]);
-            else if (L.kind == OP_DBL) { Fr t = a; for (uint32_t k = 0; k < w[2]; k++) t = add(t, t); res[i] = t; }
-            else res[i] = w[3] ? sub(a, arena[w[2]]) : add(a, arena[w[2]]);
+            else if (w[3] & 2u) { Fr t = a; for (uint32_t k = 0; k < w[2]; k++) t = add(t, t); res[i] = t; }
+            else res[i] = (w[3] & 1u) ? sub(a, arena[w[2]]) : add(a, arena[w[2]]);
         }
         for (int i = 0; i < L.count; i++) arena[S.words[(size_t)(L.first + i) * 4]] = res[i];
     }

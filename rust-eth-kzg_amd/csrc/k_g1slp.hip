@@ -6,7 +6,7 @@
 // one wave = one operation x 64 blobs, so the operation descriptor and, for multiplications, the digits of the public
 // constant are wave-uniform (scalar loads and scalar branches, no divergence).  Operations of one launch are mutually
 // independent and never write a slot that the same launch reads (linmap::make_schedule).
-// words: 4 per operation: dst slot, a slot, b (slot | number of doublings | constant id), flags (1 = subtract).
+// words: 4 per operation: dst slot, a slot, b (slot | number of doublings | constant id), flags (1 = subtract, 2 = doubling run).
 #include "engine.hpp"
 #include "g1_mulc.hpp"
 
@@ -21,26 +21,24 @@ __global__ __launch_bounds__(64, 2) void k_slp_mulc(JacQ* __restrict__ A, int st
     const JacQ src = A[(size_t)a * stride + lane];
     A[(size_t)dst * stride + lane] = mul_by_recoded(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta);
 }
+// additions, subtractions (flags & 1) and runs of doublings (flags & 2, b = count) of one step, one wave per operation
 __global__ __launch_bounds__(64) void k_slp_add(JacQ* __restrict__ A, int stride, const uint32_t* __restrict__ words) {
     const uint32_t* w = words + (size_t)blockIdx.x * 4;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
                    b = __builtin_amdgcn_readfirstlane(w[2]), fl = __builtin_amdgcn_readfirstlane(w[3]);
     const int lane = blockIdx.y * 64 + threadIdx.x;
-    A[(size_t)dst * stride + lane] = add(A[(size_t)a * stride + lane], A[(size_t)b * stride + lane], fl != 0);
-}
-__global__ __launch_bounds__(64) void k_slp_dbl(JacQ* __restrict__ A, int stride, const uint32_t* __restrict__ words) {
-    const uint32_t* w = words + (size_t)blockIdx.x * 4;
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
-                   t = __builtin_amdgcn_readfirstlane(w[2]);
-    const int lane = blockIdx.y * 64 + threadIdx.x;
     JacQ r = A[(size_t)a * stride + lane];
+    if (fl & 2u) {
 #pragma unroll 1
-    for (uint32_t k = 0; k < t; k++) r = dbl(r);
+        for (uint32_t k = 0; k < b; k++) r = dbl(r);
+    } else {
+        r = add(r, A[(size_t)b * stride + lane], (fl & 1u) != 0);
+    }
     A[(size_t)dst * stride + lane] = r;
 }
 
 namespace launch {
-// kind: 0 add / sub, 2 repeated doubling, 3 multiplication by a constant (linmap::OpKind)
+// kind: 3 multiplication by a constant, anything else the mixed addition / subtraction / doubling launch (linmap::OpKind)
 void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int count, const void* naf, const Fp12w& beta,
                    hipStream_t st) {
     const dim3 grid((unsigned)count, (unsigned)(stride / 64));
@@ -48,8 +46,6 @@ void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int
         Fp b384;
         for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
         k_slp_mulc<<<grid, 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fq_from_fp(b384));
-    } else if (kind == 2) {
-        k_slp_dbl<<<grid, 64, 0, st>>>((JacQ*)arena, stride, words);
     } else {
         k_slp_add<<<grid, 64, 0, st>>>((JacQ*)arena, stride, words);
     }
