@@ -936,8 +936,16 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
             }
             HIPCK(hipStreamWaitEvent(w.stream, w.done, 0));
             HIPCK(hipMemsetAsync(w.status, 0, ns * sizeof(int), w.stream));
-            // gather tasks for the whole super-batch, in order; gathered[i] counts the parts of sub-batch i still to copy
-            std::vector<std::atomic<int>> gathered(n_sub);
+            // Everything the helper tasks reach by reference is declared here, BEFORE the guard that waits for them: on any
+            // way out of this scope (an exception included) the guard runs first and the objects die after the last task.
+            std::vector<std::atomic<int>> gathered(n_sub);  // parts of sub-batch i still to copy
+            std::function<void(int, int, int)> scatter_cells;
+            std::function<void(int, int)> scatter_proofs;
+            struct Drain {
+                std::function<void()> f;
+                ~Drain() { f(); }
+            } drain_on_exit{drain};
+            // gather tasks for the whole super-batch, in order
             for (int i = 0; i < n_sub; i++) {
                 const int lo = i * SUB, hi = std::min(ns, lo + SUB), parts = (hi - lo + PART - 1) / PART;
                 gathered[i].store(threaded ? parts : 0, std::memory_order_relaxed);
@@ -957,7 +965,7 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
             }
             // scatter of one sub-batch's status words and cells once its copy-stream event has fired; a task that finds the
             // event pending goes back to the end of the queue instead of blocking a helper thread
-            std::function<void(int, int, int)> scatter_cells = [&](int i, int lo, int hi) {
+            scatter_cells = [&](int i, int lo, int hi) {
                 const hipError_t q = hipEventQuery(w.sub_events[2 * i + 1]);
                 if (q == hipErrorNotReady) {
                     nap();
@@ -1021,7 +1029,7 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
             HIPCK(hipStreamSynchronize(w.copy));
             if (trace) fprintf(stderr, "[host-batch] proofs of %d blobs back at %.2f ms\n", ns, now_ms());
             if (proofs) {
-                auto scatter_proofs = [&, s0](int lo, int hi) {
+                scatter_proofs = [&, s0](int lo, int hi) {
                     for (int b = lo; b < hi; b++) {
                         if (w.h_status[b]) continue;
                         const uint8_t* src = w.h_proofs + (size_t)b * N_CELLS * 48;
@@ -1035,12 +1043,10 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
                         host_pool_->submit([&, t] { scatter_proofs(t * ns / parts, (t + 1) * ns / parts); outstanding.fetch_sub(1, std::memory_order_release); });
                     }
                     scatter_proofs(0, ns / parts);
-                    drain();  // the helper tasks call scatter_proofs through a reference: it must outlive them
                 } else scatter_proofs(0, ns);
             }
-            drain();  // the pinned buffers are reused by the next super-batch
+            // drain_on_exit: the helper tasks are done before the pinned buffers are reused by the next super-batch
         }
-        drain();
         w.mu.unlock();
         held = nullptr;
         if (trace) fprintf(stderr, "[host-batch] %d blobs delivered at %.2f ms\n", n, now_ms());
