@@ -406,11 +406,19 @@ class DASContext:
         """Device-resident recovery: d_cells = flat [n][128][2048] buffer in HBM (integer address), present[b] = iterable
         of the cell indices of blob b that hold data.  Returns the per-blob status list; outputs stay on the device."""
         masks = np.zeros(2 * max(1, n), dtype=np.uint64)
+        seen = {}  # the same index list for many blobs (the usual case) is folded into its mask once
         for b in range(n):
-            for c in present[b]:
-                if not 0 <= c < CELLS_PER_EXT_BLOB:
-                    raise KzgError("InvalidCellIndex")
-                masks[2 * b + (c >> 6)] |= np.uint64(1) << np.uint64(c & 63)
+            key = id(present[b])
+            m = seen.get(key)
+            if m is None:
+                m = 0
+                for c in present[b]:
+                    if not 0 <= c < CELLS_PER_EXT_BLOB:
+                        raise KzgError("InvalidCellIndex")
+                    m |= 1 << c
+                seen[key] = m
+            masks[2 * b] = m & 0xFFFFFFFFFFFFFFFF
+            masks[2 * b + 1] = m >> 64
         st = (C.c_int32 * max(1, n))()
         self._check(self._lib.eth_kzg_amd_recover_cells_and_proofs_device(
             self._ctx, n, C.c_void_p(d_cells), _vp(masks), C.c_void_p(d_out_cells) if d_out_cells else None,
