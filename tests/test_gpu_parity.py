@@ -372,8 +372,8 @@ def test_eip4844_round_trip_on_synthetic_blobs(ctx, oracle):
 @pytest.mark.parametrize("n", [2, 3, 4, 5, 8, 9, 32, 33, 64, 65, 129, 200])
 def test_every_batch_size_regime_matches_oracle(ctx, oracle, n):
     """The engine picks its G1 schedule by batch size (<= 2 / <= 4: flat MSM over 4 / 2 scalar segments + segmented
-    doubling chains, <= 8: flat MSM + circulant transforms, <= 32: circulant, <= 128: direct 8 x 16 transforms, above:
-    the radix-2 network).  Every regime and both sides of every threshold
+    doubling chains, <= 8: flat MSM + circulant transforms, <= 32: circulant transforms, above: the compiled linear map;
+    MSM: flat <= 8, windowed below 256 blobs, chunked above).  Every regime and both sides of every threshold
     must give the oracle's bytes; blobs not checked against the oracle are checked against the single-blob path."""
     import numpy as np
     rng = np.random.RandomState(1000 + n)
@@ -397,7 +397,7 @@ def test_every_batch_size_regime_matches_oracle(ctx, oracle, n):
 
 
 def test_batch_larger_than_one_lane_group(ctx, oracle):
-    """70 blobs: more than one 64-lane group (two groups in the direct 8 x 16 mode), with a duplicate blob and the
+    """70 blobs: more than one 64-lane group, with a duplicate blob and the
     all-(r-1) fixture inside. Spot-check against the oracle and check the data-in-first-half invariant on all."""
     import numpy as np
     rng = np.random.RandomState(123)
@@ -487,7 +487,7 @@ def test_recover_device_resident(ctx):
 
 def test_second_context_shares_the_window_tables(ctx, oracle):
     """Several contexts in one process (the reference's Java test creates them freely): the second one must come up
-    without another 145 GB of tables - it shares the first one's - and give identical results."""
+    without another 249 GB of tables - it shares the first one's - and give identical results."""
     import time
     t = time.time()
     c2 = kzg.DASContext(use_precomp=True)
