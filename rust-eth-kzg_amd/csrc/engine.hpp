@@ -260,7 +260,7 @@ private:
 
     // small-batch circulant form of the two G1 transforms: term list, doubling tables (allocated on first use)
     void *d_circ_terms_ = nullptr;
-    int circ_T_ = 0, circ_per_lane_ = 0, circ_max_ = 32;  // measured cross-over with the direct 8 x 16 form: ~32 blobs
+    int circ_T_ = 0, circ_per_lane_ = 0, circ_max_ = 8;  // measured cross-over with the compiled linear map (2.8 ms flat up to 64 blobs): 8 blobs 2.5 vs 2.9 ms, 12 blobs 3.2 vs 2.9
     Fr8 seg_shift_[3];  // 2^32, 2^64, 2^96 in Montgomery form
     // the two G1 transforms as one compiled linear map (g1_linmap.hpp, k_g1slp.hip): launches, constants, slot arena
     struct SlpLaunch { int kind, first, count; };

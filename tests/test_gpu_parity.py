@@ -372,7 +372,7 @@ def test_eip4844_round_trip_on_synthetic_blobs(ctx, oracle):
 @pytest.mark.parametrize("n", [2, 3, 4, 5, 8, 9, 32, 33, 64, 65, 129, 200])
 def test_every_batch_size_regime_matches_oracle(ctx, oracle, n):
     """The engine picks its G1 schedule by batch size (<= 2 / <= 4: flat MSM over 4 / 2 scalar segments + segmented
-    doubling chains, <= 8: flat MSM + circulant transforms, <= 32: circulant transforms, above: the compiled linear map;
+    doubling chains, <= 8: flat MSM + circulant transforms, above: the compiled linear map;
     MSM: flat <= 8, windowed below 256 blobs, chunked above).  Every regime and both sides of every threshold
     must give the oracle's bytes; blobs not checked against the oracle are checked against the single-blob path."""
     import numpy as np
