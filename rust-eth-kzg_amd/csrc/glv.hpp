@@ -9,7 +9,7 @@ namespace kzg {
 
 // r = k mod lambda (< lambda < 2^128), q = floor(k / lambda) (<= lambda + 1): one multiplication by floor(2^256 / lambda) and
 // one correction.  k canonical (not Montgomery), < 2^255.
-__device__ __forceinline__ void glv_split_unsigned(const Fr& k, uint32_t r4[4], uint32_t q[4]) {
+HD void glv_split_unsigned(const Fr& k, uint32_t r4[4], uint32_t q[4]) {
     constexpr uint32_t G[5] = {0xf6cfee30u, 0x63f6e522u, 0xe01faaddu, 0x7c6becf1u, 0x1u};  // floor(2^256 / lambda)
     constexpr uint32_t L[4] = {0xffffffffu, 0x00000000u, 0x0001a402u, 0xac45a401u};        // lambda
     {   // q = (k * G) >> 256 : column sums of the 8 x 5 product, keeping limbs 8..11 (q < 2^128)
@@ -71,13 +71,13 @@ __device__ __forceinline__ void glv_split_unsigned(const Fr& k, uint32_t r4[4], 
 }
 
 // 128-bit helpers on 4 x u32
-__device__ __forceinline__ bool gt128(const uint32_t a[4], const uint32_t b[4]) {
+HD bool gt128(const uint32_t a[4], const uint32_t b[4]) {
     for (int l = 3; l >= 0; l--) {
         if (a[l] != b[l]) return a[l] > b[l];
     }
     return false;
 }
-__device__ __forceinline__ void sub128(uint32_t out[4], const uint32_t a[4], const uint32_t b[4]) {
+HD void sub128(uint32_t out[4], const uint32_t a[4], const uint32_t b[4]) {
     uint32_t br = 0;
     for (int l = 0; l < 4; l++) {
         const uint64_t d = (uint64_t)a[l] - b[l] - br;
@@ -85,16 +85,16 @@ __device__ __forceinline__ void sub128(uint32_t out[4], const uint32_t a[4], con
         br = (uint32_t)(d >> 63);
     }
 }
-__device__ __forceinline__ void add128_small(uint32_t a[4], uint32_t c) {
+HD void add128_small(uint32_t a[4], uint32_t c) {
     for (int l = 0; l < 4; l++) { const uint64_t s = (uint64_t)a[l] + c; a[l] = (uint32_t)s; c = (uint32_t)(s >> 32); }
 }
-__device__ __forceinline__ bool is_zero128(const uint32_t a[4]) { return (a[0] | a[1] | a[2] | a[3]) == 0; }
+HD bool is_zero128(const uint32_t a[4]) { return (a[0] | a[1] | a[2] | a[3]) == 0; }
 
 // Balanced form: k = s1 m1 + s2 m2 lambda with magnitudes m1, m2 <= (lambda + 1) / 2 + 1 < 2^127.  Output: 2 x 4 words,
 // the sign in bit 127 of each half.  Steps (each keeps k1 + k2 lambda fixed mod r, using lambda^2 + lambda + 1 = r):
 //   r > (lambda - 1) / 2   ->  k1 = r - lambda, k2 = q + 1
 //   k2 > (lambda + 1) / 2  ->  k2 -= lambda + 1, k1 -= 1
-__device__ __forceinline__ void glv_split_balanced(const Fr& k, uint32_t out[8]) {
+HD void glv_split_balanced(const Fr& k, uint32_t out[8]) {
     constexpr uint32_t L[4] = {0xffffffffu, 0x00000000u, 0x0001a402u, 0xac45a401u};         // lambda
     constexpr uint32_t HL[4] = {0x7fffffffu, 0x00000000u, 0x8000d201u, 0x5622d200u};        // (lambda - 1) / 2
     constexpr uint32_t L1[4] = {0x00000000u, 0x00000001u, 0x0001a402u, 0xac45a401u};        // lambda + 1

@@ -51,3 +51,12 @@ def test_fk20_proofs_map_compiles_to_its_definition(tmp_path):
     are checked for every size and split."""
     out = _build_and_run(tmp_path, "test_linmap")
     assert "0 mismatches" in out and "fk20 plan" in out
+
+
+@pytest.mark.timeout(600)
+def test_glv_split_is_balanced_and_exact(tmp_path):
+    """csrc/glv.hpp (the scalar split behind the GLV window table): k1 + k2 lambda == k mod r and |k1|, |k2| <=
+    (lambda + 1) / 2 + 1 < 2^127 for 200 k random scalars, small scalars, 0, 1, r - 1, multiples of lambda and the
+    branch points of the two balancing steps."""
+    out = _build_and_run(tmp_path, "test_glv")
+    assert "0 mismatches" in out
