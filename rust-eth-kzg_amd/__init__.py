@@ -250,6 +250,25 @@ class DASContext:
             C.byref(ok)))
         return bool(ok.value)
 
+    def prepare_verify_cell_kzg_proof_batch(self, commitments, cell_indices, cells, proofs):
+        """Marshal a verification batch into the C ABI's pointer tables ONCE and return a zero-argument callable that runs
+        eth_kzg_verify_cell_kzg_proof_batch on them: what a C caller's loop costs, without this wrapper's copying."""
+        if any(len(c) != 48 for c in commitments) or any(len(p) != 48 for p in proofs) \
+                or any(len(c) != BYTES_PER_CELL for c in cells):
+            raise KzgError("InvalidLength")
+        ca, k1 = _flat_ptrs(commitments, 48)
+        cla, k2 = _flat_ptrs(cells, BYTES_PER_CELL)
+        pa, k3 = _flat_ptrs(proofs, 48)
+        idx = np.array(cell_indices, dtype=np.uint64) if len(cell_indices) else np.zeros(1, np.uint64)
+        n = (len(commitments), len(cell_indices), len(cells), len(proofs))
+
+        def run(_keep=(k1, k2, k3)):
+            ok = C.c_bool(False)
+            self._check(self._lib.eth_kzg_verify_cell_kzg_proof_batch(
+                self._ctx, n[0], _vp(ca), n[1], _vp(idx), n[2], _vp(cla), n[3], _vp(pa), C.byref(ok)))
+            return bool(ok.value)
+        return run
+
     def verify_cell_kzg_proof_batch_partial(self, commitments, cell_indices, cells, proofs, shard_begin, shard_end):
         """This rank's share of a sharded verification: the whole batch goes in (the challenge hashes all of it), the
         cells [shard_begin, shard_end) are evaluated, 96 bytes come back (sharding.verify_cell_kzg_proof_batch_sharded)."""

@@ -7,6 +7,7 @@
 #include "kcommon.hpp"
 #include "curve29.hpp"
 #include "launch.hpp"
+#include "glv.hpp"
 
 namespace kzg {
 
@@ -200,67 +201,9 @@ __global__ void k_pip_glv_split(PipJob j0, PipJob j1, int n_max, Half128* __rest
     const int job = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     const PipJob jb = job ? j1 : j0;
     if (i >= jb.n) return;
-    constexpr uint32_t G[5] = {0xf6cfee30u, 0x63f6e522u, 0xe01faaddu, 0x7c6becf1u, 0x1u};  // floor(2^256 / lambda)
-    constexpr uint32_t L[4] = {0xffffffffu, 0x00000000u, 0x0001a402u, 0xac45a401u};        // lambda
     const Fr k = jb.scalars[i];
-    // q = (k * G) >> 256 : column sums of the 8 x 5 product, keeping limbs 8..11 (q < 2^128)
-    uint32_t q[4];
-    {
-        uint64_t carry = 0;
-        for (int col = 0; col < 12; col++) {
-            uint64_t lo = carry & 0xffffffffu, hi = carry >> 32;
-            for (int a = 0; a < 8; a++) {
-                const int b = col - a;
-                if (b < 0 || b > 4) continue;
-                const uint64_t pr = (uint64_t)k.v[a] * G[b];
-                lo += pr & 0xffffffffu;
-                hi += pr >> 32;
-            }
-            hi += lo >> 32;
-            if (col >= 8) q[col - 8] = (uint32_t)lo;
-            carry = hi;
-        }
-    }
-    // r = k - q * lambda (fits 130 bits: keep 5 limbs), then at most one correction
-    uint32_t ql[5] = {0, 0, 0, 0, 0};
-    {
-        uint64_t carry = 0;
-        for (int col = 0; col < 5; col++) {
-            uint64_t lo = carry & 0xffffffffu, hi = carry >> 32;
-            for (int a = 0; a < 4; a++) {
-                const int b = col - a;
-                if (b < 0 || b > 3) continue;
-                const uint64_t pr = (uint64_t)q[a] * L[b];
-                lo += pr & 0xffffffffu;
-                hi += pr >> 32;
-            }
-            hi += lo >> 32;
-            ql[col] = (uint32_t)lo;
-            carry = hi;
-        }
-    }
-    uint32_t r[5];
-    {
-        uint32_t br = 0;
-        for (int l = 0; l < 5; l++) {
-            const uint64_t d = (uint64_t)k.v[l] - ql[l] - br;
-            r[l] = (uint32_t)d;
-            br = (uint32_t)(d >> 63);
-        }
-    }
-    {   // if r >= lambda: r -= lambda, q += 1
-        uint32_t t[5], br = 0;
-        for (int l = 0; l < 5; l++) {
-            const uint64_t d = (uint64_t)r[l] - (l < 4 ? L[l] : 0u) - br;
-            t[l] = (uint32_t)d;
-            br = (uint32_t)(d >> 63);
-        }
-        if (!br) {
-            for (int l = 0; l < 5; l++) r[l] = t[l];
-            uint32_t c = 1;
-            for (int l = 0; l < 4; l++) { const uint64_t sum = (uint64_t)q[l] + c; q[l] = (uint32_t)sum; c = (uint32_t)(sum >> 32); }
-        }
-    }
+    uint32_t r[4], q[4];
+    glv_split_unsigned(k, r, q);  // glv.hpp: r = k mod lambda, q = floor(k / lambda)
     Half128 h1, h2;
     for (int l = 0; l < 4; l++) { h1.v[l] = r[l]; h2.v[l] = q[l]; }
     Half128* out = halves + (size_t)job * 2 * n_max;
