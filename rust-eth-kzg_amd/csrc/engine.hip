@@ -669,7 +669,7 @@ void Engine::ensure_workspace(Work& w, int n) {
         if (*p) { HIPCK(hipFree(*p)); *p = nullptr; }
     w.cap = 0;
     HIPCK(hipMalloc(&w.coeffs, (size_t)cap * N_BLOB * sizeof(Fr)));
-    HIPCK(hipMalloc(&w.canon, (size_t)cap * N_BLOB * sizeof(Fr)));
+    if (&w == &work_[0]) HIPCK(hipMalloc(&w.canon, (size_t)cap * N_BLOB * sizeof(Fr)));  // canonical coefficients: commitment / EIP-4844 paths only
     HIPCK(hipMalloc(&w.scalars, (size_t)cap * 128 * 64 * sizeof(Fr)));
     HIPCK(hipMalloc(&w.X, (size_t)cap * 128 * launch::SIZEOF_JACQ));
     HIPCK(hipMalloc(&w.status, (size_t)cap * sizeof(int)));
@@ -904,7 +904,7 @@ int Engine::blob_to_kzg_commitment_device(int n, const uint8_t* d_blobs, uint8_t
 int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs, uint8_t* const* const* cells,
                                               uint8_t* const* const* proofs, int* h_status) {
     if (n <= 0) return OK;
-    constexpr int SUPER = 4096, SUB = 256, PART = 64;
+    constexpr int SUPER = 4096, SUB = 256, PART = 32;
     const bool threaded = n >= 32;  // small calls: everything on the calling thread (latency)
     const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -922,7 +922,16 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
     auto drain = [&]() { while (outstanding.load(std::memory_order_acquire) > 0) nap(); };
     try {
         HIPCK(hipSetDevice(dev_));
-        if (threaded) std::call_once(host_pool_once_, [this] { host_pool_.reset(new HostPool(4, dev_)); });
+        if (threaded)
+            std::call_once(host_pool_once_, [this] {
+                // memcpy helpers: the gather of 2048 blobs is 268 MB and the MSMs cannot start before its last byte is uploaded,
+                // so its bandwidth is exposed time (4 threads: ~10 ms, 8: ~5 ms).  ETH_KZG_AMD_HOST_THREADS overrides.
+                int t = 8;
+                const unsigned hw = std::thread::hardware_concurrency();
+                if (hw && (int)hw < 2 * t) t = (int)hw / 2 > 1 ? (int)hw / 2 : 1;
+                if (const char* e = getenv("ETH_KZG_AMD_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) t = v; }
+                host_pool_.reset(new HostPool(t, dev_));
+            });
         Work& w = lease_work(1, NW - 1);
         held = &w;
         for (int s0 = 0; s0 < n && !failed.load(); s0 += SUPER) {

@@ -25,8 +25,15 @@ kzg = importlib.import_module("rust-eth-kzg_amd")
 INF = b"\xc0" + bytes(47)
 
 
+def _torch_first():
+    """torch initialises its HIP state before the engine creates its streams (the other order has failed to find the GPU)."""
+    import torch
+    torch.cuda.init()
+
+
 @pytest.fixture(scope="module")
 def ctx():
+    _torch_first()
     c = kzg.DASContext(use_precomp=True)
     yield c
     c.close()
@@ -64,6 +71,7 @@ def test_fallback_window_widths_match_oracle(oracle, monkeypatch, width):
     """The plain table widths the engine falls back to when HBM is short (GLV -> 14 -> 13 -> 12 -> 10 -> 8): identical
     bytes.  Runs before the module's default context exists: a width-12 table (47 GB) does not fit next to the GLV one."""
     monkeypatch.setenv("ETH_KZG_AMD_WINDOW", str(width))
+    _torch_first()
     c2 = kzg.DASContext(use_precomp=True)
     try:
         assert c2.window_bits() == width
