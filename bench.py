@@ -408,7 +408,7 @@ def main():
             "g1_fft": B * 64 * 4 * 168,
             "compress": B * 128 * (168 + 48),
             # compiled linear map: ~3.9 k point operations per blob (350 constant multiplications, 3.2 k additions, 0.4 k
-            # doubling runs), each reading one or two 168-B points and writing one, over its ~74 launches
+            # doubling runs), each reading one or two 168-B points and writing one, over its ~42 launches
             "g1_linmap": B * (sum(ctx.linmap_info()[:2]) + 400) * 3 * 168 // max(1, ctx.linmap_info()[3]),
         }[dom]
         achieved = alg_bytes / per_launch_s / 1e9
