@@ -361,3 +361,39 @@ def test_single_process_fan_out_over_contexts(ctx):
         assert np.array_equal(bufs["cells"][keep], ref["cells"][keep]) and np.array_equal(bufs["proofs"][keep], ref["proofs"][keep])
     finally:
         c2.close()
+
+
+def _blob_from_coefficients(coeffs):
+    """blob (evaluation form, bit-reversed order, as the ABI takes it) of the polynomial with the given 4096 coefficients."""
+    data = b"".join(int(c % synth.R).to_bytes(32, "big") for c in coeffs)
+    ev = oracle_lib.fr_ntt(data, inverse=False)
+    brp = lambda v: int(format(v, "012b")[::-1], 2)
+    return b"".join(ev[32 * brp(k):32 * brp(k) + 32] for k in range(4096))
+
+
+def test_sparse_polynomials_hit_the_degenerate_point_operations(ctx, oracle):
+    """Polynomials with one or two non-zero coefficients: most of the 8192 FK20 scalars are zero, whole MSMs are the
+    identity, the additions and doublings of the compiled linear map meet identity operands, equal and opposite points
+    (their exact slow paths), and the constant multiplications meet the identity.  Batches of 12 (compiled map, windowed
+    MSM), and the same blobs alone (circulant path, flat MSM) must all give the oracle's bytes."""
+    def poly(*terms):
+        c = [0] * 4096
+        for idx, val in terms:
+            c[idx] = val
+        return c
+    polys = [poly((0, 1)), poly((63, 5)), poly((64, 1)), poly((65, synth.R - 1)), poly((4032, 7)), poly((4095, 1)),
+             poly((64, 1), (128, 1)), poly((64, 1), (128, synth.R - 1)), poly((100, 3), (4000, 9)), [1] * 4096,
+             poly(*[(64 * m, 1) for m in range(64)]), poly(*[(i, i + 1) for i in range(64)])]
+    blobs = [_blob_from_coefficients(c) for c in polys]
+    st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs)
+    assert st == [0] * len(blobs)
+    for b, blob in enumerate(blobs):
+        ec, ep = oracle.compute_cells_and_kzg_proofs(blob)
+        assert cells[b] == ec and proofs[b] == ep, f"polynomial {b} in the batch"
+        c1, p1 = ctx.compute_cells_and_kzg_proofs(blob)
+        assert c1 == ec and p1 == ep, f"polynomial {b} alone"
+    # and in a batch that fills lane groups unevenly (70 = 64 + 6 lanes) next to random blobs
+    rnd = _random_blobs(58, 4242)
+    mixed = blobs + [rnd[i].tobytes() for i in range(58)]
+    st, cells2, proofs2 = ctx.compute_cells_and_kzg_proofs_batch(mixed)
+    assert st == [0] * 70 and cells2[:12] == cells and proofs2[:12] == proofs
