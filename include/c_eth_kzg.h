@@ -173,6 +173,14 @@ CResult eth_kzg_amd_compute_cells_and_kzg_proofs_device(const DASContext *ctx, u
 CResult eth_kzg_amd_blob_to_kzg_commitment_device(const DASContext *ctx, uint64_t n, const uint8_t *d_blobs,
                                                   uint8_t *d_out, int32_t *status, void *hip_stream);
 
+/* verify_cell_kzg_proof_batch on flat arrays in this GPU's HBM: n * 48 commitment bytes (one per cell, NOT deduplicated, as in
+ * the host form), n indices, n * 2048 cell bytes, n * 48 proof bytes.  The transcript hash runs on a host core, so the call
+ * copies the bytes down once and is synchronous; work already queued on `hip_stream` (NULL: the context's stream) that
+ * produces the inputs is waited for.  Result and error behaviour as eth_kzg_verify_cell_kzg_proof_batch. */
+CResult eth_kzg_amd_verify_cell_kzg_proof_batch_device(const DASContext *ctx, uint64_t n, const uint8_t *d_commitments,
+                                                       const uint64_t *d_cell_indices, const uint8_t *d_cells,
+                                                       const uint8_t *d_proofs, bool *verified, void *hip_stream);
+
 /* Introspection used by bench.py / DESIGN.md: bytes of window tables resident in HBM, window width. */
 uint64_t eth_kzg_amd_table_bytes(const DASContext *ctx);
 int eth_kzg_amd_window_bits(const DASContext *ctx);

@@ -52,6 +52,7 @@ EXPORTED_SYMBOLS = [
     "eth_kzg_amd_recover_cells_and_proofs_batch", "eth_kzg_amd_recover_cells_and_proofs_device",
     "eth_kzg_amd_verify_cell_kzg_proof_batch_partial", "eth_kzg_amd_verify_cell_kzg_proof_batch_combine",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_device", "eth_kzg_amd_blob_to_kzg_commitment_device",
+    "eth_kzg_amd_verify_cell_kzg_proof_batch_device",
     "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits", "eth_kzg_amd_glv_table", "eth_kzg_amd_linmap_info",
     "eth_kzg_amd_set_profiling", "eth_kzg_amd_get_stage_times",
     "eth_kzg_amd_comm_unique_id", "eth_kzg_amd_comm_init", "eth_kzg_amd_all_gather", "eth_kzg_amd_comm_destroy",
@@ -103,6 +104,7 @@ def load_library():
         "eth_kzg_amd_recover_cells_and_proofs_device": [P, U64, P, P, P, P, P, P],
         "eth_kzg_amd_compute_cells_and_kzg_proofs_device": [P, U64, P, P, P, P, P],
         "eth_kzg_amd_blob_to_kzg_commitment_device": [P, U64, P, P, P, P],
+        "eth_kzg_amd_verify_cell_kzg_proof_batch_device": [P, U64, P, P, P, P, P, P],
         "eth_kzg_amd_comm_unique_id": [P],
         "eth_kzg_amd_comm_init": [P, U8P, C.c_int, C.c_int],
         "eth_kzg_amd_all_gather": [P, P, P, U64, P],
@@ -479,6 +481,15 @@ class DASContext:
         contexts[0]._check(lib.eth_kzg_amd_compute_cells_and_kzg_proofs_batch_multi(
             ctxs, len(contexts), n, _vp(ba), _vp(bufs["cpp"]), _vp(bufs["ppp"]), bufs["status"]))
         return list(bufs["status"])[:n]
+
+    def verify_cell_kzg_proof_batch_device(self, n, d_commitments, d_cell_indices, d_cells, d_proofs, stream=None):
+        """Device-resident verification: integer device addresses of n*48 commitment bytes (one per cell), n uint64 indices,
+        n*2048 cell bytes, n*48 proof bytes."""
+        ok = C.c_bool(False)
+        self._check(self._lib.eth_kzg_amd_verify_cell_kzg_proof_batch_device(
+            self._ctx, int(n), C.c_void_p(d_commitments), C.c_void_p(d_cell_indices), C.c_void_p(d_cells), C.c_void_p(d_proofs),
+            C.byref(ok), C.c_void_p(stream) if stream else None))
+        return bool(ok.value)
 
     def blob_to_kzg_commitment_device(self, n, d_blobs, d_out, want_status=True, stream=None):
         st = (C.c_int32 * max(1, n))() if want_status else None

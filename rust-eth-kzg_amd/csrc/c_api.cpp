@@ -122,6 +122,18 @@ CResult eth_kzg_verify_cell_kzg_proof_batch(const DASContext* ctx, uint64_t comm
     return ok();
 }
 
+CResult eth_kzg_amd_verify_cell_kzg_proof_batch_device(const DASContext* ctx, uint64_t n, const uint8_t* d_commitments,
+                                                       const uint64_t* d_cell_indices, const uint8_t* d_cells,
+                                                       const uint8_t* d_proofs, bool* verified, void* hip_stream) {
+    kzg::Engine* e = eng(ctx);
+    int ver = 0;
+    int st = e->verify_cell_kzg_proof_batch_device(n, d_commitments, d_cell_indices, d_cells, d_proofs, &ver, (hipStream_t)hip_stream);
+    if (st == kzg::ERR_DEVICE) return device_err(e);
+    if (st) return err(status_text(st));
+    *verified = ver != 0;
+    return ok();
+}
+
 CResult eth_kzg_amd_recover_cells_and_proofs_device(const DASContext* ctx, uint64_t n, const uint8_t* d_cells,
                                                     const uint64_t* present_masks, uint8_t* d_out_cells, uint8_t* d_out_proofs,
                                                     int32_t* status, void* hip_stream) {

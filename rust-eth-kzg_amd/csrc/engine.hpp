@@ -130,6 +130,10 @@ public:
     int verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,
                                          const uint64_t* cell_indices, uint64_t n_cells, const uint8_t* const* cells,
                                          uint64_t n_proofs, const uint8_t* const* proofs, int* verified);
+    // the same check on flat arrays in this GPU's HBM: n * 48 commitment bytes (one per cell, not deduplicated), n u64 indices,
+    // n * 2048 cell bytes, n * 48 proof bytes
+    int verify_cell_kzg_proof_batch_device(uint64_t n, const uint8_t* d_commitments, const uint64_t* d_cell_indices,
+                                           const uint8_t* d_cells, const uint8_t* d_proofs, int* verified, hipStream_t stream);
     // the same check sharded over ranks: every rank passes the WHOLE batch (the Fiat-Shamir transcript covers it) and its
     // slice [lo, hi) of the cell list, gets 96 bytes back; the gathered records go to _combine on any rank.
     int verify_cell_kzg_proof_batch_partial_host(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,

@@ -282,6 +282,42 @@ bool Engine::verify_cells_pairing(const G1Affine* pts) const {
     return pairing::product_is_one(pts, q, 2);
 }
 
+// Device-resident form of the same check: the four flat arrays already sit in this GPU's HBM (cells straight from a prover or
+// recovery call, for instance).  The Fiat-Shamir transcript is a sequential SHA-256 over all of it, which belongs on a host
+// core, so the bytes come down once over PCIe into pinned memory (17.6 MB at config 3: 0.4 ms) and the host-pointer path
+// runs on them; what is saved is the caller's own round trip and its 3 n pointers.
+int Engine::verify_cell_kzg_proof_batch_device(uint64_t n, const uint8_t* d_commitments, const uint64_t* d_cell_indices,
+                                               const uint8_t* d_cells, const uint8_t* d_proofs, int* verified, hipStream_t user_stream) {
+    *verified = 0;
+    if (n == 0) { *verified = 1; return OK; }  // verifier.rs:90-93
+    std::vector<const uint8_t*> cp(n), lp(n), pp(n);
+    uint8_t* pin = nullptr;
+    int st = OK;
+    try {
+        HIPCK(hipSetDevice(dev_));
+        const size_t sz_c = n * 48, sz_i = n * sizeof(uint64_t), sz_l = n * (size_t)BYTES_PER_CELL, sz_p = n * 48;
+        HIPCK(hipHostMalloc((void**)&pin, sz_c + sz_i + sz_l + sz_p, hipHostMallocDefault));
+        hipStream_t s = user_stream ? user_stream : stream_;
+        HIPCK(hipMemcpyAsync(pin, d_commitments, sz_c, hipMemcpyDeviceToHost, s));
+        HIPCK(hipMemcpyAsync(pin + sz_c, d_cell_indices, sz_i, hipMemcpyDeviceToHost, s));
+        HIPCK(hipMemcpyAsync(pin + sz_c + sz_i, d_cells, sz_l, hipMemcpyDeviceToHost, s));
+        HIPCK(hipMemcpyAsync(pin + sz_c + sz_i + sz_l, d_proofs, sz_p, hipMemcpyDeviceToHost, s));
+        SYNC_CHECKED(s);
+        for (uint64_t k = 0; k < n; k++) {
+            cp[k] = pin + k * 48;
+            lp[k] = pin + sz_c + sz_i + k * (size_t)BYTES_PER_CELL;
+            pp[k] = pin + sz_c + sz_i + sz_l + k * 48;
+        }
+    } catch (const std::exception& e) {
+        if (pin) (void)hipHostFree(pin);
+        set_error(e);
+        return ERR_DEVICE;
+    }
+    st = verify_cell_kzg_proof_batch_host(n, cp.data(), n, reinterpret_cast<const uint64_t*>(pin + n * 48), n, lp.data(), n, pp.data(), verified);
+    (void)hipHostFree(pin);
+    return st;
+}
+
 int Engine::verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,
                                              const uint64_t* cell_indices, uint64_t n_cells, const uint8_t* const* cells,
                                              uint64_t n_proofs, const uint8_t* const* proofs, int* verified) {

@@ -397,3 +397,34 @@ def test_sparse_polynomials_hit_the_degenerate_point_operations(ctx, oracle):
     mixed = blobs + [rnd[i].tobytes() for i in range(58)]
     st, cells2, proofs2 = ctx.compute_cells_and_kzg_proofs_batch(mixed)
     assert st == [0] * 70 and cells2[:12] == cells and proofs2[:12] == proofs
+
+
+def test_verify_device_resident_matches_the_host_form(ctx):
+    """eth_kzg_amd_verify_cell_kzg_proof_batch_device on the prover's own device buffers (config 3 at full size: cells
+    and proofs never leave HBM before the call): true; a flipped proof byte pair, a swapped cell, a wrong commitment:
+    false; a malformed proof: error; an empty batch: true."""
+    import torch
+    nb = 64
+    blobs = _random_blobs(nb, 3003)
+    d_blobs = torch.from_numpy(blobs.reshape(-1)).cuda()
+    d_cells = torch.empty(nb * 128 * 2048, dtype=torch.uint8, device="cuda")
+    d_proofs = torch.empty(nb * 128 * 48, dtype=torch.uint8, device="cuda")
+    d_comm = torch.empty(nb * 48, dtype=torch.uint8, device="cuda")
+    assert ctx.compute_cells_and_kzg_proofs_device(nb, d_blobs.data_ptr(), d_cells.data_ptr(), d_proofs.data_ptr()) == [0] * nb
+    assert ctx.blob_to_kzg_commitment_device(nb, d_blobs.data_ptr(), d_comm.data_ptr()) == [0] * nb
+    n = nb * 128
+    d_c = d_comm.view(nb, 1, 48).expand(nb, 128, 48).contiguous().view(-1)  # one commitment per cell
+    d_i = torch.arange(128, dtype=torch.int64, device="cuda").repeat(nb)
+    torch.cuda.synchronize()
+    run = lambda c=d_c, i=d_i, l=d_cells, p=d_proofs: ctx.verify_cell_kzg_proof_batch_device(n, c.data_ptr(), i.data_ptr(), l.data_ptr(), p.data_ptr())
+    assert run() is True
+    p2 = d_proofs.clone(); p2[48 * 77:48 * 78] = d_proofs[48 * 78:48 * 79]
+    assert run(p=p2) is False
+    l2 = d_cells.clone(); l2[2048 * 5:2048 * 6] = d_cells[2048 * 6:2048 * 7]
+    assert run(l=l2) is False
+    c2 = d_c.clone(); c2[:48] = d_c[48 * 128:48 * 129]
+    assert run(c=c2) is False
+    p3 = d_proofs.clone(); p3[:48] = 0
+    with pytest.raises(kzg.KzgError):
+        run(p=p3)
+    assert ctx.verify_cell_kzg_proof_batch_device(0, 0, 0, 0, 0) is True
