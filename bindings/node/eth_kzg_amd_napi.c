@@ -2,7 +2,8 @@
  * N-API addon over include/c_eth_kzg.h: the reference's Node binding (bindings/node/src/lib.rs, index.d.ts -- napi-rs over the
  * Rust crate) re-expressed over the C ABI, so that `libc_eth_kzg.so` is a drop-in for Node callers too.  Same surface for
  * the EIP-7594 path: class DasContextJs { constructor(), static create({usePrecomp}), blobToKzgCommitment,
- * computeCellsAndKzgProofs, computeCells, recoverCellsAndKzgProofs, verifyCellKzgProofBatch } and the async* forms, which
+ * computeCellsAndKzgProofs, computeCells, recoverCellsAndKzgProofs, verifyCellKzgProofBatch, and the EIP-4844 operations
+ * computeKzgProof, computeBlobKzgProof, verifyKzgProof, verifyBlobKzgProof, verifyBlobKzgProofBatch } and the async* forms, which
  * run on libuv worker threads against ONE shared context, like the reference's (`async fn` over Arc<DASContext>,
  * lib.rs:92-299).  Plain C, N-API version 6 (BigInt cell indices).  Build: bindings/node/Makefile.
  */
@@ -28,7 +29,9 @@
         }                                                               \
     } while (0)
 
-enum { JOB_COMMIT, JOB_CELLS_PROOFS, JOB_CELLS, JOB_RECOVER, JOB_VERIFY };
+enum { JOB_COMMIT, JOB_CELLS_PROOFS, JOB_CELLS, JOB_RECOVER, JOB_VERIFY,
+       /* EIP-4844 single-point operations (index.d.ts: computeKzgProof ... verifyBlobKzgProofBatch) */
+       JOB_KZG_PROOF, JOB_BLOB_PROOF, JOB_VERIFY_KZG, JOB_VERIFY_BLOB, JOB_VERIFY_BLOB_BATCH };
 
 typedef struct {
     int kind;
@@ -41,6 +44,9 @@ typedef struct {
     /* outputs */
     uint8_t *cells_out, *proofs_out; /* CELLS*CELL, CELLS*G1 */
     uint8_t commitment[G1];
+    uint8_t *blobs_in;             /* verifyBlobKzgProofBatch: n blobs */
+    uint8_t small[3][G1];          /* 4844 inputs: commitment / z / y / proof, as the operation needs them */
+    uint8_t proof_out[G1], y_out[32];
     bool verified;
     CResult res;
     /* async plumbing */
@@ -50,7 +56,7 @@ typedef struct {
 
 static void job_free(Job *j) {
     if (!j) return;
-    free(j->blob); free(j->cells_in); free(j->proofs_in); free(j->commitments_in); free(j->indices);
+    free(j->blob); free(j->cells_in); free(j->proofs_in); free(j->commitments_in); free(j->indices); free(j->blobs_in);
     free(j->cells_out); free(j->proofs_out);
     if (j->res.error_msg) eth_kzg_free_error_message(j->res.error_msg);
     free(j);
@@ -69,6 +75,18 @@ static void job_run(Job *j) {
             for (uint64_t k = 0; k < j->n; k++) in[k] = j->cells_in + k * CELL;
             j->res = eth_kzg_recover_cells_and_proofs(j->ctx, j->n, in, j->n, j->indices, cp, pp);
             free(in);
+            break;
+        }
+        case JOB_KZG_PROOF: j->res = eth_kzg_compute_kzg_proof(j->ctx, j->blob, j->small[0], j->proof_out, j->y_out); break;
+        case JOB_BLOB_PROOF: j->res = eth_kzg_compute_blob_kzg_proof(j->ctx, j->blob, j->small[0], j->proof_out); break;
+        case JOB_VERIFY_KZG: j->res = eth_kzg_verify_kzg_proof(j->ctx, j->small[0], j->small[1], j->small[2], j->commitment, &j->verified); break;
+        case JOB_VERIFY_BLOB: j->res = eth_kzg_verify_blob_kzg_proof(j->ctx, j->blob, j->small[0], j->small[1], &j->verified); break;
+        case JOB_VERIFY_BLOB_BATCH: {
+            const uint64_t n = j->n ? j->n : 1;
+            const uint8_t **b = malloc(n * sizeof *b), **c = malloc(n * sizeof *c), **p = malloc(n * sizeof *p);
+            for (uint64_t k = 0; k < j->n; k++) { b[k] = j->blobs_in + k * BLOB; c[k] = j->commitments_in + k * G1; p[k] = j->proofs_in + k * G1; }
+            j->res = eth_kzg_verify_blob_kzg_proof_batch(j->ctx, j->n, b, j->n, c, j->n, p, &j->verified);
+            free(b); free(c); free(p);
             break;
         }
         default: {
@@ -164,7 +182,8 @@ static napi_value make_u8_array(napi_env env, const uint8_t *src, size_t count, 
 }
 static const char *job_name(int kind) {
     static const char *names[] = {"blob_to_kzg_commitment", "compute_cells_and_kzg_proofs", "compute_cells", "recover_cells_and_kzg_proofs",
-                                  "verify_cell_kzg_proof_batch"};
+                                  "verify_cell_kzg_proof_batch", "compute_kzg_proof", "compute_blob_kzg_proof", "verify_kzg_proof",
+                                  "verify_blob_kzg_proof", "verify_blob_kzg_proof_batch"};
     return names[kind];
 }
 /* the JS value of a finished job, or NULL with *err set to an Error object */
@@ -180,7 +199,20 @@ static napi_value job_result(napi_env env, Job *j, napi_value *err) {
     switch (j->kind) {
         case JOB_COMMIT: return make_u8(env, j->commitment, G1);
         case JOB_CELLS: return make_u8_array(env, j->cells_out, CELLS, CELL);
-        case JOB_VERIFY: { napi_value b; NAPI_OK(napi_get_boolean(env, j->verified, &b)); return b; }
+        case JOB_VERIFY: case JOB_VERIFY_KZG: case JOB_VERIFY_BLOB: case JOB_VERIFY_BLOB_BATCH: {
+            napi_value b;
+            NAPI_OK(napi_get_boolean(env, j->verified, &b));
+            return b;
+        }
+        case JOB_BLOB_PROOF: return make_u8(env, j->proof_out, G1);
+        case JOB_KZG_PROOF: {  /* [proof, y] (index.d.ts: Array<Uint8Array>) */
+            napi_value arr, p = make_u8(env, j->proof_out, G1), y = make_u8(env, j->y_out, 32);
+            if (!p || !y) return NULL;
+            NAPI_OK(napi_create_array_with_length(env, 2, &arr));
+            NAPI_OK(napi_set_element(env, arr, 0, p));
+            NAPI_OK(napi_set_element(env, arr, 1, y));
+            return arr;
+        }
         default: {
             napi_value obj, c = make_u8_array(env, j->cells_out, CELLS, CELL), p = make_u8_array(env, j->proofs_out, CELLS, G1);
             if (!c || !p) return NULL;
@@ -228,6 +260,20 @@ static napi_value method(napi_env env, napi_callback_info info) {
         uint64_t ni = 0;
         ok = argc >= 2 && get_indices(env, argv[0], &j->indices, &ni) && get_byte_arrays(env, argv[1], CELL, "cell", &j->cells_in, &j->n);
         if (ok && ni != j->n) { napi_throw_error(env, NULL, "cellIndices and cells differ in length"); ok = false; }
+    } else if (kind >= JOB_KZG_PROOF) {
+        /* fixed-size operands copied into j->small / j->commitment; `take` fetches one of them */
+        #define TAKE(arg, size, what, dst) do { uint8_t *t_ = NULL; ok = ok && argc > (arg) && get_bytes(env, argv[arg], size, what, &t_); if (ok) { memcpy(dst, t_, size); } free(t_); } while (0)
+        if (kind == JOB_KZG_PROOF) { ok = argc >= 2 && get_bytes(env, argv[0], BLOB, "blob", &j->blob); TAKE(1, 32, "z", j->small[0]); }
+        else if (kind == JOB_BLOB_PROOF) { ok = argc >= 2 && get_bytes(env, argv[0], BLOB, "blob", &j->blob); TAKE(1, G1, "commitment", j->small[0]); }
+        else if (kind == JOB_VERIFY_KZG) { TAKE(0, G1, "commitment", j->small[0]); TAKE(1, 32, "z", j->small[1]); TAKE(2, 32, "y", j->small[2]); TAKE(3, G1, "proof", j->commitment); }
+        else if (kind == JOB_VERIFY_BLOB) { ok = argc >= 3 && get_bytes(env, argv[0], BLOB, "blob", &j->blob); TAKE(1, G1, "commitment", j->small[0]); TAKE(2, G1, "proof", j->small[1]); }
+        else {
+            uint64_t nc = 0, np = 0;
+            ok = argc >= 3 && get_byte_arrays(env, argv[0], BLOB, "blob", &j->blobs_in, &j->n) &&
+                 get_byte_arrays(env, argv[1], G1, "commitment", &j->commitments_in, &nc) && get_byte_arrays(env, argv[2], G1, "proof", &j->proofs_in, &np);
+            if (ok && (nc != j->n || np != j->n)) { napi_throw_error(env, NULL, "blobs, commitments and proofs differ in length"); ok = false; }
+        }
+        #undef TAKE
     } else {
         uint64_t ni = 0, nl = 0, np = 0;
         ok = argc >= 4 && get_byte_arrays(env, argv[0], G1, "commitment", &j->commitments_in, &j->n) && get_indices(env, argv[1], &j->indices, &ni) &&
@@ -240,7 +286,7 @@ static napi_value method(napi_env env, napi_callback_info info) {
         job_free(j);
         return NULL;
     }
-    if (kind != JOB_COMMIT && kind != JOB_VERIFY) j->cells_out = malloc((size_t)CELLS * CELL);
+    if (kind == JOB_CELLS_PROOFS || kind == JOB_CELLS || kind == JOB_RECOVER) j->cells_out = malloc((size_t)CELLS * CELL);
     if (kind == JOB_CELLS_PROOFS || kind == JOB_RECOVER) j->proofs_out = malloc((size_t)CELLS * G1);
     if (!is_async) {
         job_run(j);
@@ -305,6 +351,11 @@ static napi_value init(napi_env env, napi_value exports) {
         METHOD("computeCells", JOB_CELLS, 0), METHOD("asyncComputeCells", JOB_CELLS, 1),
         METHOD("recoverCellsAndKzgProofs", JOB_RECOVER, 0), METHOD("asyncRecoverCellsAndKzgProofs", JOB_RECOVER, 1),
         METHOD("verifyCellKzgProofBatch", JOB_VERIFY, 0), METHOD("asyncVerifyCellKzgProofBatch", JOB_VERIFY, 1),
+        METHOD("computeKzgProof", JOB_KZG_PROOF, 0), METHOD("asyncComputeKzgProof", JOB_KZG_PROOF, 1),
+        METHOD("computeBlobKzgProof", JOB_BLOB_PROOF, 0), METHOD("asyncComputeBlobKzgProof", JOB_BLOB_PROOF, 1),
+        METHOD("verifyKzgProof", JOB_VERIFY_KZG, 0), METHOD("asyncVerifyKzgProof", JOB_VERIFY_KZG, 1),
+        METHOD("verifyBlobKzgProof", JOB_VERIFY_BLOB, 0), METHOD("asyncVerifyBlobKzgProof", JOB_VERIFY_BLOB, 1),
+        METHOD("verifyBlobKzgProofBatch", JOB_VERIFY_BLOB_BATCH, 0), METHOD("asyncVerifyBlobKzgProofBatch", JOB_VERIFY_BLOB_BATCH, 1),
         {"create", NULL, create, NULL, NULL, NULL, napi_static, NULL},
     };
     napi_value cls;

@@ -49,6 +49,17 @@ async function main () {
   try { ctx.blobToKzgCommitment(new Uint8Array(5)); out.error_length = false } catch (e) { out.error_length = /blob must be a Uint8Array/.test(e.message) }
   try { ctx.recoverCellsAndKzgProofs(halfIdx.slice(0, 10), half.slice(0, 10)); out.error_recover = false } catch (e) { out.error_recover = true }
 
+  // EIP-4844 single-point operations
+  const z = new Uint8Array(32); z[31] = 9
+  const [proof, y] = ctx.computeKzgProof(blob, z)
+  out.kzg_proof = proof.length === 48 && y.length === 32 && ctx.verifyKzgProof(wantCommitment, z, y, proof) === true
+  const y2 = y.slice(); y2[31] ^= 1
+  out.kzg_proof_false = (await ctx.asyncVerifyKzgProof(wantCommitment, z, y2, proof)) === false
+  const blobProof = await ctx.asyncComputeBlobKzgProof(blob, wantCommitment)
+  out.blob_proof = ctx.verifyBlobKzgProof(blob, wantCommitment, blobProof) === true
+  out.blob_proof_batch = ctx.verifyBlobKzgProofBatch([blob, blob], [wantCommitment, wantCommitment], [blobProof, blobProof]) === true &&
+    (await ctx.asyncVerifyBlobKzgProofBatch([blob], [wantCommitment], [proof])) === false
+
   // a second context (the reference's tests create several): shares the window tables
   const ctx2 = new kzg.DasContextJs()
   out.second_context = eq(ctx2.blobToKzgCommitment(blob), wantCommitment)

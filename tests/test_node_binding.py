@@ -25,7 +25,8 @@ def test_addon_builds_and_exports_the_reference_surface():
             "console.log(JSON.stringify({m, c: [k.BYTES_PER_BLOB, k.BYTES_PER_CELL, k.BYTES_PER_PROOF, k.MAX_NUM_COLUMNS], s: typeof k.DasContextJs.create}))"
             % os.path.join(ROOT, "bindings", "node"))
     out = json.loads(subprocess.check_output([NODE, "-e", code], text=True))
-    want = ["blobToKzgCommitment", "computeCells", "computeCellsAndKzgProofs", "recoverCellsAndKzgProofs", "verifyCellKzgProofBatch"]
+    want = ["blobToKzgCommitment", "computeCells", "computeCellsAndKzgProofs", "recoverCellsAndKzgProofs", "verifyCellKzgProofBatch",
+            "computeKzgProof", "computeBlobKzgProof", "verifyKzgProof", "verifyBlobKzgProof", "verifyBlobKzgProofBatch"]
     for name in want:
         assert name in out["m"] and "async" + name[0].upper() + name[1:] in out["m"], name
     assert out["c"] == [131072, 2048, 48, 128] and out["s"] == "function"
