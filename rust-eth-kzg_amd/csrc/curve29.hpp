@@ -264,6 +264,25 @@ HD XyzzQ add_mixed_slow(const XyzzQ& p, const AffQ& q, bool negq) {
     return r;
 }
 
+HD Fq<1> reduce_once(const Fq<2>& t) {  // t < 2p -> canonical
+    uint32_t d[QL];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < QL; i++) {
+        uint32_t x = t.v[i] - q29::P[i] - borrow;
+        borrow = x >> 31;
+        d[i] = x & QMASK;
+    }
+    Fq<1> r;
+#pragma unroll
+    for (int i = 0; i < QL; i++) r.v[i] = borrow ? t.v[i] : d[i];
+    return r;
+}
+template <int B>
+HD Fq<1> fq_inv(const Fq<B>& z) {  // through the saturated form, where the binary-GCD inversion lives
+    return fq_from_fp(inv_fast(fp_from_fq(z)));
+}
+
 // conversions ------------------------------------------------------------------------------------------------
 HD AffQ affq_from_affine(const G1Affine& a) {  // a canonical Montgomery-384; identity (0,0) maps to (0,0)
     AffQ r;

@@ -244,6 +244,10 @@ Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14
         }
     }
     srs_c_ = use_precomp ? 13 : 4;  // commitment table over the monomial SRS: 37.6 GB at width 13 (20 windows instead of 32)
+    if (const char* s = getenv("ETH_KZG_AMD_PIP_SHIFT_MIN")) {  // tuning knob: smallest cell count verified with byte-shifted point copies
+        const int v = atoi(s);
+        if (v >= 1) pip_shift_min_ = v;
+    }
     if (const char* s = getenv("ETH_KZG_AMD_CIRC_MAX")) {  // tuning knob: largest batch served by the circulant form (0 disables it)
         int v = atoi(s);
         if (v >= 0 && v <= 64) circ_max_ = v;

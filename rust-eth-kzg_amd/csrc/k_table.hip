@@ -63,24 +63,6 @@ __global__ __launch_bounds__(64) void k_build_table(const G1Affine* __restrict__
 //                    lane Z_(k+1) = Z_k * f_k with f_k = 2 H_k from the mixed addition, so 1 / Z_k = (1 / Z_(k+1)) * f_k:
 //                    one binary-GCD inversion per lane per 2^(c-1) / 64 entries, one multiplication per entry on the way back.
 //                    X, Y wait in the destination slot (2 x 56 B = one table entry), f_k in a 56 B/entry scratch.
-__device__ __forceinline__ Fq<1> reduce_once(const Fq<2>& t) {  // t < 2p -> canonical
-    uint32_t d[QL];
-    uint32_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < QL; i++) {
-        uint32_t x = t.v[i] - q29::P[i] - borrow;
-        borrow = x >> 31;
-        d[i] = x & QMASK;
-    }
-    Fq<1> r;
-#pragma unroll
-    for (int i = 0; i < QL; i++) r.v[i] = borrow ? t.v[i] : d[i];
-    return r;
-}
-template <int B>
-__device__ __forceinline__ Fq<1> fq_inv(const Fq<B>& z) {  // through the saturated form, where the binary-GCD inversion lives
-    return fq_from_fp(inv_fast(fp_from_fq(z)));
-}
 // p + q with the factor f = Z3 / Z1 (2 H in general; 2 Y1 when p == q and the sum is a doubling)
 __device__ __forceinline__ JacQ add_mixed_f(const JacQ& p, const AffQ& q, Fq<260>& f) {
     Fq<2> z1z1 = sqr(p.z);

@@ -120,42 +120,59 @@ __global__ __launch_bounds__(256) void k_verify_weights(const Fr* __restrict__ r
 // compute_sum_interpolation_poly (verifier.rs:348-384): for every cell k, interpolate its 64 evaluations on the
 // coset h_c <omega_64> (bit-reversed inside the cell, so the DIT network takes the cell as stored), un-shift by
 // h_c^-i, scale by r^k and accumulate.  One wave per cell; partial[block][64] is folded by k_interp_fold.
+// interp_cell: coefficient i of cell k's interpolation polynomial (lane i of the wave), without the factor r^k.
+__device__ __forceinline__ Fr interp_cell(uint32_t (*s)[64], const Fr* __restrict__ evals, const int* __restrict__ cell_idx,
+                                          const Fr* __restrict__ w8192, const Fr& inv64, int k, int i) {
+    Fr x = evals[(size_t)k * CELL_LEN + i];
+#pragma unroll
+    for (int l = 0; l < 8; l++) s[l][i] = x.v[l];
+    __syncthreads();
+    for (int half = 1; half < 64; half <<= 1) {  // DIT, inverse twiddles omega_64^-j = w8192[8192 - 128 j * (32/half)]
+        Fr a, b;
+        int q = i & 31;
+        int j = q & (half - 1);
+        int i0 = ((q - j) << 1) + j, i1 = i0 + half;
+        if (i < 32) {
+#pragma unroll
+            for (int l = 0; l < 8; l++) { a.v[l] = s[l][i0]; b.v[l] = s[l][i1]; }
+            int e = (N_EXT - j * (N_EXT / (2 * half))) & (N_EXT - 1);
+            Fr t = j ? mul(b, w8192[e]) : b;
+            Fr u = add(a, t), v = sub(a, t);
+#pragma unroll
+            for (int l = 0; l < 8; l++) { s[l][i0] = u.v[l]; s[l][i1] = v.v[l]; }
+        }
+        __syncthreads();
+    }
+    Fr c;
+#pragma unroll
+    for (int l = 0; l < 8; l++) c.v[l] = s[l][i];
+    __syncthreads();
+    int bc = (int)(__brev((unsigned)cell_idx[k]) >> 25);
+    Fr hinv_i = w8192[(N_EXT - ((bc * i) & (N_EXT - 1))) & (N_EXT - 1)];  // (h_c^-1)^i, domain.rs:214-223
+    return mul(mul(c, inv64), hinv_i);
+}
 __global__ __launch_bounds__(64) void k_interp(const Fr* __restrict__ evals, const int* __restrict__ cell_idx,
                                                const Fr* __restrict__ rp_mont, const Fr* __restrict__ w8192, Fr inv64,
                                                Fr* __restrict__ partial, int n) {
     __shared__ uint32_t s[8][64];
     const int i = threadIdx.x;
     Fr acc = zero<FrParams>();
-    for (int k = blockIdx.x; k < n; k += gridDim.x) {
-        Fr x = evals[(size_t)k * CELL_LEN + i];
-#pragma unroll
-        for (int l = 0; l < 8; l++) s[l][i] = x.v[l];
-        __syncthreads();
-        for (int half = 1; half < 64; half <<= 1) {  // DIT, inverse twiddles omega_64^-j = w8192[8192 - 128 j * (32/half)]
-            Fr a, b;
-            int q = i & 31;
-            int j = q & (half - 1);
-            int i0 = ((q - j) << 1) + j, i1 = i0 + half;
-            if (i < 32) {
-#pragma unroll
-                for (int l = 0; l < 8; l++) { a.v[l] = s[l][i0]; b.v[l] = s[l][i1]; }
-                int e = (N_EXT - j * (N_EXT / (2 * half))) & (N_EXT - 1);
-                Fr t = j ? mul(b, w8192[e]) : b;
-                Fr u = add(a, t), v = sub(a, t);
-#pragma unroll
-                for (int l = 0; l < 8; l++) { s[l][i0] = u.v[l]; s[l][i1] = v.v[l]; }
-            }
-            __syncthreads();
-        }
-        Fr c;
-#pragma unroll
-        for (int l = 0; l < 8; l++) c.v[l] = s[l][i];
-        __syncthreads();
-        int bc = (int)(__brev((unsigned)cell_idx[k]) >> 25);
-        Fr hinv_i = w8192[(N_EXT - ((bc * i) & (N_EXT - 1))) & (N_EXT - 1)];  // (h_c^-1)^i, domain.rs:214-223
-        c = mul(mul(c, inv64), mul(hinv_i, rp_mont[k]));
-        acc = add(acc, c);
-    }
+    for (int k = blockIdx.x; k < n; k += gridDim.x) acc = add(acc, mul(interp_cell(s, evals, cell_idx, w8192, inv64, k, i), rp_mont[k]));
+    partial[(size_t)blockIdx.x * 64 + i] = acc;
+}
+// The same in two steps for large batches: the per-cell polynomials do not depend on the challenge, so they are computed
+// while the host still hashes the transcript (k_interp_cells), and only the weighted sum waits for r (k_interp_sum).
+__global__ __launch_bounds__(64) void k_interp_cells(const Fr* __restrict__ evals, const int* __restrict__ cell_idx,
+                                                     const Fr* __restrict__ w8192, Fr inv64, Fr* __restrict__ coef, int n) {
+    __shared__ uint32_t s[8][64];
+    const int i = threadIdx.x;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) coef[(size_t)k * 64 + i] = interp_cell(s, evals, cell_idx, w8192, inv64, k, i);
+}
+__global__ __launch_bounds__(64) void k_interp_sum(const Fr* __restrict__ coef, const Fr* __restrict__ rp_mont,
+                                                   Fr* __restrict__ partial, int n) {
+    const int i = threadIdx.x;
+    Fr acc = zero<FrParams>();
+    for (int k = blockIdx.x; k < n; k += gridDim.x) acc = add(acc, mul(coef[(size_t)k * 64 + i], rp_mont[k]));
     partial[(size_t)blockIdx.x * 64 + i] = acc;
 }
 __global__ __launch_bounds__(64) void k_interp_fold(const Fr* __restrict__ partial, int nblocks, Fr* __restrict__ out_neg_canon) {
@@ -254,8 +271,8 @@ __global__ __launch_bounds__(64) void k_pip_buckets(const AffQ* __restrict__ pts
 }
 __global__ __launch_bounds__(256) void k_pip_window(const JacQ* __restrict__ buckets, JacQ* __restrict__ wsum) {
     __shared__ JacQ T[PIP_B];
-    const int w = blockIdx.x, job = blockIdx.y, t = threadIdx.x;
-    T[t] = buckets[((size_t)job * PIP_W + w) * PIP_B + t];  // bucket 0 is the identity
+    const int w = blockIdx.x, W = gridDim.x, job = blockIdx.y, t = threadIdx.x;
+    T[t] = buckets[((size_t)job * W + w) * PIP_B + t];  // bucket 0 is the identity
     __syncthreads();
     // suffix sums T[b] = sum_{j >= b} B_j  (Hillis-Steele), then sum_b T[b] = sum_b b * B_b
     for (int off = 1; off < PIP_B; off <<= 1) {
@@ -272,22 +289,163 @@ __global__ __launch_bounds__(256) void k_pip_window(const JacQ* __restrict__ buc
         if (t < span) T[t] = add(T[t], T[t + span]);
         __syncthreads();
     }
-    if (t == 0) wsum[job * PIP_W + w] = T[0];
+    if (t == 0) wsum[job * W + w] = T[0];
 }
-__global__ __launch_bounds__(64) void k_pip_final(const JacQ* __restrict__ wsum, G1Affine* __restrict__ out_affine) {
+// W windows (a power of two <= 16); W = 1 is the byte-shifted form below: nothing to double or fold
+__global__ __launch_bounds__(64) void k_pip_final(const JacQ* __restrict__ wsum, G1Affine* __restrict__ out_affine, int W) {
     __shared__ JacQ T[PIP_W];
     const int job = blockIdx.x, t = threadIdx.x;
-    if (t < PIP_W) {
-        JacQ acc = wsum[job * PIP_W + t];
+    if (t < W) {
+        JacQ acc = wsum[job * W + t];
         for (int k = 0; k < PIP_C * t; k++) acc = dbl(acc);
         T[t] = acc;
     }
     __syncthreads();
-    for (int span = PIP_W / 2; span >= 1; span >>= 1) {
+    for (int span = W / 2; span >= 1; span >>= 1) {
         if (t < span) T[t] = add(T[t], T[t + span]);
         __syncthreads();
     }
     if (t == 0) out_affine[job] = to_affine(jac_from_jacq(T[0]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large batches (config 3: 8192 cells): the same two lincombs with the points SHIFTED AHEAD OF TIME.  The challenge r --
+// and with it every scalar -- is known only after the host has hashed the whole transcript (17.6 MB, 7 ms), while the
+// points are there as soon as they are decompressed.  So the 120 dependent doublings that the fold of 16 windows needs
+// (k_pip_final above: 1.1 ms with one busy lane) move in front of the challenge: k_pip_shift builds, for every point,
+// the 16 byte-shifted copies 2^(8p) P and their phi images (32 affine points, one inversion per input point) while the
+// host hashes.  A 128-bit half scalar is then 16 independent bytes, each paired with its own copy, and the whole lincomb
+// is ONE window: 32 n (point, byte) items into 255 buckets.  After the challenge: split, a three-kernel counting sort,
+// one wave per bucket (64 lanes share a bucket's ~130 items and fold through LDS), the suffix-scan of k_pip_window, and a
+// conversion to affine: no doubling at all.  3.0 -> 0.8 ms of GPU time behind the hash.
+//   pts32[(phi * 16 + p) * n_max + i] = phi^phi(2^(8p) P_i)
+constexpr int PS_P = 16, PS_SLICES = 64;
+__global__ __launch_bounds__(64) void k_pip_shift(const G1Affine* __restrict__ in, AffQ* __restrict__ pts32, JacQ* __restrict__ jac,
+                                                  Fq<2>* __restrict__ pre, int n, int n_max, Fq<1> beta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    auto put = [&](int p, const AffQ& a) {
+        pts32[(size_t)p * n_max + i] = a;
+        AffQ b = a;
+        b.x = canonical(mul(a.x, beta));
+        pts32[(size_t)(PS_P + p) * n_max + i] = b;
+    };
+    const AffQ P = affq_from_affine(in[i]);
+    put(0, P);
+    if (is_inf(P)) {  // the identity (0,0) is its own image and its own multiple
+        for (int p = 1; p < PS_P; p++) put(p, P);
+        return;
+    }
+    JacQ cur = to_jacq(P);
+    Fq<2> prod = relax<2>(fq_one());
+    for (int p = 1; p < PS_P; p++) {
+        for (int k = 0; k < 8; k++) cur = dbl(cur);
+        jac[(size_t)(p - 1) * n_max + i] = cur;
+        pre[(size_t)(p - 1) * n_max + i] = prod;
+        prod = mul(prod, cur.z);
+    }
+    // a point of G1 has odd order, so no multiple by a power of two is the identity; anything else was rejected by the
+    // decoder and its (meaningless) copies are never used: inv(0) = 0 keeps even that case finite
+    Fq<2> inv = relax<2>(fq_inv(prod));
+    for (int p = PS_P - 1; p >= 1; p--) {
+        const JacQ q = jac[(size_t)(p - 1) * n_max + i];
+        const Fq<2> zi = mul(inv, pre[(size_t)(p - 1) * n_max + i]);
+        inv = mul(inv, q.z);
+        const Fq<2> zi2 = sqr(zi);
+        AffQ a;
+        a.x = reduce_once(mul(q.x, zi2));
+        a.y = reduce_once(mul(q.y, mul(zi2, zi)));
+        put(p, a);
+    }
+}
+// counting sort of the 32 n items of a job by their byte.  Half-scalar entry e < 2n (k1 of scalar e, or k2 of scalar e - n)
+// carries 16 items; slice s of PS_SLICES owns a contiguous range of entries.
+__device__ __forceinline__ int ps_byte(const Half128& v, int p) { return (v.v[p >> 2] >> ((p & 3) * 8)) & 255; }
+__global__ __launch_bounds__(256) void k_ps_hist(PipJob j0, PipJob j1, int n_max, const Half128* __restrict__ halves,
+                                                 int* __restrict__ hist /*[2][PS_SLICES][256]*/) {
+    __shared__ int h[PIP_B];
+    const int slice = blockIdx.x, job = blockIdx.y, t = threadIdx.x;
+    const int E = 2 * (job ? j1 : j0).n;
+    const Half128* hv = halves + (size_t)job * 2 * n_max;
+    h[t] = 0;
+    __syncthreads();
+    const int lo = (int)((long)E * slice / PS_SLICES), hi = (int)((long)E * (slice + 1) / PS_SLICES);
+    for (int e = lo + t; e < hi; e += 256) {
+        const Half128 v = hv[e];
+#pragma unroll
+        for (int p = 0; p < PS_P; p++) atomicAdd(&h[ps_byte(v, p)], 1);
+    }
+    __syncthreads();
+    hist[((size_t)job * PS_SLICES + slice) * PIP_B + t] = h[t];
+}
+// hist[job][slice][b] <- first position of slice's items of bucket b in the sorted list; start[job][b] = first position of bucket b
+__global__ __launch_bounds__(256) void k_ps_scan(int* __restrict__ hist, int* __restrict__ start /*[2][257]*/) {
+    __shared__ int tot[PIP_B];
+    const int job = blockIdx.x, b = threadIdx.x;
+    int* h = hist + (size_t)job * PS_SLICES * PIP_B;
+    int acc = 0;
+    for (int s = 0; s < PS_SLICES; s++) {
+        const int c = h[s * PIP_B + b];
+        h[s * PIP_B + b] = acc;
+        acc += c;
+    }
+    tot[b] = acc;
+    __syncthreads();
+    if (b == 0) {
+        int a = 0;
+        for (int j = 0; j < PIP_B; j++) { const int c = tot[j]; tot[j] = a; a += c; }
+        start[job * (PIP_B + 1) + PIP_B] = a;
+    }
+    __syncthreads();
+    const int base = tot[b];
+    start[job * (PIP_B + 1) + b] = base;
+    for (int s = 0; s < PS_SLICES; s++) h[s * PIP_B + b] += base;
+}
+__global__ __launch_bounds__(256) void k_ps_scatter(PipJob j0, PipJob j1, int n_max, const Half128* __restrict__ halves,
+                                                    const int* __restrict__ hist, int* __restrict__ items /*[2][32 n_max]*/) {
+    __shared__ int cur[PIP_B];
+    const int slice = blockIdx.x, job = blockIdx.y, t = threadIdx.x;
+    const int n = (job ? j1 : j0).n, E = 2 * n;
+    const Half128* hv = halves + (size_t)job * 2 * n_max;
+    cur[t] = hist[((size_t)job * PS_SLICES + slice) * PIP_B + t];
+    __syncthreads();
+    int* out = items + (size_t)job * 2 * PS_P * n_max;
+    const int lo = (int)((long)E * slice / PS_SLICES), hi = (int)((long)E * (slice + 1) / PS_SLICES);
+    for (int e = lo + t; e < hi; e += 256) {
+        const Half128 v = hv[e];
+        const int phi = e >= n, i = phi ? e - n : e;
+#pragma unroll
+        for (int p = 0; p < PS_P; p++) out[atomicAdd(&cur[ps_byte(v, p)], 1)] = (phi * PS_P + p) * n_max + i;
+    }
+}
+// one wave per bucket: lane l adds the bucket's items l, l + 64, ... into an XYZZ sum (the next point is requested one
+// addition ahead), then the 64 partial sums fold through LDS.  buckets: [job][256] JacQ
+__global__ __launch_bounds__(64) void k_ps_buckets(const AffQ* __restrict__ pts32, const int* __restrict__ items,
+                                                   const int* __restrict__ start, int n_max, JacQ* __restrict__ buckets) {
+    __shared__ JacQ red[64];
+    const int b = blockIdx.x, job = blockIdx.y, l = threadIdx.x;
+    XyzzQ acc = xyzz_inf();
+    if (b) {
+        const int* it = items + (size_t)job * 2 * PS_P * n_max;
+        const int end = start[job * (PIP_B + 1) + b + 1];
+        int p = start[job * (PIP_B + 1) + b] + l;
+        AffQ cur;
+        if (p < end) cur = pts32[it[p]];
+        for (; p < end; p += 64) {
+            AffQ nxt = cur;
+            if (p + 64 < end) nxt = pts32[it[p + 64]];
+            acc = add_mixed(acc, cur);
+            cur = nxt;
+        }
+    }
+    JacQ sum = to_jacq(acc);
+    for (int span = 32; span >= 1; span >>= 1) {
+        red[l] = sum;
+        __syncthreads();
+        if (l < span) sum = add(sum, red[l + span]);
+        __syncthreads();
+    }
+    if (l == 0) buckets[(size_t)job * PIP_B + b] = sum;
 }
 // points[dst_off + i] = src[i] (device gather of the 64 SRS points behind the proofs/commitments)
 __global__ void k_copy_affine(const G1Affine* __restrict__ src, G1Affine* __restrict__ dst, int n) {
@@ -440,6 +598,13 @@ void interp(const void* evals, const int* cell_idx, const void* rp_mont, const v
     k_interp<<<nblocks, 64, 0, st>>>((const Fr*)evals, cell_idx, (const Fr*)rp_mont, (const Fr*)w8192, as_fr2(inv64), (Fr*)partial, n);
     k_interp_fold<<<1, 64, 0, st>>>((const Fr*)partial, nblocks, (Fr*)out_neg_canon);
 }
+void interp_cells(const void* evals, const int* cell_idx, const void* w8192, const Fr8& inv64, void* coef, int n, hipStream_t st) {
+    k_interp_cells<<<n < 1024 ? n : 1024, 64, 0, st>>>((const Fr*)evals, cell_idx, (const Fr*)w8192, as_fr2(inv64), (Fr*)coef, n);
+}
+void interp_sum(const void* coef, const void* rp_mont, void* partial, int nblocks, void* out_neg_canon, int n, hipStream_t st) {
+    k_interp_sum<<<nblocks, 64, 0, st>>>((const Fr*)coef, (const Fr*)rp_mont, (Fr*)partial, n);
+    k_interp_fold<<<1, 64, 0, st>>>((const Fr*)partial, nblocks, (Fr*)out_neg_canon);
+}
 size_t pip_workspace_bytes(int n_max) {
     return (size_t)2 * n_max * SIZEOF_AFFQ + (size_t)2 * 2 * n_max * sizeof(Half128) + (size_t)2 * PIP_W * 2 * n_max * sizeof(int) +
            (size_t)2 * PIP_W * (PIP_B + 1) * sizeof(int) + (size_t)2 * PIP_W * PIP_B * SIZEOF_JACQ + (size_t)2 * PIP_W * SIZEOF_JACQ + 512;
@@ -468,7 +633,48 @@ void msm_pippenger2(const void* points, const void* sc0, int n0, const void* sc1
     k_pip_sort<<<dim3(PIP_W, 2), 256, 0, st>>>(j0, j1, n_max, halves, idx, start);
     k_pip_buckets<<<dim3(PIP_W * PIP_B / 64, 2), 64, 0, st>>>(pts, idx, start, n_max, buckets);
     k_pip_window<<<dim3(PIP_W, 2), 256, 0, st>>>(buckets, wsum);
-    k_pip_final<<<2, 64, 0, st>>>(wsum, (G1Affine*)out_affine2);
+    k_pip_final<<<2, 64, 0, st>>>(wsum, (G1Affine*)out_affine2, PIP_W);
+}
+// byte-shifted form: workspace = [pts32 | jac | pre | halves | items | hist | start | buckets | wsum]
+struct PsLayout {
+    AffQ* pts32; JacQ* jac; Fq<2>* pre; Half128* halves; int* items; int* hist; int* start; JacQ* buckets; JacQ* wsum;
+    size_t bytes;
+};
+static PsLayout ps_layout(void* workspace, int n_max) {
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const uintptr_t p = (uintptr_t)workspace;  // integer arithmetic: the size query passes no buffer
+    PsLayout L;
+    size_t o = 0;
+    L.pts32 = (AffQ*)(p + o); o += up((size_t)2 * PS_P * n_max * SIZEOF_AFFQ);
+    L.jac = (JacQ*)(p + o); o += up((size_t)(PS_P - 1) * n_max * SIZEOF_JACQ);
+    L.pre = (Fq<2>*)(p + o); o += up((size_t)(PS_P - 1) * n_max * sizeof(Fq<2>));
+    L.halves = (Half128*)(p + o); o += up((size_t)2 * 2 * n_max * sizeof(Half128));
+    L.items = (int*)(p + o); o += up((size_t)2 * 2 * PS_P * n_max * sizeof(int));
+    L.hist = (int*)(p + o); o += up((size_t)2 * PS_SLICES * PIP_B * sizeof(int));
+    L.start = (int*)(p + o); o += up((size_t)2 * (PIP_B + 1) * sizeof(int));
+    L.buckets = (JacQ*)(p + o); o += up((size_t)2 * PIP_B * SIZEOF_JACQ);
+    L.wsum = (JacQ*)(p + o); o += up((size_t)2 * SIZEOF_JACQ);
+    L.bytes = o;
+    return L;
+}
+size_t pip_shift_workspace_bytes(int n_max) { return ps_layout(nullptr, n_max).bytes; }
+void pip_shift_prepare(const void* points, int n_pts, int n_max, void* workspace, const Fp12w& beta, hipStream_t st) {
+    Fp b384;
+    for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
+    const PsLayout L = ps_layout(workspace, n_max);
+    k_pip_shift<<<(n_pts + 63) / 64, 64, 0, st>>>((const G1Affine*)points, L.pts32, L.jac, L.pre, n_pts, n_max, fq_from_fp(b384));
+}
+void msm_pippenger2_shifted(const void* sc0, int n0, const void* sc1, int n1, int n_max, void* workspace, void* out_affine2,
+                            hipStream_t st) {
+    const PsLayout L = ps_layout(workspace, n_max);
+    PipJob j0{(const Fr*)sc0, n0}, j1{(const Fr*)sc1, n1};
+    k_pip_glv_split<<<dim3((n_max + 63) / 64, 2), 64, 0, st>>>(j0, j1, n_max, L.halves);
+    k_ps_hist<<<dim3(PS_SLICES, 2), 256, 0, st>>>(j0, j1, n_max, L.halves, L.hist);
+    k_ps_scan<<<2, 256, 0, st>>>(L.hist, L.start);
+    k_ps_scatter<<<dim3(PS_SLICES, 2), 256, 0, st>>>(j0, j1, n_max, L.halves, L.hist, L.items);
+    k_ps_buckets<<<dim3(PIP_B, 2), 64, 0, st>>>(L.pts32, L.items, L.start, n_max, L.buckets);
+    k_pip_window<<<dim3(1, 2), 256, 0, st>>>(L.buckets, L.wsum);
+    k_pip_final<<<2, 64, 0, st>>>(L.wsum, (G1Affine*)out_affine2, 1);
 }
 void rec_vanishing_poly(const uint32_t* present, const void* w8192, void* zp, int* deg, int R, hipStream_t st) {
     k_rec_vanishing_poly<<<R, 64, 0, st>>>(present, (const Fr*)w8192, (Fr*)zp, deg, R);

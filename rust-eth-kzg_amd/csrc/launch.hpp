@@ -93,6 +93,13 @@ void verify_scalars(const Fr8* pow_table24, int k0, const int* cell_idx, const v
 void verify_weights(const void* rp_mont, const int* row, void* weights, int n, int m, hipStream_t st);
 void interp(const void* evals, const int* cell_idx, const void* rp_mont, const void* w8192, const Fr8& inv64, void* partial,
             int nblocks, void* out_neg_canon, int n, hipStream_t st);
+void interp_cells(const void* evals, const int* cell_idx, const void* w8192, const Fr8& inv64, void* coef, int n, hipStream_t st);
+void interp_sum(const void* coef, const void* rp_mont, void* partial, int nblocks, void* out_neg_canon, int n, hipStream_t st);
+// large verification batches: byte-shifted point copies built before the challenge is known (k_verify.hip)
+size_t pip_shift_workspace_bytes(int n_max);
+void pip_shift_prepare(const void* points, int n_pts, int n_max, void* workspace, const Fp12w& beta, hipStream_t st);
+void msm_pippenger2_shifted(const void* sc0, int n0, const void* sc1, int n1, int n_max, void* workspace, void* out_affine2,
+                            hipStream_t st);
 size_t pip_workspace_bytes(int n_max);
 void copy_affine(const void* src, void* dst, int n, hipStream_t st);
 void msm_pippenger2(const void* points, const void* sc0, int n0, const void* sc1, int n1, void* workspace, void* out_affine2,

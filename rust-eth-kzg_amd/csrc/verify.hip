@@ -158,7 +158,11 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
         const size_t off_s1 = o; o += up((size_t)n * sizeof(Fr));
         const size_t off_sB = o; o += up(npts * sizeof(Fr));
         const size_t off_part = o; o += up((size_t)ib * 64 * sizeof(Fr));
-        const size_t off_ws = o; o += up(launch::pip_workspace_bytes((int)npts));
+        // large batches take the byte-shifted lincombs (k_verify.hip): point copies and per-cell interpolation polynomials
+        // are built behind the hash, so only the cheap half waits for the challenge
+        const bool shifted = n >= pip_shift_min_;
+        const size_t off_ws = o; o += up(shifted ? launch::pip_shift_workspace_bytes((int)npts) : launch::pip_workspace_bytes((int)npts));
+        const size_t off_coef = o; o += shifted ? up((size_t)n * CELL_LEN * sizeof(Fr)) : 0;
         const size_t off_out = o; o += 256;
         if (o > v_dev_cap_) {
             if (v_dev_) HIPCK(hipFree(v_dev_));
@@ -214,6 +218,10 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
                 HIPCK(hipMemcpyAsync(stc, d_stc.p, m * sizeof(int), hipMemcpyDeviceToHost, st));
                 HIPCK(hipMemcpyAsync(stp, d_stp.p, n * sizeof(int), hipMemcpyDeviceToHost, st));
                 HIPCK(hipMemcpyAsync(ste_p, d_ste.p, sizeof(int), hipMemcpyDeviceToHost, st));
+                if (shifted) {  // everything that does not depend on the challenge
+                    launch::pip_shift_prepare(d_pts.p, (int)npts, (int)npts, db + off_ws, beta_, st);
+                    launch::interp_cells(d_evals.p, (const int*)d_idx.p, d_w8192_, inv64_, db + off_coef, n, st);
+                }
                 HIPCK(hipGetLastError());  // launch failures are per thread: this thread's would be lost with it
             } catch (...) {
                 stage_error = std::current_exception();
@@ -259,11 +267,13 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
         launch::verify_scalars(tab, k0, (const int*)d_idx.p, d_w8192_, d_rp.p, d_s1.p, d_s2, n, st);
         launch::verify_weights(d_rp.p, (const int*)d_row.p, d_w, n, m, st);
         View d_part{db + off_part};
-        launch::interp(d_evals.p, (const int*)d_idx.p, d_rp.p, d_w8192_, inv64_, d_part.p, ib, d_interp, n, st);
+        if (shifted) launch::interp_sum(db + off_coef, d_rp.p, d_part.p, ib, d_interp, n, st);
+        else launch::interp(d_evals.p, (const int*)d_idx.p, d_rp.p, d_w8192_, inv64_, d_part.p, ib, d_interp, n, st);
         // ---- the four lincombs (verifier.rs:186,200,224,235) as two bucket MSMs over the shared point array:
         //   out[0] = sum r^k pi_k;   out[1] = sum r^k h^64 pi_k + sum w_row C_row - commit(interpolation poly)
         View d_ws{db + off_ws}, d_out{db + off_out};
-        launch::msm_pippenger2(d_pts.p, d_s1.p, n, d_sB.p, n + m + 64, d_ws.p, d_out.p, beta_, st);
+        if (shifted) launch::msm_pippenger2_shifted(d_s1.p, n, d_sB.p, n + m + 64, (int)npts, d_ws.p, d_out.p, st);
+        else launch::msm_pippenger2(d_pts.p, d_s1.p, n, d_sB.p, n + m + 64, d_ws.p, d_out.p, beta_, st);
         HIPCK(hipMemcpyAsync(out, d_out.p, 2 * sizeof(G1Affine), hipMemcpyDeviceToHost, st));
         SYNC_CHECKED(st);
         for (int i = 0; i < 2; i++)  // the poison pattern (or anything else that is not a reduced coordinate) is a device failure

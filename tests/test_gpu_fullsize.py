@@ -143,13 +143,23 @@ def _config3_inputs(ctx, n_blobs=64):
     return blobs, comms, C, I, L, P
 
 
-def test_verify_config3_full_size(ctx, oracle):
+def test_verify_config3_full_size(ctx, oracle, monkeypatch):
     """64 blobs x 128 cells in ONE call (8192 cells, 64 distinct commitments, 17.6 MB of input): true; one tampered
     proof, one tampered cell, one swapped commitment: false each (not an error); verdicts equal the oracle's;
-    the sharded form (partial + combine) at world 8 agrees."""
+    the sharded form (partial + combine) at world 8 agrees.  At this size the lincombs run over byte-shifted point copies
+    (k_verify.hip: k_pip_shift); a context with that form switched off must produce the same two pairing inputs."""
     blobs, comms, C, I, L, P = _config3_inputs(ctx)
     assert len(L) == 8192
     assert ctx.verify_cell_kzg_proof_batch(C, I, L, P) is True
+    monkeypatch.setenv("ETH_KZG_AMD_PIP_SHIFT_MIN", "1000000")
+    windowed = kzg.DASContext()
+    try:
+        assert windowed.verify_cell_kzg_proof_batch_partial(C, I, L, P, 0, 8192) == \
+            ctx.verify_cell_kzg_proof_batch_partial(C, I, L, P, 0, 8192)
+        assert windowed.verify_cell_kzg_proof_batch(C, I, L, P) is True
+    finally:
+        windowed.close()
+    monkeypatch.delenv("ETH_KZG_AMD_PIP_SHIFT_MIN")
     assert oracle.verify_cell_kzg_proof_batch(C, I, L, P) is True
     P2 = list(P); P2[4097] = P[4098]
     L2 = list(L); L2[8191] = L[0]

@@ -253,6 +253,41 @@ def test_verify_sharded_partials_are_additive(ctx):
         ctx.verify_cell_kzg_proof_batch_partial(C_, I_, L_, P_, 5, 385)
 
 
+def test_verify_with_byte_shifted_lincombs(ctx, monkeypatch):
+    """Large batches run the two lincombs over byte-shifted point copies built before the challenge is known
+    (k_verify.hip: k_pip_shift, k_ps_*).  Forced on for every size here: all of the reference's verify vectors, unsharded
+    and in three slices, and the two pairing inputs of a 384-cell batch byte for byte against the windowed form."""
+    monkeypatch.setenv("ETH_KZG_AMD_PIP_SHIFT_MIN", "1")
+    c = kzg.DASContext()
+    try:
+        for name, case in sorted(vectors.load("verify_cell_kzg_proof_batch").items()):
+            i = case["input"]
+            args = (i["commitments"], i["cell_indices"], i["cells"], i["proofs"])
+            assert _call(c.verify_cell_kzg_proof_batch, *args) == case["output"], name
+            assert _call(_verify_in_shards, c, 3, *args) == case["output"], name
+        blobs = [synth.seeded_blob(20 + i) for i in range(3)]
+        st, cells, proofs = c.compute_cells_and_kzg_proofs_batch(blobs)
+        _, comms = c.blob_to_kzg_commitment_batch(blobs)
+        C_, I_, L_, P_ = [], [], [], []
+        for b in range(3):
+            for k in range(128):
+                C_.append(comms[b]); I_.append(k); L_.append(cells[b][k]); P_.append(proofs[b][k])
+        # identity proofs / commitments (the zero polynomial) ride along: the point (0,0) is its own shifted copy
+        zc, zp = c.compute_cells_and_kzg_proofs(bytes(131072))
+        for k in (0, 77):
+            C_.append(b"\xc0" + bytes(47)); I_.append(k); L_.append(zc[k]); P_.append(zp[k])
+        for lo, hi in [(0, len(L_)), (0, 1), (5, 200), (384, 386)]:
+            assert c.verify_cell_kzg_proof_batch_partial(C_, I_, L_, P_, lo, hi) == \
+                ctx.verify_cell_kzg_proof_batch_partial(C_, I_, L_, P_, lo, hi), (lo, hi)
+        assert c.verify_cell_kzg_proof_batch(C_, I_, L_, P_) is True
+        L2 = list(L_); L2[300] = cells[0][1]
+        assert c.verify_cell_kzg_proof_batch(C_, I_, L2, P_) is False
+        P2 = list(P_); P2[5] = proofs[1][7]
+        assert c.verify_cell_kzg_proof_batch(C_, I_, L_, P2) is False
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("name,case", sorted(vectors.load("recover_cells_and_kzg_proofs").items()))
 def test_recover_cells_and_kzg_proofs_vectors(ctx, name, case):
     i = case["input"]
