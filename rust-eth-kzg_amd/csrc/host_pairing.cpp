@@ -92,6 +92,54 @@ static inline Fp12 operator*(const Fp12& a, const Fp12& b) {  // 3 Fp6 mul
     Fp6 c1 = (a.c0 + a.c1) * (b.c0 + b.c1) - v0 - v1;
     return {v0 + mul_v(v1), c1};
 }
+// a^2 by the complex method: (a0 + a1 w)^2 = (a0 + a1)(a0 + v a1) - t - v t + 2 t w, t = a0 a1: 2 Fp6 multiplications instead of 3
+static inline Fp12 sqr12(const Fp12& a) {
+    const Fp6 t = a.c0 * a.c1;
+    const Fp6 c0 = (a.c0 + a.c1) * (a.c0 + mul_v(a.c1)) - t - mul_v(t);
+    return {c0, t + t};
+}
+// (x0 + x1 v + x2 v^2)(A + B v): 5 Fp2 multiplications
+static inline Fp6 mul6_by_01(const Fp6& x, const Fp2& A, const Fp2& B) {
+    const Fp2 aa = x.c0 * A, bb = x.c1 * B;
+    const Fp2 c0 = mul_xi((x.c1 + x.c2) * B - bb) + aa;
+    const Fp2 c2 = (x.c0 + x.c2) * A - aa + bb;
+    const Fp2 c1 = (x.c0 + x.c1) * (A + B) - aa - bb;
+    return {c0, c1, c2};
+}
+// (x0 + x1 v + x2 v^2)(y v), y in Fp: (xi x2 y, x0 y, x1 y)
+static inline Fp6 mul6_by_1fp(const Fp6& x, const Fp& y) { return {mul_xi(scale(x.c2, y)), scale(x.c0, y), scale(x.c1, y)}; }
+// f * (A + B v + y v w): the value of a line at a G1 point has three of its six Fp2 coefficients, one of them in Fp.
+// Karatsuba over w with the sparse factors: 5 + 5 Fp2 multiplications + 6 by an Fp, against 18 for a general product.
+static inline Fp12 mul12_by_line(const Fp12& f, const Fp2& A, const Fp2& B, const Fp& y) {
+    const Fp6 v0 = mul6_by_01(f.c0, A, B), v1 = mul6_by_1fp(f.c1, y);
+    const Fp2 By = {add(B.c0, y), B.c1};
+    const Fp6 c1 = mul6_by_01(f.c0 + f.c1, A, By) - v0 - v1;
+    return {v0 + mul_v(v1), c1};
+}
+// a^2 for a in the cyclotomic subgroup (a^(p^6+1) = 1, where every value sits after the easy part of the final
+// exponentiation): Granger-Scott squaring, three Fp4 squarings = 6 Fp2 multiplications instead of 18.
+static inline Fp12 cyc_sqr12(const Fp12& a) {
+    const Fp2 &r0 = a.c0.c0, &r4 = a.c0.c1, &r3 = a.c0.c2, &r2 = a.c1.c0, &r1 = a.c1.c1, &r5 = a.c1.c2;
+    auto fp4_sqr = [](const Fp2& x, const Fp2& y, Fp2& s0, Fp2& s1) {  // (x + y s)^2, s^2 = xi
+        const Fp2 t = x * y;
+        s0 = (x + y) * (mul_xi(y) + x) - t - mul_xi(t);
+        s1 = t + t;
+    };
+    Fp2 t0, t1, t2, t3, t4, t5;
+    fp4_sqr(r0, r1, t0, t1);
+    fp4_sqr(r2, r3, t2, t3);
+    fp4_sqr(r4, r5, t4, t5);
+    auto three_minus_two = [](const Fp2& t, const Fp2& z) { Fp2 d = t - z; return d + d + t; };  // 3 t - 2 z
+    auto three_plus_two = [](const Fp2& t, const Fp2& z) { Fp2 d = t + z; return d + d + t; };    // 3 t + 2 z
+    Fp12 r;
+    r.c0.c0 = three_minus_two(t0, r0);
+    r.c1.c1 = three_plus_two(t1, r1);
+    r.c1.c0 = three_plus_two(mul_xi(t5), r2);
+    r.c0.c2 = three_minus_two(t4, r3);
+    r.c0.c1 = three_minus_two(t2, r4);
+    r.c1.c2 = three_plus_two(t3, r5);
+    return r;
+}
 static inline Fp12 conj12(const Fp12& a) { return {a.c0, neg6(a.c1)}; }
 static Fp12 inv12(const Fp12& a) {
     Fp6 t = inv6(a.c0 * a.c0 - mul_v(a.c1 * a.c1));
@@ -195,7 +243,7 @@ static inline Fp12 line_value(const Line& l, const G1Affine& P) {
 static Fp12 pow_x(const Fp12& f) {  // f^x with x negative: conj(f^|x|) inside the cyclotomic subgroup
     Fp12 acc = f;
     for (int i = 62; i >= 0; i--) {
-        acc = acc * acc;
+        acc = cyc_sqr12(acc);
         if ((X_ABS >> i) & 1) acc = acc * f;
     }
     return conj12(acc);
@@ -205,16 +253,18 @@ bool product_is_one(const G1Affine* P, const G2Prepared* const* Q, int n) {
     init();
     Fp12 f = one12();
     size_t idx = 0;
-    for (int i = 62; i >= 0; i--) {
-        f = f * f;
+    auto lines = [&]() {
         for (int k = 0; k < n; k++)
-            if (!is_inf(P[k]) && !Q[k]->inf) f = f * line_value(Q[k]->lines[idx], P[k]);
+            if (!is_inf(P[k]) && !Q[k]->inf) {
+                const Line& l = Q[k]->lines[idx];
+                f = mul12_by_line(f, l.a, scale(l.b, P[k].x), P[k].y);
+            }
         idx++;
-        if ((X_ABS >> i) & 1) {
-            for (int k = 0; k < n; k++)
-                if (!is_inf(P[k]) && !Q[k]->inf) f = f * line_value(Q[k]->lines[idx], P[k]);
-            idx++;
-        }
+    };
+    for (int i = 62; i >= 0; i--) {
+        f = sqr12(f);
+        lines();
+        if ((X_ABS >> i) & 1) lines();
     }
     f = conj12(f);  // x < 0
     // easy part: f^((p^6-1)(p^2+1))

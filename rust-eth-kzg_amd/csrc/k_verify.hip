@@ -168,18 +168,37 @@ __global__ __launch_bounds__(64) void k_interp_cells(const Fr* __restrict__ eval
     const int i = threadIdx.x;
     for (int k = blockIdx.x; k < n; k += gridDim.x) coef[(size_t)k * 64 + i] = interp_cell(s, evals, cell_idx, w8192, inv64, k, i);
 }
-__global__ __launch_bounds__(64) void k_interp_sum(const Fr* __restrict__ coef, const Fr* __restrict__ rp_mont,
-                                                   Fr* __restrict__ partial, int n) {
-    const int i = threadIdx.x;
-    Fr acc = zero<FrParams>();
-    for (int k = blockIdx.x; k < n; k += gridDim.x) acc = add(acc, mul(coef[(size_t)k * 64 + i], rp_mont[k]));
-    partial[(size_t)blockIdx.x * 64 + i] = acc;
+// four waves per block, each a quarter of the block's cells; the block's sums meet in LDS
+__device__ __forceinline__ Fr fold4(uint32_t (*s)[8][64], const Fr& mine, int q, int i) {
+#pragma unroll
+    for (int l = 0; l < 8; l++) s[q][l][i] = mine.v[l];
+    __syncthreads();
+    Fr acc = mine;
+    if (q == 0)
+        for (int o = 1; o < 4; o++) {
+            Fr b;
+#pragma unroll
+            for (int l = 0; l < 8; l++) b.v[l] = s[o][l][i];
+            acc = add(acc, b);
+        }
+    return acc;
 }
-__global__ __launch_bounds__(64) void k_interp_fold(const Fr* __restrict__ partial, int nblocks, Fr* __restrict__ out_neg_canon) {
-    const int i = threadIdx.x;
+__global__ __launch_bounds__(256) void k_interp_sum(const Fr* __restrict__ coef, const Fr* __restrict__ rp_mont,
+                                                    Fr* __restrict__ partial, int n) {
+    __shared__ uint32_t s[4][8][64];
+    const int q = threadIdx.x >> 6, i = threadIdx.x & 63;
     Fr acc = zero<FrParams>();
-    for (int b = 0; b < nblocks; b++) acc = add(acc, partial[(size_t)b * 64 + i]);
-    out_neg_canon[i] = from_mont(neg(acc));  // the interpolation commitment enters the pairing input with a minus sign
+    for (int k = blockIdx.x * 4 + q; k < n; k += gridDim.x * 4) acc = add(acc, mul(coef[(size_t)k * 64 + i], rp_mont[k]));
+    acc = fold4(s, acc, q, i);
+    if (q == 0) partial[(size_t)blockIdx.x * 64 + i] = acc;
+}
+__global__ __launch_bounds__(256) void k_interp_fold(const Fr* __restrict__ partial, int nblocks, Fr* __restrict__ out_neg_canon) {
+    __shared__ uint32_t s[4][8][64];
+    const int q = threadIdx.x >> 6, i = threadIdx.x & 63;
+    Fr acc = zero<FrParams>();
+    for (int b = q; b < nblocks; b += 4) acc = add(acc, partial[(size_t)b * 64 + i]);
+    acc = fold4(s, acc, q, i);
+    if (q == 0) out_neg_canon[i] = from_mont(neg(acc));  // the interpolation commitment enters the pairing input with a minus sign
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -316,8 +335,8 @@ __global__ __launch_bounds__(64) void k_pip_final(const JacQ* __restrict__ wsum,
 // the 16 byte-shifted copies 2^(8p) P and their phi images (32 affine points, one inversion per input point) while the
 // host hashes.  A 128-bit half scalar is then 16 independent bytes, each paired with its own copy, and the whole lincomb
 // is ONE window: 32 n (point, byte) items into 255 buckets.  After the challenge: split, a three-kernel counting sort,
-// one wave per bucket (64 lanes share a bucket's ~130 items and fold through LDS), the suffix-scan of k_pip_window, and a
-// conversion to affine: no doubling at all.  3.0 -> 0.8 ms of GPU time behind the hash.
+// one wave per bucket (128 lanes share a bucket's ~1040 items and fold through LDS), the suffix-scan of k_pip_window; the host
+// normalises the two sums: no doubling at all.  3.0 -> 0.7 ms of GPU time behind the hash.
 //   pts32[(phi * 16 + p) * n_max + i] = phi^phi(2^(8p) P_i)
 constexpr int PS_P = 16, PS_SLICES = 64;
 __global__ __launch_bounds__(64) void k_pip_shift(const G1Affine* __restrict__ in, AffQ* __restrict__ pts32, JacQ* __restrict__ jac,
@@ -418,11 +437,12 @@ __global__ __launch_bounds__(256) void k_ps_scatter(PipJob j0, PipJob j1, int n_
         for (int p = 0; p < PS_P; p++) out[atomicAdd(&cur[ps_byte(v, p)], 1)] = (phi * PS_P + p) * n_max + i;
     }
 }
-// one wave per bucket: lane l adds the bucket's items l, l + 64, ... into an XYZZ sum (the next point is requested one
-// addition ahead), then the 64 partial sums fold through LDS.  buckets: [job][256] JacQ
-__global__ __launch_bounds__(64) void k_ps_buckets(const AffQ* __restrict__ pts32, const int* __restrict__ items,
-                                                   const int* __restrict__ start, int n_max, JacQ* __restrict__ buckets) {
-    __shared__ JacQ red[64];
+// two waves per bucket: lane l adds the bucket's items l, l + 128, ... into an XYZZ sum (the next point is requested one
+// addition ahead), then the 128 partial sums fold through LDS.  buckets: [job][256] JacQ
+constexpr int PS_LANES = 128;  // 256 buckets x 2 jobs x 2 waves = one wave on every SIMD of the chip
+__global__ __launch_bounds__(PS_LANES) void k_ps_buckets(const AffQ* __restrict__ pts32, const int* __restrict__ items,
+                                                         const int* __restrict__ start, int n_max, JacQ* __restrict__ buckets) {
+    __shared__ JacQ red[PS_LANES];
     const int b = blockIdx.x, job = blockIdx.y, l = threadIdx.x;
     XyzzQ acc = xyzz_inf();
     if (b) {
@@ -431,15 +451,15 @@ __global__ __launch_bounds__(64) void k_ps_buckets(const AffQ* __restrict__ pts3
         int p = start[job * (PIP_B + 1) + b] + l;
         AffQ cur;
         if (p < end) cur = pts32[it[p]];
-        for (; p < end; p += 64) {
+        for (; p < end; p += PS_LANES) {
             AffQ nxt = cur;
-            if (p + 64 < end) nxt = pts32[it[p + 64]];
+            if (p + PS_LANES < end) nxt = pts32[it[p + PS_LANES]];
             acc = add_mixed(acc, cur);
             cur = nxt;
         }
     }
     JacQ sum = to_jacq(acc);
-    for (int span = 32; span >= 1; span >>= 1) {
+    for (int span = PS_LANES / 2; span >= 1; span >>= 1) {
         red[l] = sum;
         __syncthreads();
         if (l < span) sum = add(sum, red[l + span]);
@@ -596,14 +616,14 @@ void verify_weights(const void* rp_mont, const int* row, void* weights, int n, i
 void interp(const void* evals, const int* cell_idx, const void* rp_mont, const void* w8192, const Fr8& inv64, void* partial,
             int nblocks, void* out_neg_canon, int n, hipStream_t st) {
     k_interp<<<nblocks, 64, 0, st>>>((const Fr*)evals, cell_idx, (const Fr*)rp_mont, (const Fr*)w8192, as_fr2(inv64), (Fr*)partial, n);
-    k_interp_fold<<<1, 64, 0, st>>>((const Fr*)partial, nblocks, (Fr*)out_neg_canon);
+    k_interp_fold<<<1, 256, 0, st>>>((const Fr*)partial, nblocks, (Fr*)out_neg_canon);
 }
 void interp_cells(const void* evals, const int* cell_idx, const void* w8192, const Fr8& inv64, void* coef, int n, hipStream_t st) {
     k_interp_cells<<<n < 1024 ? n : 1024, 64, 0, st>>>((const Fr*)evals, cell_idx, (const Fr*)w8192, as_fr2(inv64), (Fr*)coef, n);
 }
 void interp_sum(const void* coef, const void* rp_mont, void* partial, int nblocks, void* out_neg_canon, int n, hipStream_t st) {
-    k_interp_sum<<<nblocks, 64, 0, st>>>((const Fr*)coef, (const Fr*)rp_mont, (Fr*)partial, n);
-    k_interp_fold<<<1, 64, 0, st>>>((const Fr*)partial, nblocks, (Fr*)out_neg_canon);
+    k_interp_sum<<<nblocks, 256, 0, st>>>((const Fr*)coef, (const Fr*)rp_mont, (Fr*)partial, n);
+    k_interp_fold<<<1, 256, 0, st>>>((const Fr*)partial, nblocks, (Fr*)out_neg_canon);
 }
 size_t pip_workspace_bytes(int n_max) {
     return (size_t)2 * n_max * SIZEOF_AFFQ + (size_t)2 * 2 * n_max * sizeof(Half128) + (size_t)2 * PIP_W * 2 * n_max * sizeof(int) +
@@ -664,7 +684,7 @@ void pip_shift_prepare(const void* points, int n_pts, int n_max, void* workspace
     const PsLayout L = ps_layout(workspace, n_max);
     k_pip_shift<<<(n_pts + 63) / 64, 64, 0, st>>>((const G1Affine*)points, L.pts32, L.jac, L.pre, n_pts, n_max, fq_from_fp(b384));
 }
-void msm_pippenger2_shifted(const void* sc0, int n0, const void* sc1, int n1, int n_max, void* workspace, void* out_affine2,
+void msm_pippenger2_shifted(const void* sc0, int n0, const void* sc1, int n1, int n_max, void* workspace, void* out_jacq2,
                             hipStream_t st) {
     const PsLayout L = ps_layout(workspace, n_max);
     PipJob j0{(const Fr*)sc0, n0}, j1{(const Fr*)sc1, n1};
@@ -672,9 +692,10 @@ void msm_pippenger2_shifted(const void* sc0, int n0, const void* sc1, int n1, in
     k_ps_hist<<<dim3(PS_SLICES, 2), 256, 0, st>>>(j0, j1, n_max, L.halves, L.hist);
     k_ps_scan<<<2, 256, 0, st>>>(L.hist, L.start);
     k_ps_scatter<<<dim3(PS_SLICES, 2), 256, 0, st>>>(j0, j1, n_max, L.halves, L.hist, L.items);
-    k_ps_buckets<<<dim3(PIP_B, 2), 64, 0, st>>>(L.pts32, L.items, L.start, n_max, L.buckets);
-    k_pip_window<<<dim3(1, 2), 256, 0, st>>>(L.buckets, L.wsum);
-    k_pip_final<<<2, 64, 0, st>>>(L.wsum, (G1Affine*)out_affine2, 1);
+    k_ps_buckets<<<dim3(PIP_B, 2), PS_LANES, 0, st>>>(L.pts32, L.items, L.start, n_max, L.buckets);
+    // the two sums leave in Jacobian form: the caller's host thread normalises them (one 4 us inversion each) instead of a
+    // single GPU lane (0.17 ms)
+    k_pip_window<<<dim3(1, 2), 256, 0, st>>>(L.buckets, (JacQ*)out_jacq2);
 }
 void rec_vanishing_poly(const uint32_t* present, const void* w8192, void* zp, int* deg, int R, hipStream_t st) {
     k_rec_vanishing_poly<<<R, 64, 0, st>>>(present, (const Fr*)w8192, (Fr*)zp, deg, R);

@@ -98,8 +98,8 @@ void interp_sum(const void* coef, const void* rp_mont, void* partial, int nblock
 // large verification batches: byte-shifted point copies built before the challenge is known (k_verify.hip)
 size_t pip_shift_workspace_bytes(int n_max);
 void pip_shift_prepare(const void* points, int n_pts, int n_max, void* workspace, const Fp12w& beta, hipStream_t st);
-void msm_pippenger2_shifted(const void* sc0, int n0, const void* sc1, int n1, int n_max, void* workspace, void* out_affine2,
-                            hipStream_t st);
+void msm_pippenger2_shifted(const void* sc0, int n0, const void* sc1, int n1, int n_max, void* workspace, void* out_jacq2,
+                            hipStream_t st);  // out: two JacQ (SIZEOF_JACQ each)
 size_t pip_workspace_bytes(int n_max);
 void copy_affine(const void* src, void* dst, int n, hipStream_t st);
 void msm_pippenger2(const void* points, const void* sc0, int n0, const void* sc1, int n1, void* workspace, void* out_affine2,

@@ -7,7 +7,7 @@
 // Work split: all G1 / Fr batch arithmetic on the GPU; the sequential SHA-256 transcript and the
 // constant-size 2-pairing check on the host.
 #include "engine.hpp"
-#include "curve.hpp"
+#include "curve29.hpp"
 #include "host_pairing.hpp"
 #include "launch.hpp"
 #include "sha256.hpp"
@@ -163,7 +163,7 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
         const bool shifted = n >= pip_shift_min_;
         const size_t off_ws = o; o += up(shifted ? launch::pip_shift_workspace_bytes((int)npts) : launch::pip_workspace_bytes((int)npts));
         const size_t off_coef = o; o += shifted ? up((size_t)n * CELL_LEN * sizeof(Fr)) : 0;
-        const size_t off_out = o; o += 256;
+        const size_t off_out = o; o += 512;  // two affine points, or two Jacobian sums (shifted form)
         if (o > v_dev_cap_) {
             if (v_dev_) HIPCK(hipFree(v_dev_));
             v_dev_ = nullptr;
@@ -208,7 +208,7 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
                 memset(stc, 0xff, ((size_t)m + n + 1) * sizeof(int));
                 HIPCK(hipMemsetAsync(d_stc.p, 0xff, (size_t)m * sizeof(int), st));
                 HIPCK(hipMemsetAsync(d_stp.p, 0xff, (size_t)n * sizeof(int), st));
-                HIPCK(hipMemsetAsync(db + off_out, 0xff, 2 * sizeof(G1Affine), st));
+                HIPCK(hipMemsetAsync(db + off_out, 0xff, 512, st));
                 HIPCK(hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, st));
                 HIPCK(hipMemsetAsync(d_ste.p, 0, sizeof(int), st));
                 // deserialisation with on-curve + subgroup checks (serialization/src/lib.rs:69-99), on the GPU
@@ -272,10 +272,20 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
         // ---- the four lincombs (verifier.rs:186,200,224,235) as two bucket MSMs over the shared point array:
         //   out[0] = sum r^k pi_k;   out[1] = sum r^k h^64 pi_k + sum w_row C_row - commit(interpolation poly)
         View d_ws{db + off_ws}, d_out{db + off_out};
-        if (shifted) launch::msm_pippenger2_shifted(d_s1.p, n, d_sB.p, n + m + 64, (int)npts, d_ws.p, d_out.p, st);
-        else launch::msm_pippenger2(d_pts.p, d_s1.p, n, d_sB.p, n + m + 64, d_ws.p, d_out.p, beta_, st);
-        HIPCK(hipMemcpyAsync(out, d_out.p, 2 * sizeof(G1Affine), hipMemcpyDeviceToHost, st));
-        SYNC_CHECKED(st);
+        if (shifted) {
+            launch::msm_pippenger2_shifted(d_s1.p, n, d_sB.p, n + m + 64, (int)npts, d_ws.p, d_out.p, st);
+            JacQ sums[2];
+            HIPCK(hipMemcpyAsync(sums, d_out.p, sizeof sums, hipMemcpyDeviceToHost, st));
+            SYNC_CHECKED(st);
+            for (int i = 0; i < 2; i++) {
+                if (sums[i].x.v[0] == 0xffffffffu && sums[i].z.v[0] == 0xffffffffu) throw std::runtime_error("verification MSM left no result");
+                out[i] = to_affine(jac_from_jacq(sums[i]));
+            }
+        } else {
+            launch::msm_pippenger2(d_pts.p, d_s1.p, n, d_sB.p, n + m + 64, d_ws.p, d_out.p, beta_, st);
+            HIPCK(hipMemcpyAsync(out, d_out.p, 2 * sizeof(G1Affine), hipMemcpyDeviceToHost, st));
+            SYNC_CHECKED(st);
+        }
         for (int i = 0; i < 2; i++)  // the poison pattern (or anything else that is not a reduced coordinate) is a device failure
             if (out[i].x.v[11] > FpParams::MOD[11] || out[i].y.v[11] > FpParams::MOD[11]) throw std::runtime_error("verification MSM left no result");
         lap("scalars+interp+lincombs (GPU)");

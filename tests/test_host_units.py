@@ -11,12 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "rust-eth-kzg_amd", "csrc")
 
 
-def _build_and_run(tmp_path, name):
+def _build_and_run(tmp_path, name, *args):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     exe = str(tmp_path / name)
     subprocess.check_call([hipcc, "-O2", "-std=c++17", "-x", "hip", "--cuda-host-only", "-I", CSRC,
                            os.path.join(ROOT, "tests", "c", name + ".cpp"), "-o", exe])
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, *args], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     return out.stdout
 
@@ -60,3 +60,12 @@ def test_glv_split_is_balanced_and_exact(tmp_path):
     branch points of the two balancing steps."""
     out = _build_and_run(tmp_path, "test_glv")
     assert "0 mismatches" in out
+
+
+@pytest.mark.timeout(600)
+def test_host_pairing_building_blocks_and_bilinearity(tmp_path):
+    """csrc/host_pairing.cpp: sparse line multiplication, complex and cyclotomic (Granger-Scott) squaring against the
+    general Fp12 product on random values; the pairing check on multiples of the trusted setup's [1]_1, [tau]_1 against
+    [1]_2, [tau]_2: e(a [tau]_1, [1]_2) e(-a [1]_1, [tau]_2) = 1, the unbalanced pair is not, identities are."""
+    out = _build_and_run(tmp_path, "test_pairing", os.path.join(ROOT, "rust-eth-kzg_amd", "data", "trusted_setup_4096.bin"))
+    assert "fp12 building blocks: 0 mismatches" in out and "pairing checks: 0 mismatches" in out
