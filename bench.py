@@ -284,6 +284,26 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, t_ctx_cold):
         assert st == [0] * nb and torch.equal(d_oc, d_c) and torch.equal(d_op, d_p), "recovery does not reproduce the prover's output"
         out[key] = {"ms": round(_median(ts) * 1e3, 2), "blobs_per_s": round(nb / _median(ts)), "blobs": nb, "form": "device-resident"}
     recover_one = (list(range(0, CELLS, 2)), [cells[BYTES_PER_CELL * k:BYTES_PER_CELL * (k + 1)] for k in range(0, CELLS, 2)])
+    # the reference's own criterion shapes (benchmark-mt.rs:51-101): one blob's 128 cells against one commitment, and the
+    # worst-case recovery of one blob from its first 64 cells -- both through the reference's C entry points, latency per call
+    run_v1 = ctx.prepare_verify_cell_kzg_proof_batch(C_[:CELLS], I_[:CELLS], L_[:CELLS], P_[:CELLS])
+    ts = []
+    for it in range(12):
+        t0 = time.perf_counter()
+        ok = run_v1()
+        if it >= 2:
+            ts.append(time.perf_counter() - t0)
+        assert ok
+    out["reference_bench_verify_128_cells_one_commitment"] = {"ms": round(_median(ts) * 1e3, 3), "entry": "eth_kzg_verify_cell_kzg_proof_batch"}
+    half_idx, half_cells = list(range(CELLS // 2)), L_[:CELLS // 2]
+    ts = []
+    for it in range(9):
+        t0 = time.perf_counter()
+        rc, rp = ctx.recover_cells_and_kzg_proofs(half_idx, half_cells)
+        if it >= 2:
+            ts.append(time.perf_counter() - t0)
+    assert rc == L_[:CELLS] and rp == P_[:CELLS], "single-blob recovery does not reproduce the prover's output"
+    out["reference_bench_recover_one_blob_half_missing"] = {"ms": round(_median(ts) * 1e3, 3), "entry": "eth_kzg_recover_cells_and_kzg_proofs (ctypes wrapper included)"}
     # context creation (the reference's "Initialize context" bench): cold = first context of the process (measured by the
     # caller), warm = another context while one is alive (tables shared), fresh = after every context was closed
     t0 = time.perf_counter()

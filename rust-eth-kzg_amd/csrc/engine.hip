@@ -271,6 +271,9 @@ Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14
         }
     }
     HIPCK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    HIPCK(hipStreamCreateWithFlags(&v_side_, hipStreamNonBlocking));
+    HIPCK(hipEventCreateWithFlags(&v_decoded_, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&v_checked_, hipEventDisableTiming));
     for (Work& w : work_) {
         HIPCK(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
         HIPCK(hipEventCreateWithFlags(&w.ev_in, hipEventDisableTiming));
@@ -322,6 +325,9 @@ Engine::~Engine() {
     }
     if (v_dev_) hipFree(v_dev_);
     if (v_pin_) hipHostFree(v_pin_);
+    if (v_side_) hipStreamDestroy(v_side_);
+    if (v_decoded_) hipEventDestroy(v_decoded_);
+    if (v_checked_) hipEventDestroy(v_checked_);
     if (stream_) hipStreamDestroy(stream_);
 }
 

@@ -261,12 +261,15 @@ private:
     size_t v_dev_cap_ = 0;
     uint8_t* v_pin_ = nullptr;
     size_t v_pin_cap_ = 0;
+    hipStream_t v_side_ = nullptr;  // verification: the subgroup tests run here next to the point shifts on stream_
+    hipEvent_t v_decoded_ = nullptr, v_checked_ = nullptr;
 
     // small-batch circulant form of the two G1 transforms: term list, doubling tables (allocated on first use)
     void *d_circ_terms_ = nullptr;
-    // verification batches of at least this many cells build byte-shifted point copies behind the transcript hash
-    // (k_verify.hip: k_pip_shift); below it the hash is too short to hide the 1.3 ms that costs.  ETH_KZG_AMD_PIP_SHIFT_MIN
-    int pip_shift_min_ = 2048;
+    // verification batches of at least this many cells build byte-shifted point copies before the challenge is known
+    // (k_verify.hip: k_pip_shift): behind the transcript hash for large batches, next to the subgroup tests (second stream) for
+    // small ones.  ETH_KZG_AMD_PIP_SHIFT_MIN raises it (tests: the windowed form as the cross-check)
+    int pip_shift_min_ = 1;
     int circ_T_ = 0, circ_per_lane_ = 0, circ_max_ = 8;  // measured cross-over with the compiled linear map (2.8 ms flat up to 64 blobs): 8 blobs 2.5 vs 2.9 ms, 12 blobs 3.2 vs 2.9
     Fr8 seg_shift_[3];  // 2^32, 2^64, 2^96 in Montgomery form
     // the two G1 transforms as one compiled linear map (g1_linmap.hpp, k_g1slp.hip): launches, constants, slot arena

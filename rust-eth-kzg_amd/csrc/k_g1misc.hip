@@ -77,6 +77,17 @@ __device__ __forceinline__ JacQ mul_by_z_abs_q(const JacQ& p) {
     }
     return acc;
 }
+// Scott's test for a curve point P != O: [z^2]P - P == phi(P) = (beta x, y)
+__device__ __forceinline__ bool g1_in_subgroup_q(const AffQ& pa, const Fq<1>& beta) {
+    const JacQ p = to_jacq(pa);
+    const JacQ q = mul_by_z_abs_q(mul_by_z_abs_q(p));
+    const JacQ r = add_mixed(q, pa, true);
+    if (is_inf(r)) return false;
+    const Fq<2> zz = sqr(r.z);
+    if (!is_zero_slow(sub(r.x, mul(mul(pa.x, beta), zz)))) return false;
+    if (!is_zero_slow(sub(r.y, mul(pa.y, mul(zz, r.z))))) return false;
+    return true;
+}
 // rc 0 ok (out = affine Montgomery-384 point), 1 bad encoding / x >= p / not on the curve, 2 not in the subgroup
 __device__ __forceinline__ int g1_decompress_q(G1Affine& out, const uint8_t* in, bool subgroup_check, const Fq<1>& beta) {
     const uint8_t b0 = in[0];
@@ -107,18 +118,10 @@ __device__ __forceinline__ int g1_decompress_q(G1Affine& out, const uint8_t* in,
     out.x = xm;
     out.y = ym;
     if (!subgroup_check) return 0;
-    // Scott's test: [z^2]P - P == phi(P) = (beta x, y)
     AffQ pa;
     pa.x = xq;
     pa.y = fq_from_fp(ym);
-    const JacQ p = to_jacq(pa);
-    const JacQ q = mul_by_z_abs_q(mul_by_z_abs_q(p));
-    const JacQ r = add_mixed(q, pa, true);
-    if (is_inf(r)) return 2;
-    const Fq<2> zz = sqr(r.z);
-    if (!is_zero_slow(sub(r.x, mul(mul(pa.x, beta), zz)))) return 2;
-    if (!is_zero_slow(sub(r.y, mul(pa.y, mul(zz, r.z))))) return 2;
-    return 0;
+    return g1_in_subgroup_q(pa, beta) ? 0 : 2;
 }
 
 // Decompression with validation: thread per point, one wave per block (launch bounds tell the compiler it may use the
@@ -140,6 +143,21 @@ __global__ __launch_bounds__(64) void k_g1_decompress(const uint8_t* __restrict_
     if (rc) a = aff_inf();
     (second ? status1 : status0)[i] = rc;
     (second ? out1 : out0)[i] = a;
+}
+// The subgroup test on its own, for points k_g1_decompress has decoded with subgroup_check = 0: a verification runs it on a
+// second stream next to the work that only needs the coordinates (k_verify.hip: k_pip_shift), because each of the two is
+// a millisecond-long dependent chain of doublings whatever the number of points.  status: 0 -> 0 or 2; others are kept.
+__global__ __launch_bounds__(64) void k_g1_subgroup(const G1Affine* __restrict__ pts0, int* __restrict__ status0, int n0,
+                                                    const G1Affine* __restrict__ pts1, int* __restrict__ status1, int n1, Fq<1> beta_q) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n0 + n1) return;
+    const bool second = i >= n0;
+    if (second) i -= n0;
+    int* st = second ? status1 : status0;
+    if (st[i] != 0) return;
+    const G1Affine a = (second ? pts1 : pts0)[i];
+    if (is_inf(a)) return;
+    if (!g1_in_subgroup_q(affq_from_affine(a), beta_q)) st[i] = 2;
 }
 // The same decoding on the saturated reference forms, for the parity tests only: mode 2 = definitional [r]P == O,
 // mode 3 = the saturated endomorphism test.
@@ -209,6 +227,18 @@ void g1_decompress2(const uint8_t* in0, void* out0, int* status0, int n0, const 
     Fp b;
     for (int i = 0; i < 12; i++) b.v[i] = beta.v[i];
     k_g1_decompress<<<(n0 + n1 + 63) / 64, 64, 0, st>>>(in0, (G1Affine*)out0, status0, n0, in1, (G1Affine*)out1, status1, n1, 1, fq_from_fp(b));
+}
+// the two halves of g1_decompress2 as separate launches (decode + on-curve; subgroup)
+void g1_decode2(const uint8_t* in0, void* out0, int* status0, int n0, const uint8_t* in1, void* out1, int* status1, int n1,
+                const Fp12w& beta, hipStream_t st) {
+    Fp b;
+    for (int i = 0; i < 12; i++) b.v[i] = beta.v[i];
+    k_g1_decompress<<<(n0 + n1 + 63) / 64, 64, 0, st>>>(in0, (G1Affine*)out0, status0, n0, in1, (G1Affine*)out1, status1, n1, 0, fq_from_fp(b));
+}
+void g1_subgroup2(const void* pts0, int* status0, int n0, const void* pts1, int* status1, int n1, const Fp12w& beta, hipStream_t st) {
+    Fp b;
+    for (int i = 0; i < 12; i++) b.v[i] = beta.v[i];
+    k_g1_subgroup<<<(n0 + n1 + 63) / 64, 64, 0, st>>>((const G1Affine*)pts0, status0, n0, (const G1Affine*)pts1, status1, n1, fq_from_fp(b));
 }
 void fk20_srs_vectors(const void* srs, void* X, hipStream_t st) { k_fk20_srs_vectors<<<128 * 64 / 256, 256, 0, st>>>((const G1Affine*)srs, (JacQ*)X); }
 void fk20_gather_bases(const void* X, void* bases, hipStream_t st) { k_fk20_gather_bases<<<128 * 64 / 256, 256, 0, st>>>((const JacQ*)X, (G1Affine*)bases); }

@@ -68,6 +68,10 @@ void g1_decompress(const uint8_t* in, void* out /*G1Affine*/, int* status, int n
 // two segments in one launch, production checks (on curve + subgroup)
 void g1_decompress2(const uint8_t* in0, void* out0, int* status0, int n0, const uint8_t* in1, void* out1, int* status1, int n1,
                     const Fp12w& beta, hipStream_t st);
+// its two halves as separate launches: decode + on-curve test (status 0 / 1), then the subgroup test of the decoded points (0 -> 0 / 2)
+void g1_decode2(const uint8_t* in0, void* out0, int* status0, int n0, const uint8_t* in1, void* out1, int* status1, int n1,
+                const Fp12w& beta, hipStream_t st);
+void g1_subgroup2(const void* pts0, int* status0, int n0, const void* pts1, int* status1, int n1, const Fp12w& beta, hipStream_t st);
 void fk20_srs_vectors(const void* srs, void* X, hipStream_t st);
 void fk20_gather_bases(const void* X, void* bases, hipStream_t st);
 void test_load_points(const uint8_t* in, void* X, int n_lanes, int stride, hipStream_t st);

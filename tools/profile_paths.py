@@ -2,6 +2,8 @@
   verify   BASELINE config 3: verify_cell_kzg_proof_batch, 64 blobs x 128 cells, 5 calls
   recover  BASELINE config 5: recover_cells_and_kzg_proofs, 256 blobs at 50 % erasure (even cells), device-resident form, 3 calls
   4844     the EIP-4844 single-point operations, 5 calls each
+  single   the reference's own criterion shapes (benchmark-mt.rs:36-101): one blob through compute, verify (128 cells, one
+           commitment) and worst-case recovery (first 64 cells), 7 calls each
 Prints one JSON line with host-side timings of the same calls."""
 import importlib
 import json
@@ -20,7 +22,7 @@ def main():
     import torch
     what = sys.argv[1] if len(sys.argv) > 1 else "verify"
     ctx = kzg.DASContext(True)
-    nb = {"verify": 64, "recover": 256, "4844": 4}[what]
+    nb = {"verify": 64, "recover": 256, "4844": 4, "single": 1}[what]
     rng = np.random.RandomState(7)
     a = rng.randint(0, 256, size=(nb, 4096, 32), dtype=np.uint8)
     a[:, :, 0] &= 0x3F
@@ -61,6 +63,21 @@ def main():
             assert st == [0] * nb
         assert torch.equal(d_oc, d_cells) and torch.equal(d_op, d_proofs)
         out.update(blobs=nb, recover_ms=[round(x * 1e3, 2) for x in ts])
+    elif what == "single":
+        blob = a[0].tobytes()
+        comm = ctx.blob_to_kzg_commitment(blob)
+        cells, proofs = ctx.compute_cells_and_kzg_proofs(blob)
+        run_v = ctx.prepare_verify_cell_kzg_proof_batch([comm] * 128, list(range(128)), cells, proofs)
+        t = {}
+        for name, fn in (("compute_cells_and_kzg_proofs", lambda: ctx.compute_cells_and_kzg_proofs(blob)),
+                         ("verify_128_cells_one_commitment", run_v),
+                         ("recover_first_64_cells", lambda: ctx.recover_cells_and_kzg_proofs(list(range(64)), cells[:64]))):
+            ts = []
+            for _ in range(7):
+                t0 = time.perf_counter(); r = fn(); ts.append(time.perf_counter() - t0)
+            t[name] = round(min(ts) * 1e3, 3)
+        assert run_v() and ctx.recover_cells_and_kzg_proofs(list(range(64)), cells[:64]) == (cells, proofs)
+        out.update(t)
     else:
         blob = a[0].tobytes()
         z = (12345).to_bytes(32, "big")
