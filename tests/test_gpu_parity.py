@@ -19,6 +19,10 @@ kzg = importlib.import_module("rust-eth-kzg_amd")
 
 @pytest.fixture(scope="module")
 def ctx():
+    # the torch wheel carries its own HIP runtime: when a test of this module brings torch in, it must have been initialised
+    # before the engine's (system) runtime, or it finds no GPU -- same order as bench.py and tests/test_gpu_fullsize.py
+    import torch
+    torch.cuda.init()
     c = kzg.DASContext(use_precomp=True)
     yield c
     c.close()
