@@ -78,6 +78,7 @@ struct Work {
     int* h_status = nullptr;
     hipStream_t stream = nullptr, copy = nullptr;
     hipEvent_t ev_in = nullptr, ev_cells = nullptr, ev_cells_host = nullptr, ev_done = nullptr;
+    hipEvent_t ev_coeffs = nullptr, ev_side = nullptr;  // small batches: coefficients ready / cells written on the second stream
     std::vector<hipEvent_t> sub_events;  // per sub-batch of a host-pointer call: [2i] cells computed, [2i+1] cells on the host
 };
 // A few helper threads for the host-side memcpy work of the host-pointer entry points (gathering blobs into pinned
