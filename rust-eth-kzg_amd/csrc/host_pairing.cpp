@@ -234,12 +234,6 @@ G2Prepared prepare(const G2Affine& q) {
     return pr;
 }
 
-static inline Fp12 line_value(const Line& l, const G1Affine& P) {
-    Fp12 r;
-    r.c0 = {l.a, scale(l.b, P.x), zero2()};
-    r.c1 = {zero2(), {P.y, fz()}, zero2()};
-    return r;
-}
 static Fp12 pow_x(const Fp12& f) {  // f^x with x negative: conj(f^|x|) inside the cyclotomic subgroup
     Fp12 acc = f;
     for (int i = 62; i >= 0; i--) {

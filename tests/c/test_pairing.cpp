@@ -20,6 +20,13 @@ static Fp rfp() {  // any residue below 2^380 < p, read as a Montgomery form
 static Fp2 rfp2() { return {rfp(), rfp()}; }
 static Fp6 rfp6() { return {rfp2(), rfp2(), rfp2()}; }
 static Fp12 rfp12() { return {rfp6(), rfp6()}; }
+// the value of a line at P as a general Fp12 element: l(P) * w^3 = a + (b * xP) v + yP (v w)
+static Fp12 line_value(const Line& l, const G1Affine& P) {
+    Fp12 r;
+    r.c0 = {l.a, scale(l.b, P.x), zero2()};
+    r.c1 = {zero2(), {P.y, fz()}, zero2()};
+    return r;
+}
 static bool eq12(const Fp12& a, const Fp12& b) {
     const Fp2 *x = &a.c0.c0, *y = &b.c0.c0;
     for (int i = 0; i < 6; i++)
