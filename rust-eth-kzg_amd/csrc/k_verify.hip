@@ -310,17 +310,16 @@ __global__ __launch_bounds__(256) void k_pip_window(const JacQ* __restrict__ buc
     }
     if (t == 0) wsum[job * W + w] = T[0];
 }
-// W windows (a power of two <= 16); W = 1 is the byte-shifted form below: nothing to double or fold
-__global__ __launch_bounds__(64) void k_pip_final(const JacQ* __restrict__ wsum, G1Affine* __restrict__ out_affine, int W) {
+__global__ __launch_bounds__(64) void k_pip_final(const JacQ* __restrict__ wsum, G1Affine* __restrict__ out_affine) {
     __shared__ JacQ T[PIP_W];
     const int job = blockIdx.x, t = threadIdx.x;
-    if (t < W) {
-        JacQ acc = wsum[job * W + t];
+    if (t < PIP_W) {
+        JacQ acc = wsum[job * PIP_W + t];
         for (int k = 0; k < PIP_C * t; k++) acc = dbl(acc);
         T[t] = acc;
     }
     __syncthreads();
-    for (int span = W / 2; span >= 1; span >>= 1) {
+    for (int span = PIP_W / 2; span >= 1; span >>= 1) {
         if (t < span) T[t] = add(T[t], T[t + span]);
         __syncthreads();
     }
@@ -328,12 +327,12 @@ __global__ __launch_bounds__(64) void k_pip_final(const JacQ* __restrict__ wsum,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Large batches (config 3: 8192 cells): the same two lincombs with the points SHIFTED AHEAD OF TIME.  The challenge r --
+// verify_cell_kzg_proof_batch: the same two lincombs with the points SHIFTED AHEAD OF TIME.  The challenge r --
 // and with it every scalar -- is known only after the host has hashed the whole transcript (17.6 MB, 7 ms), while the
 // points are there as soon as they are decompressed.  So the 120 dependent doublings that the fold of 16 windows needs
 // (k_pip_final above: 1.1 ms with one busy lane) move in front of the challenge: k_pip_shift builds, for every point,
 // the 16 byte-shifted copies 2^(8p) P and their phi images (32 affine points, one inversion per input point) while the
-// host hashes.  A 128-bit half scalar is then 16 independent bytes, each paired with its own copy, and the whole lincomb
+// host hashes (small batches: next to the subgroup tests, which are as long a chain, on a second stream).  A 128-bit half scalar is then 16 independent bytes, each paired with its own copy, and the whole lincomb
 // is ONE window: 32 n (point, byte) items into 255 buckets.  After the challenge: split, a three-kernel counting sort,
 // one wave per bucket (128 lanes share a bucket's ~1040 items and fold through LDS), the suffix-scan of k_pip_window; the host
 // normalises the two sums: no doubling at all.  3.0 -> 0.7 ms of GPU time behind the hash.
@@ -645,7 +644,7 @@ void msm_pippenger2(const void* points, const void* sc0, int n0, const void* sc1
     k_pip_sort<<<dim3(PIP_W, 2), 256, 0, st>>>(j0, j1, n_max, halves, idx, start);
     k_pip_buckets<<<dim3(PIP_W * PIP_B / 64, 2), 64, 0, st>>>(pts, idx, start, n_max, buckets);
     k_pip_window<<<dim3(PIP_W, 2), 256, 0, st>>>(buckets, wsum);
-    k_pip_final<<<2, 64, 0, st>>>(wsum, (G1Affine*)out_affine2, PIP_W);
+    k_pip_final<<<2, 64, 0, st>>>(wsum, (G1Affine*)out_affine2);
 }
 // byte-shifted form: workspace = [pts32 | jac | pre | halves | items | hist | start | buckets | wsum]
 struct PsLayout {
