@@ -327,15 +327,16 @@ __global__ __launch_bounds__(64) void k_pip_final(const JacQ* __restrict__ wsum,
 }
 
 // ------------------------------------------------------------------------------------------------
-// verify_cell_kzg_proof_batch: the same two lincombs with the points SHIFTED AHEAD OF TIME.  The challenge r --
-// and with it every scalar -- is known only after the host has hashed the whole transcript (17.6 MB, 7 ms), while the
-// points are there as soon as they are decompressed.  So the 120 dependent doublings that the fold of 16 windows needs
+// verify_cell_kzg_proof_batch: the same two lincombs with the points SHIFTED AHEAD OF TIME.  The challenge r -- and with
+// it every scalar -- is known only after the host has hashed the whole transcript (17.6 MB, 7 ms, at config 3), while the
+// points are there as soon as they are decoded.  So the 120 dependent doublings that the fold of 16 windows needs
 // (k_pip_final above: 1.1 ms with one busy lane) move in front of the challenge: k_pip_shift builds, for every point,
 // the 16 byte-shifted copies 2^(8p) P and their phi images (32 affine points, one inversion per input point) while the
-// host hashes (small batches: next to the subgroup tests, which are as long a chain, on a second stream).  A 128-bit half scalar is then 16 independent bytes, each paired with its own copy, and the whole lincomb
-// is ONE window: 32 n (point, byte) items into 255 buckets.  After the challenge: split, a three-kernel counting sort,
-// one wave per bucket (128 lanes share a bucket's ~1040 items and fold through LDS), the suffix-scan of k_pip_window; the host
-// normalises the two sums: no doubling at all.  3.0 -> 0.7 ms of GPU time behind the hash.
+// host hashes -- and next to the subgroup tests, an equally long chain, which run on a second stream (small batches have
+// no hash to hide behind).  A 128-bit half scalar is then 16 independent bytes, each paired with its own copy, and the
+// whole lincomb is ONE window: 32 n (point, byte) items into 255 buckets.  After the challenge: split, a three-kernel
+// counting sort, two waves per bucket (128 lanes share a bucket's ~1040 items and fold through LDS), the suffix scan of
+// k_pip_window; the host normalises the two sums.  No doubling at all: 3.4 -> 0.8 ms of GPU time behind the hash.
 //   pts32[(phi * 16 + p) * n_max + i] = phi^phi(2^(8p) P_i)
 constexpr int PS_P = 16, PS_SLICES = 64;
 __global__ __launch_bounds__(64) void k_pip_shift(const G1Affine* __restrict__ in, AffQ* __restrict__ pts32, JacQ* __restrict__ jac,
