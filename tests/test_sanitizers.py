@@ -1,7 +1,7 @@
 """AddressSanitizer + UndefinedBehaviorSanitizer on the CPU-compilable code (the GPU pool offers no
 sanitizers, and none is needed for this: the oracle is plain C and the host units compile with hipcc's host pass).
   * oracle/*.c driven through every entry point by tests/c/oracle_sanitize_main.c
-  * the host units tests/c/test_{inverse,host_mul,linmap,glv}.cpp (csrc headers compiled for the host; test_curve29 is left
+  * the host units tests/c/test_{inverse,host_mul,linmap,glv,pairing}.cpp (csrc headers compiled for the host; test_curve29 is left
     out: the fully unrolled 14-limb field code takes the instrumenting compiler more than 15 minutes)
 A sanitizer report aborts the program (-fno-sanitize-recover): exit code 0 means a clean run."""
 import os
@@ -29,12 +29,13 @@ def test_oracle_under_asan_and_ubsan(tmp_path):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("name", ["test_inverse", "test_host_mul", "test_linmap", "test_glv"])
+@pytest.mark.parametrize("name", ["test_inverse", "test_host_mul", "test_linmap", "test_glv", "test_pairing"])
 def test_host_units_under_asan_and_ubsan(tmp_path, name):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     exe = str(tmp_path / name)
     subprocess.check_call([hipcc, "-O1", "-std=c++17", "-x", "hip", "--cuda-host-only", *SAN, "-I", CSRC,
                            os.path.join(ROOT, "tests", "c", name + ".cpp"), "-o", exe], timeout=600)
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=800, env=ENV)
+    args = [os.path.join(ROOT, "rust-eth-kzg_amd", "data", "trusted_setup_4096.bin")] if name == "test_pairing" else []
+    out = subprocess.run([exe, *args], capture_output=True, text=True, timeout=800, env=ENV)
     assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-4000:]
