@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- blobs/s of compute_cells_and_kzg_proofs on MI355X (BASELINE.json's metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1: bench.py itself starts one rank per GPU, see _launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 2 --launcher-selftest          (CPU only: the launcher and the rendezvous, no GPU work)
 
 A step = one pass of the hot path (blob bytes -> 128 cells + 128 proofs per blob) over one batch of
 synthetic blobs that is already resident in HBM, through the device-pointer C ABI
@@ -10,7 +11,9 @@ synthetic blobs that is already resident in HBM, through the device-pointer C AB
 contiguous blob index with no data-path collective; with N > 1 each step ends with one RCCL
 all-gather of the proof vectors (48 B x 128 per blob) on the library's own communicator
 (eth_kzg_amd_all_gather), which is the only exchange north_star names.
-Weak scaling: the per-GPU batch is fixed (default 2048 blobs, batch-saturated as BASELINE.md section 3 asks).
+Weak scaling: the per-GPU batch is fixed (default 2048 blobs, batch-saturated as BASELINE.md section 3 asks); at N > 1
+the JSON also carries `configs_strong`: BASELINE configs 4 and 5 AS WRITTEN (512 / 256 blobs in total, split N ways,
+gathered), timed outside the headline region next to the same total on one GPU -- the strong-scaling numbers.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`, `cpu_baseline` and, at N = 1, a
 `configs` block: BASELINE.json's other configurations and the reference's own bench set
@@ -315,6 +318,182 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, t_ctx_cold):
     return out, {"verify": (C_, I_, L_, P_), "recover": recover_one}
 
 
+def strong_configs(ctx, sharding, torch, dist, dev, world, rank, lib_comm, stream):
+    """BASELINE.json configs 4 and 5 AS WRITTEN -- a fixed total (512 blobs to prove, 256 half-erased blobs to recover) cut
+    into contiguous slices over the N ranks, each pass ending with the all-gather -- timed outside the headline region,
+    beside the same total on ONE GPU (every rank runs that leg on its own GPU; rank 0's figure is reported).  These are the
+    strong-scaling numbers; the headline is weak scaling.  Each pass is timed on its own (barrier, run, local sync, MAX over
+    ranks): a 512-blob job is one pass, not a pipeline.  The gathered bytes are checked against the one-GPU run."""
+    out = {}
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def gather(local, full):
+        if world == 1 and not lib_comm:
+            full.copy_(local)
+        elif lib_comm:
+            ctx.all_gather(local.data_ptr(), full.data_ptr(), local.numel(), stream.cuda_stream)
+        else:
+            sharding.all_gather_flat(local, full, dist)
+
+    def timed(run, reps=7, skip=2):
+        ts = []
+        for it in range(reps):
+            fence()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(stream):
+                run()
+            torch.cuda.synchronize(dev)
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if it >= skip:
+                ts.append(float(t.item()))
+        return _median(ts)
+
+    def agree(flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    PB, CB = CELLS * 48, CELLS * BYTES_PER_CELL
+    for total, key, recover in ((512, "config4_compute_512_blobs", False), (256, "config5_recover_256_blobs_half_erased", True)):
+        blobs_all = torch.from_numpy(synth_blobs(total, seed=0x4B5A47)).to(dev)  # the same batch on every rank
+        lo, hi = sharding.shard_bounds(total, world, rank)
+        per = -(-total // world)  # slabs are padded to the largest slice so that one fixed-size all-gather does the exchange
+        nb = hi - lo
+        ref_c = torch.empty(total * CB, dtype=torch.uint8, device=dev)
+        ref_p = torch.empty(total * PB, dtype=torch.uint8, device=dev)
+        ctx.compute_cells_and_kzg_proofs_device(total, blobs_all.data_ptr(), ref_c.data_ptr(), ref_p.data_ptr())
+        loc_c = torch.zeros(per * CB, dtype=torch.uint8, device=dev)
+        loc_p = torch.zeros(per * PB, dtype=torch.uint8, device=dev)
+        all_c = torch.empty(world * per * CB, dtype=torch.uint8, device=dev)
+        all_p = torch.empty(world * per * PB, dtype=torch.uint8, device=dev)
+        if recover:
+            erased = ref_c.view(total, CELLS, BYTES_PER_CELL).clone()
+            erased[:, 1::2, :] = 0xFF  # never read: only the cells named in `present` are
+            idx = list(range(0, CELLS, 2))
+            one_c, one_p = torch.empty_like(ref_c), torch.empty_like(ref_p)
+
+            def one_gpu():
+                ctx.recover_cells_and_kzg_proofs_device(total, erased.data_ptr(), [idx] * total, one_c.data_ptr(), one_p.data_ptr(), stream=stream.cuda_stream)
+
+            def sliced(full_output):
+                if nb:
+                    ctx.recover_cells_and_kzg_proofs_device(nb, erased[lo:hi].data_ptr(), [idx] * nb, loc_c.data_ptr(), loc_p.data_ptr(), stream=stream.cuda_stream)
+                gather(loc_p, all_p)
+                if full_output:
+                    gather(loc_c, all_c)
+        else:
+            one_c, one_p = torch.empty_like(ref_c), torch.empty_like(ref_p)
+
+            def one_gpu():
+                ctx.compute_cells_and_kzg_proofs_device(total, blobs_all.data_ptr(), one_c.data_ptr(), one_p.data_ptr(), want_status=False, stream=stream.cuda_stream)
+
+            def sliced(full_output):
+                if nb:
+                    ctx.compute_cells_and_kzg_proofs_device(nb, blobs_all[lo:hi].data_ptr(), loc_c.data_ptr(), loc_p.data_ptr(), want_status=False, stream=stream.cuda_stream)
+                gather(loc_p, all_p)
+                if full_output:
+                    gather(loc_c, all_c)
+        t_one = timed(one_gpu)
+        t_p = timed(lambda: sliced(False))
+        t_full = timed(lambda: sliced(True))
+        torch.cuda.synchronize(dev)
+        # the gathered slabs, un-padded, must be the one-GPU result byte for byte -- on every rank
+        same = torch.equal(one_p, ref_p) and torch.equal(one_c, ref_c)
+        for r in range(world):
+            rlo, rhi = sharding.shard_bounds(total, world, r)
+            same = same and torch.equal(all_p[r * per * PB: r * per * PB + (rhi - rlo) * PB], ref_p[rlo * PB: rhi * PB])
+            same = same and torch.equal(all_c[r * per * CB: r * per * CB + (rhi - rlo) * CB], ref_c[rlo * CB: rhi * CB])
+        if not agree(same):
+            raise SystemExit(f"bench.py: {key}: the sharded + gathered output differs from the one-GPU output")
+        out[key] = {"total_blobs": total, "blobs_per_rank": per,
+                    "one_gpu_ms": round(t_one * 1e3, 3), "one_gpu_blobs_per_s": round(total / t_one),
+                    "sharded_ms_gather_proofs": round(t_p * 1e3, 3), "sharded_blobs_per_s_gather_proofs": round(total / t_p),
+                    "sharded_ms_gather_cells_and_proofs": round(t_full * 1e3, 3), "sharded_blobs_per_s_gather_cells_and_proofs": round(total / t_full),
+                    "speedup_over_one_gpu": round(t_one / t_p, 3), "gathered_equals_one_gpu_output": True,
+                    "gather_bytes_per_rank": {"proofs": per * PB, "cells": per * CB}}
+        del blobs_all, ref_c, ref_p, loc_c, loc_p, all_c, all_p, one_c, one_p
+    out["note"] = ("strong scaling: fixed total split over the ranks; a pass = slice compute + all-gather, timed pass by pass (median "
+                   "of 5, MAX over ranks). Expect well below N x: 64 blobs per GPU do not fill an MI355X (DESIGN.md section 6)")
+    return out
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _launch(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start one rank per GPU as CHILD processes
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would) and relay rank 0's JSON line.  This
+    parent never imports torch and never touches the GPU (no exec of a GPU-initialised process either: children are
+    spawned, the parent waits and exits with the first non-zero child status)."""
+    import threading
+    port = int(os.environ.get("MASTER_PORT", "0")) or _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "KZG_BENCH_LAUNCHER": "bench.py"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line.decode(errors="replace"))
+            sys.stdout.flush()
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    rc, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with status {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for o in live:  # exactly the children started above, by their own handles
+                    procs[o].terminate()
+        time.sleep(0.05)
+    th.join(timeout=10)
+    sys.exit(rc)
+
+
+def _launcher_selftest(args):
+    """No GPU: every rank reports the environment the launcher gave it, the ranks meet on a gloo rendezvous (barrier +
+    all-gather), rank 0 prints one JSON line.  tests/test_bench_launcher.py runs this with --gpus 2."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    me = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "world": world, "pid": os.getpid(),
+          "master": os.environ.get("MASTER_ADDR", "") + ":" + os.environ.get("MASTER_PORT", ""),
+          "launcher": os.environ.get("KZG_BENCH_LAUNCHER", "external")}
+    ranks = [me]
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist.barrier()
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+        dist.barrier()
+        dist.destroy_process_group()
+    if os.environ.get("KZG_BENCH_SELFTEST_FAIL_RANK") == str(rank):  # the test of the failure path
+        sys.exit(7)
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "gpus_arg": args.gpus, "ranks": ranks}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -325,14 +504,32 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the side configurations (BASELINE configs 3-5, ABI, context creation)")
     ap.add_argument("--no-latency-probe", action="store_true",
                     help="skip the 1-blob latency launches (profiling runs: keeps rocprofv3's per-kernel averages to full-batch launches)")
+    ap.add_argument("--strong-configs", action="store_true",
+                    help="also run the strong-scaling legs (configs 4 and 5 as written) at N = 1; they always run at N > 1")
+    ap.add_argument("--launcher-selftest", action="store_true", help="CPU only: check the --gpus N launcher and the rendezvous, then exit")
+    ap.add_argument("--exchange", choices=["library", "torch"], default="library",
+                    help="N > 1: the all-gather runs on the library's own RCCL communicator (default; failure to build it is an "
+                         "error, not a silent fall-back) or on torch.distributed's")
     args = ap.parse_args()
+
+    # --gpus N is authoritative: without a launcher's environment bench.py starts the N ranks itself -- before torch or
+    # the GPU is touched in this process
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _launch(args.gpus, sys.argv[1:])
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher environment says WORLD_SIZE={world}")
+    if args.launcher_selftest:
+        return _launcher_selftest(args)
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} are visible "
+                         f"(--gpus {args.gpus})")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
@@ -354,7 +551,18 @@ def main():
     stream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream: kernels are enqueued on it without host syncs
     # the exchange runs on the library's own RCCL communicator (what a C / Go / Java host would use); torch.distributed
     # carries the 128-byte id and stays the fallback if the library cannot build its communicator
-    lib_comm = world > 1 and sharding.attach_library_comm(ctx, dist)
+    lib_comm, comm_ranks, rccl_file = False, None, None
+    if world > 1 and args.exchange == "library":
+        try:
+            rccl_file = ctx.comm_probe()  # which librccl file the library bound (torch's already-mapped copy when present)
+        except Exception:
+            rccl_file = None  # attach_library_comm below reports the reason on every rank
+        lib_comm = sharding.attach_library_comm(ctx, dist, required=True)  # raises on every rank with the reason: no silent fall-back
+        comm_ranks = ctx.comm_info()[1]
+    elif world == 1 and args.strong_configs and args.exchange == "library":  # one-GPU box: the same calls on a 1-rank communicator
+        rccl_file = ctx.comm_probe()
+        ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+        lib_comm, comm_ranks = True, ctx.comm_info()[1]
 
     def step():
         with torch.cuda.stream(stream):
@@ -380,6 +588,19 @@ def main():
     first_half = d_cells.view(B, 2, 64 * BYTES_PER_CELL)[:, 0, :]
     assert torch.equal(first_half, d_blobs), "cells[0..63] != blob"
 
+    gather_checked = None
+    if world > 1:  # the exchange itself, once, before timing: rank r's slab of the gathered vector must be rank r's proofs
+        step()
+        fence()
+        mine = d_proofs.view(-1, 8).view(torch.int64).sum().reshape(1)
+        sums = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(sums, mine)  # (torch's communicator: an independent path for the check)
+        got = d_all_proofs.view(world, -1, 8).view(torch.int64).sum(dim=(1, 2))
+        gather_checked = bool(torch.equal(sums, got)) and bool(torch.equal(d_all_proofs.view(world, -1)[rank], d_proofs))
+        flag = torch.tensor([1 if gather_checked else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not int(flag.item()):
+            raise SystemExit("bench.py: the all-gathered proof vector does not match the ranks' own proofs")
     for _ in range(args.warmup):
         step()
     fence()
@@ -407,6 +628,10 @@ def main():
                                                     want_status=False, stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
         lat.append(time.perf_counter() - t1)
+
+    strong = None
+    if world > 1 or args.strong_configs:
+        strong = strong_configs(ctx, sharding, torch, dist, dev, world, rank, lib_comm, stream)
 
     if rank == 0:
         total_blobs = B * world * args.steps
@@ -467,7 +692,10 @@ def main():
                        "table_GB": round(ctx.table_bytes() / 1e9, 2),
                        "g1_transforms": f"compiled linear map: {li[0]} constant multiplications, {li[1]} additions, {li[2]} doublings per blob, {li[3]} launches" if li[0] else "radix-2 network",
                        "exchange": ("ncclAllGather of the proof vectors per step inside libc_eth_kzg.so (eth_kzg_amd_all_gather)" if lib_comm
-                                    else "RCCL all-gather of proofs per step (torch.distributed)") if world > 1 else "none"},
+                                    else "RCCL all-gather of proofs per step (torch.distributed)") if world > 1 else "none",
+                       "ranks": world, "library_communicator_ranks": comm_ranks, "rccl_library": rccl_file,
+                       "launcher": os.environ.get("KZG_BENCH_LAUNCHER", "external (torch.distributed.run)") if world > 1 else "none",
+                       "gathered_proofs_checked": gather_checked},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": per_launch_s * 1e3, "launches_per_step": dom_launches // max(1, args.steps),
@@ -482,6 +710,8 @@ def main():
             "single_blob_latency_ms": (min(lat) * 1e3) if lat else None,
             "context_creation_s": round(t_ctx, 2),
         }
+        if strong is not None:
+            out["configs_strong"] = strong
         extra = None
         if not args.no_configs and world == 1:
             out["configs"], extra = side_configs(ctx, kzg, torch, dev, blobs_h, t_ctx)

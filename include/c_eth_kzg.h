@@ -203,10 +203,17 @@ int eth_kzg_amd_get_stage_times(const DASContext *ctx, double *ms, uint64_t *lau
  * (1) One process per GPU (torchrun / MPI style).  The library owns the RCCL communicator: rank 0 obtains an id,
  *     the caller distributes its 128 bytes by whatever it already has (MPI_Bcast, torch.distributed, a file), every
  *     rank attaches its context, and eth_kzg_amd_all_gather is one ncclAllGather over xGMI on the given stream:
- *     d_recv receives world * bytes_per_rank bytes, rank r's slab at offset r * bytes_per_rank.  RCCL is loaded with
- *     dlopen when the first of these functions is called, so the library itself does not depend on it. */
+ *     d_recv receives world * bytes_per_rank bytes, rank r's slab at offset r * bytes_per_rank.  RCCL is bound with
+ *     dlopen when the first of these functions is called, so the library itself does not depend on it: a copy the
+ *     process has already mapped (PyTorch ships one) is reused, otherwise librccl.so.1 is loaded.
+ *     eth_kzg_amd_comm_init is COLLECTIVE (ncclCommInitRank): every rank must enter it or none; call
+ *     eth_kzg_amd_comm_probe first (local, cheap: Ok iff RCCL can be bound and the context has no communicator yet;
+ *     optionally reports which library file was bound) and agree on the result before any rank calls _init.
+ *     eth_kzg_amd_comm_info returns the rank and size the communicator itself reports (ncclCommUserRank/Count). */
+CResult eth_kzg_amd_comm_probe(const DASContext *ctx, char *out_library_path /* may be NULL */, uint64_t path_capacity);
 CResult eth_kzg_amd_comm_unique_id(uint8_t *out_id /* 128 */);
 CResult eth_kzg_amd_comm_init(DASContext *ctx, const uint8_t *id /* 128 */, int rank, int world);
+CResult eth_kzg_amd_comm_info(const DASContext *ctx, int *out_rank, int *out_world);
 CResult eth_kzg_amd_all_gather(const DASContext *ctx, const void *d_send, void *d_recv, uint64_t bytes_per_rank,
                                void *hip_stream);
 void eth_kzg_amd_comm_destroy(DASContext *ctx);

@@ -55,7 +55,8 @@ EXPORTED_SYMBOLS = [
     "eth_kzg_amd_verify_cell_kzg_proof_batch_device",
     "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits", "eth_kzg_amd_glv_table", "eth_kzg_amd_linmap_info",
     "eth_kzg_amd_set_profiling", "eth_kzg_amd_get_stage_times",
-    "eth_kzg_amd_comm_unique_id", "eth_kzg_amd_comm_init", "eth_kzg_amd_all_gather", "eth_kzg_amd_comm_destroy",
+    "eth_kzg_amd_comm_probe", "eth_kzg_amd_comm_unique_id", "eth_kzg_amd_comm_init", "eth_kzg_amd_comm_info",
+    "eth_kzg_amd_all_gather", "eth_kzg_amd_comm_destroy",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_batch_multi", "eth_kzg_amd_device_count",
 ]
 # include/c_eth_kzg_test_hooks.h: stage-level hooks for tests/, not part of the drop-in ABI
@@ -106,6 +107,8 @@ def load_library():
         "eth_kzg_amd_blob_to_kzg_commitment_device": [P, U64, P, P, P, P],
         "eth_kzg_amd_verify_cell_kzg_proof_batch_device": [P, U64, P, P, P, P, P, P],
         "eth_kzg_amd_comm_unique_id": [P],
+        "eth_kzg_amd_comm_probe": [P, P, U64],
+        "eth_kzg_amd_comm_info": [P, P, P],
         "eth_kzg_amd_comm_init": [P, U8P, C.c_int, C.c_int],
         "eth_kzg_amd_all_gather": [P, P, P, U64, P],
         "eth_kzg_amd_compute_cells_and_kzg_proofs_batch_multi": [P, U64, U64, P, P, P, P],
@@ -135,6 +138,31 @@ def load_library():
     lib.eth_kzg_amd_test_field_mul.argtypes = [P, U8P, U8P, P, C.c_int, C.c_int]
     _lib = lib
     return lib
+
+
+def present_masks(n, present):
+    """Two 64-bit words per blob for eth_kzg_amd_recover_cells_and_proofs_device: bit (c % 64) of word (c / 64) set when
+    cell c of that blob carries data.  present[b] = iterable of cell indices (lists, tuples, rows of a 2-D array ...)."""
+    masks = np.zeros(2 * max(1, n), dtype=np.uint64)
+    # the same index list for many blobs (the usual case: [idx] * n) is folded into its mask once.  The cache holds the
+    # row OBJECT and compares with `is`: an id() of a temporary (a row of a 2-D numpy array is a fresh view per access)
+    # can be reused by the next row once the temporary is freed, which would silently give every blob the first mask.
+    prev_row, prev_mask = None, 0
+    for b in range(n):
+        row = present[b]
+        if row is prev_row and prev_row is not None:
+            m = prev_mask
+        else:
+            m = 0
+            for c in row:
+                c = int(c)
+                if not 0 <= c < CELLS_PER_EXT_BLOB:
+                    raise KzgError("InvalidCellIndex")
+                m |= 1 << c
+            prev_row, prev_mask = row, m
+        masks[2 * b] = m & 0xFFFFFFFFFFFFFFFF
+        masks[2 * b + 1] = m >> 64
+    return masks
 
 
 def _ptr_array(bufs):
@@ -426,20 +454,7 @@ class DASContext:
     def recover_cells_and_kzg_proofs_device(self, n, d_cells, present, d_out_cells, d_out_proofs, stream=None):
         """Device-resident recovery: d_cells = flat [n][128][2048] buffer in HBM (integer address), present[b] = iterable
         of the cell indices of blob b that hold data.  Returns the per-blob status list; outputs stay on the device."""
-        masks = np.zeros(2 * max(1, n), dtype=np.uint64)
-        seen = {}  # the same index list for many blobs (the usual case) is folded into its mask once
-        for b in range(n):
-            key = id(present[b])
-            m = seen.get(key)
-            if m is None:
-                m = 0
-                for c in present[b]:
-                    if not 0 <= c < CELLS_PER_EXT_BLOB:
-                        raise KzgError("InvalidCellIndex")
-                    m |= 1 << c
-                seen[key] = m
-            masks[2 * b] = m & 0xFFFFFFFFFFFFFFFF
-            masks[2 * b + 1] = m >> 64
+        masks = present_masks(n, present)
         st = (C.c_int32 * max(1, n))()
         self._check(self._lib.eth_kzg_amd_recover_cells_and_proofs_device(
             self._ctx, n, C.c_void_p(d_cells), _vp(masks), C.c_void_p(d_out_cells) if d_out_cells else None,
@@ -458,8 +473,22 @@ class DASContext:
             raise KzgError(msg)
         return out.raw
 
+    def comm_probe(self):
+        """Local and cheap: raises KzgError unless RCCL can be bound and this context has no communicator yet; returns the
+        library file that was bound (and whether it was the copy the process had already mapped)."""
+        buf = C.create_string_buffer(512)
+        self._check(self._lib.eth_kzg_amd_comm_probe(self._ctx, buf, 512))
+        return buf.value.decode()
+
     def comm_init(self, unique_id, rank, world):
+        """COLLECTIVE (ncclCommInitRank): every rank enters or none -- agree on comm_probe() first."""
         self._check(self._lib.eth_kzg_amd_comm_init(self._ctx, unique_id, int(rank), int(world)))
+
+    def comm_info(self):
+        """(rank, world) as the library's communicator itself reports them."""
+        r, w = C.c_int(-1), C.c_int(-1)
+        self._check(self._lib.eth_kzg_amd_comm_info(self._ctx, C.byref(r), C.byref(w)))
+        return r.value, w.value
 
     def all_gather(self, d_send, d_recv, bytes_per_rank, stream=None):
         """ncclAllGather of bytes_per_rank bytes from every rank's d_send into d_recv (device addresses), on `stream`

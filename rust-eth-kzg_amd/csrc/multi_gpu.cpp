@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <link.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -38,24 +39,49 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
-    std::string why;
+    std::string why, path;
+    bool shared_with_process = false;  // the handle is the copy some other component (torch) had already mapped
 };
+// An RCCL that the process has already mapped wins (torch ships its own copy under torch/lib and maps it with the
+// Python extension; a second copy in the same address space would keep separate bootstrap / topology state and the two
+// are not guaranteed to be the same build): dl_iterate_phdr finds it by name and RTLD_NOLOAD hands back a handle to that
+// very object.  Only when none is mapped is librccl.so.1 loaded from the usual places.
+int find_mapped_rccl(struct dl_phdr_info* info, size_t, void* out) {
+    const char* name = info->dlpi_name;
+    if (!name || !*name) return 0;
+    const char* base = strrchr(name, '/');
+    base = base ? base + 1 : name;
+    if (strncmp(base, "librccl.so", 10) != 0) return 0;
+    *(std::string*)out = name;
+    return 1;
+}
 Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        std::string mapped;
+        dl_iterate_phdr(find_mapped_rccl, &mapped);
+        if (!mapped.empty()) {
+            r.handle = dlopen(mapped.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            if (r.handle) { r.path = mapped; r.shared_with_process = true; }
+        }
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (r.handle) break;
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) r.path = name;
         }
         if (!r.handle) { r.why = "RCCL not found (librccl.so)"; return; }
         r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
         r.AllGather = (decltype(r.AllGather))dlsym(r.handle, "ncclAllGather");
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+        r.CommCount = (decltype(r.CommCount))dlsym(r.handle, "ncclCommCount");
+        r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.handle, "ncclCommUserRank");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
-        if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { r.why = "RCCL symbols missing"; r.handle = nullptr; }
+        if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { r.why = "RCCL symbols missing in " + r.path; r.handle = nullptr; }
     });
     return r;
 }
@@ -85,6 +111,34 @@ CResult eth_kzg_amd_comm_unique_id(uint8_t* out_id) {
     ncclResult_t e = r.GetUniqueId(&id);
     if (e != ncclSuccess) return err(nccl_text(e));
     memcpy(out_id, &id, 128);
+    return ok();
+}
+
+CResult eth_kzg_amd_comm_probe(const DASContext* ctx, char* out_library_path, uint64_t path_capacity) {
+    if (!ctx || !ctx->engine) abort();
+    Rccl& r = rccl();
+    if (!r.handle) return err(r.why);
+    if (ctx->engine->comm()) return err("communicator already attached to this context");
+    if (out_library_path && path_capacity) {
+        std::string p = r.path + (r.shared_with_process ? " (already mapped by the process)" : " (loaded by libc_eth_kzg)");
+        size_t n = p.size() < path_capacity - 1 ? p.size() : (size_t)path_capacity - 1;
+        memcpy(out_library_path, p.data(), n);
+        out_library_path[n] = 0;
+    }
+    return ok();
+}
+
+CResult eth_kzg_amd_comm_info(const DASContext* ctx, int* out_rank, int* out_world) {
+    if (!ctx || !ctx->engine) abort();
+    Rccl& r = rccl();
+    kzg::Comm* c = ctx->engine->comm();
+    if (!r.handle || !c) return err("no communicator: call eth_kzg_amd_comm_init first");
+    int rank = c->rank, world = c->world;
+    // what the communicator itself reports (not what the caller passed in), where RCCL exports the queries
+    if (r.CommCount && r.CommCount(c->comm, &world) != ncclSuccess) return err("RCCL: ncclCommCount failed");
+    if (r.CommUserRank && r.CommUserRank(c->comm, &rank) != ncclSuccess) return err("RCCL: ncclCommUserRank failed");
+    if (out_rank) *out_rank = rank;
+    if (out_world) *out_world = world;
     return ok();
 }
 

@@ -27,36 +27,67 @@ def all_gather_flat(local, out=None, dist=None):
     return out
 
 
-def attach_library_comm(ctx, dist) -> bool:
+def attach_library_comm(ctx, dist, required=False) -> bool:
     """Give `ctx` the library's own RCCL communicator (eth_kzg_amd_comm_init): rank 0 draws the id, torch.distributed
     only carries its 128 bytes to the other ranks.  After this, all_gather_proofs runs ncclAllGather inside
-    libc_eth_kzg.so, which is also what a C / Go / Java host would call.  Returns False (and leaves the torch path in
-    charge) if RCCL cannot be loaded or the communicator cannot be built."""
+    libc_eth_kzg.so, which is also what a C / Go / Java host would call.
+
+    comm_init is itself a collective (ncclCommInitRank), so no rank may enter it unless all do: every rank first runs the
+    local probe (RCCL bindable, no communicator attached yet; rank 0 also draws the id) and the ranks agree on the MIN of
+    those flags BEFORE anyone calls comm_init.  All ranks or none.  Returns False -- with the reason in
+    `attach_library_comm.last_error` -- if some rank cannot take part; raises instead when `required`."""
+    attach_library_comm.last_error = ""
     if dist is None or not dist.is_initialized():
+        attach_library_comm.last_error = "torch.distributed is not initialised"
+        if required:
+            raise RuntimeError(attach_library_comm.last_error)
         return False
+    import torch
     world, rank = dist.get_world_size(), dist.get_rank()
-    box = [None]
+    on_cpu = dist.get_backend() != "nccl"
+    box, ready, why = [None], 1, ""
     try:
+        ctx.comm_probe()
         if rank == 0:
             box[0] = ctx.comm_unique_id()
-    except Exception:
-        box[0] = None
-    dist.broadcast_object_list(box, src=0)
-    if box[0] is None:
+    except Exception as e:
+        ready, why = 0, f"rank {rank}: {e}"
+    flag = torch.tensor([ready], dtype=torch.int32, device="cpu" if on_cpu else "cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if not int(flag.item()):
+        reasons = [None] * world
+        dist.all_gather_object(reasons, why)
+        attach_library_comm.last_error = "; ".join(r for r in reasons if r) or "a rank could not bind RCCL"
+        if required:
+            raise RuntimeError("library communicator unavailable: " + attach_library_comm.last_error)
         return False
-    ok = True
+    dist.broadcast_object_list(box, src=0)
+    # from here on every rank is known to be able to enter the collective
+    ok, why = 1, ""
     try:
         ctx.comm_init(box[0], rank, world)
-    except Exception:
-        ok = False
-    import torch
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks or none
+        got = ctx.comm_info()
+        if got != (rank, world):
+            ok, why = 0, f"rank {rank}: communicator reports (rank, world) = {got}, expected {(rank, world)}"
+    except Exception as e:
+        ok, why = 0, f"rank {rank}: {e}"
+    flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if on_cpu else "cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if not int(flag.item()):
-        if ok:
+        reasons = [None] * world
+        dist.all_gather_object(reasons, why)
+        attach_library_comm.last_error = "; ".join(r for r in reasons if r)
+        try:
             ctx.comm_destroy()
+        except Exception:
+            pass
+        if required:
+            raise RuntimeError("library communicator could not be built: " + attach_library_comm.last_error)
         return False
     return True
+
+
+attach_library_comm.last_error = ""
 
 
 def all_gather_proofs(ctx, local, out, stream=None):

@@ -64,24 +64,48 @@ def _worker(rank, world, port, n_blobs, q):
     # the hand-over of the library's RCCL id (bench.py: attach_library_comm): rank 0 draws it, every rank attaches with the
     # same 128 bytes; if any rank cannot attach, all ranks fall back together
     class FakeComm:
-        def __init__(self, fail_on=None):
-            self.fail_on, self.attached, self.destroyed = fail_on, None, False
+        """Stands in for the context's communicator calls.  comm_init is a collective in the real library, so the fake
+        records whether it was ever entered: when one rank's probe fails, NO rank may enter it (a rank inside
+        ncclCommInitRank would wait for the missing one for ever)."""
+        def __init__(self, probe_fails_on=None, init_fails_on=None):
+            self.probe_fails_on, self.init_fails_on = probe_fails_on, init_fails_on
+            self.attached, self.destroyed, self.entered_init = None, False, False
+
+        def comm_probe(self):
+            if self.probe_fails_on == rank:
+                raise RuntimeError("RCCL not found (librccl.so)")
+            return "librccl.so.1 (fake)"
 
         def comm_unique_id(self):
             return bytes(range(128))
 
         def comm_init(self, uid, r, w):
-            if self.fail_on == r:
+            self.entered_init = True
+            if self.init_fails_on == r:
                 raise RuntimeError("no RCCL here")
             self.attached = (uid, r, w)
+
+        def comm_info(self):
+            return self.attached[1], self.attached[2]
 
         def comm_destroy(self):
             self.destroyed = True
 
     fc = FakeComm()
     assert sh.attach_library_comm(fc, dist) is True and fc.attached == (bytes(range(128)), rank, world)
-    fc = FakeComm(fail_on=1)
-    assert sh.attach_library_comm(fc, dist) is False and (fc.destroyed if rank == 0 else fc.attached is None)
+    fc = FakeComm(init_fails_on=1)
+    assert sh.attach_library_comm(fc, dist) is False and fc.destroyed
+    assert "no RCCL here" in sh.attach_library_comm.last_error  # the reason reaches every rank
+    for bad_rank in (0, 1):
+        fc = FakeComm(probe_fails_on=bad_rank)
+        assert sh.attach_library_comm(fc, dist) is False and not fc.entered_init
+        assert "RCCL not found" in sh.attach_library_comm.last_error
+        try:
+            sh.attach_library_comm(FakeComm(probe_fails_on=bad_rank), dist, required=True)
+            loud = False
+        except RuntimeError:
+            loud = True
+        assert loud  # bench.py asks for required=True: no silent fall-back
     if rank == 0:
         q.put(res)
     dist.barrier()
