@@ -524,6 +524,13 @@ def main():
     if args.launcher_selftest:
         return _launcher_selftest(args)
 
+    # stdout carries exactly ONE line, the JSON record: native libraries write banners to the C-level stdout (RCCL prints its
+    # version block there when a communicator is built, flushed at exit, i.e. after the record), so file descriptor 1 is
+    # pointed at stderr for the rest of the process and the record goes out through a private copy of the real stdout
+    sys.stdout.flush()
+    record_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -720,7 +727,7 @@ def main():
             gpu_first = (bytes(d_cells[:CELLS * BYTES_PER_CELL].cpu().numpy()), bytes(d_proofs[:CELLS * 48].cpu().numpy()))
             out["cpu_baseline"] = cpu_baseline([bytes(blobs_h[i].tobytes()) for i in range(min(B, 32))], gpu_first=gpu_first, extra=extra)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+        os.write(record_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
     ctx.close()

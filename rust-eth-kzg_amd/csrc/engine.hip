@@ -760,7 +760,25 @@ void Engine::launch_msm(const void* scalars, const void* table, void* out, int n
         const long msms = (long)n_groups * n_slices;
         int mode = 1;
         if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) mode = 0;
-        else if (msm_chunks_ >= 0 ? msm_chunks_ > 0 : (msms * 4 + 63) / 64 >= (long)wave_slots_) mode = 2;
+        else if (msm_chunks_ >= 0) mode = msm_chunks_ == 0 ? 1 : msm_chunks_ == 1 ? 3 : msm_chunks_ == 2 ? 4 : 2;  // tuning knob / tests
+        else if ((msms * 4 + 63) / 64 >= (long)wave_slots_) {
+            // The chip is full either way: S waves per 64 MSMs, each lane summing 1024 / S gathered entries.  Fewer, longer
+            // waves save the folds and the block turn-over but waste more of the last round when the wave count is not
+            // a multiple of the wave slots; pick the S with the least predicted time = rounds x (additions per wave + fold).
+            const long g = (msms + 63) / 64;
+            double best = 0;
+            for (int S : {1, 2, 4}) {
+                const long waves = g * S;
+                const long rounds = (waves + wave_slots_ - 1) / wave_slots_;
+                // the last round costs a full wave time only if more than half of its SIMDs get two waves; price it by its fill
+                const double full = (double)(waves / wave_slots_), tail = (double)(waves % wave_slots_) / wave_slots_;
+                const double t_tail = tail == 0 ? 0 : (tail <= 0.5 ? 0.62 : 1.0);  // one wave per SIMD runs ~1.6x faster than two
+                const double per_wave = 1024.0 / S + (S == 1 ? 1.0 : S == 2 ? 4.0 : 8.0) * (S == 4 ? 1.6 : 1.0);  // in gathered-addition units
+                const double t = (full + t_tail) * per_wave * (S == 4 ? 1.07 : 1.0);  // measured: the 4-wave blocks lose ~7 % outside the loop
+                (void)rounds;
+                if (best == 0 || t < best) { best = t; mode = S == 1 ? 3 : S == 2 ? 4 : 2; }
+            }
+        }
         launch::msm_glv16(mode, const_cast<void*>(scalars), table, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st);
         return;
     }

@@ -373,6 +373,97 @@ __global__ __launch_bounds__(256, 2) void k_msm_glv_chunked(const GlvScalar* __r
     }
 }
 
+// Batches that fill the chip for whole rounds: a LANE owns a whole MSM (S = 1) or one of its GLV halves (S = 2).
+// S = 1: the lane first sums the 8 x nb entries selected by k2, applies phi to that running sum IN PLACE (phi acts on an
+// XYZZ point as X <- beta X), and keeps adding the 8 x nb entries selected by k1 into the same accumulator:
+// phi(sum k2 terms) + sum k1 terms with no fold at all -- no LDS, no barrier, no Jacobian addition, one conversion per
+// 1024 gathered additions.  2048 blobs are 4096 such waves: exactly two rounds of the chip's 2-per-SIMD wave slots
+// (the four-chunk kernel above needs 16384 waves in blocks of four that retire together, and two Jacobian additions,
+// two conversions and three barriers per block).  S = 2: wave 0 of a block sums the k2 half and hands phi of it over
+// through LDS, wave 1 sums the k1 half and adds: half as long a wave for batches that would leave S = 1's last round
+// part empty (engine.hip: launch_msm picks by predicted rounds).
+template <int S>
+__global__ __launch_bounds__(64 * S, 2) void k_msm_glv_lane(const GlvScalar* __restrict__ scalars, const TabP* __restrict__ table,
+                                                            JacQ* __restrict__ out, int n_groups, int n_slices, int nb,
+                                                            int out_stride, int brp_bits, Fq<1> beta) {
+    constexpr int C = launch::GLV_C, W = launch::GLV_W;
+    static_assert(S == 1 || S == 2, "a lane owns an MSM or one GLV half of it");
+    static_assert(C == 16 && W == 8, "digit extraction below is written for eight 16-bit windows per half");
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;  // part: 0 = starts with (S = 2: owns) the k2 half
+    const long m = (long)blockIdx.x * 64 + lane;  // MSM index = slice * n_groups + group
+    const bool active = m < (long)n_groups * n_slices;
+    int slice = 0, group = 0;
+    MsmAcc acc = msm_acc_inf();
+    if (active) {
+        slice = (int)(m / n_groups);
+        group = (int)(m % n_groups);
+        const GlvScalar* sc = scalars + (size_t)m * nb;
+        const TabP* tb = table + ((((size_t)group * W) * nb) << (C - 1));  // entry (w, i, a): tb[((w * nb + i) << 15) + a]
+        // the 128-bit magnitude of the current half scalar as a shift register; `below` = the bit under the window
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, below = 0, sneg = 0;
+        auto fetch = [&](int half, int i) {
+            const uint4 h = *reinterpret_cast<const uint4*>(sc[i].h[half]);
+            r0 = h.x; r1 = h.y; r2 = h.z;
+            sneg = h.w >> 31;
+            r3 = h.w & 0x7fffffffu;
+            below = 0;
+        };
+        auto take = [&]() {  // signed Booth digit of the low 16 bits + the bit below, then shift by 16
+            const uint32_t x = ((r0 & 0xffffu) << 1) | below;
+            below = (r0 >> 15) & 1u;
+            r0 = __funnelshift_r(r0, r1, 16);
+            r1 = __funnelshift_r(r1, r2, 16);
+            r2 = __funnelshift_r(r2, r3, 16);
+            r3 >>= 16;
+            const int t = (int)((x + 1) >> 1);
+            return (x >> 16) ? t - 65536 : t;
+        };
+        const int per_half = W * nb;
+        const int total = (S == 1 ? 2 : 1) * per_half;
+        const int first_half = S == 1 ? 1 : 1 - part;  // k2 first (S = 1); S = 2: part 0 -> k2, part 1 -> k1
+        fetch(first_half, 0);
+        int d = take();
+        uint32_t dneg = sneg;
+        PackLine cur = load_pack(tb + (d ? (d < 0 ? -d : d) - 1 : 0));
+#pragma unroll 1
+        for (int e = 0; e < total; e++) {
+            // the next entry is requested before the current addition: its digit, sign and address
+            const int e2 = e + 1;
+            const uint32_t dneg_cur = dneg;
+            const int idx2 = e2 >= per_half ? e2 - per_half : e2;  // position inside its half: i2 * W + w2
+            const int w2 = idx2 & (W - 1), i2 = idx2 >> 3;
+            const bool more = e2 < total;
+            if (w2 == 0 && more) fetch(S == 1 ? (e2 >= per_half ? 0 : 1) : first_half, i2);
+            const int d2 = more ? take() : 0;
+            dneg = sneg;
+            const int a2 = d2 ? (d2 < 0 ? -d2 : d2) - 1 : 0;
+            const PackLine nxt = load_pack(tb + ((((size_t)w2 * nb + (more ? i2 : 0)) << (C - 1)) + a2));
+            if (S == 1 && e == per_half) acc.x = relax<XB>(mul(acc.x, beta));  // phi of the k2 sum, in place; k1 terms follow
+            if (d != 0) acc = add_mixed(acc, pack_to_affq(cur), (d < 0) != (dneg_cur != 0));
+            cur = nxt;
+            d = d2;
+        }
+    }
+    if (S == 1) {
+        if (active) {
+            const int pos = brp_bits ? (int)(__brev((unsigned)group) >> (32 - brp_bits)) : group;
+            out[(size_t)pos * out_stride + slice] = msm_acc_to_jacq(acc);
+        }
+    } else {
+        __shared__ JacQ red[64];
+        if (part == 0) {
+            acc.x = relax<XB>(mul(acc.x, beta));
+            red[lane] = msm_acc_to_jacq(acc);
+        }
+        __syncthreads();
+        if (part == 1 && active) {
+            const JacQ sum = add(msm_acc_to_jacq(acc), red[lane]);
+            const int pos = brp_bits ? (int)(__brev((unsigned)group) >> (32 - brp_bits)) : group;
+            out[(size_t)pos * out_stride + slice] = sum;
+        }
+    }
+}
+
 // medium batches: thread = (MSM, joint window u < 16); 16 MSMs per block
 __global__ __launch_bounds__(256, 2) void k_msm_glv_windowed(const GlvScalar* __restrict__ scalars, const TabP* __restrict__ table,
                                                              JacQ* __restrict__ out, int n_groups, int n_slices, int nb,
@@ -465,7 +556,8 @@ void msm_fixed_flat(int c, const void* scalars, const void* table, void* out, in
     else if (c == 10) msm_flat_c<10>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
     else msm_flat_c<4>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
 }
-// mode: 0 flat (one block per MSM), 1 windowed, 2 chunked.  The scalars are split IN PLACE first (they feed nothing else).
+// mode: 0 flat (one block per MSM), 1 windowed, 2 four chunks per MSM, 3 a lane per MSM, 4 a lane per GLV half.
+// The scalars are split IN PLACE first (they feed nothing else).
 void msm_glv16(int mode, void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,
                int brp_bits, const Fp12w& beta, hipStream_t st) {
     Fp b384;
@@ -479,6 +571,12 @@ void msm_glv16(int mode, void* scalars, const void* table, void* out, int n_grou
     else if (mode == 1)
         k_msm_glv_windowed<<<(unsigned)((msms + 15) / 16), 256, 0, st>>>((const GlvScalar*)scalars, (const TabP*)table, (JacQ*)out, n_groups,
                                                                         n_slices, nb, out_stride, brp_bits, bq);
+    else if (mode == 3)
+        k_msm_glv_lane<1><<<(unsigned)((msms + 63) / 64), 64, 0, st>>>((const GlvScalar*)scalars, (const TabP*)table, (JacQ*)out, n_groups,
+                                                                      n_slices, nb, out_stride, brp_bits, bq);
+    else if (mode == 4)
+        k_msm_glv_lane<2><<<(unsigned)((msms + 63) / 64), 128, 0, st>>>((const GlvScalar*)scalars, (const TabP*)table, (JacQ*)out, n_groups,
+                                                                       n_slices, nb, out_stride, brp_bits, bq);
     else
         k_msm_glv_chunked<<<(unsigned)((msms + 63) / 64), 256, 0, st>>>((const GlvScalar*)scalars, (const TabP*)table, (JacQ*)out, n_groups,
                                                                        n_slices, nb, out_stride, brp_bits, bq);
