@@ -41,10 +41,13 @@ typedef struct CResult {
 typedef struct DASContext DASContext;
 
 /* bindings/c/src/lib.rs:79-92.  use_precomp = true selects precomputed window tables (the reference: width 8,
- * RECOMMENDED_PRECOMP_WIDTH, on the CPU; here the widest tables that fit in HBM: width 14 for FK20 and 13 for
- * commitments, 206 GB on an otherwise empty MI355X, narrower automatically when memory is short), false the
- * 0.8 GB width-4 tables; results are identical.  The embedded mainnet trusted setup is loaded; GPU 0 (or the ordinal
- * in $ETH_KZG_AMD_DEVICE) is used.  Aborts if no MI355X-class GPU is usable: there is no CPU fallback. */
+ * RECOMMENDED_PRECOMP_WIDTH, on the CPU; here the widest tables that fit in HBM: a GLV table of 16-bit windows for FK20,
+ * 206 GB, and a width-13 table for commitments, 43 GB, on an otherwise empty MI355X; narrower automatically when memory
+ * is short or $ETH_KZG_AMD_TABLE_GB bounds them), false the 0.8 GB width-4 tables; results are identical.
+ * Progressive start: the call returns as soon as small start tables are up (about 0.5 s) and every entry point works from
+ * then on; the wide tables are built by a helper thread and swapped in when ready (eth_kzg_amd_tables_ready;
+ * $ETH_KZG_AMD_PROGRESSIVE=0 builds them before returning).  The embedded mainnet trusted setup is loaded; GPU 0 (or the
+ * ordinal in $ETH_KZG_AMD_DEVICE) is used.  Aborts if no MI355X-class GPU is usable: there is no CPU fallback. */
 DASContext *eth_kzg_das_context_new(bool use_precomp);
 
 /* bindings/c/src/lib.rs:109-116.  NULL-safe. */
@@ -132,8 +135,9 @@ CResult eth_kzg_amd_recover_cells_and_proofs_batch(const DASContext *ctx, uint64
  * eth_kzg_recover_cells_and_proofs (bindings/c/src/lib.rs:366): ascending unique indices hold by construction, a blob
  * needs at least 64 present cells.  Outputs as in eth_kzg_amd_compute_cells_and_kzg_proofs_device (either may be NULL);
  * status[b] (HOST, n entries) = 0 ok, 1 non-canonical field element, 3 fewer than 64 cells, 4 cells not consistent with
- * a degree < 4096 polynomial; outputs of a failed blob are unspecified.  The decode runs and completes on the
- * library's stream; the cells and proofs kernels are enqueued on hip_stream (NULL: library stream, synchronised). */
+ * a degree < 4096 polynomial; outputs of a failed blob are unspecified.  The decode runs on the library's stream, ordered
+ * after the work already queued on hip_stream (event) and completed before the call returns (the status words come back
+ * from it); the cells and proofs kernels are enqueued on hip_stream behind it (NULL: library stream, synchronised). */
 CResult eth_kzg_amd_recover_cells_and_proofs_device(const DASContext *ctx, uint64_t n, const uint8_t *d_cells,
                                                     const uint64_t *present_masks, uint8_t *d_out_cells,
                                                     uint8_t *d_out_proofs, int32_t *status, void *hip_stream);
@@ -184,9 +188,13 @@ CResult eth_kzg_amd_verify_cell_kzg_proof_batch_device(const DASContext *ctx, ui
 /* Introspection used by bench.py / DESIGN.md: bytes of window tables resident in HBM, window width. */
 uint64_t eth_kzg_amd_table_bytes(const DASContext *ctx);
 int eth_kzg_amd_window_bits(const DASContext *ctx);
-/* 1 if the FK20 window table is the GLV table (8 windows of 16 bits over the two 128-bit halves of each scalar, packed
- * 96-byte entries, 16 gathered additions per base), 0 for a plain table of eth_kzg_amd_window_bits bits. */
+/* 1 if the FK20 window table in use is a GLV table (ceil(128 / w) windows of w = eth_kzg_amd_window_bits bits over the two
+ * 128-bit halves of each scalar, packed 96-byte entries: 16 gathered additions per base at w = 16), 0 for a plain table. */
 int eth_kzg_amd_glv_table(const DASContext *ctx);
+/* 1 once the final window tables are in use, 0 while the context still runs on its start tables (waits up to wait_ms
+ * milliseconds for the switch; negative: until it happened), 2 if the wide tables could not be built (memory) and the
+ * context stays on what it has.  Results never depend on the table in use. */
+int eth_kzg_amd_tables_ready(const DASContext *ctx, int wait_ms);
 /* The compiled linear map that replaces the two G1 transforms of the prover: out4 = constant multiplications, point
  * additions, point doublings per blob, kernel launches per call (all 0 when ETH_KZG_AMD_G1FFT=radix2 keeps the butterfly network). */
 void eth_kzg_amd_linmap_info(const DASContext *ctx, int32_t *out4);

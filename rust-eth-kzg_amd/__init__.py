@@ -53,7 +53,7 @@ EXPORTED_SYMBOLS = [
     "eth_kzg_amd_verify_cell_kzg_proof_batch_partial", "eth_kzg_amd_verify_cell_kzg_proof_batch_combine",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_device", "eth_kzg_amd_blob_to_kzg_commitment_device",
     "eth_kzg_amd_verify_cell_kzg_proof_batch_device",
-    "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits", "eth_kzg_amd_glv_table", "eth_kzg_amd_linmap_info",
+    "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits", "eth_kzg_amd_glv_table", "eth_kzg_amd_tables_ready", "eth_kzg_amd_linmap_info",
     "eth_kzg_amd_set_profiling", "eth_kzg_amd_get_stage_times",
     "eth_kzg_amd_comm_probe", "eth_kzg_amd_comm_unique_id", "eth_kzg_amd_comm_init", "eth_kzg_amd_comm_info",
     "eth_kzg_amd_all_gather", "eth_kzg_amd_comm_destroy",
@@ -126,6 +126,8 @@ def load_library():
     lib.eth_kzg_amd_table_bytes.argtypes = [P]
     lib.eth_kzg_amd_window_bits.argtypes = [P]
     lib.eth_kzg_amd_glv_table.argtypes = [P]
+    lib.eth_kzg_amd_tables_ready.argtypes = [P, C.c_int]
+    lib.eth_kzg_amd_tables_ready.restype = C.c_int
     lib.eth_kzg_amd_linmap_info.argtypes = [P, P]
     lib.eth_kzg_amd_linmap_info.restype = None
     lib.eth_kzg_amd_set_profiling.argtypes = [P, C.c_int]
@@ -209,7 +211,10 @@ class DASContext:
 
     device_index = 0
 
-    def __init__(self, use_precomp=True, device=None):
+    def __init__(self, use_precomp=True, device=None, wait_tables=True):
+        """wait_tables: the C entry point returns as soon as the start tables are up (progressive start); by default this
+        wrapper then waits for the wide tables, so that timing and table introspection see the final state.  Pass False to
+        use the context at once (results are identical on every table)."""
         self.device_index = int(device) if device is not None else int(os.environ.get("ETH_KZG_AMD_DEVICE", "0"))
         self._lib = load_library()
         if device is None:
@@ -218,6 +223,12 @@ class DASContext:
             self._ctx = C.c_void_p(self._lib.eth_kzg_amd_das_context_new_on_device(bool(use_precomp), int(device)))
         if not self._ctx.value:
             raise RuntimeError("eth_kzg_das_context_new returned NULL")
+        if wait_tables:
+            self.tables_ready(-1)
+
+    def tables_ready(self, wait_ms=0):
+        """1 = final window tables in use, 0 = still on the start tables, 2 = the wide build failed (stays on what it has)."""
+        return int(self._lib.eth_kzg_amd_tables_ready(self._ctx, int(wait_ms)))
 
     def close(self):
         if getattr(self, "_ctx", None) and self._ctx.value:

@@ -93,7 +93,7 @@ int Engine::open_blobs_at(int n, const uint8_t* const* blobs, const Fr8* z_mont,
     if (want_proofs) {
         // proof = g1_lincomb(g1s[..4095], quotient) (kzg_single_open/src/prover.rs:40-43): the commitment MSM path
         launch::g1_set_inf(d_X_, (size_t)64 * bp, st);
-        launch_msm(d_canon_, d_srs_table_, d_X_, 64, n, bp, 0, st);
+        launch_msm(d_canon_, TAB_SRS, d_X_, 64, n, bp, 0, st);
         launch::g1_sum_positions(d_X_, 64, bp, n, st);
         launch::g1_compress(d_X_, (uint8_t*)d_pr.p, 1, bp, n, st);
         HIPCK(hipMemcpyAsync(h_proofs, d_pr.p, (size_t)n * 48, hipMemcpyDeviceToHost, st));

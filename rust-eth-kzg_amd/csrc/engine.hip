@@ -233,17 +233,22 @@ PoolBuf::~PoolBuf() {
 }
 
 // ---------------------------------------------------------------------------------------------
-Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14 : 4) {
+Engine::Engine(bool use_precomp, int device) : dev_(device), use_precomp_(use_precomp) {
     if (use_precomp) {
-        // default: the GLV table (8 windows of 16 bits per 128-bit half scalar, packed 96-B entries, 206 GB: 1024 gathered
-        // additions per MSM); if HBM is short, plain tables of width 14 (163 GB, 19 windows -> 1216 additions), 13, 12, 10, 8, 4.
-        want_glv_ = true;
+        // default: the widest GLV table that fits (16-bit windows: 206 GB, 16 gathered additions per base), see build_final_tables
         if (const char* s = getenv("ETH_KZG_AMD_WINDOW")) {  // tuning knob: plain FK20 table of this window width (8, 10, 12, 13, 14)
             int c = atoi(s);
-            if (c == 8 || c == 10 || c == 12 || c == 13 || c == 14) { c_ = c; want_glv_ = false; }
+            if (c == 8 || c == 10 || c == 12 || c == 13 || c == 14) want_plain_c_ = c;
+        }
+        if (const char* s = getenv("ETH_KZG_AMD_GLV_WINDOW")) {  // tuning knob: exactly this GLV width (16, 15, 14, 12, 8)
+            int c = atoi(s);
+            if (launch::glv_width_supported(c)) want_glv_c_ = c;
+        }
+        if (const char* s = getenv("ETH_KZG_AMD_TABLE_GB")) {  // memory budget for the window tables (both together), in GB
+            const double g = atof(s);
+            if (g > 0) table_budget_gb_ = g;
         }
     }
-    srs_c_ = use_precomp ? 13 : 4;  // commitment table over the monomial SRS: 37.6 GB at width 13 (20 windows instead of 32)
     if (const char* s = getenv("ETH_KZG_AMD_PIP_SHIFT_MIN")) {  // tuning knob: smallest cell count verified with byte-shifted point copies
         const int v = atoi(s);
         if (v >= 1) pip_shift_min_ = v;
@@ -271,6 +276,7 @@ Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14
         }
     }
     HIPCK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    HIPCK(hipStreamCreateWithFlags(&build_stream_, hipStreamNonBlocking));
     HIPCK(hipStreamCreateWithFlags(&v_side_, hipStreamNonBlocking));
     HIPCK(hipEventCreateWithFlags(&v_decoded_, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&v_checked_, hipEventDisableTiming));
@@ -298,7 +304,7 @@ Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14
     init_srs();
     lap("SRS decompress");
     init_fk20();
-    lap("FK20 bases + window tables");
+    lap("FK20 bases + start tables");
     init_verifier();
     HIPCK(hipStreamSynchronize(stream_));
     lap("verifier (G2 lines, cosets)");
@@ -306,6 +312,8 @@ Engine::Engine(bool use_precomp, int device) : dev_(device), c_(use_precomp ? 14
 
 Engine::~Engine() {
     hipSetDevice(dev_);
+    if (builder_.joinable()) builder_.join();  // the wide tables finish building (seconds at most) before the context goes
+    if (build_stream_) hipStreamDestroy(build_stream_);
     host_pool_.reset();  // joins the helper threads before anything they might touch goes away
     void* ptrs[] = {d_w8192_, d_naf_, d_srs_, d_fk_bases_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_circ_terms_,
                     d_slp_naf_, d_slp_words_};
@@ -576,13 +584,13 @@ static bool build_table(int c, const void* bases, void** table, size_t* bytes, i
     return true;
 }
 
-// the GLV table (k_table.hip: build_table_glv16): packed 96-B entries, built in chunks of groups with 168 B of scratch per entry
-static bool build_table_glv(const void* bases, void** table, size_t* bytes, int n_groups, int nb, hipStream_t st) {
-    const size_t per_group = launch::table_glv16_entries(1, nb), entries = per_group * n_groups;
+// a GLV table of width c (k_table.hip: build_table_glv): packed 96-B entries, built in chunks of groups with 168 B of scratch per entry
+static bool build_table_glv(int c, const void* bases, void** table, size_t* bytes, int n_groups, int nb, hipStream_t st) {
+    const size_t per_group = launch::table_glv_entries(c, 1, nb), entries = per_group * n_groups;
     int chunk = (int)((9ull << 30) / (per_group * 168));
     if (chunk < 1) chunk = 1;
     if (chunk > n_groups) chunk = n_groups;
-    const size_t side_bytes = launch::table_glv16_side_bytes(chunk, nb);
+    const size_t side_bytes = launch::table_glv_side_bytes(c, chunk, nb);
     *table = nullptr;
     size_t free_b = 0, total_b = 0;
     HIPCK(hipMemGetInfo(&free_b, &total_b));
@@ -603,13 +611,14 @@ static bool build_table_glv(const void* bases, void** table, size_t* bytes, int 
         *table = nullptr;
         return false;
     }
-    if (trace) fprintf(stderr, "[context]   GLV table (8 x 16-bit windows): hipMalloc %.1f GB  %8.1f ms\n",
+    if (trace) fprintf(stderr, "[context]   GLV table (%d x %d-bit windows): hipMalloc %.1f GB  %8.1f ms\n", launch::glv_windows(c), c,
                        (entries * launch::SIZEOF_TABP + per_group * chunk * 168 + side_bytes) / 1e9, ms());
     HIPCK(hipMemsetAsync(d_err, 0, sizeof(int), st));
     for (int g0 = 0; g0 < n_groups; g0 += chunk) {
         const int g = n_groups - g0 < chunk ? n_groups - g0 : chunk;
-        launch::build_table_glv16((const char*)bases + (size_t)g0 * nb * sizeof(G1Affine),
-                                  (char*)*table + (size_t)g0 * per_group * launch::SIZEOF_TABP, scratch, side, g, nb, d_err, st);
+        if (!launch::build_table_glv(c, (const char*)bases + (size_t)g0 * nb * sizeof(G1Affine),
+                                     (char*)*table + (size_t)g0 * per_group * launch::SIZEOF_TABP, scratch, side, g, nb, d_err, st))
+            throw std::runtime_error("GLV table width not built in");
         HIPCK(hipStreamSynchronize(st));
     }
     int err = 0;
@@ -618,9 +627,43 @@ static bool build_table_glv(const void* bases, void** table, size_t* bytes, int 
     HIPCK(hipFree(side));
     HIPCK(hipFree(scratch));
     if (err) throw std::runtime_error("window table: a base point of small order");
-    if (trace) fprintf(stderr, "[context]   GLV table: built            %8.1f ms\n", ms());
+    if (trace) fprintf(stderr, "[context]   GLV table width %d: built            %8.1f ms\n", c, ms());
     *bytes = entries * launch::SIZEOF_TABP;
     return true;
+}
+
+// shared tables of a device: (kind, width) -> table; kind 0 = commitments (plain, over the monomial SRS as [64][64]),
+// 1 = FK20 plain, 2 = FK20 GLV.  Callers hold g_tables_mu.
+static std::shared_ptr<Engine::SharedTable> obtain_table(int dev, int kind, int w, const void* bases, int n_groups, hipStream_t st,
+                                                         bool only_if_live = false) {
+    auto key = std::make_tuple(dev, kind, w);
+    if (auto live = g_tables[key].lock()) return live;
+    if (only_if_live) return nullptr;
+    auto t = std::make_shared<Engine::SharedTable>();
+    t->dev = dev;
+    const bool ok = kind == 2 ? build_table_glv(w, bases, &t->p, &t->bytes, n_groups, 64, st)
+                              : build_table(w, bases, &t->p, &t->bytes, n_groups, 64, st);
+    if (!ok) return nullptr;
+    g_tables[key] = t;
+    return t;
+}
+static size_t plain_table_bytes(int c, int n_groups) { return launch::table_entries(c, n_groups, 64) * launch::SIZEOF_TABQ; }
+static size_t glv_table_bytes(int c) { return launch::table_glv_entries(c, 128, 64) * launch::SIZEOF_TABP; }
+
+Engine::TableView Engine::table_view(TableSel which) const {
+    std::lock_guard<std::mutex> lk(tab_mu_);
+    return views_[which];
+}
+void Engine::publish(TableSel which, const TableView& v) {
+    std::lock_guard<std::mutex> lk(tab_mu_);
+    if (views_[which].owner && views_[which].owner != v.owner) retired_.push_back(views_[which].owner);  // kernels in flight may still read it
+    views_[which] = v;
+}
+int Engine::tables_ready(int wait_ms) {
+    std::unique_lock<std::mutex> lk(tab_mu_);
+    if (wait_ms < 0) tab_cv_.wait(lk, [&] { return tables_state_ != 0; });
+    else if (wait_ms > 0) tab_cv_.wait_for(lk, std::chrono::milliseconds(wait_ms), [&] { return tables_state_ != 0; });
+    return tables_state_;
 }
 
 void Engine::init_fk20() {
@@ -633,45 +676,106 @@ void Engine::init_fk20() {
     launch::fk20_gather_bases(X, d_fk_bases_, stream_);
     HIPCK(hipStreamSynchronize(stream_));
     HIPCK(hipFree(X));
-    std::lock_guard<std::mutex> lk(g_tables_mu);  // one builder at a time per process
-    auto obtain = [&](int kind, int w, const void* bases, int n_groups) -> std::shared_ptr<SharedTable> {
-        auto key = std::make_tuple(dev_, kind, w);
-        if (auto live = g_tables[key].lock()) return live;
-        auto t = std::make_shared<SharedTable>();
-        t->dev = dev_;
-        if (!build_table(w, bases, &t->p, &t->bytes, n_groups, 64, stream_)) return nullptr;
-        g_tables[key] = t;
-        return t;
-    };
-    static const int srs_widths[] = {13, 12, 10, 8, 4};
-    for (int w : srs_widths) {  // SRS viewed as [64][64]; the widest table that is resident already or still fits
-        if (w > srs_c_) continue;
-        if ((srs_tab_ = obtain(0, w, d_srs_, 64))) { srs_c_ = w; break; }
+    if (!use_precomp_) {  // UsePrecomp::No: the 0.8 GB width-4 tables, nothing else to build
+        std::lock_guard<std::mutex> lk(g_tables_mu);
+        auto srs = obtain_table(dev_, 0, 4, d_srs_, 64, stream_), fk = obtain_table(dev_, 1, 4, d_fk_bases_, 128, stream_);
+        if (!srs || !fk) throw std::runtime_error("not enough device memory for the window tables");
+        publish(TAB_SRS, TableView{srs->p, 4, false, srs->bytes, srs});
+        publish(TAB_FK, TableView{fk->p, 4, false, fk->bytes, fk});
+        std::lock_guard<std::mutex> lk2(tab_mu_);
+        tables_state_ = 1;
+        return;
     }
-    if (!srs_tab_) throw std::runtime_error("not enough device memory for the commitment window table");
-    d_srs_table_ = srs_tab_->p;
-    srs_table_bytes_ = srs_tab_->bytes;
-    // the FK20 table: the GLV table if wanted and it is resident already or still fits, else the widest plain table that does
-    // (another process may hold part of the HBM)
-    if (want_glv_) {
-        auto key = std::make_tuple(dev_, 2, launch::GLV_C);
-        if (auto live = g_tables[key].lock()) fk_tab_ = live;
-        else {
-            auto t = std::make_shared<SharedTable>();
-            t->dev = dev_;
-            if (build_table_glv(d_fk_bases_, &t->p, &t->bytes, 128, 64, stream_)) { g_tables[key] = t; fk_tab_ = t; }
+    bool progressive = true;
+    if (const char* e = getenv("ETH_KZG_AMD_PROGRESSIVE")) progressive = atoi(e) != 0;
+    if (!progressive) {
+        build_final_tables();
+        if (!table_view(TAB_FK).p || !table_view(TAB_SRS).p) throw std::runtime_error("not enough device memory for the window tables: " + tables_error_);
+        return;
+    }
+    // Progressive start (the reference's "Initialize context" bench, benchmark-mt.rs:103-113): serve from small tables at once --
+    // or from whatever wider table another context of this process already holds -- and build the wide ones on a helper thread.
+    {
+        std::lock_guard<std::mutex> lk(g_tables_mu);
+        std::shared_ptr<SharedTable> fk, srs;
+        int fk_c = 0, srs_c = 0;
+        if (!want_plain_c_)
+            for (int w : launch::GLV_WIDTHS)
+                if (!fk && (fk = obtain_table(dev_, 2, w, nullptr, 128, stream_, /*only_if_live=*/true))) fk_c = w;
+        if (!fk && (fk = obtain_table(dev_, 2, 8, d_fk_bases_, 128, stream_))) fk_c = 8;
+        for (int w : {13, 12, 10, 8})
+            if (!srs && (srs = obtain_table(dev_, 0, w, nullptr, 64, stream_, true))) srs_c = w;
+        if (!srs && (srs = obtain_table(dev_, 0, 8, d_srs_, 64, stream_))) srs_c = 8;
+        if (!fk || !srs) throw std::runtime_error("not enough device memory for the start window tables");
+        publish(TAB_FK, TableView{fk->p, fk_c, true, fk->bytes, fk});
+        publish(TAB_SRS, TableView{srs->p, srs_c, false, srs->bytes, srs});
+    }
+    builder_ = std::thread([this] {
+        (void)hipSetDevice(dev_);
+        build_final_tables();
+    });
+}
+
+// The wide tables, widest first, each taken from the process-wide map if another context of this GPU holds it already:
+//   commitments: plain width 13 (43 GB; 20 windows), 12, 10, 8
+//   FK20: GLV width 16 (206 GB; 16 gathered additions per base), 15 (116 GB; 18), 14 (64 GB; 20), 12 (18 GB; 22), 8 (1.6 GB; 32)
+//         -- GLV first at every size: the endomorphism halves the memory per window bit (a plain width-14 table costs
+//         163 GB for 19 additions) -- or the plain width ETH_KZG_AMD_WINDOW names;
+// bounded by what the HBM still holds (another process may own part of it) and by ETH_KZG_AMD_TABLE_GB (both tables
+// together; the commitment table gets at most 18 % of it).  Never throws: a failure leaves the context on the tables it has.
+void Engine::build_final_tables() {
+    int state = 1;
+    std::string why;
+    try {
+        std::lock_guard<std::mutex> lk(g_tables_mu);  // one builder at a time per process
+        const double budget = table_budget_gb_ > 0 ? table_budget_gb_ * 1e9 : 1e18;
+        const TableView srs_now = table_view(TAB_SRS), fk_now = table_view(TAB_FK);
+        std::shared_ptr<SharedTable> srs;
+        int srs_c = 0;
+        for (int w : {13, 12, 10, 8}) {
+            if (srs) break;
+            if (srs_now.p && w <= srs_now.c) break;  // nothing wider than what is in use fits
+            if ((double)plain_table_bytes(w, 64) > std::max(0.18 * budget, 2.2e9)) continue;
+            if ((srs = obtain_table(dev_, 0, w, d_srs_, 64, build_stream_))) srs_c = w;
         }
-        if (fk_tab_) { fk_glv_ = true; c_ = launch::GLV_C; }
+        if (srs) publish(TAB_SRS, TableView{srs->p, srs_c, false, srs->bytes, srs});
+        const double left = budget - (double)table_view(TAB_SRS).bytes;
+        std::shared_ptr<SharedTable> fk;
+        int fk_c = 0;
+        bool fk_glv = true;
+        if (want_plain_c_) {
+            static const int widths[] = {14, 13, 12, 10, 8};
+            for (int w : widths) {
+                if (fk || w > want_plain_c_) continue;
+                if ((fk = obtain_table(dev_, 1, w, d_fk_bases_, 128, build_stream_))) { fk_c = w; fk_glv = false; }
+            }
+        } else {
+            for (int w : launch::GLV_WIDTHS) {
+                if (fk) break;
+                if (want_glv_c_ && w != want_glv_c_) continue;
+                if (fk_now.p && fk_now.glv && w <= fk_now.c) break;
+                if ((double)glv_table_bytes(w) > std::max(left, 1.7e9)) continue;
+                if ((fk = obtain_table(dev_, 2, w, d_fk_bases_, 128, build_stream_))) fk_c = w;
+            }
+        }
+        if (fk) publish(TAB_FK, TableView{fk->p, fk_c, fk_glv, fk->bytes, fk});
+        if (!table_view(TAB_FK).p) {  // not even the narrowest GLV table fits: the plain width-4 tables (0.8 GB)
+            auto f4 = obtain_table(dev_, 1, 4, d_fk_bases_, 128, build_stream_);
+            if (f4) publish(TAB_FK, TableView{f4->p, 4, false, f4->bytes, f4});
+        }
+        if (!table_view(TAB_SRS).p) {
+            auto s4 = obtain_table(dev_, 0, 4, d_srs_, 64, build_stream_);
+            if (s4) publish(TAB_SRS, TableView{s4->p, 4, false, s4->bytes, s4});
+        }
+    } catch (const std::exception& e) {
+        (void)hipGetLastError();
+        state = 2;
+        why = e.what();
     }
-    static const int widths[] = {14, 13, 12, 10, 8, 4};
-    for (int w : widths) {
-        if (fk_tab_) break;
-        if (w > c_) continue;
-        if ((fk_tab_ = obtain(1, w, d_fk_bases_, 128))) { c_ = w; break; }
-    }
-    if (!fk_tab_) throw std::runtime_error("not enough device memory for the FK20 window table");
-    d_fk_table_ = fk_tab_->p;
-    fk_table_bytes_ = fk_tab_->bytes;
+    std::lock_guard<std::mutex> lk(tab_mu_);
+    tables_state_ = state;
+    tables_error_ = why;
+    tab_cv_.notify_all();
 }
 
 // Per-stage HIP events (bench.py's roofline leg).  Meant for one caller at a time: marks of concurrent calls would interleave.
@@ -753,33 +857,35 @@ Work& Engine::lease_work(int first, int last) {
 }
 
 // ---------------------------------------------------------------------------------------------
-void Engine::launch_msm(const void* scalars, const void* table, void* out, int n_groups, int n_slices, int out_stride,
+void Engine::launch_msm(const void* scalars, TableSel which, void* out, int n_groups, int n_slices, int out_stride,
                         int brp_bits, hipStream_t st) {
-    const int c = table == d_srs_table_ ? srs_c_ : c_;
-    if (table == d_fk_table_ && fk_glv_) {  // GLV table: the scalars are split in place by the launcher (they feed nothing else)
+    const TableView tv = table_view(which);  // one consistent snapshot: the builder thread may publish a wider table at any time
+    const void* table = tv.p;
+    const int c = tv.c;
+    if (tv.glv) {  // GLV table: the scalars are split in place by the launcher (they feed nothing else)
         const long msms = (long)n_groups * n_slices;
+        const int adds_per_wave = 2 * launch::glv_windows(c) * 64;  // gathered additions of one MSM
         int mode = 1;
         if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) mode = 0;
-        else if (msm_chunks_ >= 0) mode = msm_chunks_ == 0 ? 1 : msm_chunks_ == 1 ? 3 : msm_chunks_ == 2 ? 4 : 2;  // tuning knob / tests
+        else if (msm_chunks_ >= 0) mode = msm_chunks_ == 0 ? 1 : msm_chunks_ == 1 ? 3 : msm_chunks_ == 2 ? 4 : (c == 16 ? 2 : 4);  // tuning knob / tests
         else if ((msms * 4 + 63) / 64 >= (long)wave_slots_) {
-            // The chip is full either way: S waves per 64 MSMs, each lane summing 1024 / S gathered entries.  Fewer, longer
-            // waves save the folds and the block turn-over but waste more of the last round when the wave count is not
-            // a multiple of the wave slots; pick the S with the least predicted time = rounds x (additions per wave + fold).
+            // The chip is full either way: S waves per 64 MSMs, each lane summing 1 / S of the MSM's gathered entries.  Fewer,
+            // longer waves save the folds but waste more of the last round when the wave count is not a multiple of the wave
+            // slots; pick the S with the least predicted time = rounds x (additions per wave + fold), a part-filled last
+            // round priced by its fill (one wave per SIMD runs ~1.6x faster than two).
             const long g = (msms + 63) / 64;
             double best = 0;
             for (int S : {1, 2, 4}) {
+                if (S == 4 && c != 16) continue;
                 const long waves = g * S;
-                const long rounds = (waves + wave_slots_ - 1) / wave_slots_;
-                // the last round costs a full wave time only if more than half of its SIMDs get two waves; price it by its fill
                 const double full = (double)(waves / wave_slots_), tail = (double)(waves % wave_slots_) / wave_slots_;
-                const double t_tail = tail == 0 ? 0 : (tail <= 0.5 ? 0.62 : 1.0);  // one wave per SIMD runs ~1.6x faster than two
-                const double per_wave = 1024.0 / S + (S == 1 ? 1.0 : S == 2 ? 4.0 : 8.0) * (S == 4 ? 1.6 : 1.0);  // in gathered-addition units
-                const double t = (full + t_tail) * per_wave * (S == 4 ? 1.07 : 1.0);  // measured: the 4-wave blocks lose ~7 % outside the loop
-                (void)rounds;
+                const double t_tail = tail == 0 ? 0 : (tail <= 0.5 ? 0.62 : 1.0);
+                const double per_wave = (double)adds_per_wave / S + (S == 1 ? 1.0 : S == 2 ? 4.0 : 13.0);  // in gathered-addition units
+                const double t = (full + t_tail) * per_wave * (S == 4 ? 1.03 : 1.0);  // measured: the 4-wave blocks lose ~3 % outside the loop
                 if (best == 0 || t < best) { best = t; mode = S == 1 ? 3 : S == 2 ? 4 : 2; }
             }
         }
-        launch::msm_glv16(mode, const_cast<void*>(scalars), table, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st);
+        launch::msm_glv(c, mode, const_cast<void*>(scalars), table, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st);
         return;
     }
     if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) {
@@ -848,7 +954,7 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
     launch::g1_set_inf(X, (size_t)128 * bp, st);
     const bool latency_mode = bp <= LATENCY_MODE_MAX_LANES;  // few 64-blob groups: direct 8 x 16 transforms, 4 rounds instead of 14
     mark_begin(ST_MSM_FIXED, st);
-    launch_msm(w.scalars, d_fk_table_, X, 128, segs * n, bp, (latency_mode || linmap_mode) ? 0 : 7, st);
+    launch_msm(w.scalars, TAB_FK, X, 128, segs * n, bp, (latency_mode || linmap_mode) ? 0 : 7, st);
     mark_end(1, st);
     if (linmap_mode) {
         mark_begin(ST_G1_LINMAP, st);
@@ -959,7 +1065,7 @@ int Engine::blob_to_kzg_commitment_device(int n, const uint8_t* d_blobs, uint8_t
         // 64 groups of 64 bases through the window-table kernel, then a fold over the groups.
         launch::blob_to_coeffs(n, d_blobs, d_coeffs_, d_canon_, d_status_, d_w8192_, n_inv4096_, st);
         launch::g1_set_inf(d_X_, (size_t)64 * bp, st);
-        launch_msm(d_canon_, d_srs_table_, d_X_, 64, n, bp, 0, st);
+        launch_msm(d_canon_, TAB_SRS, d_X_, 64, n, bp, 0, st);
         launch::g1_sum_positions(d_X_, 64, bp, n, st);
         launch::g1_compress(d_X_, d_commitments, 1, bp, n, st);
         if (h_status) HIPCK(hipMemcpyAsync(h_status, d_status_, n * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1276,7 +1382,7 @@ int Engine::test_fixed_msm(const uint8_t* scalars_be, int n_msm, uint8_t* out) {
         HIPCK(hipMemcpy(di, scalars_be, ns * 32, hipMemcpyHostToDevice));
         launch::test_scalars_be(di, sc, ns, stream_);
         launch::g1_set_inf(X, (size_t)128 * stride, stream_);
-        launch_msm(sc, d_fk_table_, X, 128, n_msm, stride, 0, stream_);
+        launch_msm(sc, TAB_FK, X, 128, n_msm, stride, 0, stream_);
         launch::g1_compress(X, dout, 128, stride, n_msm, stream_);
         HIPCK(hipStreamSynchronize(stream_));
         HIPCK(hipMemcpy(out, dout, (size_t)n_msm * 128 * 48, hipMemcpyDeviceToHost));

@@ -179,9 +179,26 @@ public:
     // sums since the last call: ms[ST_COUNT], launches[ST_COUNT]; synchronises the device
     void get_stage_times(double* ms, uint64_t* launches);
 
-    size_t table_bytes() const { return fk_table_bytes_ + srs_table_bytes_; }
-    int window_bits() const { return c_; }          // 16 for the GLV table
-    bool glv_table() const { return fk_glv_; }
+    // ---- window tables.  A context is usable as soon as its START tables are up (FK20: GLV width 8, 1.6 GB; commitments:
+    // plain width 8, 2.1 GB); the wide ones (GLV 16 / plain 13 by default, or the widest inside ETH_KZG_AMD_TABLE_GB) are
+    // built by a helper thread and published with one pointer swap: every MSM launch takes a snapshot of the view, results
+    // are identical for every table (tests), only the speed changes.  ETH_KZG_AMD_PROGRESSIVE=0 builds them before the
+    // constructor returns.
+    struct TableView {  // immutable once published
+        const void* p = nullptr;
+        int c = 0;          // window width
+        bool glv = false;   // packed GLV table (k_msm_glv.inc) or plain (k_msm.hip)
+        size_t bytes = 0;
+        std::shared_ptr<SharedTable> owner;
+    };
+    enum TableSel { TAB_FK = 0, TAB_SRS = 1 };
+    TableView table_view(TableSel which) const;
+    // 1 = final tables in place, 0 = still on the start tables (waits up to wait_ms; < 0: until done), 2 = the wide build
+    // failed (out of memory ...) and the context stays on what it has
+    int tables_ready(int wait_ms);
+    size_t table_bytes() const { return table_view(TAB_FK).bytes + table_view(TAB_SRS).bytes; }
+    int window_bits() const { return table_view(TAB_FK).c; }  // of the FK20 table in use
+    bool glv_table() const { return table_view(TAB_FK).glv; }
     const int* linmap_info() const { return slp_info_; }
 
 private:
@@ -210,8 +227,10 @@ private:
                          hipEvent_t after_cells);
     Work& lease_work(int first, int last);  // locks and returns a free set among work_[first..last] (blocks if none)
     void set_error(const std::exception& e);
-    void launch_msm(const void* scalars, const void* table, void* out, int n_groups, int n_slices, int out_stride,
+    void launch_msm(const void* scalars, TableSel table, void* out, int n_groups, int n_slices, int out_stride,
                     int brp_bits, hipStream_t st);
+    void build_final_tables();  // the wide tables: on the helper thread (progressive start) or inline
+    void publish(TableSel which, const TableView& v);
     void g1_ifft128_take64(void* X, int stride, hipStream_t st);
     void g1_fft128_from64(void* X, int stride, hipStream_t st);
     void g1_fft128_full(void* X, int stride, int inverse, hipStream_t st);
@@ -225,9 +244,18 @@ private:
 
     int dev_ = 0;
     Comm* comm_ = nullptr;
-    int c_ = 8;      // window width of the FK20 table
-    int srs_c_ = 13;  // window width of the commitment (monomial SRS) table (falls back like the FK20 table)
-    bool want_glv_ = false, fk_glv_ = false;  // FK20 table kind: GLV (8 x 16-bit windows over the half scalars, packed entries) or plain
+    bool use_precomp_ = true;
+    int want_plain_c_ = 0;   // ETH_KZG_AMD_WINDOW: a plain FK20 table of this width instead of the GLV ladder (0: none)
+    int want_glv_c_ = 0;     // ETH_KZG_AMD_GLV_WINDOW: this GLV width exactly (0: the widest that fits memory and budget)
+    double table_budget_gb_ = 0;  // ETH_KZG_AMD_TABLE_GB: upper bound for both tables together (0: what the HBM holds)
+    mutable std::mutex tab_mu_;
+    std::condition_variable tab_cv_;
+    TableView views_[2];
+    std::vector<std::shared_ptr<SharedTable>> retired_;  // start tables stay alive for kernels already in flight
+    int tables_state_ = 0;  // 0 building, 1 final, 2 wide build failed (guarded by tab_mu_)
+    std::string tables_error_;
+    std::thread builder_;
+    hipStream_t build_stream_ = nullptr;
     int wave_slots_ = 2048;  // CUs x 4 SIMDs x 2 waves: what one round of a ~240-VGPR point kernel occupies
     int msm_chunks_ = -1;    // -1: pick per launch (launch_msm); otherwise forced by ETH_KZG_AMD_MSM_CHUNKS
     hipStream_t stream_ = nullptr;
@@ -244,10 +272,6 @@ private:
     void* d_srs_ = nullptr;       // G1Affine[4096] monomial SRS
     void* d_fk_bases_ = nullptr;  // G1Affine[128][64] FFT'd SRS vectors (batch_toeplitz.rs:46-61)
     BufferPool dev_pool_{false}, pin_pool_{true};
-    std::shared_ptr<SharedTable> fk_tab_, srs_tab_;  // owners of the two tables below (shared by the contexts of a device)
-    void* d_fk_table_ = nullptr;  // window table over d_fk_bases_
-    void* d_srs_table_ = nullptr; // window table over d_srs_ viewed as [64][64]
-    size_t fk_table_bytes_ = 0, srs_table_bytes_ = 0;
     Fr8 n_inv4096_, inv128_;
 
     // verifier / recovery constants

@@ -270,22 +270,33 @@ bool build_table_fast(int c, const void* bases, void* table, void* scratch /*56 
     else return false;
     return true;
 }
-// GLV table of width 16 over 8 windows: packed 96-B entries; scratch = 168 B per entry of the chunk (56 for the Z factors,
-// 112 for the waiting X, Y); side as for the plain builder with W = 8
-size_t table_glv16_entries(int n_groups, int nb) { return ((size_t)n_groups * nb * GLV_W) << (GLV_C - 1); }
-size_t table_glv16_side_bytes(int n_groups, int nb) {
+// GLV tables: W = glv_windows(c) windows of c bits, packed 96-B entries; scratch = 168 B per entry of the chunk (56 for the
+// Z factors, 112 for the waiting X, Y); side as for the plain builder with that W
+size_t table_glv_entries(int c, int n_groups, int nb) { return ((size_t)n_groups * nb * glv_windows(c)) << (c - 1); }
+size_t table_glv_side_bytes(int c, int n_groups, int nb) {
     const size_t n = (size_t)n_groups * nb;
-    return n * 2 * GLV_W * (SIZEOF_AFFQ + SIZEOF_JACQ + 56) + 256;
+    return n * 2 * glv_windows(c) * (SIZEOF_AFFQ + SIZEOF_JACQ + 56) + 256;
 }
-void build_table_glv16(const void* bases, void* table, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st) {
-    const size_t n = (size_t)n_groups * nb, entries = table_glv16_entries(n_groups, nb);
+template <int C>
+static void table_glv_c(const void* bases, void* table, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st) {
+    constexpr int W = glv_windows(C);
+    const size_t n = (size_t)n_groups * nb, entries = table_glv_entries(C, n_groups, nb);
     char* qw = (char*)side;
-    char* tmp = qw + n * 2 * GLV_W * SIZEOF_AFFQ;
-    char* pre = tmp + n * 2 * GLV_W * SIZEOF_JACQ;
+    char* tmp = qw + n * 2 * W * SIZEOF_AFFQ;
+    char* pre = tmp + n * 2 * W * SIZEOF_JACQ;
     char* scr_f = (char*)scratch;
     char* scr_xy = scr_f + entries * 56;
-    k_table_windows<GLV_C, GLV_W><<<((int)n + 63) / 64, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)qw, (JacQ*)tmp, (Fq<2>*)pre, (int)n);
-    k_table_fill_packed<GLV_C, GLV_W><<<(unsigned)(n * GLV_W), 64, 0, st>>>((const AffQ*)qw, (TabP*)table, (Fq<260>*)scr_f, (Fq<XB>*)scr_xy, nb, err);
+    k_table_windows<C, W><<<((int)n + 63) / 64, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)qw, (JacQ*)tmp, (Fq<2>*)pre, (int)n);
+    k_table_fill_packed<C, W><<<(unsigned)(n * W), 64, 0, st>>>((const AffQ*)qw, (TabP*)table, (Fq<260>*)scr_f, (Fq<XB>*)scr_xy, nb, err);
+}
+bool build_table_glv(int c, const void* bases, void* table, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st) {
+    if (c == 16) table_glv_c<16>(bases, table, scratch, side, n_groups, nb, err, st);
+    else if (c == 15) table_glv_c<15>(bases, table, scratch, side, n_groups, nb, err, st);
+    else if (c == 14) table_glv_c<14>(bases, table, scratch, side, n_groups, nb, err, st);
+    else if (c == 12) table_glv_c<12>(bases, table, scratch, side, n_groups, nb, err, st);
+    else if (c == 8) table_glv_c<8>(bases, table, scratch, side, n_groups, nb, err, st);
+    else return false;
+    return true;
 }
 size_t table_entries(int c, int n_groups, int nb) {
     int W = (255 + c) / c;

@@ -28,18 +28,23 @@ void msm_fixed(int c, const void* scalars, const void* table, void* out /*G1Jac*
 // S = 1, 2 or 4 threads per MSM, each summing a chunk of the windows (large batches: no window-sum fold to speak of)
 void msm_fixed_chunked(int c, const void* scalars, const void* table, void* out /*JacQ*/, int n_groups, int n_slices, int nb,
                        int out_stride, int brp_bits, int S, hipStream_t st);
-// GLV table of width 16 (packed entries): mode 0 flat, 1 windowed, 2 chunked; splits the scalars in place
-void msm_glv16(int mode, void* scalars, const void* table, void* out /*JacQ*/, int n_groups, int n_slices, int nb, int out_stride,
-               int brp_bits, const Fp12w& beta, hipStream_t st);
+// GLV tables (packed 96-B entries, W = glv_windows(c) windows of c bits over the 128-bit half scalars; k_msm_glv.inc, one
+// translation unit per width): mode 0 flat, 1 windowed, 2 four chunks per MSM (width 16), 3 a lane per MSM, 4 a lane per
+// GLV half.  msm_glv splits the scalars in place first (they feed nothing else).
+constexpr int glv_windows(int c) { return (128 + c - 1) / c; }
+constexpr int GLV_WIDTHS[] = {16, 15, 14, 12, 8};  // widest first: the order the engine tries them in
+bool glv_width_supported(int c);
+void glv_split(void* scalars, size_t n, hipStream_t st);
+void msm_glv(int c, int mode, void* scalars, const void* table, void* out /*JacQ*/, int n_groups, int n_slices, int nb, int out_stride,
+             int brp_bits, const Fp12w& beta, hipStream_t st);
 void msm_fixed_flat(int c, const void* scalars, const void* table, void* out /*G1Jac*/, int n_groups, int n_slices, int nb,
                int out_stride, int brp_bits, hipStream_t st);
 // k_table.hip
-constexpr int GLV_C = 16, GLV_W = 8;  // the GLV table: 8 windows of 16 bits cover a 128-bit half scalar
-constexpr size_t SIZEOF_TABP = 96;    // its packed entries
-size_t table_glv16_entries(int n_groups, int nb);
-size_t table_glv16_side_bytes(int n_groups, int nb);
-// scratch: 168 B per entry of the chunk; side: table_glv16_side_bytes
-void build_table_glv16(const void* bases, void* table, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st);
+constexpr size_t SIZEOF_TABP = 96;    // a packed GLV table entry
+size_t table_glv_entries(int c, int n_groups, int nb);
+size_t table_glv_side_bytes(int c, int n_groups, int nb);
+// scratch: 168 B per entry of the chunk; side: table_glv_side_bytes; false if the width is not built in
+bool build_table_glv(int c, const void* bases, void* table, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st);
 size_t table_entries(int c, int n_groups, int nb);
 size_t table_fast_side_bytes(int c, int n_groups, int nb);
 // widths >= 8: wave-per-(base, window) builder; scratch = 56 B per entry of the chunk, side = table_fast_side_bytes; false if c unsupported

@@ -1,0 +1,161 @@
+"""Window tables: every GLV table width against the oracle at stage and
+end-to-end level, the memory budget knob, and the progressive start -- a context serves from small start tables at once
+and switches to the wide ones when a helper thread has built them; bytes never depend on the table in use.
+Reference knob: UsePrecomp::Yes{width} (crates/cryptography/bls12_381/src/fixed_base_msm.rs:41-49); reference bench:
+"Initialize context" (crates/eip7594/benches/benchmark-mt.rs:103-113).
+
+This module holds no module-wide context: a 116 GB table does not fit next to the default 249 GB ones."""
+import ctypes as C
+import importlib
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import oracle_lib
+import synth
+import test_gpu_fullsize as full
+
+pytestmark = pytest.mark.gpu
+kzg = importlib.import_module("rust-eth-kzg_amd")
+INF = b"\xc0" + bytes(47)
+GLV_ADDS = {16: 16, 15: 18, 14: 20, 12: 22, 8: 32}  # gathered additions per (scalar, base) = 2 ceil(128 / w)
+GLV_GB = {16: 206.2, 15: 116.0, 14: 64.4, 12: 17.7, 8: 1.6}
+
+
+def _msm_stage_check(ctx, tag):
+    """128 fixed-base MSM_64 per scalar set through the stage hook against oracle_g1_msm (edge scalars included)."""
+    lib = kzg.load_library()
+    n_msm = 9
+    sc = [synth.seeded_scalars(128 * 64, b"tab%d" % m) for m in range(n_msm)]
+    w = ctx.window_bits()
+    lam = 0xac45a4010001a40200000000ffffffff
+    edge = [0, 1, synth.R - 1, 1 << (w - 1), (1 << (w - 1)) + 1, (1 << w) - 1, (1 << 254), (1 << (w * 3)) - (1 << (w - 1)),
+            lam, lam - 1, lam + 1, (lam - 1) // 2, (lam + 1) // 2, (lam + 1) // 2 + 1, lam * ((lam + 1) // 2), synth.R - lam,
+            (1 << 127), (1 << 128) - 1, (1 << 126) + (1 << (w - 1)), ((1 << 127) - 1) * lam % synth.R]
+    for k, v in enumerate(edge):
+        sc[0][k] = (v % synth.R).to_bytes(32, "big")
+    sc[1] = [bytes(32)] * (128 * 64)
+    flat = b"".join(b"".join(s) for s in sc)
+    out = C.create_string_buffer(n_msm * 128 * 48)
+    assert lib.eth_kzg_amd_test_fixed_msm(ctx.handle, flat, n_msm, out) == 0
+    got = lambda m, j: out.raw[(m * 128 + j) * 48:(m * 128 + j + 1) * 48]
+    assert all(got(1, j) == INF for j in range(128)), tag
+    for (m, j) in [(0, 0), (2, 64), (8, 77)]:
+        pts = b"".join(full._fk20_base_column(i)[j] for i in range(64))
+        scal = b"".join(sc[m][j * 64:(j + 1) * 64])
+        assert got(m, j) == oracle_lib.g1_msm(pts, scal), (tag, m, j)
+
+
+@pytest.mark.parametrize("width", [15, 14, 12, 8])
+def test_every_glv_width_matches_oracle(oracle, monkeypatch, width):
+    """ETH_KZG_AMD_GLV_WINDOW: the GLV table of that width (W = ceil(128 / w) windows per half), every MSM schedule at
+    stage level and every batch regime end to end.  (Width 16 is the default table of every other GPU test.)"""
+    full._torch_first()
+    monkeypatch.setenv("ETH_KZG_AMD_GLV_WINDOW", str(width))
+    keep = kzg.DASContext(use_precomp=True)  # holds the table while the schedule variants come and go
+    try:
+        assert keep.glv_table() and keep.window_bits() == width and keep.tables_ready() == 1
+        assert abs(keep.table_bytes() / 1e9 - GLV_GB[width]) < 0.06 * GLV_GB[width] + 50  # + the commitment table (<= 43 GB)
+        for chunks in ("auto", "0", "1", "2", "4"):
+            if chunks == "auto":
+                monkeypatch.delenv("ETH_KZG_AMD_MSM_CHUNKS", raising=False)
+            else:
+                monkeypatch.setenv("ETH_KZG_AMD_MSM_CHUNKS", chunks)
+            c2 = kzg.DASContext(use_precomp=True)
+            try:
+                assert c2.window_bits() == width
+                _msm_stage_check(c2, (width, chunks))
+            finally:
+                c2.close()
+        monkeypatch.delenv("ETH_KZG_AMD_MSM_CHUNKS", raising=False)
+        # end to end: flat (<= 8 blobs), windowed, lane kernels
+        for n, seed in ((1, 1), (5, 2), (70, 3), (600, 4)):
+            blobs = full._random_blobs(n, 7000 + 10 * width + seed)
+            if n > 2:
+                blobs[2] = 0
+            st, cells, proofs = full._compute_on_device(keep, blobs)
+            assert st == [0] * n
+            full._check_sample_against_oracle(oracle, blobs, cells, proofs, sorted({0, min(2, n - 1), n // 2, n - 1}))
+    finally:
+        keep.close()
+
+
+def test_table_budget_picks_the_widest_glv_table_that_fits(oracle, monkeypatch):
+    """ETH_KZG_AMD_TABLE_GB bounds both tables together; the FK20 table stays a GLV table at every budget (a plain one of
+    the same speed needs 2.5x the memory)."""
+    full._torch_first()
+    for budget, want_w in ((80, 14), (25, 12), (3, 8)):
+        monkeypatch.setenv("ETH_KZG_AMD_TABLE_GB", str(budget))
+        c = kzg.DASContext(use_precomp=True)
+        try:
+            assert c.glv_table() and c.window_bits() == want_w, (budget, c.window_bits())
+            assert c.table_bytes() <= budget * 1e9 + 2.2e9
+            blobs = full._random_blobs(20, 7700 + budget)
+            st, cells, proofs = full._compute_on_device(c, blobs)
+            assert st == [0] * 20
+            full._check_sample_against_oracle(oracle, blobs, cells, proofs, [0, 19])
+            assert c.blob_to_kzg_commitment(blobs[3].tobytes()) == oracle.blob_to_kzg_commitment(blobs[3].tobytes())
+        finally:
+            c.close()
+
+
+def test_progressive_start_serves_at_once_and_switches_tables(oracle, monkeypatch):
+    """eth_kzg_das_context_new returns on the start tables (GLV width 8 / plain width 8); calls made before, during and
+    after the switch to the wide tables give identical bytes (and match the oracle)."""
+    import torch
+    full._torch_first()
+    monkeypatch.delenv("ETH_KZG_AMD_PROGRESSIVE", raising=False)
+    t0 = time.perf_counter()
+    c = kzg.DASContext(use_precomp=True, wait_tables=False)
+    t_new = time.perf_counter() - t0
+    try:
+        first_state, first_w = c.tables_ready(0), c.window_bits()
+        blobs = full._random_blobs(40, 4242)
+        blobs[1] = 0
+        st, cells0, proofs0 = full._compute_on_device(c, blobs)
+        t_first = time.perf_counter() - t0
+        assert st == [0] * 40
+        comm0 = c.blob_to_kzg_commitment(blobs[5].tobytes())
+        full._check_sample_against_oracle(oracle, blobs, cells0, proofs0, [0, 1, 39])
+        assert comm0 == oracle.blob_to_kzg_commitment(blobs[5].tobytes())
+        # keep calling while the helper thread builds and publishes the wide tables
+        widths_seen, n_calls = {first_w}, 0
+        while c.tables_ready(0) == 0 and n_calls < 4000:
+            st, cells, proofs = full._compute_on_device(c, blobs)
+            assert st == [0] * 40 and np.array_equal(cells, cells0) and np.array_equal(proofs, proofs0)
+            widths_seen.add(c.window_bits())
+            n_calls += 1
+        assert c.tables_ready(-1) == 1
+        assert c.glv_table() and c.window_bits() == 16
+        st, cells, proofs = full._compute_on_device(c, blobs)
+        assert np.array_equal(cells, cells0) and np.array_equal(proofs, proofs0)
+        assert c.blob_to_kzg_commitment(blobs[5].tobytes()) == comm0
+        print(f"progressive start: context_new {t_new:.2f} s, first 40-blob result after {t_first:.2f} s, start state {first_state} "
+              f"on width {first_w}, {n_calls} calls during the build, widths seen {sorted(widths_seen)}")
+        if first_state == 0:
+            assert first_w == 8
+    finally:
+        c.close()
+
+
+def test_non_progressive_start_returns_on_the_final_tables(monkeypatch):
+    full._torch_first()
+    monkeypatch.setenv("ETH_KZG_AMD_PROGRESSIVE", "0")
+    c = kzg.DASContext(use_precomp=True, wait_tables=False)
+    try:
+        assert c.tables_ready(0) == 1 and c.glv_table() and c.window_bits() == 16
+    finally:
+        c.close()
+    c = kzg.DASContext(use_precomp=False, wait_tables=False)
+    try:
+        assert c.tables_ready(0) == 1 and not c.glv_table() and c.window_bits() == 4
+    finally:
+        c.close()
