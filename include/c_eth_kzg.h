@@ -12,7 +12,9 @@
  * Ownership: inputs are borrowed for the duration of the call; outputs are written into
  * caller-allocated memory; only `CResult.error_msg` and the context are library-allocated
  * (free with eth_kzg_free_error_message / eth_kzg_das_context_free).
- * Threading: a context may be used from many threads at once (calls serialise on the GPU).
+ * Threading: a context may be used from many threads at once.  Prover calls take one of several scratch sets; the
+ * verification / recovery / commitment / EIP-4844 calls run on up to $ETH_KZG_AMD_SERIAL_LANES (default 4) engine lanes
+ * that the context creates on demand, so calls from different threads overlap on the GPU.
  */
 #ifndef C_ETH_KZG_H
 #define C_ETH_KZG_H
@@ -159,6 +161,22 @@ CResult eth_kzg_amd_verify_cell_kzg_proof_batch_partial(const DASContext *ctx, u
                                                         uint64_t shard_end, uint8_t *out_partial /* 96 */);
 CResult eth_kzg_amd_verify_cell_kzg_proof_batch_combine(const DASContext *ctx, uint64_t n_partials,
                                                         const uint8_t *partials /* n_partials * 96 */, bool *verified);
+
+/* MANY independent verifications in one call -- the throughput form of eth_kzg_verify_cell_kzg_proof_batch (the reference gets
+ * its throughput by verifying from many threads on one context, bindings/node/src/lib.rs:92-299).  Problem b is described by
+ * commitments[b] / cell_indices[b] / cells[b] / proofs[b] with the four lengths *_lengths[b], exactly as one call of the
+ * single form; the problems share every GPU launch (one lane per scalar multiplication), their transcripts are hashed and
+ * their pairings checked on host threads in parallel.  Per problem: status[b] = 0 and verified[b] = the verdict, or
+ * status[b] = 1 (a cell holds a non-canonical field element), 2 (bad G1 encoding / not in the subgroup), 3 (invalid lengths
+ * or indices) and verified[b] = false -- what the single form reports as Err (status may be NULL).  The CResult is Err only
+ * for a call-level (device) failure.  An empty problem verifies (verifier.rs:90-93). */
+CResult eth_kzg_amd_verify_cell_kzg_proof_batch_many(const DASContext *ctx, uint64_t n_batches,
+                                                     const uint64_t *commitments_lengths,
+                                                     const uint8_t *const *const *commitments,
+                                                     const uint64_t *cell_indices_lengths,
+                                                     const uint64_t *const *cell_indices, const uint64_t *cells_lengths,
+                                                     const uint8_t *const *const *cells, const uint64_t *proofs_lengths,
+                                                     const uint8_t *const *const *proofs, bool *verified, int32_t *status);
 
 /* Device-resident batches: flat buffers already in this GPU's HBM.
  *   d_blobs        n * 131072 bytes

@@ -52,7 +52,7 @@ EXPORTED_SYMBOLS = [
     "eth_kzg_amd_recover_cells_and_proofs_batch", "eth_kzg_amd_recover_cells_and_proofs_device",
     "eth_kzg_amd_verify_cell_kzg_proof_batch_partial", "eth_kzg_amd_verify_cell_kzg_proof_batch_combine",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_device", "eth_kzg_amd_blob_to_kzg_commitment_device",
-    "eth_kzg_amd_verify_cell_kzg_proof_batch_device",
+    "eth_kzg_amd_verify_cell_kzg_proof_batch_device", "eth_kzg_amd_verify_cell_kzg_proof_batch_many",
     "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits", "eth_kzg_amd_glv_table", "eth_kzg_amd_tables_ready", "eth_kzg_amd_linmap_info",
     "eth_kzg_amd_set_profiling", "eth_kzg_amd_get_stage_times",
     "eth_kzg_amd_comm_probe", "eth_kzg_amd_comm_unique_id", "eth_kzg_amd_comm_init", "eth_kzg_amd_comm_info",
@@ -106,6 +106,7 @@ def load_library():
         "eth_kzg_amd_compute_cells_and_kzg_proofs_device": [P, U64, P, P, P, P, P],
         "eth_kzg_amd_blob_to_kzg_commitment_device": [P, U64, P, P, P, P],
         "eth_kzg_amd_verify_cell_kzg_proof_batch_device": [P, U64, P, P, P, P, P, P],
+        "eth_kzg_amd_verify_cell_kzg_proof_batch_many": [P, U64, P, P, P, P, P, P, P, P, P, P],
         "eth_kzg_amd_comm_unique_id": [P],
         "eth_kzg_amd_comm_probe": [P, P, U64],
         "eth_kzg_amd_comm_info": [P, P, P],
@@ -309,6 +310,42 @@ class DASContext:
                 self._ctx, n[0], _vp(ca), n[1], _vp(idx), n[2], _vp(cla), n[3], _vp(pa), C.byref(ok)))
             return bool(ok.value)
         return run
+
+    def prepare_verify_cell_kzg_proof_batch_many(self, problems):
+        """problems = [(commitments, cell_indices, cells, proofs), ...]: marshal them into the pointer tables of
+        eth_kzg_amd_verify_cell_kzg_proof_batch_many ONCE and return a zero-argument callable that runs the call and
+        returns (verified list[bool], status list[int]) -- status 0 ok, 1 bad field element, 2 bad G1 point, 3 invalid
+        lengths / indices: what the single form raises as KzgError."""
+        nb = len(problems)
+        keep, lens = [], np.zeros((4, max(1, nb)), dtype=np.uint64)
+        tabs = [np.zeros(max(1, nb), dtype=np.uint64) for _ in range(4)]  # per problem: commitments**, indices*, cells**, proofs**
+        for b, (commitments, cell_indices, cells, proofs) in enumerate(problems):
+            if any(len(c) != 48 for c in commitments) or any(len(p) != 48 for p in proofs) \
+                    or any(len(c) != BYTES_PER_CELL for c in cells):
+                # a wrong byte length cannot cross the C ABI (fixed-size buffers carry no length): the single form raises
+                # InvalidLength before the call; here the problem goes in with inconsistent lengths and comes back status 3
+                commitments, cell_indices, cells, proofs = [], [0], [], []
+            ca, k1 = _flat_ptrs(commitments, 48)
+            cla, k2 = _flat_ptrs(cells, BYTES_PER_CELL)
+            pa, k3 = _flat_ptrs(proofs, 48)
+            idx = np.array(cell_indices, dtype=np.uint64) if len(cell_indices) else np.zeros(1, np.uint64)
+            keep += [ca, k1, cla, k2, pa, k3, idx]
+            lens[:, b] = (len(commitments), len(cell_indices), len(cells), len(proofs))
+            tabs[0][b], tabs[1][b], tabs[2][b], tabs[3][b] = ca.ctypes.data, idx.ctypes.data, cla.ctypes.data, pa.ctypes.data
+        lens = np.ascontiguousarray(lens)
+        ver = (C.c_bool * max(1, nb))()
+        st = (C.c_int32 * max(1, nb))()
+
+        def run(_keep=keep):
+            self._check(self._lib.eth_kzg_amd_verify_cell_kzg_proof_batch_many(
+                self._ctx, nb, _vp(lens[0]), _vp(tabs[0]), _vp(lens[1]), _vp(tabs[1]), _vp(lens[2]), _vp(tabs[2]), _vp(lens[3]), _vp(tabs[3]),
+                ver, st))
+            return [bool(v) for v in ver][:nb], list(st)[:nb]
+        return run
+
+    def verify_cell_kzg_proof_batch_many(self, problems):
+        """Many independent verify_cell_kzg_proof_batch problems in one call (see prepare_verify_cell_kzg_proof_batch_many)."""
+        return self.prepare_verify_cell_kzg_proof_batch_many(problems)()
 
     def verify_cell_kzg_proof_batch_partial(self, commitments, cell_indices, cells, proofs, shard_begin, shard_end):
         """This rank's share of a sharded verification: the whole batch goes in (the challenge hashes all of it), the

@@ -79,7 +79,8 @@ void eth_kzg_free_error_message(char* c_message) {
 }
 
 CResult eth_kzg_blob_to_kzg_commitment(const DASContext* ctx, const uint8_t* blob, uint8_t* out) {
-    kzg::Engine* e = eng(ctx);
+    auto lane = eng(ctx)->lease_serial();
+    kzg::Engine* e = lane.e;
     int st = 0;
     const uint8_t* blobs[1] = {blob};
     uint8_t* outs[1] = {out};
@@ -112,7 +113,8 @@ CResult eth_kzg_verify_cell_kzg_proof_batch(const DASContext* ctx, uint64_t comm
                                             const uint64_t* cell_indices, uint64_t cells_length,
                                             const uint8_t* const* cells, uint64_t proofs_length,
                                             const uint8_t* const* proofs, bool* verified) {
-    kzg::Engine* e = eng(ctx);
+    auto lane = eng(ctx)->lease_serial();
+    kzg::Engine* e = lane.e;
     int ver = 0;
     int st = e->verify_cell_kzg_proof_batch_host(commitments_length, commitments, cell_indices_length, cell_indices,
                                                  cells_length, cells, proofs_length, proofs, &ver);
@@ -122,10 +124,34 @@ CResult eth_kzg_verify_cell_kzg_proof_batch(const DASContext* ctx, uint64_t comm
     return ok();
 }
 
+CResult eth_kzg_amd_verify_cell_kzg_proof_batch_many(const DASContext* ctx, uint64_t n_batches, const uint64_t* commitments_lengths,
+                                                     const uint8_t* const* const* commitments, const uint64_t* cell_indices_lengths,
+                                                     const uint64_t* const* cell_indices, const uint64_t* cells_lengths,
+                                                     const uint8_t* const* const* cells, const uint64_t* proofs_lengths,
+                                                     const uint8_t* const* const* proofs, bool* verified, int32_t* status) {
+    kzg::Engine* e = eng(ctx);  // own lock, stream and scratch inside (verify_many.hip): no lane needed
+    if (n_batches == 0) return ok();
+    if (n_batches > (1u << 24)) return err("InvalidInput");
+    try {
+        std::vector<int> ver(n_batches), st(n_batches);
+        const int rc = e->verify_cell_kzg_proof_batch_many_host(n_batches, commitments_lengths, commitments, cell_indices_lengths,
+                                                                cell_indices, cells_lengths, cells, proofs_lengths, proofs, ver.data(), st.data());
+        if (rc == kzg::ERR_DEVICE) return device_err(e);
+        for (uint64_t b = 0; b < n_batches; b++) {
+            verified[b] = st[b] == 0 && ver[b] != 0;
+            if (status) status[b] = st[b];
+        }
+        return ok();
+    } catch (const std::exception& ex) {
+        return err(std::string("DeviceError(") + ex.what() + ")");
+    }
+}
+
 CResult eth_kzg_amd_verify_cell_kzg_proof_batch_device(const DASContext* ctx, uint64_t n, const uint8_t* d_commitments,
                                                        const uint64_t* d_cell_indices, const uint8_t* d_cells,
                                                        const uint8_t* d_proofs, bool* verified, void* hip_stream) {
-    kzg::Engine* e = eng(ctx);
+    auto lane = eng(ctx)->lease_serial();
+    kzg::Engine* e = lane.e;
     int ver = 0;
     int st = e->verify_cell_kzg_proof_batch_device(n, d_commitments, d_cell_indices, d_cells, d_proofs, &ver, (hipStream_t)hip_stream);
     if (st == kzg::ERR_DEVICE) return device_err(e);
@@ -137,7 +163,8 @@ CResult eth_kzg_amd_verify_cell_kzg_proof_batch_device(const DASContext* ctx, ui
 CResult eth_kzg_amd_recover_cells_and_proofs_device(const DASContext* ctx, uint64_t n, const uint8_t* d_cells,
                                                     const uint64_t* present_masks, uint8_t* d_out_cells, uint8_t* d_out_proofs,
                                                     int32_t* status, void* hip_stream) {
-    kzg::Engine* e = eng(ctx);
+    auto lane = eng(ctx)->lease_serial();
+    kzg::Engine* e = lane.e;
     static_assert(sizeof(int32_t) == sizeof(int), "status array");
     int st = e->recover_cells_and_kzg_proofs_device((int)n, d_cells, present_masks, d_out_cells, d_out_proofs, (int*)status,
                                                     (hipStream_t)hip_stream);
@@ -152,7 +179,8 @@ CResult eth_kzg_amd_verify_cell_kzg_proof_batch_partial(const DASContext* ctx, u
                                                         const uint8_t* const* cells, uint64_t proofs_length,
                                                         const uint8_t* const* proofs, uint64_t shard_begin,
                                                         uint64_t shard_end, uint8_t* out_partial) {
-    kzg::Engine* e = eng(ctx);
+    auto lane = eng(ctx)->lease_serial();
+    kzg::Engine* e = lane.e;
     int st = e->verify_cell_kzg_proof_batch_partial_host(commitments_length, commitments, cell_indices_length, cell_indices,
                                                          cells_length, cells, proofs_length, proofs, shard_begin, shard_end,
                                                          out_partial);
@@ -162,7 +190,8 @@ CResult eth_kzg_amd_verify_cell_kzg_proof_batch_partial(const DASContext* ctx, u
 
 CResult eth_kzg_amd_verify_cell_kzg_proof_batch_combine(const DASContext* ctx, uint64_t n_partials, const uint8_t* partials,
                                                         bool* verified) {
-    kzg::Engine* e = eng(ctx);
+    auto lane = eng(ctx)->lease_serial();
+    kzg::Engine* e = lane.e;
     int ver = 0;
     int st = e->verify_cell_kzg_proof_batch_combine_host(n_partials, partials, &ver);
     if (st) return err(status_text(st));
@@ -173,7 +202,8 @@ CResult eth_kzg_amd_verify_cell_kzg_proof_batch_combine(const DASContext* ctx, u
 CResult eth_kzg_recover_cells_and_proofs(const DASContext* ctx, uint64_t cells_length, const uint8_t* const* cells,
                                          uint64_t cell_indices_length, const uint64_t* cell_indices,
                                          uint8_t** out_cells, uint8_t** out_proofs) {
-    kzg::Engine* e = eng(ctx);
+    auto lane = eng(ctx)->lease_serial();
+    kzg::Engine* e = lane.e;
     int st = e->recover_cells_and_kzg_proofs_host(cells_length, cells, cell_indices_length, cell_indices, out_cells, out_proofs);
     if (st == kzg::ERR_DEVICE) return device_err(e);
     return st ? err(status_text(st)) : ok();
@@ -189,16 +219,19 @@ static CResult finish(kzg::Engine* e, int st) {
     return st ? err(status_text(st)) : ok();
 }
 CResult eth_kzg_compute_kzg_proof(const DASContext* ctx, const uint8_t* blob, const uint8_t* z, uint8_t* out_proof, uint8_t* out_y) {
-    kzg::Engine* e = eng(ctx);
+    auto lane = eng(ctx)->lease_serial();
+    kzg::Engine* e = lane.e;
     return finish(e, e->compute_kzg_proof_host(blob, z, out_proof, out_y));
 }
 CResult eth_kzg_compute_blob_kzg_proof(const DASContext* ctx, const uint8_t* blob, const uint8_t* commitment, uint8_t* out) {
-    kzg::Engine* e = eng(ctx);
+    auto lane = eng(ctx)->lease_serial();
+    kzg::Engine* e = lane.e;
     return finish(e, e->compute_blob_kzg_proof_host(blob, commitment, out));
 }
 CResult eth_kzg_verify_kzg_proof(const DASContext* ctx, const uint8_t* commitment, const uint8_t* z, const uint8_t* y,
                                  const uint8_t* proof, bool* verified) {
-    kzg::Engine* e = eng(ctx);
+    auto lane = eng(ctx)->lease_serial();
+    kzg::Engine* e = lane.e;
     int ver = 0;
     int st = e->verify_kzg_proof_host(commitment, z, y, proof, &ver);
     if (!st) *verified = ver != 0;
@@ -206,7 +239,8 @@ CResult eth_kzg_verify_kzg_proof(const DASContext* ctx, const uint8_t* commitmen
 }
 CResult eth_kzg_verify_blob_kzg_proof(const DASContext* ctx, const uint8_t* blob, const uint8_t* commitment, const uint8_t* proof,
                                       bool* verified) {
-    kzg::Engine* e = eng(ctx);
+    auto lane = eng(ctx)->lease_serial();
+    kzg::Engine* e = lane.e;
     int ver = 0;
     int st = e->verify_blob_kzg_proof_host(blob, commitment, proof, &ver);
     if (!st) *verified = ver != 0;
@@ -215,7 +249,8 @@ CResult eth_kzg_verify_blob_kzg_proof(const DASContext* ctx, const uint8_t* blob
 CResult eth_kzg_verify_blob_kzg_proof_batch(const DASContext* ctx, uint64_t blobs_length, const uint8_t* const* blobs,
                                             uint64_t commitments_length, const uint8_t* const* commitments, uint64_t proofs_length,
                                             const uint8_t* const* proofs, bool* verified) {
-    kzg::Engine* e = eng(ctx);
+    auto lane = eng(ctx)->lease_serial();
+    kzg::Engine* e = lane.e;
     int ver = 0;
     int st = e->verify_blob_kzg_proof_batch_host(blobs_length, blobs, commitments_length, commitments, proofs_length, proofs, &ver);
     if (!st) *verified = ver != 0;
@@ -234,7 +269,8 @@ CResult eth_kzg_amd_compute_cells_and_kzg_proofs_batch(const DASContext* ctx, ui
 }
 CResult eth_kzg_amd_blob_to_kzg_commitment_batch(const DASContext* ctx, uint64_t n, const uint8_t* const* blobs,
                                                  uint8_t* const* out, int32_t* status) {
-    kzg::Engine* e = eng(ctx);
+    auto lane = eng(ctx)->lease_serial();
+    kzg::Engine* e = lane.e;
     std::vector<int> st(n);
     if (e->blob_to_kzg_commitment_host((int)n, blobs, out, st.data())) return device_err(e);
     if (status) for (uint64_t i = 0; i < n; i++) status[i] = st[i];
@@ -244,7 +280,8 @@ CResult eth_kzg_amd_recover_cells_and_proofs_batch(const DASContext* ctx, uint64
                                                    const uint8_t* const* const* cells, const uint64_t* cell_indices_lengths,
                                                    const uint64_t* const* cell_indices, uint8_t* const* const* out_cells,
                                                    uint8_t* const* const* out_proofs, int32_t* status) {
-    kzg::Engine* e = eng(ctx);
+    auto lane = eng(ctx)->lease_serial();
+    kzg::Engine* e = lane.e;
     std::vector<int> st(n);
     if (e->recover_cells_and_kzg_proofs_batch_host((int)n, cells_lengths, cells, cell_indices_lengths, cell_indices, out_cells,
                                                    out_proofs, st.data()))
@@ -264,7 +301,8 @@ CResult eth_kzg_amd_compute_cells_and_kzg_proofs_device(const DASContext* ctx, u
 }
 CResult eth_kzg_amd_blob_to_kzg_commitment_device(const DASContext* ctx, uint64_t n, const uint8_t* d_blobs, uint8_t* d_out,
                                                   int32_t* status, void* hip_stream) {
-    kzg::Engine* e = eng(ctx);
+    auto lane = eng(ctx)->lease_serial();
+    kzg::Engine* e = lane.e;
     bool sync = hip_stream == nullptr;
     if (e->blob_to_kzg_commitment_device((int)n, d_blobs, d_out, status, (hipStream_t)hip_stream, sync)) return device_err(e);
     if (status) for (uint64_t i = 0; i < n; i++) status[i] = status[i] ? kzg::ERR_SCALAR : 0;

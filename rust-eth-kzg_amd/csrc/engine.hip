@@ -233,7 +233,69 @@ PoolBuf::~PoolBuf() {
 }
 
 // ---------------------------------------------------------------------------------------------
-Engine::Engine(bool use_precomp, int device) : dev_(device), use_precomp_(use_precomp) {
+// Engines whose helper thread may still be building tables.  A process that exits without freeing its context (legal for the
+// reference's API users: the context is often a process-lifetime object) must not tear the HIP runtime down under that
+// thread: the handler below runs before the runtime's own exit handlers (it is registered later), raises the cancel flags
+// and waits for the builders, each of which gives up within one 2 GB piece.
+static std::atomic<bool> g_exiting{false};
+static std::mutex g_engines_mu;
+static std::vector<Engine*> g_engines;
+void Engine::stop_builder() {
+    cancel_build_.store(true);
+    if (builder_.joinable()) builder_.join();
+}
+static void stop_all_builders_at_exit() {
+    g_exiting.store(true);
+    std::vector<Engine*> live;
+    {
+        std::lock_guard<std::mutex> lk(g_engines_mu);
+        live = g_engines;
+    }
+    for (Engine* e : live) e->stop_builder();
+}
+
+Engine::SerialLease Engine::lease_serial() {
+    SerialLease L;
+    L.busy = std::unique_lock<std::mutex>(lane_busy_, std::try_to_lock);
+    if (L.busy.owns_lock() || auxiliary_ || max_lanes_ <= 1) {
+        if (!L.busy.owns_lock()) L.busy.lock();
+        L.e = this;
+        return L;
+    }
+    {
+        std::lock_guard<std::mutex> lk(lanes_mu_);
+        for (auto& a : aux_) {
+            L.busy = std::unique_lock<std::mutex>(a->lane_busy_, std::try_to_lock);
+            if (L.busy.owns_lock()) { L.e = a.get(); return L; }
+        }
+        if ((int)aux_.size() + 1 < max_lanes_) {
+            try {
+                aux_.emplace_back(new Engine(use_precomp_, dev_, /*auxiliary=*/true));
+                L.busy = std::unique_lock<std::mutex>(aux_.back()->lane_busy_);
+                L.e = aux_.back().get();
+                return L;
+            } catch (const std::exception&) {
+                (void)hipGetLastError();  // no room for another lane: queue on an existing one
+            }
+        }
+    }
+    // all lanes busy: wait on one of them, round-robin
+    Engine* pick = this;
+    {
+        std::lock_guard<std::mutex> lk(lanes_mu_);
+        const unsigned k = lane_rr_.fetch_add(1) % (unsigned)(aux_.size() + 1);
+        if (k > 0) pick = aux_[k - 1].get();
+    }
+    L.busy = std::unique_lock<std::mutex>(pick->lane_busy_);
+    L.e = pick;
+    return L;
+}
+
+Engine::Engine(bool use_precomp, int device, bool auxiliary) : dev_(device), use_precomp_(use_precomp), auxiliary_(auxiliary) {
+    if (const char* s = getenv("ETH_KZG_AMD_SERIAL_LANES")) {
+        const int v = atoi(s);
+        if (v >= 1 && v <= 16) max_lanes_ = v;
+    }
     if (use_precomp) {
         // default: the widest GLV table that fits (16-bit windows: 206 GB, 16 gathered additions per base), see build_final_tables
         if (const char* s = getenv("ETH_KZG_AMD_WINDOW")) {  // tuning knob: plain FK20 table of this window width (8, 10, 12, 13, 14)
@@ -312,7 +374,15 @@ Engine::Engine(bool use_precomp, int device) : dev_(device), use_precomp_(use_pr
 
 Engine::~Engine() {
     hipSetDevice(dev_);
-    if (builder_.joinable()) builder_.join();  // the wide tables finish building (seconds at most) before the context goes
+    {
+        std::lock_guard<std::mutex> lk(lanes_mu_);
+        aux_.clear();
+    }
+    stop_builder();  // an unfinished build of the wide tables is abandoned (within one 2 GB piece)
+    {
+        std::lock_guard<std::mutex> lk(g_engines_mu);
+        g_engines.erase(std::remove(g_engines.begin(), g_engines.end(), this), g_engines.end());
+    }
     if (build_stream_) hipStreamDestroy(build_stream_);
     host_pool_.reset();  // joins the helper threads before anything they might touch goes away
     void* ptrs[] = {d_w8192_, d_naf_, d_srs_, d_fk_bases_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_circ_terms_,
@@ -335,6 +405,10 @@ Engine::~Engine() {
     }
     if (v_dev_) hipFree(v_dev_);
     if (v_pin_) hipHostFree(v_pin_);
+    if (vm_dev_) hipFree(vm_dev_);
+    if (vm_pin_) hipHostFree(vm_pin_);
+    if (vd_pin_) hipHostFree(vd_pin_);
+    if (vm_stream_) hipStreamDestroy(vm_stream_);
     if (v_side_) hipStreamDestroy(v_side_);
     if (v_decoded_) hipEventDestroy(v_decoded_);
     if (v_checked_) hipEventDestroy(v_checked_);
@@ -517,14 +591,80 @@ void Engine::init_srs() {
 // Window tables are immutable once built and depend only on (device, which bases, width), so the contexts of one
 // process share them: the second DASContext on a GPU costs neither another 206 GB nor another build
 // (the reference's Java test creates several contexts, LibEthKZGTest.java:32).  The last context to go frees the table.
+// Large tables are not hipMalloc'ed in one piece: mapping 200+ GB takes the driver seconds during which every other HIP call of
+// the process waits (measured: a 214 GB hipMalloc on the helper thread stalled the caller's launches for 4.3 s), and the call
+// cannot be abandoned when the context -- or the process -- goes away.  Instead the address range is reserved and backed
+// PIECE BY PIECE (hipMemCreate / hipMemMap / hipMemSetAccess, 2 GB at a time, a few tens of milliseconds each), just ahead
+// of the builder kernels: other threads' calls slip in between the pieces, mapping overlaps the build of the previous
+// groups, and a cancellation is honoured within one piece.  Small tables and any failure of the VMM calls fall back to hipMalloc.
 struct Engine::SharedTable {
     void* p = nullptr;
     size_t bytes = 0;
     int dev = 0;
-    ~SharedTable() {
-        if (p) { (void)hipSetDevice(dev); (void)hipFree(p); }
+    // VMM backing (empty for a hipMalloc'ed table)
+    size_t reserved = 0, mapped = 0, piece = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    bool vmm() const { return reserved != 0; }
+    // reserve the address range; false -> use hipMalloc instead
+    bool reserve(size_t n) {
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) { (void)hipGetLastError(); return false; }
+        piece = ((size_t)(2ull << 30) + gran - 1) / gran * gran;
+        const size_t total = (n + gran - 1) / gran * gran;
+        void* base = nullptr;
+        if (hipMemAddressReserve(&base, total, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+        p = base;
+        reserved = total;
+        return true;
     }
+    // back the range up to byte offset `end` (rounded up to whole pieces); false on failure (out of memory) or cancellation
+    bool map_until(size_t end, const std::atomic<bool>* cancel) {
+        if (end > reserved) end = reserved;
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        while (mapped < end) {
+            if (cancel && cancel->load()) return false;
+            const size_t sz = std::min(piece, reserved - mapped);
+            hipMemGenericAllocationHandle_t h;
+            if (hipMemCreate(&h, sz, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (hipMemMap((char*)p + mapped, sz, 0, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(h); return false; }
+            handles.push_back(h);
+            if (hipMemSetAccess((char*)p + mapped, sz, &acc, 1) != hipSuccess) { (void)hipGetLastError(); mapped += sz; return false; }
+            mapped += sz;
+        }
+        return true;
+    }
+    void release() {
+        if (!p) return;
+        (void)hipSetDevice(dev);
+        if (vmm()) {
+            size_t off = 0;
+            for (auto h : handles) {
+                const size_t sz = std::min(piece, reserved - off);
+                (void)hipMemUnmap((char*)p + off, sz);
+                (void)hipMemRelease(h);
+                off += sz;
+            }
+            (void)hipMemAddressFree(p, reserved);
+            handles.clear();
+            reserved = mapped = 0;
+        } else {
+            (void)hipFree(p);
+        }
+        p = nullptr;
+    }
+    ~SharedTable() { release(); }
 };
+struct BuildCancelled {};  // thrown out of a table build when its context (or the process) is going away
 static std::mutex g_tables_mu;
 static std::map<std::tuple<int, int, int>, std::weak_ptr<Engine::SharedTable>> g_tables;  // (device, kind, width)
 
@@ -584,64 +724,88 @@ static bool build_table(int c, const void* bases, void** table, size_t* bytes, i
     return true;
 }
 
-// a GLV table of width c (k_table.hip: build_table_glv): packed 96-B entries, built in chunks of groups with 168 B of scratch per entry
-static bool build_table_glv(int c, const void* bases, void** table, size_t* bytes, int n_groups, int nb, hipStream_t st) {
+// a GLV table of width c (k_table.hip: build_table_glv): packed 96-B entries, built in chunks of groups with 168 B of scratch per
+// entry; the table memory is backed piece by piece just ahead of the builder kernels (SharedTable::map_until).
+// false: the device cannot hold it.  Throws BuildCancelled when `cancel` is raised.
+static bool build_table_glv(int c, const void* bases, Engine::SharedTable& t, int n_groups, int nb, hipStream_t st,
+                            const std::atomic<bool>* cancel) {
     const size_t per_group = launch::table_glv_entries(c, 1, nb), entries = per_group * n_groups;
+    const size_t table_bytes = entries * launch::SIZEOF_TABP;
     int chunk = (int)((9ull << 30) / (per_group * 168));
     if (chunk < 1) chunk = 1;
     if (chunk > n_groups) chunk = n_groups;
     const size_t side_bytes = launch::table_glv_side_bytes(c, chunk, nb);
-    *table = nullptr;
     size_t free_b = 0, total_b = 0;
     HIPCK(hipMemGetInfo(&free_b, &total_b));
-    const size_t need = entries * launch::SIZEOF_TABP + per_group * chunk * 168 + side_bytes + (8ull << 30);  // + head-room for batches
+    const size_t need = table_bytes + per_group * chunk * 168 + side_bytes + (8ull << 30);  // + head-room for batches
     if (need > free_b) return false;
     const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     void *scratch = nullptr, *side = nullptr;
     int* d_err = nullptr;
-    if (hipMalloc(table, entries * launch::SIZEOF_TABP) != hipSuccess) { (void)hipGetLastError(); *table = nullptr; return false; }
+    const bool piecewise = table_bytes > (8ull << 30) && getenv("ETH_KZG_AMD_NO_VMM") == nullptr && t.reserve(table_bytes);
+    if (!piecewise && hipMalloc(&t.p, table_bytes) != hipSuccess) { (void)hipGetLastError(); t.p = nullptr; return false; }
+    auto cleanup = [&] {
+        (void)hipStreamSynchronize(st);
+        if (scratch) (void)hipFree(scratch);
+        if (side) (void)hipFree(side);
+        if (d_err) (void)hipFree(d_err);
+        scratch = side = nullptr;
+        d_err = nullptr;
+    };
     if (hipMalloc(&scratch, per_group * chunk * 168) != hipSuccess || hipMalloc(&side, side_bytes) != hipSuccess ||
         hipMalloc(&d_err, sizeof(int)) != hipSuccess) {
         (void)hipGetLastError();
-        if (scratch) (void)hipFree(scratch);
-        if (side) (void)hipFree(side);
-        HIPCK(hipFree(*table));
-        *table = nullptr;
+        cleanup();
+        t.release();
         return false;
     }
-    if (trace) fprintf(stderr, "[context]   GLV table (%d x %d-bit windows): hipMalloc %.1f GB  %8.1f ms\n", launch::glv_windows(c), c,
-                       (entries * launch::SIZEOF_TABP + per_group * chunk * 168 + side_bytes) / 1e9, ms());
-    HIPCK(hipMemsetAsync(d_err, 0, sizeof(int), st));
-    for (int g0 = 0; g0 < n_groups; g0 += chunk) {
-        const int g = n_groups - g0 < chunk ? n_groups - g0 : chunk;
-        if (!launch::build_table_glv(c, (const char*)bases + (size_t)g0 * nb * sizeof(G1Affine),
-                                     (char*)*table + (size_t)g0 * per_group * launch::SIZEOF_TABP, scratch, side, g, nb, d_err, st))
-            throw std::runtime_error("GLV table width not built in");
+    if (trace) fprintf(stderr, "[context]   GLV table (%d x %d-bit windows): %.1f GB %s, scratch allocated  %8.1f ms\n", launch::glv_windows(c), c,
+                       table_bytes / 1e9, piecewise ? "reserved (backed piece by piece)" : "hipMalloc'ed", ms());
+    try {
+        HIPCK(hipMemsetAsync(d_err, 0, sizeof(int), st));
+        for (int g0 = 0; g0 < n_groups; g0 += chunk) {
+            const int g = n_groups - g0 < chunk ? n_groups - g0 : chunk;
+            if (cancel && cancel->load()) throw BuildCancelled{};
+            // back this chunk's part of the table while the GPU still builds the previous one
+            if (piecewise && !t.map_until((size_t)(g0 + g) * per_group * launch::SIZEOF_TABP, cancel)) {
+                if (cancel && cancel->load()) throw BuildCancelled{};
+                cleanup();
+                t.release();
+                return false;  // out of memory after all (another process took it meanwhile)
+            }
+            HIPCK(hipStreamSynchronize(st));  // the previous chunk has left the scratch
+            if (!launch::build_table_glv(c, (const char*)bases + (size_t)g0 * nb * sizeof(G1Affine),
+                                         (char*)t.p + (size_t)g0 * per_group * launch::SIZEOF_TABP, scratch, side, g, nb, d_err, st))
+                throw std::runtime_error("GLV table width not built in");
+        }
         HIPCK(hipStreamSynchronize(st));
+        int err = 0;
+        HIPCK(hipMemcpy(&err, d_err, sizeof(int), hipMemcpyDeviceToHost));
+        if (err) throw std::runtime_error("window table: a base point of small order");
+    } catch (...) {
+        cleanup();
+        t.release();
+        throw;
     }
-    int err = 0;
-    HIPCK(hipMemcpy(&err, d_err, sizeof(int), hipMemcpyDeviceToHost));
-    HIPCK(hipFree(d_err));
-    HIPCK(hipFree(side));
-    HIPCK(hipFree(scratch));
-    if (err) throw std::runtime_error("window table: a base point of small order");
+    cleanup();
     if (trace) fprintf(stderr, "[context]   GLV table width %d: built            %8.1f ms\n", c, ms());
-    *bytes = entries * launch::SIZEOF_TABP;
+    t.bytes = table_bytes;
     return true;
 }
 
 // shared tables of a device: (kind, width) -> table; kind 0 = commitments (plain, over the monomial SRS as [64][64]),
 // 1 = FK20 plain, 2 = FK20 GLV.  Callers hold g_tables_mu.
 static std::shared_ptr<Engine::SharedTable> obtain_table(int dev, int kind, int w, const void* bases, int n_groups, hipStream_t st,
-                                                         bool only_if_live = false) {
+                                                         bool only_if_live = false, const std::atomic<bool>* cancel = nullptr) {
     auto key = std::make_tuple(dev, kind, w);
     if (auto live = g_tables[key].lock()) return live;
     if (only_if_live) return nullptr;
+    if (cancel && cancel->load()) throw BuildCancelled{};
     auto t = std::make_shared<Engine::SharedTable>();
     t->dev = dev;
-    const bool ok = kind == 2 ? build_table_glv(w, bases, &t->p, &t->bytes, n_groups, 64, st)
+    const bool ok = kind == 2 ? build_table_glv(w, bases, *t, n_groups, 64, st, cancel)
                               : build_table(w, bases, &t->p, &t->bytes, n_groups, 64, st);
     if (!ok) return nullptr;
     g_tables[key] = t;
@@ -710,6 +874,12 @@ void Engine::init_fk20() {
         publish(TAB_FK, TableView{fk->p, fk_c, true, fk->bytes, fk});
         publish(TAB_SRS, TableView{srs->p, srs_c, false, srs->bytes, srs});
     }
+    {
+        std::lock_guard<std::mutex> lk(g_engines_mu);
+        static bool registered = false;
+        if (!registered) { atexit(stop_all_builders_at_exit); registered = true; }
+        g_engines.push_back(this);
+    }
     builder_ = std::thread([this] {
         (void)hipSetDevice(dev_);
         build_final_tables();
@@ -728,6 +898,7 @@ void Engine::build_final_tables() {
     std::string why;
     try {
         std::lock_guard<std::mutex> lk(g_tables_mu);  // one builder at a time per process
+        if (cancel_build_.load()) throw BuildCancelled{};
         const double budget = table_budget_gb_ > 0 ? table_budget_gb_ * 1e9 : 1e18;
         const TableView srs_now = table_view(TAB_SRS), fk_now = table_view(TAB_FK);
         std::shared_ptr<SharedTable> srs;
@@ -736,7 +907,7 @@ void Engine::build_final_tables() {
             if (srs) break;
             if (srs_now.p && w <= srs_now.c) break;  // nothing wider than what is in use fits
             if ((double)plain_table_bytes(w, 64) > std::max(0.18 * budget, 2.2e9)) continue;
-            if ((srs = obtain_table(dev_, 0, w, d_srs_, 64, build_stream_))) srs_c = w;
+            if ((srs = obtain_table(dev_, 0, w, d_srs_, 64, build_stream_, false, &cancel_build_))) srs_c = w;
         }
         if (srs) publish(TAB_SRS, TableView{srs->p, srs_c, false, srs->bytes, srs});
         const double left = budget - (double)table_view(TAB_SRS).bytes;
@@ -747,7 +918,7 @@ void Engine::build_final_tables() {
             static const int widths[] = {14, 13, 12, 10, 8};
             for (int w : widths) {
                 if (fk || w > want_plain_c_) continue;
-                if ((fk = obtain_table(dev_, 1, w, d_fk_bases_, 128, build_stream_))) { fk_c = w; fk_glv = false; }
+                if ((fk = obtain_table(dev_, 1, w, d_fk_bases_, 128, build_stream_, false, &cancel_build_))) { fk_c = w; fk_glv = false; }
             }
         } else {
             for (int w : launch::GLV_WIDTHS) {
@@ -755,7 +926,7 @@ void Engine::build_final_tables() {
                 if (want_glv_c_ && w != want_glv_c_) continue;
                 if (fk_now.p && fk_now.glv && w <= fk_now.c) break;
                 if ((double)glv_table_bytes(w) > std::max(left, 1.7e9)) continue;
-                if ((fk = obtain_table(dev_, 2, w, d_fk_bases_, 128, build_stream_))) fk_c = w;
+                if ((fk = obtain_table(dev_, 2, w, d_fk_bases_, 128, build_stream_, false, &cancel_build_))) fk_c = w;
             }
         }
         if (fk) publish(TAB_FK, TableView{fk->p, fk_c, fk_glv, fk->bytes, fk});
@@ -767,6 +938,9 @@ void Engine::build_final_tables() {
             auto s4 = obtain_table(dev_, 0, 4, d_srs_, 64, build_stream_);
             if (s4) publish(TAB_SRS, TableView{s4->p, 4, false, s4->bytes, s4});
         }
+    } catch (const BuildCancelled&) {
+        state = 2;
+        why = "cancelled: the context is being freed";
     } catch (const std::exception& e) {
         (void)hipGetLastError();
         state = 2;

@@ -104,9 +104,21 @@ public:
     // use_precomp: true -> the widest FK20 window table that fits in HBM (width 14 = 163 GB on an otherwise empty
     //              MI355X; the reference's UsePrecomp::Yes uses width 8 on the CPU), false -> width-4 tables (0.8 GB,
     //              ~3.4x the additions).  Results identical.  Tables are shared by the contexts of a device.
-    Engine(bool use_precomp, int device);
+    Engine(bool use_precomp, int device, bool auxiliary = false);
     ~Engine();
     Engine(const Engine&) = delete;
+
+    // The verification / recovery / commitment / EIP-4844 entry points serialise on one lock per Engine (they share its stream
+    // and scratch).  So that calls from different host threads overlap, as they do on the reference's immutable context
+    // (bindings/node/src/lib.rs:92-299), the context keeps up to ETH_KZG_AMD_SERIAL_LANES (default 4) engines: the primary one
+    // and auxiliaries created on demand (0.1 s each; the window tables are shared, so no memory to speak of).  lease_serial()
+    // hands out a free one -- the primary when it is idle -- and blocks only when all are busy.
+    struct SerialLease {
+        Engine* e = nullptr;
+        std::unique_lock<std::mutex> busy;
+        Engine* operator->() const { return e; }
+    };
+    SerialLease lease_serial();
 
     int device() const { return dev_; }
     Comm* comm() const { return comm_; }       // RCCL communicator attached by eth_kzg_amd_comm_init (multi_gpu.cpp)
@@ -135,6 +147,13 @@ public:
     // n * 2048 cell bytes, n * 48 proof bytes
     int verify_cell_kzg_proof_batch_device(uint64_t n, const uint8_t* d_commitments, const uint64_t* d_cell_indices,
                                            const uint8_t* d_cells, const uint8_t* d_proofs, int* verified, hipStream_t stream);
+    // MANY independent verifications in one call (verify_many.hip): problem b has n_*[b] entries in commitments[b] / cell_indices[b]
+    // / cells[b] / proofs[b]; status[b] = a Status (OK, ERR_INPUT, ERR_G1, ERR_SCALAR), verified[b] set when OK.  Returns
+    // ERR_DEVICE on a HIP failure, OK otherwise.  Does not take mu_: runs next to the other entry points.
+    int verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint64_t* n_commitments, const uint8_t* const* const* commitments,
+                                              const uint64_t* n_indices, const uint64_t* const* cell_indices, const uint64_t* n_cells,
+                                              const uint8_t* const* const* cells, const uint64_t* n_proofs,
+                                              const uint8_t* const* const* proofs, int* verified, int* status);
     // the same check sharded over ranks: every rank passes the WHOLE batch (the Fiat-Shamir transcript covers it) and its
     // slice [lo, hi) of the cell list, gets 96 bytes back; the gathered records go to _combine on any rank.
     int verify_cell_kzg_proof_batch_partial_host(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,
@@ -196,6 +215,7 @@ public:
     // 1 = final tables in place, 0 = still on the start tables (waits up to wait_ms; < 0: until done), 2 = the wide build
     // failed (out of memory ...) and the context stays on what it has
     int tables_ready(int wait_ms);
+    void stop_builder();  // abandon an unfinished build of the wide tables and join the helper thread
     size_t table_bytes() const { return table_view(TAB_FK).bytes + table_view(TAB_SRS).bytes; }
     int window_bits() const { return table_view(TAB_FK).c; }  // of the FK20 table in use
     bool glv_table() const { return table_view(TAB_FK).glv; }
@@ -255,6 +275,7 @@ private:
     int tables_state_ = 0;  // 0 building, 1 final, 2 wide build failed (guarded by tab_mu_)
     std::string tables_error_;
     std::thread builder_;
+    std::atomic<bool> cancel_build_{false};
     hipStream_t build_stream_ = nullptr;
     int wave_slots_ = 2048;  // CUs x 4 SIMDs x 2 waves: what one round of a ~240-VGPR point kernel occupies
     int msm_chunks_ = -1;    // -1: pick per launch (launch_msm); otherwise forced by ETH_KZG_AMD_MSM_CHUNKS
@@ -288,6 +309,24 @@ private:
     size_t v_pin_cap_ = 0;
     hipStream_t v_side_ = nullptr;  // verification: the subgroup tests run here next to the point shifts on stream_
     hipEvent_t v_decoded_ = nullptr, v_checked_ = nullptr;
+
+    // serial-path lanes (lease_serial)
+    bool auxiliary_ = false;
+    std::mutex lane_busy_;              // held while a leased call runs on THIS engine
+    std::mutex lanes_mu_;               // guards aux_
+    std::vector<std::unique_ptr<Engine>> aux_;
+    int max_lanes_ = 4;
+    std::atomic<unsigned> lane_rr_{0};
+
+    // many-verification path (verify_many.hip): its own lock, stream, device arena and pinned slab
+    std::mutex vm_mu_;
+    hipStream_t vm_stream_ = nullptr;
+    void* vm_dev_ = nullptr;
+    size_t vm_dev_cap_ = 0;
+    uint8_t* vm_pin_ = nullptr;
+    size_t vm_pin_cap_ = 0;
+    uint8_t* vd_pin_ = nullptr;  // device-resident verification: the bytes come down here once (grow-only, guarded by mu_)
+    size_t vd_pin_cap_ = 0;
 
     // small-batch circulant form of the two G1 transforms: term list, doubling tables (allocated on first use)
     void *d_circ_terms_ = nullptr;

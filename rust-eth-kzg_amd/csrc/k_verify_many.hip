@@ -1,0 +1,230 @@
+// Kernels of eth_kzg_amd_verify_cell_kzg_proof_batch_many: MANY independent verify_cell_kzg_proof_batch problems in one pass
+// (the reference verifies concurrently from many threads on one context, bindings/node/src/lib.rs:92-299; here the
+// problems ride side by side on the GPU).  Per problem b the equation of FK20Verifier::verify_multi_opening
+// (crates/cryptography/kzg_multi_open/src/fk20/verifier.rs:129-260) needs two G1 sums,
+//     A_b = sum_k r_b^k pi_k
+//     B_b = sum_k r_b^k h_k^64 pi_k + sum_row w_row C_row - commit(sum_k r_b^k I_k)
+// with its own Fiat-Shamir challenge r_b.  What does not depend on the challenge (point decoding, subgroup tests, cell
+// decoding, per-cell interpolation) runs over the concatenation of all problems with the single-problem kernels of
+// k_g1misc.hip / k_verify.hip; this file adds what is per problem:
+//   k_vm_scalars      r_b^k, the two proof scalars, from a per-problem table of r_b^(2^i)
+//   k_vm_weights      w_row = sum of r_b^k over the cells of that commitment (block per unique commitment, its problem's cells only)
+//   k_vm_interp_sum   the 64 coefficients of sum_k r_b^k I_k per problem (block per problem), negated, canonical
+//   k_vm_mul          ONE LANE PER (point, scalar) product: a verification of 128 cells is 257 independent scalar
+//                     multiplications, a thousand of them fill the chip, so no bucket method and no sorting: GLV split, both
+//                     halves in signed 4-bit fixed windows over ONE table of 1..8 P brought to a common Z (g1_mulc.hpp's
+//                     isomorphic-curve trick): 128 doublings + 64 mixed additions, every lane in lockstep
+//   k_vm_reduce       per problem: the two sums of its products (+ the fixed-base commitment of the interpolation polynomial,
+//                     which comes from the commitment window table: the first 64 SRS points are its group 0)
+#include "engine.hpp"
+#include "kcommon.hpp"
+#include "curve29.hpp"
+#include "launch.hpp"
+#include "glv.hpp"
+
+namespace kzg {
+
+struct VmPow { Fr p[24]; };  // r^(2^i), Montgomery
+
+__global__ void k_vm_scalars(const VmPow* __restrict__ tabs, const int* __restrict__ batch_of, const int* __restrict__ pos_in_batch,
+                             const int* __restrict__ cell_idx, const Fr* __restrict__ w8192, Fr* __restrict__ rp_mont,
+                             Fr* __restrict__ s1, Fr* __restrict__ s2, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const VmPow* tab = tabs + batch_of[k];
+    const int e = pos_in_batch[k];
+    Fr acc = one<FrParams>();
+    for (int i = 0; i < 24; i++)
+        if ((e >> i) & 1) acc = mul(acc, tab->p[i]);  // compute_powers (verifier.rs:333-343)
+    rp_mont[k] = acc;
+    s1[k] = from_mont(acc);
+    // coset generator h_c = omega_8192^brp7(c) (cosets.rs:89-112); h_c^64 = omega_128^brp7(c) = w8192[64 * brp7(c)]
+    const int bc = (int)(__brev((unsigned)cell_idx[k]) >> 25);
+    s2[k] = from_mont(mul(acc, w8192[64 * bc]));
+}
+
+__device__ __forceinline__ Fr vm_block_sum(uint32_t (*part)[256], Fr acc, int t) {
+#pragma unroll
+    for (int l = 0; l < 8; l++) part[l][t] = acc.v[l];
+    __syncthreads();
+    for (int span = 128; span >= 1; span >>= 1) {
+        if (t < span) {
+            Fr a, b;
+#pragma unroll
+            for (int l = 0; l < 8; l++) { a.v[l] = part[l][t]; b.v[l] = part[l][t + span]; }
+            a = add(a, b);
+#pragma unroll
+            for (int l = 0; l < 8; l++) part[l][t] = a.v[l];
+        }
+        __syncthreads();
+    }
+    Fr a;
+#pragma unroll
+    for (int l = 0; l < 8; l++) a.v[l] = part[l][0];
+    return a;
+}
+// weights[row] = sum_{k in the row's problem : row_k == row} r^k (verifier.rs:216-219), canonical; rows are global
+// (problem's first row + local row), row_batch[row] = its problem, [cell_start[b], cell_start[b + 1]) that problem's cells
+__global__ __launch_bounds__(256) void k_vm_weights(const Fr* __restrict__ rp_mont, const int* __restrict__ row,
+                                                    const int* __restrict__ row_batch, const int* __restrict__ cell_start,
+                                                    Fr* __restrict__ weights) {
+    __shared__ uint32_t part[8][256];
+    const int r = blockIdx.x, t = threadIdx.x, b = row_batch[r];
+    const int lo = cell_start[b], hi = cell_start[b + 1];
+    Fr acc = zero<FrParams>();
+    for (int k = lo + t; k < hi; k += 256)
+        if (row[k] == r) acc = add(acc, rp_mont[k]);
+    acc = vm_block_sum(part, acc, t);
+    if (t == 0) weights[r] = from_mont(acc);
+}
+// out[b][i] = -(sum_{k in b} r^k coef[k][i]), canonical: the scalars of the interpolation commitment (verifier.rs:348-384, :235)
+__global__ __launch_bounds__(256) void k_vm_interp_sum(const Fr* __restrict__ coef, const Fr* __restrict__ rp_mont,
+                                                       const int* __restrict__ cell_start, Fr* __restrict__ out_neg_canon) {
+    __shared__ uint32_t s[4][8][64];
+    const int b = blockIdx.x, q = threadIdx.x >> 6, i = threadIdx.x & 63;
+    const int lo = cell_start[b], hi = cell_start[b + 1];
+    Fr acc = zero<FrParams>();
+    for (int k = lo + q; k < hi; k += 4) acc = add(acc, mul(coef[(size_t)k * 64 + i], rp_mont[k]));
+#pragma unroll
+    for (int l = 0; l < 8; l++) s[q][l][i] = acc.v[l];
+    __syncthreads();
+    if (q == 0) {
+        for (int o = 1; o < 4; o++) {
+            Fr x;
+#pragma unroll
+            for (int l = 0; l < 8; l++) x.v[l] = s[o][l][i];
+            acc = add(acc, x);
+        }
+        out_neg_canon[(size_t)b * 64 + i] = from_mont(neg(acc));
+    }
+}
+
+// signed Booth digit of 4-bit window w (< 32) of a 127-bit magnitude held in four words (bit 127 = sign, masked by the caller)
+__device__ __forceinline__ int vm_booth4(const uint32_t m[4], int w) {
+    uint32_t x;
+    if (w == 0) x = (m[0] << 1) & 0x1fu;
+    else {
+        const int lo = 4 * w - 1, word = lo >> 5, sh = lo & 31;
+        uint64_t two = m[word];
+        if (word + 1 < 4) two |= (uint64_t)m[word + 1] << 32;
+        x = (uint32_t)(two >> sh) & 0x1fu;
+    }
+    const int t = (int)((x + 1) >> 1);
+    return (x >> 4) ? t - 16 : t;
+}
+// k P for a PER-LANE scalar k = s1 m1 + s2 m2 lambda (balanced GLV halves, glv.hpp): the table (j + 1) P, j < 8, is built with
+// mixed additions (P is affine) and brought to one common Z without an inversion -- (X_j l_j^2, Y_j l_j^3), l_j = Z / z_j,
+// are affine coordinates on the isomorphic curve y^2 = x^3 + 4 Z^6, whose group law (a = 0) and endomorphism are the same
+// (g1_mulc.hpp) -- so the 64 additions of the main loop are mixed additions too.  All lanes run the same 32 windows:
+// 4 doublings, one addition for k1's digit, one for k2's (phi of a table entry only swaps in beta x); a zero digit masks its lane.
+__device__ JacQ vm_mul_by_scalar(const AffQ& P, const uint32_t split[8], const Fq<1>& beta) {
+    constexpr int NT = 8;
+    AffQ2 A[NT];
+    Fq<2> bx[NT];
+    Fq<ZB> zc;
+    {
+        JacQ T[NT];
+        Fq<ZB> pre[NT];  // pre[j] = z_0 ... z_j
+        T[0] = to_jacq(P);
+        pre[0] = T[0].z;
+#pragma unroll 1
+        for (int j = 1; j < NT; j++) {
+            T[j] = j == 1 ? dbl(T[0]) : add_mixed(T[j - 1], P);
+            pre[j] = relax<ZB>(mul(pre[j - 1], T[j].z));
+        }
+        zc = pre[NT - 1];
+        Fq<ZB> suf = relax<ZB>(fq_one());  // z_(j+1) ... z_(NT-1)
+#pragma unroll 1
+        for (int j = NT - 1; j >= 0; j--) {
+            const Fq<ZB> lam = j > 0 ? relax<ZB>(mul(pre[j > 0 ? j - 1 : 0], suf)) : suf;  // product of all the other z
+            const Fq<2> l2 = sqr(lam);
+            A[j].x = mul(T[j].x, l2);
+            A[j].y = mul(T[j].y, mul(l2, lam));
+            bx[j] = mul(A[j].x, beta);
+            suf = relax<ZB>(mul(suf, T[j].z));
+        }
+    }
+    uint32_t m1[4] = {split[0], split[1], split[2], split[3] & 0x7fffffffu};
+    uint32_t m2[4] = {split[4], split[5], split[6], split[7] & 0x7fffffffu};
+    const bool n1 = (split[3] >> 31) != 0, n2 = (split[7] >> 31) != 0;
+    JacQ acc = jacq_inf();
+#pragma unroll 1
+    for (int w = 31; w >= 0; w--) {
+        if (w != 31) {
+#pragma unroll 1
+            for (int s = 0; s < 4; s++) acc = dbl(acc);
+        }
+        const int d1 = vm_booth4(m1, w), d2 = vm_booth4(m2, w);
+        if (d1 != 0) acc = add_mixed(acc, A[(d1 < 0 ? -d1 : d1) - 1], (d1 < 0) != n1);
+        if (d2 != 0) {
+            AffQ2 op = A[(d2 < 0 ? -d2 : d2) - 1];
+            op.x = bx[(d2 < 0 ? -d2 : d2) - 1];
+            acc = add_mixed(acc, op, (d2 < 0) != n2);
+        }
+    }
+    acc.z = relax<ZB>(mul(acc.z, zc));  // back from the isomorphic curve (an identity P gives zc = 0: the identity)
+    return acc;
+}
+// products e < n: s1[e] pi_e;  n <= e < 2n: s2[e - n] pi_(e - n);  2n <= e < 2n + m: w[e - 2n] C_(e - 2n)
+// pts = [proofs n | commitments m] affine Montgomery-384 (decoded); scalars canonical
+__global__ __launch_bounds__(64, 2) void k_vm_mul(const G1Affine* __restrict__ pts, const Fr* __restrict__ s1, const Fr* __restrict__ s2,
+                                                  const Fr* __restrict__ wts, JacQ* __restrict__ prod, int n, int m, Fq<1> beta) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= 2 * n + m) return;
+    const int pi = e < n ? e : e < 2 * n ? e - n : n + (e - 2 * n);
+    const Fr k = e < n ? s1[e] : e < 2 * n ? s2[e - n] : wts[e - 2 * n];
+    uint32_t split[8];
+    glv_split_balanced(k, split);
+    prod[e] = vm_mul_by_scalar(affq_from_affine(pts[pi]), split, beta);
+}
+// per problem b: out[2b] = sum of prod[cells of b], out[2b + 1] = sum of prod[n + cells of b] + sum of prod[2n + rows of b]
+// + icommit[b]; threads 0-127 take the first sum, 128-255 the second, 7-level trees in LDS
+__global__ __launch_bounds__(256) void k_vm_reduce(const JacQ* __restrict__ prod, const JacQ* __restrict__ icommit,
+                                                   const int* __restrict__ cell_start, const int* __restrict__ row_start,
+                                                   JacQ* __restrict__ out, int n) {
+    __shared__ JacQ red[256];
+    const int b = blockIdx.x, t = threadIdx.x, job = t >> 7, l = t & 127;
+    const int lo = cell_start[b], hi = cell_start[b + 1], rlo = row_start[b], rhi = row_start[b + 1];
+    JacQ acc = jacq_inf();
+    const JacQ* src = prod + (job ? n : 0);
+    for (int k = lo + l; k < hi; k += 128) acc = add(acc, src[k]);
+    if (job) {
+        for (int r = rlo + l; r < rhi; r += 128) acc = add(acc, prod[2 * (size_t)n + r]);
+        if (l == 0) acc = add(acc, icommit[b]);
+    }
+#pragma unroll 1
+    for (int span = 64; span >= 1; span >>= 1) {
+        red[t] = acc;
+        __syncthreads();
+        if (l < span) acc = add(acc, red[t + span]);
+        __syncthreads();
+    }
+    if (l == 0) out[2 * (size_t)b + job] = acc;
+}
+
+namespace launch {
+static Fr vm_fr(const Fr8& x) { Fr r; for (int i = 0; i < 8; i++) r.v[i] = x.v[i]; return r; }
+void vm_scalars(const void* pow_tables /*[B][24] Fr, device*/, const int* batch_of, const int* pos_in_batch, const int* cell_idx,
+                const void* w8192, void* rp_mont, void* s1, void* s2, int n, hipStream_t st) {
+    if (n > 0) k_vm_scalars<<<(n + 255) / 256, 256, 0, st>>>((const VmPow*)pow_tables, batch_of, pos_in_batch, cell_idx, (const Fr*)w8192,
+                                                               (Fr*)rp_mont, (Fr*)s1, (Fr*)s2, n);
+}
+void vm_weights(const void* rp_mont, const int* row, const int* row_batch, const int* cell_start, void* weights, int m, hipStream_t st) {
+    if (m > 0) k_vm_weights<<<m, 256, 0, st>>>((const Fr*)rp_mont, row, row_batch, cell_start, (Fr*)weights);
+}
+void vm_interp_sum(const void* coef, const void* rp_mont, const int* cell_start, void* out_neg_canon, int n_batches, hipStream_t st) {
+    if (n_batches > 0) k_vm_interp_sum<<<n_batches, 256, 0, st>>>((const Fr*)coef, (const Fr*)rp_mont, cell_start, (Fr*)out_neg_canon);
+}
+void vm_mul(const void* pts, const void* s1, const void* s2, const void* wts, void* prod, int n, int m, const Fp12w& beta, hipStream_t st) {
+    Fp b384;
+    for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
+    const int total = 2 * n + m;
+    if (total > 0)
+        k_vm_mul<<<(total + 63) / 64, 64, 0, st>>>((const G1Affine*)pts, (const Fr*)s1, (const Fr*)s2, (const Fr*)wts, (JacQ*)prod, n, m, fq_from_fp(b384));
+}
+void vm_reduce(const void* prod, const void* icommit, const int* cell_start, const int* row_start, void* out, int n, int n_batches,
+               hipStream_t st) {
+    if (n_batches > 0) k_vm_reduce<<<n_batches, 256, 0, st>>>((const JacQ*)prod, (const JacQ*)icommit, cell_start, row_start, (JacQ*)out, n);
+}
+}  // namespace launch
+}  // namespace kzg

@@ -118,6 +118,16 @@ void rec_dit_last(int R, const void* T, const void* shift, const Fr8& n_inv, voi
                   const void* w8192, int final_pass, hipStream_t st);
 void rec_dif_half(int R, const void* U, const void* fac, void* V, const void* w8192, hipStream_t st);
 
+// k_verify_many.hip: many independent verifications in one pass (per-problem scalars, one lane per scalar multiplication)
+void vm_scalars(const void* pow_tables /*[B][24] Fr*/, const int* batch_of, const int* pos_in_batch, const int* cell_idx, const void* w8192,
+                void* rp_mont, void* s1, void* s2, int n, hipStream_t st);
+void vm_weights(const void* rp_mont, const int* row, const int* row_batch, const int* cell_start, void* weights, int m, hipStream_t st);
+void vm_interp_sum(const void* coef, const void* rp_mont, const int* cell_start, void* out_neg_canon, int n_batches, hipStream_t st);
+// pts = [proofs n | commitments m] (G1Affine); prod[2n + m] JacQ: s1[e] pi_e | s2[e] pi_e | w[j] C_j
+void vm_mul(const void* pts, const void* s1, const void* s2, const void* wts, void* prod, int n, int m, const Fp12w& beta, hipStream_t st);
+void vm_reduce(const void* prod, const void* icommit, const int* cell_start, const int* row_start, void* out /*[B][2] JacQ*/, int n,
+               int n_batches, hipStream_t st);
+
 // k_4844.hip
 void quotient_by_linear(int n, const void* coeffs, const void* z_mont, void* quotient, void* y_out, hipStream_t st);
 

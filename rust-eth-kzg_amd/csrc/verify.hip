@@ -322,13 +322,18 @@ int Engine::verify_cell_kzg_proof_batch_device(uint64_t n, const uint8_t* d_comm
                                                const uint8_t* d_cells, const uint8_t* d_proofs, int* verified, hipStream_t user_stream) {
     *verified = 0;
     if (n == 0) { *verified = 1; return OK; }  // verifier.rs:90-93
-    std::vector<const uint8_t*> cp(n), lp(n), pp(n);
-    uint8_t* pin = nullptr;
-    int st = OK;
+    std::lock_guard<std::recursive_mutex> lk(mu_);  // the pinned landing buffer is the context's (grow-only, reused by every call)
     try {
+        std::vector<const uint8_t*> cp(n), lp(n), pp(n);  // inside the try: a bogus n must not unwind through the C ABI
         HIPCK(hipSetDevice(dev_));
         const size_t sz_c = n * 48, sz_i = n * sizeof(uint64_t), sz_l = n * (size_t)BYTES_PER_CELL, sz_p = n * 48;
-        HIPCK(hipHostMalloc((void**)&pin, sz_c + sz_i + sz_l + sz_p, hipHostMallocDefault));
+        const size_t need = sz_c + sz_i + sz_l + sz_p;
+        if (need > vd_pin_cap_) {
+            if (vd_pin_) { HIPCK(hipHostFree(vd_pin_)); vd_pin_ = nullptr; vd_pin_cap_ = 0; }
+            HIPCK(hipHostMalloc((void**)&vd_pin_, need + (need >> 2), hipHostMallocDefault));
+            vd_pin_cap_ = need + (need >> 2);
+        }
+        uint8_t* pin = vd_pin_;
         hipStream_t s = user_stream ? user_stream : stream_;
         HIPCK(hipMemcpyAsync(pin, d_commitments, sz_c, hipMemcpyDeviceToHost, s));
         HIPCK(hipMemcpyAsync(pin + sz_c, d_cell_indices, sz_i, hipMemcpyDeviceToHost, s));
@@ -340,14 +345,11 @@ int Engine::verify_cell_kzg_proof_batch_device(uint64_t n, const uint8_t* d_comm
             lp[k] = pin + sz_c + sz_i + k * (size_t)BYTES_PER_CELL;
             pp[k] = pin + sz_c + sz_i + sz_l + k * 48;
         }
+        return verify_cell_kzg_proof_batch_host(n, cp.data(), n, reinterpret_cast<const uint64_t*>(pin + n * 48), n, lp.data(), n, pp.data(), verified);
     } catch (const std::exception& e) {
-        if (pin) (void)hipHostFree(pin);
         set_error(e);
         return ERR_DEVICE;
     }
-    st = verify_cell_kzg_proof_batch_host(n, cp.data(), n, reinterpret_cast<const uint64_t*>(pin + n * 48), n, lp.data(), n, pp.data(), verified);
-    (void)hipHostFree(pin);
-    return st;
 }
 
 int Engine::verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,

@@ -1,0 +1,300 @@
+// eth_kzg_amd_verify_cell_kzg_proof_batch_many: MANY independent verify_cell_kzg_proof_batch problems in one call.
+// Reference semantics per problem: DASContext::verify_cell_kzg_proof_batch (crates/eip7594/src/verifier.rs:72-164) ->
+// FK20Verifier::verify_multi_opening (crates/cryptography/kzg_multi_open/src/fk20/verifier.rs:129-260); the reference gets
+// its throughput by verifying from many threads on one context (bindings/node/src/lib.rs:92-299,
+// crates/cryptography/bls12_381/src/lib.rs:45-50).  Here the problems of a call share every GPU launch:
+//   host threads : validation + de-duplication per problem, staging into one pinned slab, one SHA-256 transcript per problem
+//                  (in parallel, behind the GPU's decoding), one 2-pairing check per problem (in parallel)
+//   GPU          : decode + subgroup-check all points, decode all cells, per-cell interpolation (challenge-free: behind the
+//                  hashes), then per-problem scalars / weights / interpolation sums, ONE LANE PER SCALAR MULTIPLICATION
+//                  (k_verify_many.hip), the 64-term interpolation commitments from the commitment window table, per-problem sums
+// The path owns its stream, device arena and pinned slab (vm_mu_): it does not take the context's big lock, so it runs next
+// to prover, recovery and single verification calls.
+#include "engine.hpp"
+#include "curve29.hpp"
+#include "host_pairing.hpp"
+#include "launch.hpp"
+#include "sha256.hpp"
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <thread>
+
+namespace kzg {
+
+#define HIPCK(x)                                                                                              \
+    do {                                                                                                      \
+        hipError_t e_ = (x);                                                                                  \
+        if (e_ != hipSuccess)                                                                                 \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " + __FILE__ + ":" + \
+                                     std::to_string(__LINE__));                                               \
+    } while (0)
+#define SYNC_CHECKED(stream)                 \
+    do {                                     \
+        HIPCK(hipGetLastError());            \
+        HIPCK(hipStreamSynchronize(stream)); \
+        HIPCK(hipGetLastError());            \
+    } while (0)
+
+static constexpr int N_BLOB = 4096, N_CELLS = 128, CELL_LEN = 64, BYTES_PER_CELL = 2048;
+
+namespace {
+// fork-join over [0, n) on `threads` host threads (work stealing by an atomic counter); the first exception is rethrown
+template <class F>
+void parallel_for(int n, int threads, int device, F fn) {
+    if (n <= 0) return;
+    if (threads > n) threads = n;
+    if (threads <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    std::atomic<int> next{0};
+    std::exception_ptr err;
+    std::mutex err_mu;
+    auto body = [&] {
+        (void)hipSetDevice(device);
+        try {
+            for (int i; (i = next.fetch_add(1)) < n;) fn(i);
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(err_mu);
+            if (!err) err = std::current_exception();
+            next.store(n);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; t++) th.emplace_back(body);
+    body();
+    for (auto& t : th) t.join();
+    if (err) std::rethrow_exception(err);
+}
+int host_threads() {
+    int t = 16;
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && (int)hw < t) t = (int)hw;
+    if (const char* e = getenv("ETH_KZG_AMD_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) t = v; }
+    return t;
+}
+// reduce_bytes_to_scalar_bias (crates/cryptography/bls12_381/src/lib.rs:128-140): 256-bit big-endian integer mod r
+Fr reduce_be32(const uint8_t* b) {
+    Fr x;
+    for (int i = 0; i < 8; i++)
+        x.v[7 - i] = ((uint32_t)b[4 * i] << 24) | ((uint32_t)b[4 * i + 1] << 16) | ((uint32_t)b[4 * i + 2] << 8) | b[4 * i + 3];
+    while (geq_mod<FrParams>(x.v)) {
+        uint32_t t[8];
+        sub_limbs<8>(t, x.v, FrParams::MOD);
+        memcpy(x.v, t, 32);
+    }
+    return to_mont(x);
+}
+struct Problem {  // one verification of the call, after validation
+    std::vector<const uint8_t*> uniq;  // de-duplicated commitments, first-occurrence order (verifier.rs:49-65)
+    std::vector<int> row;              // per cell: index into uniq
+    int n = 0, m = 0;                  // cells, unique commitments (0, 0 when the problem is skipped)
+};
+}  // namespace
+
+int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint64_t* n_commitments,
+                                                  const uint8_t* const* const* commitments, const uint64_t* n_indices,
+                                                  const uint64_t* const* cell_indices, const uint64_t* n_cells,
+                                                  const uint8_t* const* const* cells, const uint64_t* n_proofs,
+                                                  const uint8_t* const* const* proofs, int* verified, int* status) {
+    const int B = (int)n_batches;
+    for (int b = 0; b < B; b++) { verified[b] = 0; status[b] = OK; }
+    if (B == 0) return OK;
+    const int T = host_threads();
+    std::lock_guard<std::mutex> lk(vm_mu_);
+    try {
+        HIPCK(hipSetDevice(dev_));
+        if (!vm_stream_) HIPCK(hipStreamCreateWithFlags(&vm_stream_, hipStreamNonBlocking));
+        hipStream_t st = vm_stream_;
+        // ---- per problem: validation (verifier.rs:123-164) and de-duplication
+        std::vector<Problem> pr(B);
+        parallel_for(B, T, dev_, [&](int b) {
+            const uint64_t nc = n_commitments[b];
+            if (!(nc == n_indices[b] && nc == n_cells[b] && nc == n_proofs[b])) { status[b] = ERR_INPUT; return; }
+            for (uint64_t i = 0; i < nc; i++)
+                if (cell_indices[b][i] >= (uint64_t)N_CELLS) { status[b] = ERR_INPUT; return; }
+            if (nc == 0) { verified[b] = 1; return; }  // verifier.rs:90-93
+            Problem& p = pr[b];
+            p.row.resize(nc);
+            std::map<std::string, int> seen;
+            for (uint64_t i = 0; i < nc; i++) {
+                std::string key((const char*)commitments[b][i], 48);
+                auto it = seen.find(key);
+                if (it == seen.end()) { it = seen.emplace(key, (int)p.uniq.size()).first; p.uniq.push_back(commitments[b][i]); }
+                p.row[i] = it->second;
+            }
+            p.n = (int)nc;
+            p.m = (int)p.uniq.size();
+        });
+        // ---- chunks of problems: at most CHUNK_CELLS cells per pass (the pinned slab and the arena stay bounded)
+        constexpr int CHUNK_CELLS = 32768;
+        for (int b0 = 0; b0 < B;) {
+            int b1 = b0, nn = 0, mm = 0;
+            while (b1 < B && (b1 == b0 || nn + pr[b1].n <= CHUNK_CELLS)) { nn += pr[b1].n; mm += pr[b1].m; b1++; }
+            const int Bc = b1 - b0, n = nn, m = mm;
+            if (n == 0) { b0 = b1; continue; }
+            std::vector<int> cell_start(Bc + 1, 0), row_start(Bc + 1, 0);
+            for (int i = 0; i < Bc; i++) { cell_start[i + 1] = cell_start[i] + pr[b0 + i].n; row_start[i + 1] = row_start[i] + pr[b0 + i].m; }
+            // ---- layout: [inputs, uploaded in one copy][device-only]; pinned slab = inputs + read-backs
+            auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+            size_t o = 0;
+            const size_t off_p = o; o += up((size_t)n * 48);
+            const size_t off_c = o; o += up((size_t)m * 48);
+            const size_t off_cells = o; o += up((size_t)n * BYTES_PER_CELL);
+            const size_t off_idx = o; o += up((size_t)n * 4);
+            const size_t off_row = o; o += up((size_t)n * 4);
+            const size_t off_bat = o; o += up((size_t)n * 4);
+            const size_t off_pos = o; o += up((size_t)n * 4);
+            const size_t off_rowb = o; o += up((size_t)m * 4);
+            const size_t off_cs = o; o += up((size_t)(Bc + 1) * 4);
+            const size_t off_rs = o; o += up((size_t)(Bc + 1) * 4);
+            const size_t in_bytes = o;
+            const size_t off_pow = o; o += up((size_t)Bc * 24 * sizeof(Fr));  // second upload (after the hashes)
+            const size_t in2_bytes = o;
+            // device only
+            const size_t off_pts = o; o += up((size_t)(n + m) * sizeof(G1Affine));
+            const size_t off_evals = o; o += up((size_t)n * CELL_LEN * sizeof(Fr));
+            const size_t off_coef = o; o += up((size_t)n * CELL_LEN * sizeof(Fr));
+            const size_t off_stp = o; o += up((size_t)(n + m) * 4);  // [proofs n | commitments m]
+            const size_t off_ste = o; o += up((size_t)Bc * 4);
+            const size_t off_rp = o; o += up((size_t)n * sizeof(Fr));
+            const size_t off_s1 = o; o += up((size_t)n * sizeof(Fr));
+            const size_t off_s2 = o; o += up((size_t)n * sizeof(Fr));
+            const size_t off_w = o; o += up((size_t)m * sizeof(Fr));
+            const size_t off_isc = o; o += up((size_t)Bc * 64 * sizeof(Fr));
+            const size_t off_icm = o; o += up((size_t)Bc * launch::SIZEOF_JACQ);
+            const size_t off_prod = o; o += up((size_t)(2 * n + m) * launch::SIZEOF_JACQ);
+            const size_t off_out = o; o += up((size_t)2 * Bc * launch::SIZEOF_JACQ);
+            const size_t dev_bytes = o;
+            // pinned read-backs behind the inputs
+            size_t po = in2_bytes;
+            const size_t poff_st = po; po += up((size_t)(n + m + Bc) * 4);
+            const size_t poff_out = po; po += up((size_t)2 * Bc * launch::SIZEOF_JACQ);
+            const size_t pin_bytes = po;
+            if (dev_bytes > vm_dev_cap_) {
+                if (vm_dev_) { HIPCK(hipStreamSynchronize(st)); HIPCK(hipFree(vm_dev_)); vm_dev_ = nullptr; vm_dev_cap_ = 0; }
+                HIPCK(hipMalloc(&vm_dev_, dev_bytes + (dev_bytes >> 2)));
+                vm_dev_cap_ = dev_bytes + (dev_bytes >> 2);
+            }
+            if (pin_bytes > vm_pin_cap_) {
+                if (vm_pin_) { HIPCK(hipHostFree(vm_pin_)); vm_pin_ = nullptr; vm_pin_cap_ = 0; }
+                HIPCK(hipHostMalloc((void**)&vm_pin_, pin_bytes + (pin_bytes >> 2), hipHostMallocDefault));
+                vm_pin_cap_ = pin_bytes + (pin_bytes >> 2);
+            }
+            uint8_t* hb = vm_pin_;
+            uint8_t* db = (uint8_t*)vm_dev_;
+            int* h_idx = (int*)(hb + off_idx);
+            int* h_row = (int*)(hb + off_row);
+            int* h_bat = (int*)(hb + off_bat);
+            int* h_pos = (int*)(hb + off_pos);
+            int* h_rowb = (int*)(hb + off_rowb);
+            memcpy(hb + off_cs, cell_start.data(), (size_t)(Bc + 1) * 4);
+            memcpy(hb + off_rs, row_start.data(), (size_t)(Bc + 1) * 4);
+            // ---- staging (parallel over problems)
+            parallel_for(Bc, T, dev_, [&](int i) {
+                const int b = b0 + i;
+                const Problem& p = pr[b];
+                const int c0 = cell_start[i], r0 = row_start[i];
+                for (int j = 0; j < p.m; j++) { memcpy(hb + off_c + (size_t)(r0 + j) * 48, p.uniq[j], 48); h_rowb[r0 + j] = i; }
+                for (int k = 0; k < p.n; k++) {
+                    memcpy(hb + off_p + (size_t)(c0 + k) * 48, proofs[b][k], 48);
+                    memcpy(hb + off_cells + (size_t)(c0 + k) * BYTES_PER_CELL, cells[b][k], BYTES_PER_CELL);
+                    h_idx[c0 + k] = (int)cell_indices[b][k];
+                    h_row[c0 + k] = r0 + p.row[k];
+                    h_bat[c0 + k] = i;
+                    h_pos[c0 + k] = k;
+                }
+            });
+            // stale contents of the persistent arena must fail closed: poison the status words and the result slots
+            int* h_st = (int*)(hb + poff_st);
+            memset(h_st, 0xff, (size_t)(n + m + Bc) * 4);
+            memset(hb + poff_out, 0xff, (size_t)2 * Bc * launch::SIZEOF_JACQ);
+            HIPCK(hipMemsetAsync(db + off_stp, 0xff, (size_t)(n + m) * 4, st));
+            HIPCK(hipMemsetAsync(db + off_out, 0xff, (size_t)2 * Bc * launch::SIZEOF_JACQ, st));
+            HIPCK(hipMemsetAsync(db + off_ste, 0, (size_t)Bc * 4, st));
+            HIPCK(hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, st));
+            // ---- challenge-free GPU work: decode (on curve) + subgroup tests of [proofs | commitments], cells, interpolation
+            G1Affine* d_pts = (G1Affine*)(db + off_pts);
+            int* d_stp = (int*)(db + off_stp);
+            launch::g1_decode2(db + off_p, d_pts, d_stp, n, db + off_c, d_pts + n, d_stp + n, m, beta_, st);
+            launch::g1_subgroup2(d_pts, d_stp, n, d_pts + n, d_stp + n, m, beta_, st);
+            launch::cells_to_fr(db + off_cells, db + off_evals, nullptr, (int*)(db + off_ste), (const int*)(db + off_bat), nullptr, n, st);
+            launch::interp_cells(db + off_evals, (const int*)(db + off_idx), d_w8192_, inv64_, db + off_coef, n, st);
+            HIPCK(hipMemcpyAsync(h_st, d_stp, (size_t)(n + m) * 4, hipMemcpyDeviceToHost, st));
+            HIPCK(hipMemcpyAsync(h_st + n + m, db + off_ste, (size_t)Bc * 4, hipMemcpyDeviceToHost, st));
+            HIPCK(hipGetLastError());
+            // ---- Fiat-Shamir challenges on the host threads meanwhile (verifier.rs:269-328): valid inputs are canonical
+            // encodings, so the transcript is the input bytes themselves; then the table r^(2^i) per problem
+            Fr* h_pow = (Fr*)(hb + off_pow);
+            parallel_for(Bc, T, dev_, [&](int i) {
+                const int b = b0 + i;
+                const Problem& p = pr[b];
+                Fr* tab = h_pow + (size_t)i * 24;
+                if (p.n == 0) { for (int j = 0; j < 24; j++) tab[j] = one<FrParams>(); return; }
+                Sha256 sh;
+                auto be64 = [](uint64_t v, uint8_t* out) { for (int q = 0; q < 8; q++) out[q] = (uint8_t)(v >> (56 - 8 * q)); };
+                uint8_t hdr[16 + 32];
+                memcpy(hdr, "RCKZGCBATCH__V1_", 16);
+                be64(N_BLOB, hdr + 16); be64(CELL_LEN, hdr + 24); be64((uint64_t)p.m, hdr + 32); be64((uint64_t)p.n, hdr + 40);
+                sh.update(hdr, sizeof hdr);
+                for (int j = 0; j < p.m; j++) sh.update(p.uniq[j], 48);
+                for (int k = 0; k < p.n; k++) {
+                    uint8_t ix[16];
+                    be64((uint64_t)p.row[k], ix); be64(cell_indices[b][k], ix + 8);
+                    sh.update(ix, 16);
+                    sh.update(cells[b][k], BYTES_PER_CELL);
+                    sh.update(proofs[b][k], 48);
+                }
+                uint8_t dig[32];
+                sh.finish(dig);
+                Fr cur = reduce_be32(dig);
+                for (int j = 0; j < 24; j++) { tab[j] = cur; cur = sqr(cur); }
+            });
+            HIPCK(hipMemcpyAsync(db + off_pow, hb + off_pow, (size_t)Bc * 24 * sizeof(Fr), hipMemcpyHostToDevice, st));
+            // ---- per-problem scalars, weights, interpolation sums; every scalar multiplication; the two sums per problem
+            const int* d_cs = (const int*)(db + off_cs);
+            const int* d_rs = (const int*)(db + off_rs);
+            launch::vm_scalars(db + off_pow, (const int*)(db + off_bat), (const int*)(db + off_pos), (const int*)(db + off_idx), d_w8192_,
+                               db + off_rp, db + off_s1, db + off_s2, n, st);
+            launch::vm_weights(db + off_rp, (const int*)(db + off_row), (const int*)(db + off_rowb), d_cs, db + off_w, m, st);
+            launch::vm_interp_sum(db + off_coef, db + off_rp, d_cs, db + off_isc, Bc, st);
+            launch::vm_mul(d_pts, db + off_s1, db + off_s2, db + off_w, db + off_prod, n, m, beta_, st);
+            // - commit(interpolation polynomial): 64 fixed bases = group 0 of the commitment window table (verification_key.rs:66-70)
+            launch_msm(db + off_isc, TAB_SRS, db + off_icm, 1, Bc, Bc, 0, st);
+            launch::vm_reduce(db + off_prod, db + off_icm, d_cs, d_rs, db + off_out, n, Bc, st);
+            HIPCK(hipMemcpyAsync(hb + poff_out, db + off_out, (size_t)2 * Bc * launch::SIZEOF_JACQ, hipMemcpyDeviceToHost, st));
+            SYNC_CHECKED(st);
+            // ---- verdicts: decoding errors per problem (order of the reference: commitments, proofs, cells), then the pairing
+            const JacQ* sums = (const JacQ*)(hb + poff_out);
+            std::atomic<int> device_fault{0};
+            parallel_for(Bc, T, dev_, [&](int i) {
+                const int b = b0 + i;
+                const Problem& p = pr[b];
+                if (p.n == 0) return;
+                const int c0 = cell_start[i], r0 = row_start[i];
+                for (int j = 0; j < p.m; j++) if (h_st[n + r0 + j]) { status[b] = ERR_G1; return; }
+                for (int k = 0; k < p.n; k++) if (h_st[c0 + k]) { status[b] = ERR_G1; return; }
+                if (h_st[n + m + i]) { status[b] = ERR_SCALAR; return; }
+                G1Affine pts[2];
+                for (int j = 0; j < 2; j++) {
+                    const JacQ& s = sums[2 * (size_t)i + j];
+                    if (s.x.v[0] == 0xffffffffu && s.z.v[0] == 0xffffffffu) { device_fault.store(1); return; }  // the poison pattern
+                    pts[j] = to_affine(jac_from_jacq(s));
+                }
+                verified[b] = verify_cells_pairing(pts) ? 1 : 0;
+            });
+            if (device_fault.load()) throw std::runtime_error("many-verification pass left no result");
+            b0 = b1;
+        }
+    } catch (const std::exception& e) {
+        set_error(e);
+        return ERR_DEVICE;
+    }
+    return OK;
+}
+
+}  // namespace kzg

@@ -588,3 +588,156 @@ def test_empty_and_degenerate_batches(ctx):
     assert all(p == b"\xc0" + b"\x00" * 47 for p in proofs) and all(c == b"\x00" * 2048 for c in cells)
     assert ctx.blob_to_kzg_commitment(zero) == b"\xc0" + b"\x00" * 47
     assert ctx.verify_cell_kzg_proof_batch([b"\xc0" + b"\x00" * 47] * 128, list(range(128)), cells, proofs) is True
+
+
+# ------------------------------------------------------------------ many verifications in one call
+def _expect_many(case_output):
+    """(verified, ok) a problem must come back with: the reference's Ok(true) / Ok(false) / Err."""
+    return (False, False) if case_output is None else (bool(case_output), True)
+
+
+def test_verify_many_reproduces_every_vector_in_one_call(ctx):
+    """All 30 reference vectors of verify_cell_kzg_proof_batch as ONE eth_kzg_amd_verify_cell_kzg_proof_batch_many call: every
+    problem comes back with its own verdict -- true, false, or an error status where the single form raises -- and the
+    malformed problems poison nothing around them.  Twice in a different order, and interleaved with empty problems."""
+    cases = sorted(vectors.load("verify_cell_kzg_proof_batch").items())
+    problems = [(c["input"]["commitments"], c["input"]["cell_indices"], c["input"]["cells"], c["input"]["proofs"]) for _, c in cases]
+    for order in (list(range(len(cases))), list(reversed(range(len(cases))))):
+        probs = []
+        for k in order:
+            probs.append(problems[k])
+            probs.append(([], [], [], []))
+        ver, st = ctx.verify_cell_kzg_proof_batch_many(probs)
+        for j, k in enumerate(order):
+            want_ver, want_ok = _expect_many(cases[k][1]["output"])
+            assert (st[2 * j] == 0) == want_ok and ver[2 * j] == want_ver, (cases[k][0], st[2 * j], ver[2 * j])
+            assert st[2 * j + 1] == 0 and ver[2 * j + 1] is True  # the empty problem verifies (verifier.rs:90-93)
+    assert ctx.verify_cell_kzg_proof_batch_many([]) == ([], [])
+
+
+def test_verify_many_matches_single_calls_and_oracle(ctx, oracle):
+    """Synthetic problems of every shape in one call: one blob's 128 cells against one commitment (the reference's bench shape,
+    benchmark-mt.rs:77-101), several blobs mixed, ragged subsets with duplicates, a single cell, tampered proofs / cells /
+    commitments, identity points.  Verdicts equal the single-call form and the CPU oracle."""
+    blobs = [synth.seeded_blob(70 + i) for i in range(4)] + [b"\x00" * 131072]
+    st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs)
+    _, comms = ctx.blob_to_kzg_commitment_batch(blobs)
+
+    def whole(b):
+        return ([comms[b]] * 128, list(range(128)), list(cells[b]), list(proofs[b]))
+    probs = [whole(b) for b in range(5)]
+    C_, I_, L_, P_ = [], [], [], []
+    for b in (0, 1, 2):
+        for k in range(0, 128, 3):
+            C_.append(comms[b]); I_.append(k); L_.append(cells[b][k]); P_.append(proofs[b][k])
+    probs.append((C_, I_, L_, P_))                                               # three blobs interleaved
+    sel = [3, 40, 41, 3, 127, 64, 64]
+    probs.append(([comms[1]] * len(sel), sel, [cells[1][k] for k in sel], [proofs[1][k] for k in sel]))  # duplicates, any order
+    probs.append(([comms[3]], [77], [cells[3][77]], [proofs[3][77]]))             # a single cell
+    t = whole(0); t[3][5] = proofs[1][7]; probs.append(t)                         # tampered proof        -> false
+    t = whole(1); t[2][100] = cells[0][1]; probs.append(t)                        # tampered cell         -> false
+    t = whole(2); t[0][0] = comms[3]; probs.append(t)                             # swapped commitment    -> false
+    t = whole(3); t[3][9] = b"\xc0" + bytes(47); probs.append(t)                  # identity as a proof   -> false
+    t = whole(0); t[1][4] = 128; probs.append(t)                                  # index out of range    -> error
+    t = whole(0); t[2][4] = b"\xff" * 2048; probs.append(t)                       # non-canonical element -> error
+    t = whole(0); t[3][4] = b"\x80" + bytes(46) + b"\x05"; probs.append(t)        # a proof that is not a curve point / not in G1 -> error
+    ver, stt = ctx.verify_cell_kzg_proof_batch_many(probs)
+    for j, p in enumerate(probs):
+        single = _call(ctx.verify_cell_kzg_proof_batch, *p)
+        ref = _call(oracle.verify_cell_kzg_proof_batch, *p)
+        assert single == ref, j
+        want_ver, want_ok = _expect_many(ref)
+        assert (stt[j] == 0) == want_ok and ver[j] == want_ver, (j, stt[j], ver[j], ref)
+    assert ver[:8] == [True] * 8 and ver[8:12] == [False] * 4 and stt[12] == 3 and stt[13] == 1 and stt[14] == 2
+
+
+def test_verify_many_large_call_in_chunks_and_concurrent_with_other_calls(ctx):
+    """700 problems of 128 cells (three passes of at most 32768 cells) with a sprinkling of tampered ones, while another thread
+    keeps proving and verifying on the same context: the path owns its lock, stream and scratch."""
+    import threading
+    blobs = [synth.seeded_blob(90 + i) for i in range(7)]
+    st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs)
+    _, comms = ctx.blob_to_kzg_commitment_batch(blobs)
+    probs, want = [], []
+    for j in range(700):
+        b = j % 7
+        P = list(proofs[b])
+        bad = j % 50 == 17
+        if bad:
+            P[j % 128] = proofs[(b + 1) % 7][j % 128]
+        probs.append(([comms[b]] * 128, list(range(128)), list(cells[b]), P))
+        want.append(not bad)
+    run = ctx.prepare_verify_cell_kzg_proof_batch_many(probs)
+    stop, errors = threading.Event(), []
+
+    def other():
+        try:
+            while not stop.is_set():
+                assert ctx.compute_cells_and_kzg_proofs(blobs[0]) == (cells[0], proofs[0])
+                assert ctx.verify_cell_kzg_proof_batch(*probs[0]) is True
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+    th = threading.Thread(target=other)
+    th.start()
+    try:
+        for _ in range(2):
+            ver, stt = run()
+            assert stt == [0] * 700 and ver == want
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors
+
+
+def test_serial_paths_overlap_across_threads(ctx):
+    """The verification / recovery / commitment entry points run on engine lanes created on demand (c_eth_kzg.h, "Threading"):
+    four threads calling at once all get correct answers, and take clearly less than four times one thread's time."""
+    import threading
+    import time
+    blobs = [synth.seeded_blob(120 + i) for i in range(4)]
+    st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs)
+    _, comms = ctx.blob_to_kzg_commitment_batch(blobs)
+    runs = [ctx.prepare_verify_cell_kzg_proof_batch([comms[b]] * 128, list(range(128)), cells[b], proofs[b]) for b in range(4)]
+    for r in runs:
+        assert r() is True  # warm-up: creates nothing yet (one caller), loads code
+    reps = 30
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        assert runs[0]() is True
+    t_one = time.perf_counter() - t0
+    errors = []
+
+    def worker(b):
+        try:
+            for _ in range(reps):
+                assert runs[b]() is True
+                assert ctx.blob_to_kzg_commitment(blobs[b]) == comms[b]
+                half = list(range(64))
+                rc, rp = ctx.recover_cells_and_kzg_proofs(half, cells[b][:64])
+                assert rc == cells[b] and rp == proofs[b]
+        except Exception as e:  # pragma: no cover
+            errors.append((b, e))
+    ths = [threading.Thread(target=worker, args=(b,)) for b in range(4)]
+    for _ in range(1):  # first round creates the lanes
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    assert not errors, errors
+
+    def verify_only(b):
+        try:
+            for _ in range(reps):
+                assert runs[b]() is True
+        except Exception as e:  # pragma: no cover
+            errors.append((b, e))
+    ths = [threading.Thread(target=verify_only, args=(b,)) for b in range(4)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    t_four = time.perf_counter() - t0
+    assert not errors, errors
+    print(f"verify 128 cells: 1 thread {t_one / reps * 1e3:.2f} ms per call; 4 threads {t_four / reps * 1e3:.2f} ms per round of 4")
+    assert t_four < 3.0 * t_one  # serialised calls would need 4x
