@@ -604,6 +604,7 @@ struct Engine::SharedTable {
     // VMM backing (empty for a hipMalloc'ed table)
     size_t reserved = 0, mapped = 0, piece = 0;
     std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::string why;  // the HIP call that failed in map_until
     bool vmm() const { return reserved != 0; }
     // reserve the address range; false -> use hipMalloc instead
     bool reserve(size_t n) {
@@ -614,7 +615,8 @@ struct Engine::SharedTable {
         size_t gran = 0;
         if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) { (void)hipGetLastError(); return false; }
         piece = ((size_t)(2ull << 30) + gran - 1) / gran * gran;
-        const size_t total = (n + gran - 1) / gran * gran;
+        // whole pieces only: hipMemSetAccess rejected a smaller last piece ("invalid argument", ROCm 7.0.2); the price is < 2 GB of slack
+        const size_t total = (n + piece - 1) / piece * piece;
         void* base = nullptr;
         if (hipMemAddressReserve(&base, total, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
         p = base;
@@ -635,10 +637,11 @@ struct Engine::SharedTable {
             if (cancel && cancel->load()) return false;
             const size_t sz = std::min(piece, reserved - mapped);
             hipMemGenericAllocationHandle_t h;
-            if (hipMemCreate(&h, sz, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
-            if (hipMemMap((char*)p + mapped, sz, 0, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(h); return false; }
+            hipError_t e;
+            if ((e = hipMemCreate(&h, sz, &prop, 0)) != hipSuccess) { why = std::string("hipMemCreate: ") + hipGetErrorString(e); (void)hipGetLastError(); return false; }
+            if ((e = hipMemMap((char*)p + mapped, sz, 0, h, 0)) != hipSuccess) { why = std::string("hipMemMap: ") + hipGetErrorString(e); (void)hipGetLastError(); (void)hipMemRelease(h); return false; }
             handles.push_back(h);
-            if (hipMemSetAccess((char*)p + mapped, sz, &acc, 1) != hipSuccess) { (void)hipGetLastError(); mapped += sz; return false; }
+            if ((e = hipMemSetAccess((char*)p + mapped, sz, &acc, 1)) != hipSuccess) { why = std::string("hipMemSetAccess: ") + hipGetErrorString(e); (void)hipGetLastError(); mapped += sz; return false; }
             mapped += sz;
         }
         return true;
@@ -771,6 +774,7 @@ static bool build_table_glv(int c, const void* bases, Engine::SharedTable& t, in
             // back this chunk's part of the table while the GPU still builds the previous one
             if (piecewise && !t.map_until((size_t)(g0 + g) * per_group * launch::SIZEOF_TABP, cancel)) {
                 if (cancel && cancel->load()) throw BuildCancelled{};
+                if (trace) fprintf(stderr, "[context]   GLV table width %d: backing failed at %.1f of %.1f GB (%s)\n", c, t.mapped / 1e9, table_bytes / 1e9, t.why.c_str());
                 cleanup();
                 t.release();
                 return false;  // out of memory after all (another process took it meanwhile)
@@ -946,6 +950,7 @@ void Engine::build_final_tables() {
         state = 2;
         why = e.what();
     }
+    if (state == 2 && getenv("ETH_KZG_AMD_TRACE")) fprintf(stderr, "[context] wide tables not built: %s\n", why.c_str());
     std::lock_guard<std::mutex> lk(tab_mu_);
     tables_state_ = state;
     tables_error_ = why;
