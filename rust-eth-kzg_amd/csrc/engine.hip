@@ -595,8 +595,7 @@ void Engine::init_srs() {
 // the process waits (measured: a 214 GB hipMalloc on the helper thread stalled the caller's launches for 4.3 s), and the call
 // cannot be abandoned when the context -- or the process -- goes away.  Instead the address range is reserved and backed
 // PIECE BY PIECE (hipMemCreate / hipMemMap / hipMemSetAccess, 2 GB at a time, a few tens of milliseconds each), just ahead
-// of the builder kernels: other threads' calls slip in between the pieces, mapping overlaps the build of the previous
-// groups, and a cancellation is honoured within one piece.  Small tables and any failure of the VMM calls fall back to hipMalloc.
+// of the builder kernels: other threads' calls slip in between the pieces and a cancellation is honoured within one piece.  Small tables and any failure of the VMM calls fall back to hipMalloc.
 struct Engine::SharedTable {
     void* p = nullptr;
     size_t bytes = 0;
@@ -771,7 +770,10 @@ static bool build_table_glv(int c, const void* bases, Engine::SharedTable& t, in
         for (int g0 = 0; g0 < n_groups; g0 += chunk) {
             const int g = n_groups - g0 < chunk ? n_groups - g0 : chunk;
             if (cancel && cancel->load()) throw BuildCancelled{};
-            // back this chunk's part of the table while the GPU still builds the previous one
+            // The previous chunk must have left the table before more of it is backed: hipMemSetAccess on a later piece was
+            // seen to fault a builder kernel still writing an earlier one ("write access to a read-only page", ROCm 7.0.2),
+            // so mapping and building alternate instead of overlapping.  Other streams (callers on the start tables) go on.
+            HIPCK(hipStreamSynchronize(st));
             if (piecewise && !t.map_until((size_t)(g0 + g) * per_group * launch::SIZEOF_TABP, cancel)) {
                 if (cancel && cancel->load()) throw BuildCancelled{};
                 if (trace) fprintf(stderr, "[context]   GLV table width %d: backing failed at %.1f of %.1f GB (%s)\n", c, t.mapped / 1e9, table_bytes / 1e9, t.why.c_str());
