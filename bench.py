@@ -169,6 +169,44 @@ def cpu_baseline(blobs, gpu_first=None, extra=None):
             out_extra["note"] = "one sample each (a verification of 8192 cells and a round of recoveries take seconds on the CPU)"
         except Exception as e:  # the baseline of the side configs must never sink the headline record
             out_extra["error"] = repr(e)
+    # the reference's own criterion shapes (benchmark-mt.rs:36-113, benchmark-st.rs:36-48), each by the criterion-like protocol
+    # (shorter: 1 s warm-up, <= 12 samples): BASELINE.json config 1 is `blob_to_kzg_commitment` on one blob, single thread
+    shapes = {}
+    try:
+        b0 = blobs[0]
+        ts = _criterion(lambda: o.blob_to_kzg_commitment(b0), 1.0, 12, 4.0)
+        shapes["config1_blob_to_kzg_commitment_one_blob_single_thread_ms"] = {"median": round(_median(ts) * 1e3, 2), "min": round(min(ts) * 1e3, 2), "samples": len(ts)}
+        om = Oracle(use_precomp=True, threads=cores)
+        ts = _criterion(lambda: om.blob_to_kzg_commitment(b0), 1.0, 12, 3.0)
+        shapes["blob_to_kzg_commitment_one_blob_all_cores_ms"] = {"median": round(_median(ts) * 1e3, 2), "min": round(min(ts) * 1e3, 2), "samples": len(ts), "threads": cores}
+        if extra is not None and "verify128" in extra:
+            C1, I1, L1, P1 = extra["verify128"]
+            assert om.verify_cell_kzg_proof_batch(C1, I1, L1, P1) is True
+            for nm, orc, thr in (("verify_128_cells_one_commitment_single_thread_ms", o, 1), ("verify_128_cells_one_commitment_all_cores_ms", om, cores)):
+                ts = _criterion(lambda: orc.verify_cell_kzg_proof_batch(C1, I1, L1, P1), 1.0, 12, 4.0)
+                shapes[nm] = {"median": round(_median(ts) * 1e3, 2), "min": round(min(ts) * 1e3, 2), "samples": len(ts), "threads": thr}
+            # many such verifications at once: one single-threaded verifier per core (how the reference gets verification throughput)
+            t0 = time.perf_counter()
+            rounds = 3
+            for _ in range(rounds):
+                list(ex.map(lambda w: o.verify_cell_kzg_proof_batch(C1, I1, L1, P1), range(cores)))
+            shapes["verify_128_cells_verifications_per_s_all_cores"] = round(rounds * cores / (time.perf_counter() - t0), 1)
+        if extra is not None and "recover" in extra:
+            idx, cells_h = extra["recover"]
+            for nm, orc, thr in (("recover_one_blob_half_missing_single_thread_ms", o, 1), ("recover_one_blob_half_missing_all_cores_ms", om, cores)):
+                ts = _criterion(lambda: orc.recover_cells_and_kzg_proofs(idx, cells_h), 1.0, 8, 4.0)
+                shapes[nm] = {"median": round(_median(ts) * 1e3, 2), "min": round(min(ts) * 1e3, 2), "samples": len(ts), "threads": thr}
+        om.close()
+        ts = []
+        for _ in range(3):  # "Initialize context" (benchmark-mt.rs:103-113): width-8 tables for the 128 x 64 FK20 bases, on all cores
+            t0 = time.perf_counter()
+            oc = Oracle(use_precomp=True, threads=cores)
+            ts.append(time.perf_counter() - t0)
+            oc.close()
+        shapes["initialize_context_s"] = {"median": round(_median(ts), 3), "min": round(min(ts), 3), "samples": 3, "threads": cores}
+        shapes["note"] = "C oracle (portable __int128 arithmetic, not blst assembly); medians of criterion-like samples, context built once outside unless timed"
+    except Exception as e:  # the side shapes must never sink the headline record
+        shapes["error"] = repr(e)
     ex.shutdown()
     o.close()
     best_value, best_cores = (par, cores) if par >= rayon["value"] else (rayon["value"], cores)
@@ -183,7 +221,13 @@ def cpu_baseline(blobs, gpu_first=None, extra=None):
             "blob_parallel": {"value": par, "best": par_best, "threads": cores, "samples": len(tsp)},
             "single_thread": single_thread,
             "rayon_like": rayon,
-            "other_configs_cpu": out_extra}
+            "other_configs_cpu": out_extra,
+            "reference_bench_shapes_cpu": shapes}
+
+
+def _mark(what):
+    if os.environ.get("KZG_BENCH_VERBOSE"):
+        print(f"[bench {time.strftime('%H:%M:%S')}] {what}", file=sys.stderr, flush=True)
 
 
 def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
@@ -214,6 +258,7 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
         return nb / _median(ts), _median(ts) * 1e3, (d_b, d_c, d_p)
 
     B = blobs_h.shape[0]
+    _mark("side configs: device rates")
     r64, ms64, _ = dev_rate(min(64, B))
     out["config4_per_gpu_share_64_blobs"] = {"blobs_per_s": round(r64), "ms": round(ms64, 2), "form": "device-resident"}
     r512, ms512, _ = dev_rate(min(512, B))
@@ -223,6 +268,7 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
     rk, msk, _ = dev_rate(B, "commit")
     out["blob_to_kzg_commitment"] = {"commitments_per_s": round(rk), "ms": round(msk, 2), "blobs": B, "form": "device-resident"}
     # the reference's ABI: host pointers (pageable memory in, 256 caller buffers per blob out)
+    _mark("side configs: host-pointer ABI")
     bufs = ctx.host_batch_buffers(B)
     ctx.compute_cells_and_kzg_proofs_batch_np(blobs_h, bufs)
     ts = []
@@ -241,6 +287,7 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
         ts.append(time.perf_counter() - t0)
     out["abi_single_call_latency_ms"] = {"ms": round(_median(ts) * 1e3, 3), "entry": "eth_kzg_compute_cells_and_kzg_proofs (ctypes wrapper included)"}
     # config 3: verify 64 blobs x 128 cells (host-pointer ABI; its transcript hash needs the bytes on the host anyway)
+    _mark("side configs: config 3")
     nb = 64
     d_b = torch.from_numpy(blobs_h[:nb]).to(dev)
     d_c = torch.empty(nb * CELLS * BYTES_PER_CELL, dtype=torch.uint8, device=dev)
@@ -267,6 +314,7 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
     out["config3_verify_64x128_cells"] = {"ms": round(_median(ts) * 1e3, 2), "cells": len(L_), "cells_per_s": round(len(L_) / _median(ts)),
                                           "entry": "eth_kzg_verify_cell_kzg_proof_batch (host pointers, 17.6 MB of input; tampered proof -> false checked)"}
     # config 5: recover 256 blobs at 50 % erasure, device-resident form; and its per-GPU share on 8 GPUs (32 blobs)
+    _mark("side configs: config 5")
     for nb, key in ((min(256, B), "config5_recover_256_blobs_half_erased"), (32, "config5_per_gpu_share_32_blobs")):
         d_b = torch.from_numpy(blobs_h[:nb]).to(dev)
         d_c = torch.empty(nb * CELLS * BYTES_PER_CELL, dtype=torch.uint8, device=dev)
@@ -298,6 +346,44 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
             ts.append(time.perf_counter() - t0)
         assert ok
     out["reference_bench_verify_128_cells_one_commitment"] = {"ms": round(_median(ts) * 1e3, 3), "entry": "eth_kzg_verify_cell_kzg_proof_batch"}
+    # many independent verifications of that shape in ONE call (eth_kzg_amd_verify_cell_kzg_proof_batch_many): 64 distinct
+    # problems (one per blob) repeated to 1024, one of them tampered; and the same problems from 4 host threads through the
+    # single-call entry point (engine lanes)
+    _mark("side configs: verify_many")
+    probs = [(C_[b * CELLS:(b + 1) * CELLS], I_[b * CELLS:(b + 1) * CELLS], L_[b * CELLS:(b + 1) * CELLS], P_[b * CELLS:(b + 1) * CELLS]) for b in range(nb)]
+    many = [probs[j % nb] for j in range(1024)]
+    bad = list(many[77][3]); bad[5] = many[78][3][5]
+    many[77] = (many[77][0], many[77][1], many[77][2], bad)
+    run_many = ctx.prepare_verify_cell_kzg_proof_batch_many(many)
+    ver, stt = run_many()
+    assert stt == [0] * 1024 and ver == [j != 77 for j in range(1024)], "verify_many verdicts"
+    ts = []
+    for it in range(5):
+        t0 = time.perf_counter()
+        run_many()
+        if it >= 1:
+            ts.append(time.perf_counter() - t0)
+    out["verify_many_1024_x_128_cells"] = {"ms": round(_median(ts) * 1e3, 2), "verifications_per_s": round(1024 / _median(ts)), "cells_per_s": round(1024 * CELLS / _median(ts)),
+                                           "entry": "eth_kzg_amd_verify_cell_kzg_proof_batch_many (host pointers: 275 MB of input per call, staging, 1024 transcript hashes and "
+                                                    "1024 pairing checks on the host threads included; one tampered problem -> false checked)"}
+    _mark("side configs: 4 threads")
+    import threading
+    runs4 = [ctx.prepare_verify_cell_kzg_proof_batch(*probs[b]) for b in range(4)]
+
+    def hammer(r, reps=25):
+        for _ in range(reps):
+            assert r()
+    for r in runs4:
+        r()
+    ths = [threading.Thread(target=hammer, args=(r,)) for r in runs4]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt4 = time.perf_counter() - t0
+    out["verify_128_cells_from_4_threads"] = {"verifications_per_s": round(100 / dt4), "entry": "eth_kzg_verify_cell_kzg_proof_batch from 4 host threads on one context (engine lanes)"}
+    _mark("side configs: recover one")
     half_idx, half_cells = list(range(CELLS // 2)), L_[:CELLS // 2]
     ts = []
     for it in range(9):
@@ -309,6 +395,7 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
     out["reference_bench_recover_one_blob_half_missing"] = {"ms": round(_median(ts) * 1e3, 3), "entry": "eth_kzg_recover_cells_and_kzg_proofs (ctypes wrapper included)"}
     # context creation (the reference's "Initialize context" bench): cold = first context of the process (measured by the
     # caller), warm = another context while one is alive (tables shared), fresh = after every context was closed
+    _mark("side configs: warm context, fresh process")
     t0 = time.perf_counter()
     c2 = kzg.DASContext(use_precomp=True, device=ctx.device_index)
     warm = time.perf_counter() - t0
@@ -338,7 +425,7 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
                                      note="first context of the process: eth_kzg_das_context_new returns on the start tables (GLV width 8 + plain "
                                           "width 8, 3.7 GB; HIP runtime start ~0.45 s included), first_result = one compute_cells_and_kzg_proofs "
                                           "on them, wide tables (hipMalloc of ~250 GB: seconds of driver time, + ~0.9 s of build) swapped in by a helper thread")
-    return out, {"verify": (C_, I_, L_, P_), "recover": recover_one}
+    return out, {"verify": (C_, I_, L_, P_), "recover": recover_one, "verify128": (C_[:CELLS], I_[:CELLS], L_[:CELLS], P_[:CELLS])}
 
 
 def strong_configs(ctx, sharding, torch, dist, dev, world, rank, lib_comm, stream):
@@ -573,12 +660,15 @@ def main():
     t_ctx0 = time.perf_counter()
     ctx = kzg.DASContext(use_precomp=True, device=local_rank, wait_tables=False)  # no CPU fallback: raises/aborts without the HIP path
     t_ctx_new = time.perf_counter() - t_ctx0
+    _mark("context constructed")
     start_width = ctx.window_bits()
     first_blob = synth_blobs(1, seed=0x4B5A47)[0].tobytes()
     first_out = ctx.compute_cells_and_kzg_proofs(first_blob)
     t_ctx_first = time.perf_counter() - t_ctx0
+    _mark("first result computed")
     tables_state = ctx.tables_ready(-1)
     t_ctx = time.perf_counter() - t_ctx0
+    _mark("wide tables ready")
     assert ctx.compute_cells_and_kzg_proofs(first_blob) == first_out, "start tables and wide tables disagree"
     ctx_times = {"constructor_returns_s": round(t_ctx_new, 3), "first_result_s": round(t_ctx_first, 3), "wide_tables_in_use_s": round(t_ctx, 2),
                  "start_table_window_bits": start_width, "final_state": tables_state}
@@ -642,6 +732,7 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if not int(flag.item()):
             raise SystemExit("bench.py: the all-gathered proof vector does not match the ranks' own proofs")
+    _mark("correctness gate passed; warm-up")
     for _ in range(args.warmup):
         step()
     fence()
@@ -761,10 +852,48 @@ def main():
             gpu_first = (bytes(d_cells[:CELLS * BYTES_PER_CELL].cpu().numpy()), bytes(d_proofs[:CELLS * 48].cpu().numpy()))
             out["cpu_baseline"] = cpu_baseline([bytes(blobs_h[i].tobytes()) for i in range(min(B, 32))], gpu_first=gpu_first, extra=extra)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if not args.no_configs and world == 1:
+            # blobs/s against window-table memory: the main context goes first (its 249 GB leave no room),
+            # then one context per table size on the same resident batch.  UsePrecomp::Yes{width} is the reference's knob
+            # (fixed_base_msm.rs:41-49).
+            curve = [{"table": f"GLV width {ctx.window_bits()}" if ctx.glv_table() else f"plain width {ctx.window_bits()}", "table_GB": round(ctx.table_bytes() / 1e9, 1),
+                      "gathered_additions_per_base": 2 * -(-128 // ctx.window_bits()) if ctx.glv_table() else -(-255 // ctx.window_bits()),
+                      "blobs_per_s": round(value), "ms_per_step": round(dt / args.steps * 1e3, 2)}]
+            ctx.close()
+            ctx = None
+            _mark("table curve")
+            for label, env, precomp in (("GLV width 15", {"ETH_KZG_AMD_GLV_WINDOW": "15"}, True), ("GLV width 14", {"ETH_KZG_AMD_GLV_WINDOW": "14"}, True),
+                                        ("GLV width 12", {"ETH_KZG_AMD_GLV_WINDOW": "12"}, True), ("GLV width 8 (the start table)", {"ETH_KZG_AMD_GLV_WINDOW": "8"}, True),
+                                        ("plain width 4 (use_precomp = false)", {}, False)):
+                try:
+                    _mark("table curve: " + label)
+                    os.environ.update(env)
+                    c2 = kzg.DASContext(use_precomp=precomp, device=local_rank)
+                    ts = []
+                    for it in range(4):
+                        torch.cuda.synchronize(dev)
+                        t0 = time.perf_counter()
+                        with torch.cuda.stream(stream):
+                            c2.compute_cells_and_kzg_proofs_device(B, d_blobs.data_ptr(), d_cells.data_ptr(), d_proofs.data_ptr(), want_status=False, stream=stream.cuda_stream)
+                        torch.cuda.synchronize(dev)
+                        if it >= 1:
+                            ts.append(time.perf_counter() - t0)
+                    w = c2.window_bits()
+                    curve.append({"table": label, "table_GB": round(c2.table_bytes() / 1e9, 1),
+                                  "gathered_additions_per_base": 2 * -(-128 // w) if c2.glv_table() else -(-255 // w),
+                                  "blobs_per_s": round(B / _median(ts)), "ms_per_step": round(_median(ts) * 1e3, 2)})
+                    c2.close()
+                except Exception as e:
+                    curve.append({"table": label, "error": repr(e)})
+                finally:
+                    for k in env:
+                        os.environ.pop(k, None)
+            out["configs"]["blobs_per_s_vs_table_memory"] = {"batch": B, "note": "table_GB = FK20 table + commitment table (43 GB at its default width 13); same resident batch, median of 3 steps", "points": curve}
         os.write(record_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
 
 
 if __name__ == "__main__":
