@@ -591,11 +591,12 @@ void Engine::init_srs() {
 // Window tables are immutable once built and depend only on (device, which bases, width), so the contexts of one
 // process share them: the second DASContext on a GPU costs neither another 206 GB nor another build
 // (the reference's Java test creates several contexts, LibEthKZGTest.java:32).  The last context to go frees the table.
-// Large tables are not hipMalloc'ed in one piece: mapping 200+ GB takes the driver seconds during which every other HIP call of
-// the process waits (measured: a 214 GB hipMalloc on the helper thread stalled the caller's launches for 4.3 s), and the call
-// cannot be abandoned when the context -- or the process -- goes away.  Instead the address range is reserved and backed
-// PIECE BY PIECE (hipMemCreate / hipMemMap / hipMemSetAccess, 2 GB at a time, a few tens of milliseconds each), just ahead
-// of the builder kernels: other threads' calls slip in between the pieces and a cancellation is honoured within one piece.  Small tables and any failure of the VMM calls fall back to hipMalloc.
+// Optional piecewise backing of a large table (ETH_KZG_AMD_VMM=1; see build_table_glv for why it is not the default): mapping
+// 200+ GB with one hipMalloc takes the driver seconds during which every other HIP call of the process waits (measured: a
+// 214 GB hipMalloc on the helper thread stalled the caller's launches for 4.3 s) and cannot be abandoned.  With the virtual
+// memory API the address range is reserved and backed PIECE BY PIECE (hipMemCreate / hipMemMap / hipMemSetAccess, 2 GB at a
+// time, a few tens of milliseconds each), just ahead of the builder kernels: other threads' calls slip in between the
+// pieces and a cancellation is honoured within one piece.
 struct Engine::SharedTable {
     void* p = nullptr;
     size_t bytes = 0;
@@ -746,7 +747,13 @@ static bool build_table_glv(int c, const void* bases, Engine::SharedTable& t, in
     auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     void *scratch = nullptr, *side = nullptr;
     int* d_err = nullptr;
-    const bool piecewise = table_bytes > (8ull << 30) && getenv("ETH_KZG_AMD_NO_VMM") == nullptr && t.reserve(table_bytes);
+    // Piecewise backing is OPT-IN (ETH_KZG_AMD_VMM=1).  It keeps other threads' calls flowing during the build (22 prover calls
+    // completed during a build against 1 with a single hipMalloc, which blocks the process's HIP calls for ~4 s) and makes the
+    // build cancellable within 2 GB, but on ROCm 7.0.2 two GPU memory faults were seen with it in ~10 runs (a builder kernel
+    // hit "write access to a read-only page" while a later piece was given its access rights; one bench process died of a
+    // fault of unknown reason while calls overlapped the mapping), none without it.  Correctness first: one hipMalloc by default.
+    const char* vmm_env = getenv("ETH_KZG_AMD_VMM");
+    const bool piecewise = table_bytes > (8ull << 30) && vmm_env && atoi(vmm_env) != 0 && t.reserve(table_bytes);
     if (!piecewise && hipMalloc(&t.p, table_bytes) != hipSuccess) { (void)hipGetLastError(); t.p = nullptr; return false; }
     auto cleanup = [&] {
         (void)hipStreamSynchronize(st);
