@@ -386,11 +386,11 @@ Engine::~Engine() {
     if (build_stream_) hipStreamDestroy(build_stream_);
     host_pool_.reset();  // joins the helper threads before anything they might touch goes away
     void* ptrs[] = {d_w8192_, d_naf_, d_srs_, d_fk_bases_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_circ_terms_,
-                    d_slp_naf_, d_slp_words_};
+                    d_slp_naf_, d_slp_words_, d_slp_levels_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (Work& w : work_) {
-        void* dev[] = {w.coeffs, w.canon, w.scalars, w.X, w.status, w.dft_tmp, w.dft_prod, w.circ_table, w.slp_arena, w.d_in, w.d_cells, w.d_proofs};
+        void* dev[] = {w.coeffs, w.canon, w.scalars, w.X, w.status, w.dft_tmp, w.dft_prod, w.circ_table, w.slp_arena, w.slp_sync, w.d_in, w.d_cells, w.d_proofs};
         for (void* p : dev)
             if (p) hipFree(p);
         void* pin[] = {w.h_in, w.h_cells, w.h_proofs, w.h_status};
@@ -537,12 +537,38 @@ void Engine::init_linmap(const Fr8* w8192_mont) {
     HIPCK(hipMemcpy(d_slp_words_, sched.words.data(), sched.words.size() * 4, hipMemcpyHostToDevice));
     slp_launches_.clear();
     for (auto& L : sched.launches) slp_launches_.push_back(SlpLaunch{(int)L.kind, L.first, L.count});
+    // phases for the ticket walker (k_g1slp.hip: k_slp_walk): every maximal run of cheap launches becomes ONE launch
+    {
+        std::vector<int> lf, lc;
+        slp_phases_.clear();
+        for (size_t i = 0; i < slp_launches_.size();) {
+            if (slp_launches_[i].kind == (int)linmap::OP_MULC) { slp_phases_.push_back(SlpPhase{(int)i, -1, 0, 0, 0}); i++; continue; }
+            SlpPhase ph{(int)i, (int)lf.size(), 0, 0, 0};
+            while (i < slp_launches_.size() && slp_launches_[i].kind != (int)linmap::OP_MULC) {
+                lf.push_back(slp_launches_[i].first);
+                lc.push_back(slp_launches_[i].count);
+                ph.n_levels++;
+                ph.max_count = std::max(ph.max_count, slp_launches_[i].count);
+                ph.total_ops += slp_launches_[i].count;
+                i++;
+            }
+            slp_phases_.push_back(ph);
+        }
+        slp_max_levels_ = 0;
+        for (auto& ph : slp_phases_) slp_max_levels_ = std::max(slp_max_levels_, ph.n_levels);
+        HIPCK(hipMalloc(&d_slp_levels_, (lf.size() * 2 + 2) * sizeof(int)));
+        HIPCK(hipMemcpy(d_slp_levels_, lf.data(), lf.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCK(hipMemcpy((int*)d_slp_levels_ + lf.size(), lc.data(), lc.size() * sizeof(int), hipMemcpyHostToDevice));
+        slp_level_total_ = (int)lf.size();
+        slp_walk_ = true;
+        if (const char* e = getenv("ETH_KZG_AMD_SLP_WALK")) slp_walk_ = atoi(e) != 0;  // 0: one launch per dependency level (round 2's executor)
+    }
     slp_slots_ = sched.n_slots;
     slp_mulc_ = (int)sched.mulc_total;
     slp_info_[0] = (int)plan.count(linmap::OP_MULC);
     slp_info_[1] = (int)(plan.count(linmap::OP_ADD) + plan.count(linmap::OP_SUB));
     slp_info_[2] = (int)plan.doublings();
-    slp_info_[3] = (int)sched.launches.size();
+    slp_info_[3] = slp_walk_ ? (int)slp_phases_.size() : (int)sched.launches.size();
     const Fr h = inv(fr_from_u64(2));
     memcpy(&half_, &h, 32);
     use_linmap_ = true;
@@ -1146,9 +1172,34 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
     mark_end(1, st);
     if (linmap_mode) {
         mark_begin(ST_G1_LINMAP, st);
-        for (auto& L : slp_launches_)
-            launch::g1_slp_launch(L.kind, w.slp_arena, bp, (const uint32_t*)d_slp_words_ + (size_t)L.first * 4, L.count, d_slp_naf_, beta_, st);
-        mark_end((int)slp_launches_.size(), st);
+        int n_launches = 0;
+        if (slp_walk_) {
+            // the constant multiplications as one launch each (there is one), every run of cheap levels as ONE ticket-walking launch
+            const size_t ints = launch::g1_slp_walk_sync_ints(bp / 64, slp_max_levels_);
+            if (ints > w.slp_sync_ints) {
+                if (w.slp_sync) { HIPCK(hipStreamSynchronize(st)); HIPCK(hipFree(w.slp_sync)); w.slp_sync = nullptr; }
+                HIPCK(hipMalloc(&w.slp_sync, 2 * ints * sizeof(int)));  // two phases may be in flight back to back: one block each
+                w.slp_sync_ints = ints;
+            }
+            int walk = 0;
+            for (auto& ph : slp_phases_) {
+                if (ph.level0 < 0) {
+                    const SlpLaunch& L = slp_launches_[ph.launch0];
+                    launch::g1_slp_launch(L.kind, w.slp_arena, bp, (const uint32_t*)d_slp_words_ + (size_t)L.first * 4, L.count, d_slp_naf_, beta_, st);
+                } else {
+                    launch::g1_slp_walk(w.slp_arena, bp, (const uint32_t*)d_slp_words_, (const int*)d_slp_levels_ + ph.level0,
+                                        (const int*)d_slp_levels_ + slp_level_total_ + ph.level0, ph.n_levels, ph.max_count, ph.total_ops,
+                                        w.slp_sync + (size_t)(walk & 1) * w.slp_sync_ints, wave_slots_, st);
+                    walk++;
+                }
+                n_launches++;
+            }
+        } else {
+            for (auto& L : slp_launches_)
+                launch::g1_slp_launch(L.kind, w.slp_arena, bp, (const uint32_t*)d_slp_words_ + (size_t)L.first * 4, L.count, d_slp_naf_, beta_, st);
+            n_launches = (int)slp_launches_.size();
+        }
+        mark_end(n_launches, st);
         mark_begin(ST_COMPRESS, st);
         launch::g1_compress((const char*)w.slp_arena + (size_t)128 * bp * launch::SIZEOF_JACQ, d_proofs, 128, bp, n, st);
         mark_end(1, st);

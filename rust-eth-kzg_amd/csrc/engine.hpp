@@ -70,6 +70,8 @@ struct Work {
     int* status = nullptr;
     void *dft_tmp = nullptr, *dft_prod = nullptr, *circ_table = nullptr, *slp_arena = nullptr;
     size_t slp_arena_bytes = 0;
+    int* slp_sync = nullptr;  // tickets and completion counters of the linear map's ticket walker (two blocks of slp_sync_ints)
+    size_t slp_sync_ints = 0;
     hipEvent_t done = nullptr;  // recorded after the last kernel that touches the set; the next user's stream waits on it
     // host-pointer path: device and pinned-host staging for one chunk, a compute stream, a copy stream, events
     int stage_cap = 0;
@@ -339,6 +341,12 @@ private:
     // the two G1 transforms as one compiled linear map (g1_linmap.hpp, k_g1slp.hip): launches, constants, slot arena
     struct SlpLaunch { int kind, first, count; };
     std::vector<SlpLaunch> slp_launches_;
+    // a phase = one multiplication launch (level0 < 0) or a run of cheap dependency levels executed by ONE ticket-walking launch
+    struct SlpPhase { int launch0, level0, n_levels, max_count, total_ops; };
+    std::vector<SlpPhase> slp_phases_;
+    void* d_slp_levels_ = nullptr;  // int[2][slp_level_total_]: first operation / operation count of every cheap level
+    int slp_level_total_ = 0, slp_max_levels_ = 0;
+    bool slp_walk_ = true;
     void *d_slp_words_ = nullptr, *d_slp_naf_ = nullptr;
     int slp_slots_ = 0, slp_mulc_ = 0;
     int slp_info_[4] = {0, 0, 0, 0};  // constant multiplications, additions, doublings, launches of the compiled map

@@ -63,6 +63,12 @@ void g1_dft128_direct(void* X, void* tmpA, void* prod, int stride, int n_in, int
 void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int count, const void* naf, const Fp12w& beta,
                    hipStream_t st);
 
+// the cheap operations of one phase (before / after the constant multiplications) in ONE launch: a ticket walker with
+// per-(lane group, level) completion counters; returns the error word's position in `sync` (checked by the caller later)
+size_t g1_slp_walk_sync_ints(int n_groups, int n_levels);
+void g1_slp_walk(void* arena, int stride, const uint32_t* words, const int* level_first, const int* level_count, int n_levels,
+                 int max_level_count, int total_ops, int* sync, int wave_slots, hipStream_t st);
+
 // k_g1misc.hip
 void g1_set_inf(void* X, size_t n, hipStream_t st);
 void g1_compress(const void* X, uint8_t* out, int n_pos, int stride, int n_slices, hipStream_t st);
