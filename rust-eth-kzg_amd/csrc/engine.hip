@@ -560,8 +560,13 @@ void Engine::init_linmap(const Fr8* w8192_mont) {
         HIPCK(hipMemcpy(d_slp_levels_, lf.data(), lf.size() * sizeof(int), hipMemcpyHostToDevice));
         HIPCK(hipMemcpy((int*)d_slp_levels_ + lf.size(), lc.data(), lc.size() * sizeof(int), hipMemcpyHostToDevice));
         slp_level_total_ = (int)lf.size();
-        slp_walk_ = true;
-        if (const char* e = getenv("ETH_KZG_AMD_SLP_WALK")) slp_walk_ = atoi(e) != 0;  // 0: one launch per dependency level (round 2's executor)
+        // Measured (MI355X, profiles/r3_slp_walk_ab.log): the walker LOSES to one launch per level at every batch size -- g1_linmap
+        // 2.75 -> 2.89 ms at 64 blobs, 5.60 -> 7.27 at 512, 18.1 -> 23.0 at 2048 -- because every operation pays an agent-scope
+        // release (buffer_wbl2: the XCD's L2 writes its dirty lines back) and an acquire (buffer_inv: the CU's L1 goes cold), which
+        // cost more than the part-empty rounds at the 41 level boundaries they remove.  Kept as an option (and parity-tested);
+        // the default stays one launch per dependency level.
+        slp_walk_ = false;
+        if (const char* e = getenv("ETH_KZG_AMD_SLP_WALK")) slp_walk_ = atoi(e) != 0;
     }
     slp_slots_ = sched.n_slots;
     slp_mulc_ = (int)sched.mulc_total;
@@ -1190,6 +1195,22 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
                     launch::g1_slp_walk(w.slp_arena, bp, (const uint32_t*)d_slp_words_, (const int*)d_slp_levels_ + ph.level0,
                                         (const int*)d_slp_levels_ + slp_level_total_ + ph.level0, ph.n_levels, ph.max_count, ph.total_ops,
                                         w.slp_sync + (size_t)(walk & 1) * w.slp_sync_ints, wave_slots_, st);
+                    if (getenv("ETH_KZG_AMD_SLP_DEBUG")) {  // debugging aid: the walker's counters after the phase
+                        fprintf(stderr, "[slp walk %d] launched: level0 %d n_levels %d max_count %d total_ops %d level_total %d\n", walk, ph.level0, ph.n_levels,
+                                ph.max_count, ph.total_ops, slp_level_total_);
+                        HIPCK(hipStreamSynchronize(st));
+                        std::vector<int> h(ints);
+                        HIPCK(hipMemcpy(h.data(), w.slp_sync + (size_t)(walk & 1) * w.slp_sync_ints, ints * sizeof(int), hipMemcpyDeviceToHost));
+                        const int G = bp / 64;
+                        const size_t eo = 256 + 16 * (size_t)G * ph.n_levels;
+                        fprintf(stderr, "[slp walk %d] groups %d levels %d tickets drawn:", walk, G, ph.n_levels);
+                        for (int sh = 0; sh < std::min(G, 8); sh++) fprintf(stderr, " %d", h[32 * sh]);
+                        fprintf(stderr, "\n  done[group 0]:");
+                        for (int l = 0; l < ph.n_levels; l++) fprintf(stderr, " %d", h[256 + 16 * l]);
+                        fprintf(stderr, "\n  error %d reporters %d first: ticket %d level %d group %d op %d saw %d need %d tickets %d groups_here %d\n", h[eo], h[eo + 1],
+                                h[eo + 4], h[eo + 5], h[eo + 6], h[eo + 7], h[eo + 8], h[eo + 9], h[eo + 10], h[eo + 11]);
+                        fprintf(stderr, "  kernel saw: total %d tickets %d n_levels %d level_count[0] %d\n", h[eo + 12], h[eo + 13], h[eo + 14], h[eo + 15]);
+                    }
                     walk++;
                 }
                 n_launches++;

@@ -60,6 +60,8 @@ struct SlpWalk {
     const int* level_first;     // [n_levels] first operation of the level (index into words / 4)
     const int* level_count;     // [n_levels]
     int n_levels, n_groups, n_shards;
+    int spin_limit;             // polls before a waiting wave gives up (about a second)
+    int debug;
     // counters (zeroed before the launch): ticket[shard] at stride 32 ints, then done[group][level] at stride 16 ints, then error
     int* sync;
 };
@@ -76,7 +78,15 @@ __global__ __launch_bounds__(64) void k_slp_walk(JacQ* __restrict__ A, int strid
     int total = 0;
     for (int l = 0; l < w.n_levels; l++) total += w.level_count[l];
     const int tickets = total * groups_here;
-    for (;;) {
+    if (w.debug && blockIdx.x == 0 && threadIdx.x == 0) {
+        int* dbg = slp_error(w) + 4;
+        dbg[8] = total; dbg[9] = tickets; dbg[10] = w.n_levels; dbg[11] = w.level_count[0];
+    }
+    for (int guard = 0;; guard++) {
+        if (guard > 200000) {  // no wave can have this many operations: the tables are corrupt
+            if (threadIdx.x == 0) __hip_atomic_store(slp_error(w), 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
         int t = 0;
         if (threadIdx.x == 0) t = __hip_atomic_fetch_add(slp_ticket(w, shard), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         t = __builtin_amdgcn_readfirstlane(t);
@@ -97,8 +107,16 @@ __global__ __launch_bounds__(64) void k_slp_walk(JacQ* __restrict__ A, int strid
             int spins = 0;
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                 __builtin_amdgcn_s_sleep(16);
-                if (++spins > (1 << 22)) {  // seconds: something is badly wrong; fail loudly instead of hanging the GPU
-                    if (threadIdx.x == 0) __hip_atomic_store(slp_error(w), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // a stuck counter (or another wave's verdict that one is stuck) ends the walk: fail loudly, never hang the GPU
+                if ((++spins & 1023) == 0 && (spins > w.spin_limit || __hip_atomic_load(slp_error(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    if (threadIdx.x == 0) {
+                        __hip_atomic_store(slp_error(w), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        int* dbg = slp_error(w) + 4;  // first reporter: ticket, level, group, operation, counter seen, needed
+                        if (__hip_atomic_fetch_add(slp_error(w) + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                            dbg[0] = t; dbg[1] = level; dbg[2] = group; dbg[3] = i;
+                            dbg[4] = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dbg[5] = need; dbg[6] = tickets; dbg[7] = groups_here;
+                        }
+                    }
                     return;
                 }
             }
@@ -135,7 +153,7 @@ void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int
         k_slp_add<<<grid, 64, 0, st>>>((JacQ*)arena, stride, words);
     }
 }
-size_t g1_slp_walk_sync_ints(int n_groups, int n_levels) { return 32 * 8 + 16 * (size_t)n_groups * n_levels + 16; }
+size_t g1_slp_walk_sync_ints(int n_groups, int n_levels) { return 32 * 8 + 16 * (size_t)n_groups * n_levels + 32; }
 // one phase of cheap operations in one launch; sync = g1_slp_walk_sync_ints ints (zeroed here); wave_slots = what the chip holds
 void g1_slp_walk(void* arena, int stride, const uint32_t* words, const int* level_first, const int* level_count, int n_levels,
                  int max_level_count, int total_ops, int* sync, int wave_slots, hipStream_t st) {
@@ -148,6 +166,9 @@ void g1_slp_walk(void* arena, int stride, const uint32_t* words, const int* leve
     w.n_groups = n_groups;
     w.n_shards = n_groups < 8 ? n_groups : 8;
     w.sync = sync;
+    w.spin_limit = 1 << 20;
+    w.debug = getenv("ETH_KZG_AMD_SLP_DEBUG") != nullptr;
+    if (const char* e = getenv("ETH_KZG_AMD_SLP_SPIN_LIMIT")) w.spin_limit = atoi(e);
     (void)hipMemsetAsync(sync, 0, g1_slp_walk_sync_ints(n_groups, n_levels) * sizeof(int), st);
     // enough waves to keep every level's operations of every group in flight, at most what the chip holds at once
     long want = (long)max_level_count * n_groups;

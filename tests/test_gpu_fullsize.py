@@ -268,6 +268,24 @@ def test_fixed_base_msm_stage_matches_oracle(oracle, monkeypatch, chunks, table)
         c2.close()
 
 
+def test_ticket_walking_executor_matches_oracle(oracle, monkeypatch):
+    """ETH_KZG_AMD_SLP_WALK=1: the cheap operations of the compiled linear map as one ticket-walking launch per phase (k_slp_walk:
+    per-(lane group, level) completion counters, agent-scope release / acquire) instead of one launch per dependency level.
+    A measured negative (profiles/r3_slp_walk_ab.log) kept as an option: same bytes at one lane group, several, and a ragged count."""
+    monkeypatch.setenv("ETH_KZG_AMD_SLP_WALK", "1")
+    c2 = kzg.DASContext(use_precomp=True)
+    try:
+        assert c2.linmap_info()[3] == 3  # two walks around the one multiplication launch
+        for n in (9, 64, 200, 1100):
+            blobs = _random_blobs(n, 500 + n)
+            blobs[2] = 0
+            st, cells, proofs = _compute_on_device(c2, blobs)
+            assert st == [0] * n
+            _check_sample_against_oracle(oracle, blobs, cells, proofs, [0, 2, min(63, n - 1), n // 2, n - 1])
+    finally:
+        c2.close()
+
+
 def test_radix2_transform_schedule_still_matches_oracle(oracle, monkeypatch):
     """ETH_KZG_AMD_G1FFT=radix2 keeps the butterfly network (and the direct 8 x 16 form below 129 blobs) instead of the
     compiled linear map: same bytes."""
