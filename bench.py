@@ -794,10 +794,11 @@ def main():
         traffic, traffic_source = None, None
         try:
             import glob
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r2*_pmc_b2048*.json")))
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_pmc_b2048*.json")))
             pm = json.load(open(files[-1]))["kernels"]
-            key = {"msm_fixed": "kzg::k_msm_glv_chunked" if ctx.glv_table() else "void kzg::k_msm_fixed_chunked<14>", "g1_linmap": "kzg::k_slp_mulc"}.get(dom)
-            if key in pm and B == 2048:
+            want = {"msm_fixed": ("k_msm_glv_lane<1>", "k_msm_glv_chunked") if ctx.glv_table() else ("k_msm_fixed_chunked<14>",), "g1_linmap": ("k_slp_mulc",)}.get(dom, ())
+            key = next((k for w_ in want for k in pm if w_ in k), None)  # the newest profile names the kernel the default schedule runs
+            if key in pm and B == 2048 and ctx.glv_table() and ctx.window_bits() == 16:
                 # gfx950 correction (MI355X_MICROARCH.md, calibrated for this kernel's 16-B-per-lane gathers in
                 # profiles/r1f_calib_fetch.log): FETCH_SIZE tallies every 128-B line request at 64 B -> double it; WRITE_SIZE is exact
                 traffic = (2.0 * pm[key]["FETCH_SIZE_per_launch_max"] + pm[key]["WRITE_SIZE_per_launch_max"]) * 1024.0

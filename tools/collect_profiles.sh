@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (gpurun -- bash tools/collect_profiles.sh TAG): the kernel-trace summary and the three PMC passes
 # behind profiles/<TAG>_*.  rocprofv3 gets the program directly after `--` (no env / bash -c hops).
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 SUFFIX=${2:-glv16}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/$TAG

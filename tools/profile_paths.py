@@ -4,6 +4,8 @@
   4844     the EIP-4844 single-point operations, 5 calls each
   single   the reference's own criterion shapes (benchmark-mt.rs:36-101): one blob through compute, verify (128 cells, one
            commitment) and worst-case recovery (first 64 cells), 7 calls each
+  verify_many  1024 independent verifications of 128 cells (64 distinct problems repeated) in ONE call of
+           eth_kzg_amd_verify_cell_kzg_proof_batch_many, 4 calls
 Prints one JSON line with host-side timings of the same calls."""
 import importlib
 import json
@@ -22,7 +24,7 @@ def main():
     import torch
     what = sys.argv[1] if len(sys.argv) > 1 else "verify"
     ctx = kzg.DASContext(True)
-    nb = {"verify": 64, "recover": 256, "4844": 4, "single": 1}[what]
+    nb = {"verify": 64, "recover": 256, "4844": 4, "single": 1, "verify_many": 64}[what]
     rng = np.random.RandomState(7)
     a = rng.randint(0, 256, size=(nb, 4096, 32), dtype=np.uint8)
     a[:, :, 0] &= 0x3F
@@ -47,6 +49,22 @@ def main():
             assert ctx.verify_cell_kzg_proof_batch(C, I, L, P)
             ts.append(time.perf_counter() - t)
         out.update(cells=len(L), verify_ms=[round(x * 1e3, 2) for x in ts])
+    elif what == "verify_many":
+        cells = d_cells.cpu().numpy().tobytes()
+        proofs = d_proofs.cpu().numpy().tobytes()
+        _, comms = ctx.blob_to_kzg_commitment_batch([a[b].tobytes() for b in range(nb)])
+        probs = []
+        for b in range(nb):
+            probs.append(([comms[b]] * 128, list(range(128)), [cells[2048 * (b * 128 + k):2048 * (b * 128 + k + 1)] for k in range(128)],
+                          [proofs[48 * (b * 128 + k):48 * (b * 128 + k + 1)] for k in range(128)]))
+        run = ctx.prepare_verify_cell_kzg_proof_batch_many([probs[j % nb] for j in range(1024)])
+        ts = []
+        for _ in range(4):
+            t = time.perf_counter()
+            ver, st = run()
+            ts.append(time.perf_counter() - t)
+            assert all(ver) and not any(st)
+        out.update(problems=1024, cells_per_problem=128, call_ms=[round(x * 1e3, 2) for x in ts], verifications_per_s=round(1024 / min(ts)))
     elif what == "recover":
         idx = list(range(0, 128, 2))
         flat = d_cells.view(nb, 128, 2048).clone()
