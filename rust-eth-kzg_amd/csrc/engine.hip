@@ -999,20 +999,25 @@ void Engine::build_final_tables() {
 
 // Per-stage HIP events (bench.py's roofline leg).  Meant for one caller at a time: marks of concurrent calls would interleave.
 void Engine::set_profiling(bool on) { std::lock_guard<std::mutex> lk(marks_mu_); profiling_ = on; }
-void Engine::mark_begin(int stage, hipStream_t st) {
-    if (!profiling_) return;
+// Marks are paired by the index mark_begin returns: concurrent prover calls (work sets 1..3, side streams) each close their
+// own mark instead of "the last one pushed" (ADVICE r2).
+int Engine::mark_begin(int stage, hipStream_t st) {
+    if (!profiling_) return -1;
     std::lock_guard<std::mutex> lk(marks_mu_);
     StageMark m{stage, 0, nullptr, nullptr};
     HIPCK(hipEventCreate(&m.a));
     HIPCK(hipEventCreate(&m.b));
     HIPCK(hipEventRecord(m.a, st));
     marks_.push_back(m);
+    return (int)((marks_gen_ & 0x7ff) << 20) | ((int)marks_.size() - 1);  // generation: get_stage_times may clear the list under a running call
 }
-void Engine::mark_end(int launches, hipStream_t st) {
-    if (!profiling_) return;
+void Engine::mark_end(int mark, int launches, hipStream_t st) {
+    if (mark < 0) return;
     std::lock_guard<std::mutex> lk(marks_mu_);
-    marks_.back().launches = launches;
-    HIPCK(hipEventRecord(marks_.back().b, st));
+    const int idx = mark & 0xfffff;
+    if (((mark >> 20) & 0x7ff) != (int)(marks_gen_ & 0x7ff) || idx >= (int)marks_.size()) return;  // collected in between
+    marks_[idx].launches = launches;
+    HIPCK(hipEventRecord(marks_[idx].b, st));
 }
 void Engine::get_stage_times(double* ms, uint64_t* launches) {
     std::lock_guard<std::mutex> lk(marks_mu_);
@@ -1026,6 +1031,7 @@ void Engine::get_stage_times(double* ms, uint64_t* launches) {
         hipEventDestroy(m.b);
     }
     marks_.clear();
+    marks_gen_++;
 }
 
 void Engine::ensure_workspace(int n) {
@@ -1069,10 +1075,17 @@ void Engine::ensure_staging(Work& w, int n) {
 }
 // a free set among work_[first..last]: the first one whose lock is free, else wait for `first`
 Work& Engine::lease_work(int first, int last) {
-    for (int i = first; i <= last; i++)
-        if (work_[i].mu.try_lock()) return work_[i];
-    work_[first].mu.lock();
-    return work_[first];
+    // any free set; when all are taken, wait for WHICHEVER frees first (release_work notifies) instead of queueing on one of them
+    std::unique_lock<std::mutex> lk(lease_mu_);
+    for (;;) {
+        for (int i = first; i <= last; i++)
+            if (work_[i].mu.try_lock()) return work_[i];
+        lease_cv_.wait_for(lk, std::chrono::milliseconds(2));
+    }
+}
+void Engine::release_work(Work& w) {
+    w.mu.unlock();
+    lease_cv_.notify_one();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1167,16 +1180,16 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         }
         X = w.slp_arena;
     }
-    mark_begin(ST_FK20_SCALARS, st);
+    const int mk1 = mark_begin(ST_FK20_SCALARS, st);
     launch::fk20_scalars(n, w.coeffs, w.scalars, d_w8192_, linmap_mode ? half_ : inv128_, segs, segs == 2 ? two_segments : seg_shift_, st);
-    mark_end(1, st);
+    mark_end(mk1, 1, st);
     launch::g1_set_inf(X, (size_t)128 * bp, st);
     const bool latency_mode = bp <= LATENCY_MODE_MAX_LANES;  // few 64-blob groups: direct 8 x 16 transforms, 4 rounds instead of 14
-    mark_begin(ST_MSM_FIXED, st);
+    const int mk2 = mark_begin(ST_MSM_FIXED, st);
     launch_msm(w.scalars, TAB_FK, X, 128, segs * n, bp, (latency_mode || linmap_mode) ? 0 : 7, st);
-    mark_end(1, st);
+    mark_end(mk2, 1, st);
     if (linmap_mode) {
-        mark_begin(ST_G1_LINMAP, st);
+        const int mk3 = mark_begin(ST_G1_LINMAP, st);
         int n_launches = 0;
         if (slp_walk_) {
             // the constant multiplications as one launch each (there is one), every run of cheap levels as ONE ticket-walking launch
@@ -1220,39 +1233,39 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
                 launch::g1_slp_launch(L.kind, w.slp_arena, bp, (const uint32_t*)d_slp_words_ + (size_t)L.first * 4, L.count, d_slp_naf_, beta_, st);
             n_launches = (int)slp_launches_.size();
         }
-        mark_end(n_launches, st);
-        mark_begin(ST_COMPRESS, st);
+        mark_end(mk3, n_launches, st);
+        const int mk4 = mark_begin(ST_COMPRESS, st);
         launch::g1_compress((const char*)w.slp_arena + (size_t)128 * bp * launch::SIZEOF_JACQ, d_proofs, 128, bp, n, st);
-        mark_end(1, st);
+        mark_end(mk4, 1, st);
         return;
     }
     if (n <= circ_max_) {  // a handful of blobs: the two transforms as one circulant product (k_g1circ.hip)
         if (!w.circ_table) HIPCK(hipMalloc(&w.circ_table, launch::g1_circ_table_bytes(circ_max_, circ_T_)));
-        mark_begin(ST_G1_IFFT, st);
+        const int mk5 = mark_begin(ST_G1_IFFT, st);
         launch::g1_circ128(w.X, bp, n, segs, w.circ_table, circ_T_, d_circ_terms_, circ_per_lane_, beta_, st);
-        mark_end(2, st);
+        mark_end(mk5, 2, st);
     } else if (latency_mode) {
         if (!w.dft_tmp) {
             HIPCK(hipMalloc(&w.dft_tmp, (size_t)128 * LATENCY_MODE_MAX_LANES * launch::SIZEOF_JACQ));
             HIPCK(hipMalloc(&w.dft_prod, (size_t)128 * 16 * LATENCY_MODE_MAX_LANES * launch::SIZEOF_JACQ));
         }
-        mark_begin(ST_G1_IFFT, st);
+        const int mk6 = mark_begin(ST_G1_IFFT, st);
         launch::g1_dft128_direct(w.X, w.dft_tmp, w.dft_prod, bp, 128, 64, 1, 0, d_naf_, beta_, st);  // h = first 64 outputs
-        mark_end(2, st);
-        mark_begin(ST_G1_FFT, st);
+        mark_end(mk6, 2, st);
+        const int mk7 = mark_begin(ST_G1_FFT, st);
         launch::g1_dft128_direct(w.X, w.dft_tmp, w.dft_prod, bp, 64, 128, 0, 1, d_naf_, beta_, st);  // proofs, bit-reversed
-        mark_end(2, st);
+        mark_end(mk7, 2, st);
     } else {
-        mark_begin(ST_G1_IFFT, st);
+        const int mk8 = mark_begin(ST_G1_IFFT, st);
         g1_ifft128_take64(w.X, bp, st);
-        mark_end(7, st);  // 7 layers (each = one twiddle-multiplication launch + one butterfly launch)
-        mark_begin(ST_G1_FFT, st);
+        mark_end(mk8, 7, st);  // 7 layers (each = one twiddle-multiplication launch + one butterfly launch)
+        const int mk9 = mark_begin(ST_G1_FFT, st);
         g1_fft128_from64(w.X, bp, st);
-        mark_end(7, st);
+        mark_end(mk9, 7, st);
     }
-    mark_begin(ST_COMPRESS, st);
+    const int mk10 = mark_begin(ST_COMPRESS, st);
     launch::g1_compress(w.X, d_proofs, 128, bp, n, st);
-    mark_end(1, st);
+    mark_end(mk10, 1, st);
 }
 
 // the kernels of one prover call on `st`, scratch from `w`; optionally records `after_cells` once the cells are written
@@ -1261,9 +1274,9 @@ void Engine::enqueue_compute(Work& w, int n, const uint8_t* d_blobs, uint8_t* d_
     ensure_workspace(w, n);
     HIPCK(hipStreamWaitEvent(st, w.done, 0));  // an earlier call may still be using this set on another stream
     HIPCK(hipMemsetAsync(w.status, 0, n * sizeof(int), st));
-    mark_begin(ST_BLOB_TO_COEFFS, st);
+    const int mk11 = mark_begin(ST_BLOB_TO_COEFFS, st);
     launch::blob_to_coeffs(n, d_blobs, w.coeffs, nullptr, w.status, d_w8192_, n_inv4096_, st);
-    mark_end(1, st);
+    mark_end(mk11, 1, st);
     // a handful of blobs is a chain of latencies: the cells (one 8192-point transform, 0.08 ms) then run on the set's second
     // stream next to the proof stages instead of in front of them
     const bool side = d_cells && d_proofs && n <= circ_max_ && w.copy && !profiling_;
@@ -1278,9 +1291,9 @@ void Engine::enqueue_compute(Work& w, int n, const uint8_t* d_blobs, uint8_t* d_
         return;
     }
     if (d_cells) {
-        mark_begin(ST_COEFFS_TO_CELLS, st);
+        const int mk12 = mark_begin(ST_COEFFS_TO_CELLS, st);
         launch::coeffs_to_cells(n, w.coeffs, d_cells, d_w8192_, st);
-        mark_end(1, st);
+        mark_end(mk12, 1, st);
     }
     if (after_cells) HIPCK(hipEventRecord(after_cells, st));
     if (d_proofs) run_proofs_from_coeffs(w, n, d_proofs, st);
@@ -1299,11 +1312,11 @@ int Engine::compute_cells_and_kzg_proofs_device(int n, const uint8_t* d_blobs, u
         if (h_status) HIPCK(hipMemcpyAsync(h_status, w.status, n * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCK(hipEventRecord(w.done, st));
         HIPCK(hipGetLastError());
-        w.mu.unlock();
+        release_work(w);
         held = nullptr;
         if (sync || h_status) HIPCK(hipStreamSynchronize(st));
     } catch (const std::exception& e) {
-        if (held) held->mu.unlock();
+        if (held) release_work(*held);
         set_error(e);
         return ERR_DEVICE;
     }
@@ -1506,7 +1519,7 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
             }
             // drain_on_exit: the helper tasks are done before the pinned buffers are reused by the next super-batch
         }
-        w.mu.unlock();
+        release_work(w);
         held = nullptr;
         if (trace) fprintf(stderr, "[host-batch] %d blobs delivered at %.2f ms\n", n, now_ms());
         if (failed.load()) throw std::runtime_error(err_text);
@@ -1515,7 +1528,7 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
             (void)hipStreamSynchronize(held->stream);
             (void)hipStreamSynchronize(held->copy);
             drain();
-            held->mu.unlock();
+            release_work(*held);
         }
         set_error(e);
         return ERR_DEVICE;

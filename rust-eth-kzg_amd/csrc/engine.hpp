@@ -247,7 +247,10 @@ private:
     void run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream_t st);
     void enqueue_compute(Work& w, int n, const uint8_t* d_blobs, uint8_t* d_cells, uint8_t* d_proofs, hipStream_t st,
                          hipEvent_t after_cells);
-    Work& lease_work(int first, int last);  // locks and returns a free set among work_[first..last] (blocks if none)
+    Work& lease_work(int first, int last);  // locks and returns a free set among work_[first..last] (waits for whichever frees first)
+    void release_work(Work& w);
+    std::mutex lease_mu_;
+    std::condition_variable lease_cv_;
     void set_error(const std::exception& e);
     void launch_msm(const void* scalars, TableSel table, void* out, int n_groups, int n_slices, int out_stride,
                     int brp_bits, hipStream_t st);
@@ -258,10 +261,11 @@ private:
     void g1_fft128_full(void* X, int stride, int inverse, hipStream_t st);
 
     struct StageMark { int stage; int launches; hipEvent_t a, b; };
-    void mark_begin(int stage, hipStream_t st);
-    void mark_end(int launches, hipStream_t st);
+    int mark_begin(int stage, hipStream_t st);  // -> handle for mark_end (-1 when profiling is off)
+    void mark_end(int mark, int launches, hipStream_t st);
     bool profiling_ = false;
     std::vector<StageMark> marks_;
+    unsigned marks_gen_ = 0;
     std::mutex marks_mu_;
 
     int dev_ = 0;

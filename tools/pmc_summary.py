@@ -9,7 +9,7 @@ for d in dirs:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         per_dispatch = {}
         for r in csv.DictReader(open(f)):
-            name = re.sub(r"\(.*", "", r["Kernel_Name"]).strip()
+            name = re.sub(r"\((?!anonymous namespace\)).*", "", r["Kernel_Name"]).strip()  # drop the argument list, keep "(anonymous namespace)"
             key = (name, r["Dispatch_Id"], r["Counter_Name"])
             per_dispatch[key] = per_dispatch.get(key, 0.0) + float(r["Counter_Value"])  # sum over XCDs / instances
         for (name, _, ctr), v in per_dispatch.items():
