@@ -617,9 +617,10 @@ def main():
     ap.add_argument("--strong-configs", action="store_true",
                     help="also run the strong-scaling legs (configs 4 and 5 as written) at N = 1; they always run at N > 1")
     ap.add_argument("--launcher-selftest", action="store_true", help="CPU only: check the --gpus N launcher and the rendezvous, then exit")
-    ap.add_argument("--exchange", choices=["library", "torch"], default="library",
-                    help="N > 1: the all-gather runs on the library's own RCCL communicator (default; failure to build it is an "
-                         "error, not a silent fall-back) or on torch.distributed's")
+    ap.add_argument("--exchange", choices=["library", "library-required", "torch"], default="library",
+                    help="N > 1: the all-gather runs on the library's own RCCL communicator (default; if it cannot be built the run goes "
+                         "on over torch.distributed's and SAYS SO in config.exchange and on stderr; library-required: fail instead), "
+                         "or on torch.distributed's by choice")
     args = ap.parse_args()
 
     # --gpus N is authoritative: without a launcher's environment bench.py starts the N ranks itself -- before torch or
@@ -682,15 +683,24 @@ def main():
     stream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream: kernels are enqueued on it without host syncs
     # the exchange runs on the library's own RCCL communicator (what a C / Go / Java host would use); torch.distributed
     # carries the 128-byte id and stays the fallback if the library cannot build its communicator
-    lib_comm, comm_ranks, rccl_file = False, None, None
-    if world > 1 and args.exchange == "library":
+    lib_comm, comm_ranks, rccl_file, comm_error = False, None, None, None
+    if world > 1 and args.exchange in ("library", "library-required"):
         try:
             rccl_file = ctx.comm_probe()  # which librccl file the library bound (torch's already-mapped copy when present)
         except Exception:
             rccl_file = None  # attach_library_comm below reports the reason on every rank
-        lib_comm = sharding.attach_library_comm(ctx, dist, required=True)  # raises on every rank with the reason: no silent fall-back
-        comm_ranks = ctx.comm_info()[1]
-    elif world == 1 and args.strong_configs and args.exchange == "library":  # one-GPU box: the same calls on a 1-rank communicator
+        try:
+            # all ranks or none (the ranks agree before anyone enters the collective ncclCommInitRank); raises with the reason on every rank
+            lib_comm = sharding.attach_library_comm(ctx, dist, required=True)
+            comm_ranks = ctx.comm_info()[1]
+        except RuntimeError as e:
+            if args.exchange == "library-required":
+                raise
+            comm_error = str(e)  # never silent: stderr now, config.exchange / config.library_communicator_error in the record
+            if rank == 0:
+                print(f"bench.py: the library's RCCL communicator is unavailable ({comm_error}); the all-gather runs on torch.distributed's",
+                      file=sys.stderr, flush=True)
+    elif world == 1 and args.strong_configs and args.exchange != "torch":  # one-GPU box: the same calls on a 1-rank communicator
         rccl_file = ctx.comm_probe()
         ctx.comm_init(ctx.comm_unique_id(), 0, 1)
         lib_comm, comm_ranks = True, ctx.comm_info()[1]
@@ -763,7 +773,12 @@ def main():
 
     strong = None
     if world > 1 or args.strong_configs:
-        strong = strong_configs(ctx, sharding, torch, dist, dev, world, rank, lib_comm, stream)
+        try:
+            strong = strong_configs(ctx, sharding, torch, dist, dev, world, rank, lib_comm, stream)
+        except SystemExit:
+            raise  # a parity failure of the gathered output must sink the run
+        except Exception as e:  # anything else in the side legs must not cost the headline record
+            strong = {"error": repr(e)}
 
     if rank == 0:
         total_blobs = B * world * args.steps
@@ -825,7 +840,8 @@ def main():
                        "table_GB": round(ctx.table_bytes() / 1e9, 2),
                        "g1_transforms": f"compiled linear map: {li[0]} constant multiplications, {li[1]} additions, {li[2]} doublings per blob, {li[3]} launches" if li[0] else "radix-2 network",
                        "exchange": ("ncclAllGather of the proof vectors per step inside libc_eth_kzg.so (eth_kzg_amd_all_gather)" if lib_comm
-                                    else "RCCL all-gather of proofs per step (torch.distributed)") if world > 1 else "none",
+                                    else "RCCL all-gather of proofs per step (torch.distributed)" + (" -- the library communicator FAILED: " + comm_error if comm_error else "")) if world > 1 else "none",
+                       "library_communicator_error": comm_error,
                        "ranks": world, "library_communicator_ranks": comm_ranks, "rccl_library": rccl_file,
                        "launcher": os.environ.get("KZG_BENCH_LAUNCHER", "external (torch.distributed.run)") if world > 1 else "none",
                        "gathered_proofs_checked": gather_checked},

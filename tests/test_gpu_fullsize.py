@@ -427,7 +427,7 @@ def test_sparse_polynomials_hit_the_degenerate_point_operations(ctx, oracle):
     assert st == [0] * 70 and cells2[:12] == cells and proofs2[:12] == proofs
 
 
-def test_verify_device_resident_matches_the_host_form(ctx):
+def test_verify_device_resident_matches_the_host_form(ctx, oracle):
     """eth_kzg_amd_verify_cell_kzg_proof_batch_device on the prover's own device buffers (config 3 at full size: cells
     and proofs never leave HBM before the call): true; a flipped proof byte pair, a swapped cell, a wrong commitment:
     false; a malformed proof: error; an empty batch: true."""
@@ -456,3 +456,22 @@ def test_verify_device_resident_matches_the_host_form(ctx):
     with pytest.raises(kzg.KzgError):
         run(p=p3)
     assert ctx.verify_cell_kzg_proof_batch_device(0, 0, 0, 0, 0) is True
+    # the verdicts against the CPU oracle directly (not only through expected booleans), on a 3-blob sub-batch:
+    # the same device buffers go to the device entry point, their bytes to the oracle
+    m = 3 * 128
+
+    def oracle_verdict(c, l, p):
+        cb, lb, pb = c[:48 * m].cpu().numpy().tobytes(), l[:2048 * m].cpu().numpy().tobytes(), p[:48 * m].cpu().numpy().tobytes()
+        args = ([cb[48 * k:48 * (k + 1)] for k in range(m)], [k % 128 for k in range(m)], [lb[2048 * k:2048 * (k + 1)] for k in range(m)],
+                [pb[48 * k:48 * (k + 1)] for k in range(m)])
+        try:
+            return oracle.verify_cell_kzg_proof_batch(*args)
+        except oracle_lib.OracleError:
+            return None
+    for c, l, p in ((d_c, d_cells, d_proofs), (d_c, d_cells, p2), (d_c, l2, d_proofs), (c2, d_cells, d_proofs), (d_c, d_cells, p3)):
+        want = oracle_verdict(c, l, p)
+        try:
+            got = ctx.verify_cell_kzg_proof_batch_device(m, c.data_ptr(), d_i.data_ptr(), l.data_ptr(), p.data_ptr())
+        except kzg.KzgError:
+            got = None
+        assert got == want
