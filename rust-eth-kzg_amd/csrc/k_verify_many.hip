@@ -117,7 +117,12 @@ __device__ __forceinline__ int vm_booth4(const uint32_t m[4], int w) {
 // are affine coordinates on the isomorphic curve y^2 = x^3 + 4 Z^6, whose group law (a = 0) and endomorphism are the same
 // (g1_mulc.hpp) -- so the 64 additions of the main loop are mixed additions too.  All lanes run the same 32 windows:
 // 4 doublings, one addition for k1's digit, one for k2's (phi of a table entry only swaps in beta x); a zero digit masks its lane.
-__device__ JacQ vm_mul_by_scalar(const AffQ& P, const uint32_t split[8], const Fq<1>& beta) {
+__device__ __forceinline__ JacQ vm_step(const JacQ& t, const AffQ& p) { return add_mixed(t, p); }
+__device__ __forceinline__ JacQ vm_step(const JacQ& t, const JacQ& p) { return add(t, p); }
+__device__ __forceinline__ JacQ vm_lift(const AffQ& p) { return to_jacq(p); }
+__device__ __forceinline__ JacQ vm_lift(const JacQ& p) { return p; }
+template <class Base>  // AffQ (decoded input points) or JacQ (sums that are multiplied again: the folded pairing inputs)
+__device__ JacQ vm_mul_by_scalar(const Base& P, const uint32_t split[8], const Fq<1>& beta) {
     constexpr int NT = 8;
     AffQ2 A[NT];
     Fq<2> bx[NT];
@@ -125,11 +130,11 @@ __device__ JacQ vm_mul_by_scalar(const AffQ& P, const uint32_t split[8], const F
     {
         JacQ T[NT];
         Fq<ZB> pre[NT];  // pre[j] = z_0 ... z_j
-        T[0] = to_jacq(P);
+        T[0] = vm_lift(P);
         pre[0] = T[0].z;
 #pragma unroll 1
         for (int j = 1; j < NT; j++) {
-            T[j] = j == 1 ? dbl(T[0]) : add_mixed(T[j - 1], P);
+            T[j] = j == 1 ? dbl(T[0]) : vm_step(T[j - 1], P);
             pre[j] = relax<ZB>(mul(pre[j - 1], T[j].z));
         }
         zc = pre[NT - 1];
@@ -202,6 +207,34 @@ __global__ __launch_bounds__(256) void k_vm_reduce(const JacQ* __restrict__ prod
     if (l == 0) out[2 * (size_t)b + job] = acc;
 }
 
+// Folding the problems' pairing checks into ONE: with weights rho_b (128 bits, derived by the host from ALL the problems'
+// challenges, 0 for a problem that is excluded) the 2 x B sums become  S_j = sum_b rho_b out[b][j],  and
+// e(S_0, [tau^64]_2) e(S_1, -[1]_2) = 1 holds for every choice of weights iff every problem's own equation holds (up to 2^-128
+// for weights the prover cannot predict: the same argument as the powers of r inside one batch, verifier.rs:148-160).
+// k_vm_fold_mul: lane = (problem, j): rho_b * out[b][j] (a 128-bit scalar: k1 only);  k_vm_fold_sum: one block, two trees.
+__global__ __launch_bounds__(64, 2) void k_vm_fold_mul(const JacQ* __restrict__ sums, const uint32_t* __restrict__ rho /*[B][4]*/,
+                                                       JacQ* __restrict__ prod, int n_batches, Fq<1> beta) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= 2 * n_batches) return;
+    const int b = e >> 1;
+    uint32_t split[8] = {rho[4 * b], rho[4 * b + 1], rho[4 * b + 2], rho[4 * b + 3] & 0x7fffffffu, 0, 0, 0, 0};
+    prod[e] = vm_mul_by_scalar(sums[e], split, beta);
+}
+__global__ __launch_bounds__(256) void k_vm_fold_sum(const JacQ* __restrict__ prod, JacQ* __restrict__ out2, int n_batches) {
+    __shared__ JacQ red[256];
+    const int t = threadIdx.x, job = t >> 7, l = t & 127;
+    JacQ acc = jacq_inf();
+    for (int b = l; b < n_batches; b += 128) acc = add(acc, prod[2 * (size_t)b + job]);
+#pragma unroll 1
+    for (int span = 64; span >= 1; span >>= 1) {
+        red[t] = acc;
+        __syncthreads();
+        if (l < span) acc = add(acc, red[t + span]);
+        __syncthreads();
+    }
+    if (l == 0) out2[job] = acc;
+}
+
 namespace launch {
 static Fr vm_fr(const Fr8& x) { Fr r; for (int i = 0; i < 8; i++) r.v[i] = x.v[i]; return r; }
 void vm_scalars(const void* pow_tables /*[B][24] Fr, device*/, const int* batch_of, const int* pos_in_batch, const int* cell_idx,
@@ -221,6 +254,13 @@ void vm_mul(const void* pts, const void* s1, const void* s2, const void* wts, vo
     const int total = 2 * n + m;
     if (total > 0)
         k_vm_mul<<<(total + 63) / 64, 64, 0, st>>>((const G1Affine*)pts, (const Fr*)s1, (const Fr*)s2, (const Fr*)wts, (JacQ*)prod, n, m, fq_from_fp(b384));
+}
+void vm_fold(const void* sums, const uint32_t* rho, void* prod, void* out2, int n_batches, const Fp12w& beta, hipStream_t st) {
+    if (n_batches <= 0) return;
+    Fp b384;
+    for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
+    k_vm_fold_mul<<<(2 * n_batches + 63) / 64, 64, 0, st>>>((const JacQ*)sums, rho, (JacQ*)prod, n_batches, fq_from_fp(b384));
+    k_vm_fold_sum<<<1, 256, 0, st>>>((const JacQ*)prod, (JacQ*)out2, n_batches);
 }
 void vm_reduce(const void* prod, const void* icommit, const int* cell_start, const int* row_start, void* out, int n, int n_batches,
                hipStream_t st) {

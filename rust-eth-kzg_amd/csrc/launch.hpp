@@ -133,6 +133,8 @@ void vm_interp_sum(const void* coef, const void* rp_mont, const int* cell_start,
 void vm_mul(const void* pts, const void* s1, const void* s2, const void* wts, void* prod, int n, int m, const Fp12w& beta, hipStream_t st);
 void vm_reduce(const void* prod, const void* icommit, const int* cell_start, const int* row_start, void* out /*[B][2] JacQ*/, int n,
                int n_batches, hipStream_t st);
+// out2[j] = sum_b rho_b sums[b][j] (rho: 4 words per problem, 0 excludes it); prod: scratch of 2 B JacQ
+void vm_fold(const void* sums, const uint32_t* rho, void* prod, void* out2, int n_batches, const Fp12w& beta, hipStream_t st);
 
 // k_4844.hip
 void quotient_by_linear(int n, const void* coeffs, const void* z_mont, void* quotient, void* y_out, hipStream_t st);

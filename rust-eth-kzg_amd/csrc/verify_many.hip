@@ -4,7 +4,9 @@
 // its throughput by verifying from many threads on one context (bindings/node/src/lib.rs:92-299,
 // crates/cryptography/bls12_381/src/lib.rs:45-50).  Here the problems of a call share every GPU launch:
 //   host threads : validation + de-duplication per problem, staging into one pinned slab, one SHA-256 transcript per problem
-//                  (in parallel, behind the GPU's decoding), one 2-pairing check per problem (in parallel)
+//                  (in parallel, behind the GPU's decoding), then ONE 2-pairing check per pass: the problems' two G1 sums are
+//                  folded on the GPU with 127-bit weights derived from all the challenges; a pass whose folded check fails
+//                  (some proof is wrong) is re-checked problem by problem, in parallel ($ETH_KZG_AMD_VM_FOLD=0: always so)
 //   GPU          : decode + subgroup-check all points, decode all cells, per-cell interpolation (challenge-free: behind the
 //                  hashes), then per-problem scalars / weights / interpolation sums, ONE LANE PER SCALAR MULTIPLICATION
 //                  (k_verify_many.hip), the 64-term interpolation commitments from the commitment window table, per-problem sums
@@ -131,7 +133,9 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
             p.m = (int)p.uniq.size();
         });
         // ---- chunks of problems: at most CHUNK_CELLS cells per pass (the pinned slab and the arena stay bounded)
-        constexpr int CHUNK_CELLS = 32768;
+        constexpr int CHUNK_CELLS = 131072;  // 1024 verifications of 128 cells: 275 MB of pinned staging, ~1 GB of device arena
+        bool fold = true;  // one folded pairing check per pass instead of one per problem (falls back to per-problem checks when it fails)
+        if (const char* e = getenv("ETH_KZG_AMD_VM_FOLD")) fold = atoi(e) != 0;
         for (int b0 = 0; b0 < B;) {
             int b1 = b0, nn = 0, mm = 0;
             while (b1 < B && (b1 == b0 || nn + pr[b1].n <= CHUNK_CELLS)) { nn += pr[b1].n; mm += pr[b1].m; b1++; }
@@ -154,6 +158,7 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
             const size_t off_rs = o; o += up((size_t)(Bc + 1) * 4);
             const size_t in_bytes = o;
             const size_t off_pow = o; o += up((size_t)Bc * 24 * sizeof(Fr));  // second upload (after the hashes)
+            const size_t off_rho = o; o += up((size_t)Bc * 16);               // folding weights, 128 bits per problem
             const size_t in2_bytes = o;
             // device only
             const size_t off_pts = o; o += up((size_t)(n + m) * sizeof(G1Affine));
@@ -169,11 +174,14 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
             const size_t off_icm = o; o += up((size_t)Bc * launch::SIZEOF_JACQ);
             const size_t off_prod = o; o += up((size_t)(2 * n + m) * launch::SIZEOF_JACQ);
             const size_t off_out = o; o += up((size_t)2 * Bc * launch::SIZEOF_JACQ);
+            const size_t off_fprod = o; o += up((size_t)2 * Bc * launch::SIZEOF_JACQ);
+            const size_t off_fold = o; o += up((size_t)2 * launch::SIZEOF_JACQ);
             const size_t dev_bytes = o;
             // pinned read-backs behind the inputs
             size_t po = in2_bytes;
             const size_t poff_st = po; po += up((size_t)(n + m + Bc) * 4);
             const size_t poff_out = po; po += up((size_t)2 * Bc * launch::SIZEOF_JACQ);
+            const size_t poff_fold = po; po += up((size_t)2 * launch::SIZEOF_JACQ);
             const size_t pin_bytes = po;
             if (dev_bytes > vm_dev_cap_) {
                 if (vm_dev_) { HIPCK(hipStreamSynchronize(st)); HIPCK(hipFree(vm_dev_)); vm_dev_ = nullptr; vm_dev_cap_ = 0; }
@@ -213,8 +221,10 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
             int* h_st = (int*)(hb + poff_st);
             memset(h_st, 0xff, (size_t)(n + m + Bc) * 4);
             memset(hb + poff_out, 0xff, (size_t)2 * Bc * launch::SIZEOF_JACQ);
+            memset(hb + poff_fold, 0xff, (size_t)2 * launch::SIZEOF_JACQ);
             HIPCK(hipMemsetAsync(db + off_stp, 0xff, (size_t)(n + m) * 4, st));
             HIPCK(hipMemsetAsync(db + off_out, 0xff, (size_t)2 * Bc * launch::SIZEOF_JACQ, st));
+            HIPCK(hipMemsetAsync(db + off_fold, 0xff, (size_t)2 * launch::SIZEOF_JACQ, st));
             HIPCK(hipMemsetAsync(db + off_ste, 0, (size_t)Bc * 4, st));
             HIPCK(hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, st));
             // ---- challenge-free GPU work: decode (on curve) + subgroup tests of [proofs | commitments], cells, interpolation
@@ -230,6 +240,7 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
             // ---- Fiat-Shamir challenges on the host threads meanwhile (verifier.rs:269-328): valid inputs are canonical
             // encodings, so the transcript is the input bytes themselves; then the table r^(2^i) per problem
             Fr* h_pow = (Fr*)(hb + off_pow);
+            std::vector<uint8_t> digests((size_t)Bc * 32, 0);
             parallel_for(Bc, T, dev_, [&](int i) {
                 const int b = b0 + i;
                 const Problem& p = pr[b];
@@ -249,12 +260,55 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
                     sh.update(cells[b][k], BYTES_PER_CELL);
                     sh.update(proofs[b][k], 48);
                 }
-                uint8_t dig[32];
+                uint8_t* dig = &digests[(size_t)i * 32];
                 sh.finish(dig);
                 Fr cur = reduce_be32(dig);
                 for (int j = 0; j < 24; j++) { tab[j] = cur; cur = sqr(cur); }
             });
-            HIPCK(hipMemcpyAsync(db + off_pow, hb + off_pow, (size_t)Bc * 24 * sizeof(Fr), hipMemcpyHostToDevice, st));
+            // ---- decoding verdicts per problem (order of the reference: commitments, proofs, cells): the challenge-free GPU work
+            // has long finished under the hashes, so this wait is short; a problem with an error takes no part in what follows
+            SYNC_CHECKED(st);
+            std::vector<char> live(Bc, 0);
+            for (int i = 0; i < Bc; i++) {
+                const int b = b0 + i;
+                const Problem& p = pr[b];
+                if (p.n == 0) continue;
+                const int c0 = cell_start[i], r0 = row_start[i];
+                int bad = OK;
+                for (int j = 0; j < p.m && !bad; j++) if (h_st[n + r0 + j]) bad = ERR_G1;
+                for (int k = 0; k < p.n && !bad; k++) if (h_st[c0 + k]) bad = ERR_G1;
+                if (!bad && h_st[n + m + i]) bad = ERR_SCALAR;
+                if (bad) status[b] = bad; else live[i] = 1;
+            }
+            // ---- folding weights: rho_b = SHA-256(seed || b) truncated to 127 bits, seed = SHA-256 over ALL challenges' digests of the
+            // pass (so no weight can be predicted before every input byte is fixed); 0 for problems that are out
+            uint32_t* h_rho = (uint32_t*)(hb + off_rho);
+            int n_live = 0;
+            for (int i = 0; i < Bc; i++) n_live += live[i];
+            const bool folded = fold && n_live >= 2;
+            if (folded) {
+                uint8_t seed[32];
+                {
+                    Sha256 sh;
+                    sh.update((const uint8_t*)"RCKZGCBATCHFOLD1", 16);
+                    sh.update(digests.data(), digests.size());
+                    sh.finish(seed);
+                }
+                parallel_for(Bc, T, dev_, [&](int i) {
+                    uint32_t* r4 = h_rho + 4 * (size_t)i;
+                    if (!live[i]) { r4[0] = r4[1] = r4[2] = r4[3] = 0; return; }
+                    Sha256 sh;
+                    uint8_t ix[8], dg[32];
+                    for (int q = 0; q < 8; q++) ix[q] = (uint8_t)((uint64_t)i >> (56 - 8 * q));
+                    sh.update(seed, 32);
+                    sh.update(ix, 8);
+                    sh.finish(dg);
+                    memcpy(r4, dg, 16);
+                    r4[3] &= 0x7fffffffu;
+                    if ((r4[0] | r4[1] | r4[2] | r4[3]) == 0) r4[0] = 1;
+                });
+            }
+            HIPCK(hipMemcpyAsync(db + off_pow, hb + off_pow, in2_bytes - off_pow, hipMemcpyHostToDevice, st));  // power tables + weights
             // ---- per-problem scalars, weights, interpolation sums; every scalar multiplication; the two sums per problem
             const int* d_cs = (const int*)(db + off_cs);
             const int* d_rs = (const int*)(db + off_rs);
@@ -266,27 +320,41 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
             // - commit(interpolation polynomial): 64 fixed bases = group 0 of the commitment window table (verification_key.rs:66-70)
             launch_msm(db + off_isc, TAB_SRS, db + off_icm, 1, Bc, Bc, 0, st);
             launch::vm_reduce(db + off_prod, db + off_icm, d_cs, d_rs, db + off_out, n, Bc, st);
+            if (folded) {
+                launch::vm_fold(db + off_out, (const uint32_t*)(db + off_rho), db + off_fprod, db + off_fold, Bc, beta_, st);
+                HIPCK(hipMemcpyAsync(hb + poff_fold, db + off_fold, (size_t)2 * launch::SIZEOF_JACQ, hipMemcpyDeviceToHost, st));
+            }
             HIPCK(hipMemcpyAsync(hb + poff_out, db + off_out, (size_t)2 * Bc * launch::SIZEOF_JACQ, hipMemcpyDeviceToHost, st));
             SYNC_CHECKED(st);
-            // ---- verdicts: decoding errors per problem (order of the reference: commitments, proofs, cells), then the pairing
+            // ---- verdicts: ONE pairing check of the folded sums; only if that fails (some problem's proof is wrong) one per problem
             const JacQ* sums = (const JacQ*)(hb + poff_out);
             std::atomic<int> device_fault{0};
-            parallel_for(Bc, T, dev_, [&](int i) {
-                const int b = b0 + i;
-                const Problem& p = pr[b];
-                if (p.n == 0) return;
-                const int c0 = cell_start[i], r0 = row_start[i];
-                for (int j = 0; j < p.m; j++) if (h_st[n + r0 + j]) { status[b] = ERR_G1; return; }
-                for (int k = 0; k < p.n; k++) if (h_st[c0 + k]) { status[b] = ERR_G1; return; }
-                if (h_st[n + m + i]) { status[b] = ERR_SCALAR; return; }
-                G1Affine pts[2];
-                for (int j = 0; j < 2; j++) {
-                    const JacQ& s = sums[2 * (size_t)i + j];
-                    if (s.x.v[0] == 0xffffffffu && s.z.v[0] == 0xffffffffu) { device_fault.store(1); return; }  // the poison pattern
-                    pts[j] = to_affine(jac_from_jacq(s));
-                }
-                verified[b] = verify_cells_pairing(pts) ? 1 : 0;
-            });
+            auto poisoned = [](const JacQ& s) { return s.x.v[0] == 0xffffffffu && s.z.v[0] == 0xffffffffu; };
+            bool all_true = false;
+            if (folded) {
+                const JacQ* f2 = (const JacQ*)(hb + poff_fold);
+                if (poisoned(f2[0]) || poisoned(f2[1])) throw std::runtime_error("many-verification pass left no folded result");
+                G1Affine pts[2] = {to_affine(jac_from_jacq(f2[0])), to_affine(jac_from_jacq(f2[1]))};
+                all_true = verify_cells_pairing(pts);
+            }
+            if (all_true) {
+                for (int i = 0; i < Bc; i++)
+                    if (live[i]) {
+                        if (poisoned(sums[2 * (size_t)i]) || poisoned(sums[2 * (size_t)i + 1])) { device_fault.store(1); break; }
+                        verified[b0 + i] = 1;
+                    }
+            } else {
+                parallel_for(Bc, T, dev_, [&](int i) {
+                    if (!live[i]) return;
+                    G1Affine pts[2];
+                    for (int j = 0; j < 2; j++) {
+                        const JacQ& s = sums[2 * (size_t)i + j];
+                        if (poisoned(s)) { device_fault.store(1); return; }
+                        pts[j] = to_affine(jac_from_jacq(s));
+                    }
+                    verified[b0 + i] = verify_cells_pairing(pts) ? 1 : 0;
+                });
+            }
             if (device_fault.load()) throw std::runtime_error("many-verification pass left no result");
             b0 = b1;
         }

@@ -668,6 +668,11 @@ def test_verify_many_large_call_in_chunks_and_concurrent_with_other_calls(ctx):
         probs.append(([comms[b]] * 128, list(range(128)), list(cells[b]), P))
         want.append(not bad)
     run = ctx.prepare_verify_cell_kzg_proof_batch_many(probs)
+    # every problem valid: ONE folded pairing check per pass decides them all (verify_many.hip); then the mixed call, whose
+    # folded check fails and falls back to per-problem checks
+    good = [p for p, w in zip(probs, want) if w]
+    ver, stt = ctx.verify_cell_kzg_proof_batch_many(good)
+    assert stt == [0] * len(good) and ver == [True] * len(good)
     stop, errors = threading.Event(), []
 
     def other():
@@ -687,6 +692,33 @@ def test_verify_many_large_call_in_chunks_and_concurrent_with_other_calls(ctx):
         stop.set()
         th.join()
     assert not errors, errors
+
+
+def test_verify_many_without_folding_gives_the_same_verdicts(ctx, monkeypatch):
+    """ETH_KZG_AMD_VM_FOLD=0: one pairing check per problem, always (round 3's first form): same verdicts as the folded form on a
+    mix of valid, invalid and malformed problems."""
+    blobs = [synth.seeded_blob(140 + i) for i in range(3)]
+    st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs)
+    _, comms = ctx.blob_to_kzg_commitment_batch(blobs)
+    probs = []
+    for j in range(40):
+        b = j % 3
+        P, L, I = list(proofs[b]), list(cells[b]), list(range(128))
+        if j % 7 == 3:
+            P[j] = proofs[(b + 1) % 3][j]
+        if j == 20:
+            I[0] = 200
+        if j == 30:
+            L[3] = b"\xff" * 2048
+        probs.append(([comms[b]] * 128, I, L, P))
+    folded = ctx.verify_cell_kzg_proof_batch_many(probs)
+    monkeypatch.setenv("ETH_KZG_AMD_VM_FOLD", "0")
+    plain = ctx.verify_cell_kzg_proof_batch_many(probs)
+    assert folded == plain
+    assert plain[1][20] == 3 and plain[1][30] == 1 and [v for j, v in enumerate(plain[0]) if j % 7 == 3] == [False] * 6
+    monkeypatch.delenv("ETH_KZG_AMD_VM_FOLD")
+    all_good = [p for j, p in enumerate(probs) if j % 7 != 3 and j not in (20, 30)]
+    assert ctx.verify_cell_kzg_proof_batch_many(all_good) == ([True] * len(all_good), [0] * len(all_good))
 
 
 def test_serial_paths_overlap_across_threads(ctx):
