@@ -11,7 +11,8 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ASM_MAC = {"k_msm.hip", "k_g1fft.hip", "k_g1slp.hip", "k_g1circ.hip", "k_g1misc.hip", "k_verify.hip", "k_table.hip"}
+ASM_MAC = {"k_msm.hip", "k_g1fft.hip", "k_g1slp.hip", "k_g1circ.hip", "k_g1misc.hip", "k_verify.hip", "k_verify_many.hip", "k_table.hip",
+           "k_msm_glv16.hip", "k_msm_glv15.hip", "k_msm_glv14.hip", "k_msm_glv12.hip", "k_msm_glv8.hip"}  # = ASM_MAC_TUS of csrc/Makefile
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
