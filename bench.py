@@ -379,23 +379,27 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
                                            "entry": "eth_kzg_amd_verify_cell_kzg_proof_batch_many (host pointers: 275 MB of input per call, staging and 1024 transcript hashes on the "
                                                     "host threads included; all problems valid: ONE folded pairing check per pass; with an invalid proof in the call: "
                                                     "1024 pairing checks on the host threads, verdicts checked)"}
-    _mark("side configs: 4 threads")
+    _mark("side configs: single verifications from many threads")
     import threading
-    runs4 = [ctx.prepare_verify_cell_kzg_proof_batch(*probs[b]) for b in range(4)]
+    for n_thr, key in ((4, "verify_128_cells_from_4_threads"), (32, "verify_128_cells_from_32_threads")):
+        runs_t = [ctx.prepare_verify_cell_kzg_proof_batch(*probs[b % nb]) for b in range(n_thr)]
+        reps = 25
 
-    def hammer(r, reps=25):
-        for _ in range(reps):
-            assert r()
-    for r in runs4:
-        r()
-    ths = [threading.Thread(target=hammer, args=(r,)) for r in runs4]
-    t0 = time.perf_counter()
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    dt4 = time.perf_counter() - t0
-    out["verify_128_cells_from_4_threads"] = {"verifications_per_s": round(100 / dt4), "entry": "eth_kzg_verify_cell_kzg_proof_batch from 4 host threads on one context (engine lanes)"}
+        def hammer(r):
+            for _ in range(reps):
+                assert r()
+        for r in runs_t[:2]:
+            r()
+        ths = [threading.Thread(target=hammer, args=(r,)) for r in runs_t]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dtt = time.perf_counter() - t0
+        out[key] = {"verifications_per_s": round(n_thr * reps / dtt),
+                    "entry": f"eth_kzg_verify_cell_kzg_proof_batch from {n_thr} host threads on one context: a lone caller takes the latency path, "
+                             "concurrent callers are combined into many-verification passes"}
     _mark("side configs: recover one")
     half_idx, half_cells = list(range(CELLS // 2)), L_[:CELLS // 2]
     ts = []

@@ -113,11 +113,11 @@ CResult eth_kzg_verify_cell_kzg_proof_batch(const DASContext* ctx, uint64_t comm
                                             const uint64_t* cell_indices, uint64_t cells_length,
                                             const uint8_t* const* cells, uint64_t proofs_length,
                                             const uint8_t* const* proofs, bool* verified) {
-    auto lane = eng(ctx)->lease_serial();
-    kzg::Engine* e = lane.e;
+    // a lone caller runs the latency path on an engine lane; concurrent callers are combined into many-verification passes
+    kzg::Engine* e = eng(ctx);
     int ver = 0;
-    int st = e->verify_cell_kzg_proof_batch_host(commitments_length, commitments, cell_indices_length, cell_indices,
-                                                 cells_length, cells, proofs_length, proofs, &ver);
+    int st = e->verify_cell_kzg_proof_batch_combined(commitments_length, commitments, cell_indices_length, cell_indices,
+                                                     cells_length, cells, proofs_length, proofs, &ver);
     if (st == kzg::ERR_DEVICE) return device_err(e);
     if (st) return err(status_text(st));
     *verified = ver != 0;

@@ -156,6 +156,14 @@ public:
                                               const uint64_t* n_indices, const uint64_t* const* cell_indices, const uint64_t* n_cells,
                                               const uint8_t* const* const* cells, const uint64_t* n_proofs,
                                               const uint8_t* const* const* proofs, int* verified, int* status);
+    // verify_cell_kzg_proof_batch as the reference's users call it -- one problem per call, from many threads on one context
+    // (bindings/node/src/lib.rs:92-299) -- WITHOUT asking them to batch: a lone caller takes the latency-optimised path
+    // (verify_cell_kzg_proof_batch_host on an engine lane); callers that arrive while another verification is in flight
+    // are COMBINED: they queue their problems, one of them becomes the leader and runs everything queued as one
+    // many-verification pass, the others sleep until their verdict is in.  Same verdicts and error split as the single path.
+    int verify_cell_kzg_proof_batch_combined(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,
+                                             const uint64_t* cell_indices, uint64_t n_cells, const uint8_t* const* cells,
+                                             uint64_t n_proofs, const uint8_t* const* proofs, int* verified);
     // the same check sharded over ranks: every rank passes the WHOLE batch (the Fiat-Shamir transcript covers it) and its
     // slice [lo, hi) of the cell list, gets 96 bytes back; the gathered records go to _combine on any rank.
     int verify_cell_kzg_proof_batch_partial_host(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,
@@ -323,6 +331,15 @@ private:
     std::vector<std::unique_ptr<Engine>> aux_;
     int max_lanes_ = 4;
     std::atomic<unsigned> lane_rr_{0};
+
+    // combiner of concurrent single verifications (verify_many.hip: verify_cell_kzg_proof_batch_combined)
+    struct VerifyRequest;
+    std::mutex comb_mu_;
+    std::condition_variable comb_cv_;
+    std::vector<VerifyRequest*> comb_queue_;
+    bool comb_running_ = false;
+    std::atomic<int> verify_inflight_{0};  // single verifications on the latency path right now
+    int comb_max_cells_ = 1024;            // larger problems always take the single path (their transcript hash is the bound)
 
     // many-verification path (verify_many.hip): its own lock, stream, device arena and pinned slab
     std::mutex vm_mu_;

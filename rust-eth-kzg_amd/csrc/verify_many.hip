@@ -365,4 +365,71 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
     return OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+struct Engine::VerifyRequest {
+    uint64_t n[4];
+    const uint8_t* const* commitments;
+    const uint64_t* cell_indices;
+    const uint8_t* const* cells;
+    const uint8_t* const* proofs;
+    int verified = 0, status = OK;
+    bool done = false;
+    std::string error;  // of a device failure of the pass that carried this request
+};
+
+int Engine::verify_cell_kzg_proof_batch_combined(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,
+                                                 const uint64_t* cell_indices, uint64_t n_cells, const uint8_t* const* cells,
+                                                 uint64_t n_proofs, const uint8_t* const* proofs, int* verified) {
+    *verified = 0;
+    static const bool enabled = [] { const char* e = getenv("ETH_KZG_AMD_VERIFY_COMBINE"); return !e || atoi(e) != 0; }();
+    // a lone caller, a large batch, or the feature switched off: the latency-optimised single path on an engine lane
+    if (!enabled || n_cells > (uint64_t)comb_max_cells_ || verify_inflight_.fetch_add(1) == 0) {
+        struct Leave { std::atomic<int>* c; bool on; ~Leave() { if (on) c->fetch_sub(1); } } leave{&verify_inflight_, enabled && n_cells <= (uint64_t)comb_max_cells_};
+        auto lane = lease_serial();
+        const int st = lane.e->verify_cell_kzg_proof_batch_host(n_commitments, commitments, n_indices, cell_indices, n_cells, cells, n_proofs,
+                                                                proofs, verified);
+        if (st == ERR_DEVICE && lane.e != this) set_error(std::runtime_error(lane.e->last_error()));
+        return st;
+    }
+    verify_inflight_.fetch_sub(1);  // this call goes through the combiner instead
+    VerifyRequest me;
+    me.n[0] = n_commitments; me.n[1] = n_indices; me.n[2] = n_cells; me.n[3] = n_proofs;
+    me.commitments = commitments; me.cell_indices = cell_indices; me.cells = cells; me.proofs = proofs;
+    std::unique_lock<std::mutex> lk(comb_mu_);
+    comb_queue_.push_back(&me);
+    while (!me.done) {
+        if (comb_running_) { comb_cv_.wait(lk); continue; }
+        // become the leader: run everything queued so far (this request included) as ONE many-verification pass
+        comb_running_ = true;
+        std::vector<VerifyRequest*> batch;
+        batch.swap(comb_queue_);
+        lk.unlock();
+        const size_t B = batch.size();
+        std::vector<uint64_t> l0(B), l1(B), l2(B), l3(B);
+        std::vector<const uint8_t* const*> pc(B), pl(B), pp(B);
+        std::vector<const uint64_t*> pi(B);
+        std::vector<int> ver(B), st(B);
+        for (size_t i = 0; i < B; i++) {
+            l0[i] = batch[i]->n[0]; l1[i] = batch[i]->n[1]; l2[i] = batch[i]->n[2]; l3[i] = batch[i]->n[3];
+            pc[i] = batch[i]->commitments; pi[i] = batch[i]->cell_indices; pl[i] = batch[i]->cells; pp[i] = batch[i]->proofs;
+        }
+        const int rc = verify_cell_kzg_proof_batch_many_host(B, l0.data(), pc.data(), l1.data(), pi.data(), l2.data(), pl.data(), l3.data(),
+                                                             pp.data(), ver.data(), st.data());
+        const std::string why = rc == ERR_DEVICE ? last_error() : std::string();
+        lk.lock();
+        for (size_t i = 0; i < B; i++) {
+            batch[i]->status = rc == ERR_DEVICE ? (int)ERR_DEVICE : st[i];
+            batch[i]->verified = ver[i];
+            batch[i]->error = why;
+            batch[i]->done = true;
+        }
+        comb_running_ = false;
+        comb_cv_.notify_all();
+    }
+    lk.unlock();
+    if (me.status == ERR_DEVICE) set_error(std::runtime_error(me.error));  // the error text belongs to the calling thread
+    *verified = me.status == OK ? me.verified : 0;
+    return me.status;
+}
+
 }  // namespace kzg

@@ -773,3 +773,46 @@ def test_serial_paths_overlap_across_threads(ctx):
     assert not errors, errors
     print(f"verify 128 cells: 1 thread {t_one / reps * 1e3:.2f} ms per call; 4 threads {t_four / reps * 1e3:.2f} ms per round of 4")
     assert t_four < 3.0 * t_one  # serialised calls would need 4x
+
+
+def test_concurrent_single_verifications_are_combined(ctx):
+    """eth_kzg_verify_cell_kzg_proof_batch from many threads at once, as the reference's Node binding drives one context
+    (bindings/node/src/lib.rs:92-299): a lone caller takes the latency path, concurrent callers are combined into
+    many-verification passes (Engine::verify_cell_kzg_proof_batch_combined).  Every caller gets ITS verdict -- true, false or
+    the error the single path raises -- whatever else rode in the same pass."""
+    import threading
+    import time
+    blobs = [synth.seeded_blob(160 + i) for i in range(4)]
+    st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs)
+    _, comms = ctx.blob_to_kzg_commitment_batch(blobs)
+    kinds = []
+    for b in range(4):
+        good = ([comms[b]] * 128, list(range(128)), list(cells[b]), list(proofs[b]))
+        badp = (good[0], good[1], good[2], [proofs[b][1]] + list(proofs[b][1:]))
+        sub = ([comms[b]] * 5, [3, 9, 9, 100, 127], [cells[b][k] for k in (3, 9, 9, 100, 127)], [proofs[b][k] for k in (3, 9, 9, 100, 127)])
+        malformed = (good[0], [128] + list(range(1, 128)), good[2], good[3])
+        noncanon = (good[0], good[1], [b"\xff" * 2048] + list(cells[b][1:]), good[3])
+        kinds += [(good, True), (badp, False), (sub, True), (malformed, None), (noncanon, None), (([], [], [], []), True)]
+    prepared = [(ctx.prepare_verify_cell_kzg_proof_batch(*args), want) for args, want in kinds]
+    errors, n_threads, reps = [], 12, 12
+
+    def worker(t):
+        try:
+            for r in range(reps):
+                run, want = prepared[(5 * t + 7 * r) % len(prepared)]
+                try:
+                    got = run()
+                except kzg.KzgError:
+                    got = None
+                assert got == want, (t, r, got, want)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    assert not errors, errors[:3]
+    print(f"{n_threads} threads x {reps} single verifications (mixed shapes): {n_threads * reps / dt:.0f} calls/s")
