@@ -398,8 +398,8 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
             t.join()
         dtt = time.perf_counter() - t0
         out[key] = {"verifications_per_s": round(n_thr * reps / dtt),
-                    "entry": f"eth_kzg_verify_cell_kzg_proof_batch from {n_thr} host threads on one context: a lone caller takes the latency path, "
-                             "concurrent callers are combined into many-verification passes"}
+                    "entry": f"eth_kzg_verify_cell_kzg_proof_batch from {n_thr} host threads on one context: up to one caller per engine lane (4) takes the "
+                             "latency path, callers beyond that are combined into many-verification passes"}
     _mark("side configs: recover one")
     half_idx, half_cells = list(range(CELLS // 2)), L_[:CELLS // 2]
     ts = []

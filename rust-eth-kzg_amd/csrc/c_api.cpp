@@ -113,7 +113,7 @@ CResult eth_kzg_verify_cell_kzg_proof_batch(const DASContext* ctx, uint64_t comm
                                             const uint64_t* cell_indices, uint64_t cells_length,
                                             const uint8_t* const* cells, uint64_t proofs_length,
                                             const uint8_t* const* proofs, bool* verified) {
-    // a lone caller runs the latency path on an engine lane; concurrent callers are combined into many-verification passes
+    // up to one caller per engine lane runs the latency path; callers beyond that are combined into many-verification passes
     kzg::Engine* e = eng(ctx);
     int ver = 0;
     int st = e->verify_cell_kzg_proof_batch_combined(commitments_length, commitments, cell_indices_length, cell_indices,

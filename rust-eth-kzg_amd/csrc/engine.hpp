@@ -157,8 +157,8 @@ public:
                                               const uint8_t* const* const* cells, const uint64_t* n_proofs,
                                               const uint8_t* const* const* proofs, int* verified, int* status);
     // verify_cell_kzg_proof_batch as the reference's users call it -- one problem per call, from many threads on one context
-    // (bindings/node/src/lib.rs:92-299) -- WITHOUT asking them to batch: a lone caller takes the latency-optimised path
-    // (verify_cell_kzg_proof_batch_host on an engine lane); callers that arrive while another verification is in flight
+    // (bindings/node/src/lib.rs:92-299) -- WITHOUT asking them to batch: the first callers take the latency-optimised path
+    // (verify_cell_kzg_proof_batch_host, one per engine lane); callers that arrive while every lane is verifying
     // are COMBINED: they queue their problems, one of them becomes the leader and runs everything queued as one
     // many-verification pass, the others sleep until their verdict is in.  Same verdicts and error split as the single path.
     int verify_cell_kzg_proof_batch_combined(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,

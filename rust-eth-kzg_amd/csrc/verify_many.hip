@@ -382,8 +382,10 @@ int Engine::verify_cell_kzg_proof_batch_combined(uint64_t n_commitments, const u
                                                  uint64_t n_proofs, const uint8_t* const* proofs, int* verified) {
     *verified = 0;
     static const bool enabled = [] { const char* e = getenv("ETH_KZG_AMD_VERIFY_COMBINE"); return !e || atoi(e) != 0; }();
-    // a lone caller, a large batch, or the feature switched off: the latency-optimised single path on an engine lane
-    if (!enabled || n_cells > (uint64_t)comb_max_cells_ || verify_inflight_.fetch_add(1) == 0) {
+    // up to one caller per engine lane, a large batch, or the feature switched off: the latency-optimised single path on a lane
+    // (measured at 4 threads: 8.6 ms per round of four on lanes against 12.7 ms through passes of 1-3 problems, whose
+    // floor is one scalar multiplication's dependent chain; at 32 threads the passes carry ~26 problems: 1.7 k/s against 0.4 k/s)
+    if (!enabled || n_cells > (uint64_t)comb_max_cells_ || verify_inflight_.fetch_add(1) < max_lanes_) {
         struct Leave { std::atomic<int>* c; bool on; ~Leave() { if (on) c->fetch_sub(1); } } leave{&verify_inflight_, enabled && n_cells <= (uint64_t)comb_max_cells_};
         auto lane = lease_serial();
         const int st = lane.e->verify_cell_kzg_proof_batch_host(n_commitments, commitments, n_indices, cell_indices, n_cells, cells, n_proofs,
@@ -405,6 +407,8 @@ int Engine::verify_cell_kzg_proof_batch_combined(uint64_t n_commitments, const u
         batch.swap(comb_queue_);
         lk.unlock();
         const size_t B = batch.size();
+        static const bool trace = getenv("ETH_KZG_AMD_TRACE_COMBINE") != nullptr;
+        if (trace) fprintf(stderr, "[combine] leader %p runs %zu problems\n", (void*)&me, B);
         std::vector<uint64_t> l0(B), l1(B), l2(B), l3(B);
         std::vector<const uint8_t* const*> pc(B), pl(B), pp(B);
         std::vector<const uint64_t*> pi(B);
@@ -416,6 +420,7 @@ int Engine::verify_cell_kzg_proof_batch_combined(uint64_t n_commitments, const u
         const int rc = verify_cell_kzg_proof_batch_many_host(B, l0.data(), pc.data(), l1.data(), pi.data(), l2.data(), pl.data(), l3.data(),
                                                              pp.data(), ver.data(), st.data());
         const std::string why = rc == ERR_DEVICE ? last_error() : std::string();
+        if (trace) fprintf(stderr, "[combine] leader %p done rc=%d\n", (void*)&me, rc);
         lk.lock();
         for (size_t i = 0; i < B; i++) {
             batch[i]->status = rc == ERR_DEVICE ? (int)ERR_DEVICE : st[i];

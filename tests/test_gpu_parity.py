@@ -777,8 +777,8 @@ def test_serial_paths_overlap_across_threads(ctx):
 
 def test_concurrent_single_verifications_are_combined(ctx):
     """eth_kzg_verify_cell_kzg_proof_batch from many threads at once, as the reference's Node binding drives one context
-    (bindings/node/src/lib.rs:92-299): a lone caller takes the latency path, concurrent callers are combined into
-    many-verification passes (Engine::verify_cell_kzg_proof_batch_combined).  Every caller gets ITS verdict -- true, false or
+    (bindings/node/src/lib.rs:92-299): up to one caller per engine lane takes the latency path, callers beyond that are
+    combined into many-verification passes (Engine::verify_cell_kzg_proof_batch_combined).  Every caller gets ITS verdict -- true, false or
     the error the single path raises -- whatever else rode in the same pass."""
     import threading
     import time
