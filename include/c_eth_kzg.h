@@ -14,7 +14,8 @@
  * (free with eth_kzg_free_error_message / eth_kzg_das_context_free).
  * Threading: a context may be used from many threads at once.  Prover calls take one of several scratch sets; the
  * verification / recovery / commitment / EIP-4844 calls run on up to $ETH_KZG_AMD_SERIAL_LANES (default 4) engine lanes
- * that the context creates on demand, so calls from different threads overlap on the GPU.
+ * that the context creates on demand, so calls from different threads overlap on the GPU; eth_kzg_verify_cell_kzg_proof_batch
+ * callers beyond one per lane are combined into many-verification passes behind the ABI (same verdicts and error split).
  */
 #ifndef C_ETH_KZG_H
 #define C_ETH_KZG_H
@@ -165,8 +166,10 @@ CResult eth_kzg_amd_verify_cell_kzg_proof_batch_combine(const DASContext *ctx, u
 /* MANY independent verifications in one call -- the throughput form of eth_kzg_verify_cell_kzg_proof_batch (the reference gets
  * its throughput by verifying from many threads on one context, bindings/node/src/lib.rs:92-299).  Problem b is described by
  * commitments[b] / cell_indices[b] / cells[b] / proofs[b] with the four lengths *_lengths[b], exactly as one call of the
- * single form; the problems share every GPU launch (one lane per scalar multiplication), their transcripts are hashed and
- * their pairings checked on host threads in parallel.  Per problem: status[b] = 0 and verified[b] = the verdict, or
+ * single form; the problems share every GPU launch (one lane per scalar multiplication), their transcripts are hashed on host
+ * threads in parallel, and the pairing checks of a pass are folded into one with 127-bit weights derived from all the
+ * challenges (error 2^-127, the argument of the powers of r inside one batch); a pass that contains a wrong proof is
+ * re-checked problem by problem, so a false verdict is always exact and per problem.  Per problem: status[b] = 0 and verified[b] = the verdict, or
  * status[b] = 1 (a cell holds a non-canonical field element), 2 (bad G1 encoding / not in the subgroup), 3 (invalid lengths
  * or indices) and verified[b] = false -- what the single form reports as Err (status may be NULL).  The CResult is Err only
  * for a call-level (device) failure.  An empty problem verifies (verifier.rs:90-93). */
