@@ -445,7 +445,39 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
     return out, {"verify": (C_, I_, L_, P_), "recover": recover_one, "verify128": (C_[:CELLS], I_[:CELLS], L_[:CELLS], P_[:CELLS])}
 
 
-def strong_configs(ctx, sharding, torch, dist, dev, world, rank, lib_comm, stream):
+class _Harness:
+    """The harness's own collectives (timing maxima, agreement flags, checksums, the torch-side all-gather): on the GPU with the
+    "nccl" backend; through CPU copies with "gloo" -- the REHEARSAL mode (KZG_BENCH_REHEARSAL=1: N ranks share GPU 0, each with
+    a small table budget), which exists so that the N > 1 code paths (launcher, seeds, slices, gather checks, strong legs) can
+    run on a one-GPU box.  RCCL refuses two ranks on one GPU, so the rehearsal never measures an exchange."""
+    def __init__(self, torch, dist, dev, rehearsal):
+        self.torch, self.dist, self.dev, self.rehearsal = torch, dist, dev, rehearsal
+
+    def _c(self, t):
+        return t.cpu() if self.rehearsal else t
+
+    def all_reduce(self, t, op):
+        c = self._c(t)
+        self.dist.all_reduce(c, op=op)
+        if self.rehearsal:
+            t.copy_(c)
+        return t
+
+    def all_gather_into(self, out, local):
+        if not self.rehearsal:
+            self.dist.all_gather_into_tensor(out, local.reshape(-1))
+            return out
+        self.torch.cuda.synchronize(self.dev)
+        co = self.torch.empty(out.numel(), dtype=out.dtype)
+        self.dist.all_gather_into_tensor(co, local.reshape(-1).cpu())
+        out.copy_(co)
+        return out
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def strong_configs(ctx, sharding, torch, dist, dev, world, rank, lib_comm, stream, hz):
     """BASELINE.json configs 4 and 5 AS WRITTEN -- a fixed total (512 blobs to prove, 256 half-erased blobs to recover) cut
     into contiguous slices over the N ranks, each pass ending with the all-gather -- timed outside the headline region,
     beside the same total on ONE GPU (every rank runs that leg on its own GPU; rank 0's figure is reported).  These are the
@@ -456,7 +488,7 @@ def strong_configs(ctx, sharding, torch, dist, dev, world, rank, lib_comm, strea
     def fence():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier()
+            hz.barrier()
         torch.cuda.synchronize(dev)
 
     def gather(local, full):
@@ -465,7 +497,7 @@ def strong_configs(ctx, sharding, torch, dist, dev, world, rank, lib_comm, strea
         elif lib_comm:
             ctx.all_gather(local.data_ptr(), full.data_ptr(), local.numel(), stream.cuda_stream)
         else:
-            sharding.all_gather_flat(local, full, dist)
+            hz.all_gather_into(full, local)
 
     def timed(run, reps=7, skip=2):
         ts = []
@@ -477,7 +509,7 @@ def strong_configs(ctx, sharding, torch, dist, dev, world, rank, lib_comm, strea
             torch.cuda.synchronize(dev)
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
             if world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                hz.all_reduce(t, dist.ReduceOp.MAX)
             if it >= skip:
                 ts.append(float(t.item()))
         return _median(ts)
@@ -485,7 +517,7 @@ def strong_configs(ctx, sharding, torch, dist, dev, world, rank, lib_comm, strea
     def agree(flag):
         t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
         if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            hz.all_reduce(t, dist.ReduceOp.MIN)
         return bool(int(t.item()))
 
     PB, CB = CELLS * 48, CELLS * BYTES_PER_CELL
@@ -662,12 +694,16 @@ def main():
     import torch
     import torch.distributed as dist
 
+    rehearsal = world > 1 and os.environ.get("KZG_BENCH_REHEARSAL") == "1"
+    if rehearsal:  # N ranks on GPU 0 (see _Harness): small tables so that N contexts fit, torch's gloo for the harness collectives
+        local_rank = 0
+        os.environ.setdefault("ETH_KZG_AMD_TABLE_GB", "24")
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} are visible "
                          f"(--gpus {args.gpus})")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo" if rehearsal else "nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -698,6 +734,7 @@ def main():
     d_proofs = torch.empty(B * CELLS * 48, dtype=torch.uint8, device=dev)
     d_all_proofs = torch.empty(world * B * CELLS * 48, dtype=torch.uint8, device=dev) if world > 1 else None
     stream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream: kernels are enqueued on it without host syncs
+    hz = _Harness(torch, dist, dev, rehearsal)
     # the exchange runs on the library's own RCCL communicator (what a C / Go / Java host would use); torch.distributed
     # carries the 128-byte id and stays the fallback if the library cannot build its communicator
     lib_comm, comm_ranks, rccl_file, comm_error = False, None, None, None
@@ -730,12 +767,12 @@ def main():
                 if lib_comm:
                     sharding.all_gather_proofs(ctx, d_proofs, d_all_proofs, stream)
                 else:
-                    sharding.all_gather_flat(d_proofs, d_all_proofs, dist)
+                    hz.all_gather_into(d_all_proofs, d_proofs)
 
     def fence():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier()
+            hz.barrier()
         torch.cuda.synchronize(dev)
 
     # correctness gate on the first run (status + the data-in-first-half invariant, fk20/prover.rs:251-275)
@@ -752,11 +789,11 @@ def main():
         fence()
         mine = d_proofs.view(-1, 8).view(torch.int64).sum().reshape(1)
         sums = torch.empty(world, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(sums, mine)  # (torch's communicator: an independent path for the check)
+        hz.all_gather_into(sums, mine)  # (torch's communicator: an independent path for the check)
         got = d_all_proofs.view(world, -1, 8).view(torch.int64).sum(dim=(1, 2))
         gather_checked = bool(torch.equal(sums, got)) and bool(torch.equal(d_all_proofs.view(world, -1)[rank], d_proofs))
         flag = torch.tensor([1 if gather_checked else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        hz.all_reduce(flag, dist.ReduceOp.MIN)
         if not int(flag.item()):
             raise SystemExit("bench.py: the all-gathered proof vector does not match the ranks' own proofs")
     _mark("correctness gate passed; warm-up")
@@ -774,7 +811,7 @@ def main():
     ctx.set_profiling(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        hz.all_reduce(t, dist.ReduceOp.MAX)
         dt = float(t.item())
 
     # single-blob latency (BASELINE.json config 2), outside the timed region
@@ -791,7 +828,7 @@ def main():
     strong = None
     if world > 1 or args.strong_configs:
         try:
-            strong = strong_configs(ctx, sharding, torch, dist, dev, world, rank, lib_comm, stream)
+            strong = strong_configs(ctx, sharding, torch, dist, dev, world, rank, lib_comm, stream, hz)
         except SystemExit:
             raise  # a parity failure of the gathered output must sink the run
         except Exception as e:  # anything else in the side legs must not cost the headline record
@@ -861,6 +898,7 @@ def main():
                        "library_communicator_error": comm_error,
                        "ranks": world, "library_communicator_ranks": comm_ranks, "rccl_library": rccl_file,
                        "launcher": os.environ.get("KZG_BENCH_LAUNCHER", "external (torch.distributed.run)") if world > 1 else "none",
+                       "rehearsal": "KZG_BENCH_REHEARSAL=1: all ranks share GPU 0, gloo for the harness, small tables -- a check of the N > 1 code paths, NOT a measurement" if rehearsal else None,
                        "gathered_proofs_checked": gather_checked},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg_bytes,
