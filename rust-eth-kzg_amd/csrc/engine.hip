@@ -1096,26 +1096,18 @@ void Engine::launch_msm(const void* scalars, TableSel which, void* out, int n_gr
     const int c = tv.c;
     if (tv.glv) {  // GLV table: the scalars are split in place by the launcher (they feed nothing else)
         const long msms = (long)n_groups * n_slices;
-        const int adds_per_wave = 2 * launch::glv_windows(c) * 64;  // gathered additions of one MSM
         int mode = 1;
         if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) mode = 0;
-        else if (msm_chunks_ >= 0) mode = msm_chunks_ == 0 ? 1 : msm_chunks_ == 1 ? 3 : msm_chunks_ == 2 ? 4 : (c == 16 ? 2 : 4);  // tuning knob / tests
+        else if (msm_chunks_ >= 0) mode = msm_chunks_ == 0 ? 1 : msm_chunks_ == 1 ? 3 : msm_chunks_ == 2 ? 4 : 2;  // tuning knob / tests
         else if ((msms * 4 + 63) / 64 >= (long)wave_slots_) {
-            // The chip is full either way: S waves per 64 MSMs, each lane summing 1 / S of the MSM's gathered entries.  Fewer,
-            // longer waves save the folds but waste more of the last round when the wave count is not a multiple of the wave
-            // slots; pick the S with the least predicted time = rounds x (additions per wave + fold), a part-filled last
-            // round priced by its fill (one wave per SIMD runs ~1.6x faster than two).
-            const long g = (msms + 63) / 64;
-            double best = 0;
-            for (int S : {1, 2, 4}) {
-                if (S == 4 && c != 16) continue;
-                const long waves = g * S;
-                const double full = (double)(waves / wave_slots_), tail = (double)(waves % wave_slots_) / wave_slots_;
-                const double t_tail = tail == 0 ? 0 : (tail <= 0.5 ? 0.62 : 1.0);
-                const double per_wave = (double)adds_per_wave / S + (S == 1 ? 1.0 : S == 2 ? 4.0 : 13.0);  // in gathered-addition units
-                const double t = (full + t_tail) * per_wave * (S == 4 ? 1.03 : 1.0);  // measured: the 4-wave blocks lose ~3 % outside the loop
-                if (best == 0 || t < best) { best = t; mode = S == 1 ? 3 : S == 2 ? 4 : 2; }
-            }
+            // The chip is full: four chunks per MSM.  Measured on one box, alternating runs (MSM stage, ms; S = lanes per MSM of
+            // the lane kernels):        blobs   256   512   768   1024  1536  2048         3072
+            //   four chunks                     6.2  11.5  16.8  21.4  31.1  40.5-40.7   59.7
+            //   a lane per MSM (S = 1)          9.9  18.5  19.9  22.0  31.3  41.0-42.0   60.9
+            //   a lane per GLV half (S = 2)     9.2  11.9  21.4  24.9  34.3  44.9        61.9
+            // The lane kernels save the folds and the barriers, and at 2048 / 3072 blobs their waves make exact rounds -- and
+            // still lose 1-2 %: 16384 short waves dealt out as slots free up balance the SIMDs better than 4096 long ones.
+            mode = 2;
         }
         launch::msm_glv(c, mode, const_cast<void*>(scalars), table, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st);
         return;
