@@ -865,7 +865,7 @@ def main():
             import glob
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_pmc_b2048*.json")))
             pm = json.load(open(files[-1]))["kernels"]
-            want = {"msm_fixed": ("k_msm_glv_lane<1>", "k_msm_glv_chunked") if ctx.glv_table() else ("k_msm_fixed_chunked<14>",), "g1_linmap": ("k_slp_mulc",)}.get(dom, ())
+            want = {"msm_fixed": ("k_msm_glv_chunked", "k_msm_glv_lane<1>") if ctx.glv_table() else ("k_msm_fixed_chunked<14>",), "g1_linmap": ("k_slp_mulc",)}.get(dom, ())
             key = next((k for w_ in want for k in pm if w_ in k), None)  # the newest profile names the kernel the default schedule runs
             if key in pm and B == 2048 and ctx.glv_table() and ctx.window_bits() == 16:
                 # gfx950 correction (MI355X_MICROARCH.md, calibrated for this kernel's 16-B-per-lane gathers in
