@@ -88,7 +88,7 @@ int Engine::open_blobs_at(int n, const uint8_t* const* blobs, const Fr8* z_mont,
         HIPCK(hipMemcpyAsync((uint8_t*)d_blobs.p + (size_t)b * BYTES_PER_BLOB, blobs[b], BYTES_PER_BLOB, hipMemcpyHostToDevice, st));
     HIPCK(hipMemcpyAsync(d_z.p, z_mont, (size_t)n * 32, hipMemcpyHostToDevice, st));
     HIPCK(hipMemsetAsync(d_status_, 0, n * sizeof(int), st));
-    launch::blob_to_coeffs(n, (const uint8_t*)d_blobs.p, d_coeffs_, nullptr, d_status_, d_w8192_, n_inv4096_, st);
+    launch::blob_to_coeffs(n, (const uint8_t*)d_blobs.p, d_coeffs_, nullptr, d_status_, d_w29_, n_inv4096_, st);
     launch::quotient_by_linear(n, d_coeffs_, d_z.p, d_canon_, d_y.p, st);
     if (want_proofs) {
         // proof = g1_lincomb(g1s[..4095], quotient) (kzg_single_open/src/prover.rs:40-43): the commitment MSM path

@@ -385,7 +385,7 @@ Engine::~Engine() {
     }
     if (build_stream_) hipStreamDestroy(build_stream_);
     host_pool_.reset();  // joins the helper threads before anything they might touch goes away
-    void* ptrs[] = {d_w8192_, d_naf_, d_srs_, d_fk_bases_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_circ_terms_,
+    void* ptrs[] = {d_w8192_, d_w29_, d_naf_, d_srs_, d_fk_bases_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_circ_terms_,
                     d_slp_naf_, d_slp_words_, d_slp_levels_};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -424,6 +424,12 @@ void Engine::init_constants() {
     if (!eq(mul(w[N_EXT - 1], g), one<FrParams>())) throw std::runtime_error("omega_8192 has wrong order");
     HIPCK(hipMalloc(&d_w8192_, N_EXT * sizeof(Fr)));
     HIPCK(hipMemcpy(d_w8192_, w.data(), N_EXT * sizeof(Fr), hipMemcpyHostToDevice));
+    {   // the same table in the unsaturated 9 x 29-bit form of the prover's Fr stages (k_ntt.hip, fr29.hpp)
+        std::vector<uint32_t> w29((size_t)N_EXT * 9);
+        launch::ntt_twiddles29(w.data(), w29.data());
+        HIPCK(hipMalloc(&d_w29_, w29.size() * 4));
+        HIPCK(hipMemcpy(d_w29_, w29.data(), w29.size() * 4, hipMemcpyHostToDevice));
+    }
     // GLV + width-w NAF recoding of omega_128^k = w[64k] (the G1-FFT twiddles)
     {
         Fr lam = zero<FrParams>();
@@ -1173,7 +1179,7 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         X = w.slp_arena;
     }
     const int mk1 = mark_begin(ST_FK20_SCALARS, st);
-    launch::fk20_scalars(n, w.coeffs, w.scalars, d_w8192_, linmap_mode ? half_ : inv128_, segs, segs == 2 ? two_segments : seg_shift_, st);
+    launch::fk20_scalars(n, w.coeffs, w.scalars, d_w29_, linmap_mode ? half_ : inv128_, segs, segs == 2 ? two_segments : seg_shift_, st);
     mark_end(mk1, 1, st);
     launch::g1_set_inf(X, (size_t)128 * bp, st);
     const bool latency_mode = bp <= LATENCY_MODE_MAX_LANES;  // few 64-blob groups: direct 8 x 16 transforms, 4 rounds instead of 14
@@ -1267,7 +1273,7 @@ void Engine::enqueue_compute(Work& w, int n, const uint8_t* d_blobs, uint8_t* d_
     HIPCK(hipStreamWaitEvent(st, w.done, 0));  // an earlier call may still be using this set on another stream
     HIPCK(hipMemsetAsync(w.status, 0, n * sizeof(int), st));
     const int mk11 = mark_begin(ST_BLOB_TO_COEFFS, st);
-    launch::blob_to_coeffs(n, d_blobs, w.coeffs, nullptr, w.status, d_w8192_, n_inv4096_, st);
+    launch::blob_to_coeffs(n, d_blobs, w.coeffs, nullptr, w.status, d_w29_, n_inv4096_, st);
     mark_end(mk11, 1, st);
     // a handful of blobs is a chain of latencies: the cells (one 8192-point transform, 0.08 ms) then run on the set's second
     // stream next to the proof stages instead of in front of them
@@ -1275,7 +1281,7 @@ void Engine::enqueue_compute(Work& w, int n, const uint8_t* d_blobs, uint8_t* d_
     if (side) {
         HIPCK(hipEventRecord(w.ev_coeffs, st));
         HIPCK(hipStreamWaitEvent(w.copy, w.ev_coeffs, 0));
-        launch::coeffs_to_cells(n, w.coeffs, d_cells, d_w8192_, w.copy);
+        launch::coeffs_to_cells(n, w.coeffs, d_cells, d_w29_, w.copy);
         if (after_cells) HIPCK(hipEventRecord(after_cells, w.copy));
         HIPCK(hipEventRecord(w.ev_side, w.copy));
         run_proofs_from_coeffs(w, n, d_proofs, st);
@@ -1284,7 +1290,7 @@ void Engine::enqueue_compute(Work& w, int n, const uint8_t* d_blobs, uint8_t* d_
     }
     if (d_cells) {
         const int mk12 = mark_begin(ST_COEFFS_TO_CELLS, st);
-        launch::coeffs_to_cells(n, w.coeffs, d_cells, d_w8192_, st);
+        launch::coeffs_to_cells(n, w.coeffs, d_cells, d_w29_, st);
         mark_end(mk12, 1, st);
     }
     if (after_cells) HIPCK(hipEventRecord(after_cells, st));
@@ -1328,7 +1334,7 @@ int Engine::blob_to_kzg_commitment_device(int n, const uint8_t* d_blobs, uint8_t
         HIPCK(hipMemsetAsync(d_status_, 0, n * sizeof(int), st));
         // commit = MSM_4096(coeffs, g1_monomial)  (fk20/prover.rs:128-145, commit_key.rs:38-44):
         // 64 groups of 64 bases through the window-table kernel, then a fold over the groups.
-        launch::blob_to_coeffs(n, d_blobs, d_coeffs_, d_canon_, d_status_, d_w8192_, n_inv4096_, st);
+        launch::blob_to_coeffs(n, d_blobs, d_coeffs_, d_canon_, d_status_, d_w29_, n_inv4096_, st);
         launch::g1_set_inf(d_X_, (size_t)64 * bp, st);
         launch_msm(d_canon_, TAB_SRS, d_X_, 64, n, bp, 0, st);
         launch::g1_sum_positions(d_X_, 64, bp, n, st);
@@ -1448,17 +1454,17 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
                 HIPCK(hipMemcpyAsync(w.d_in + (size_t)lo * BYTES_PER_BLOB, w.h_in + (size_t)lo * BYTES_PER_BLOB, (size_t)nb * BYTES_PER_BLOB,
                                      hipMemcpyHostToDevice, w.stream));
                 launch::blob_to_coeffs(nb, w.d_in + (size_t)lo * BYTES_PER_BLOB, (char*)w.coeffs + (size_t)lo * N_BLOB * sizeof(Fr), nullptr,
-                                       w.status + lo, d_w8192_, n_inv4096_, w.stream);
+                                       w.status + lo, d_w29_, n_inv4096_, w.stream);
                 // a handful of blobs: the cells are computed on the copy stream, next to the proof stages (enqueue_compute does the same)
                 const bool side = cells && proofs && ns <= circ_max_;
                 if (cells && !side)
                     launch::coeffs_to_cells(nb, (char*)w.coeffs + (size_t)lo * N_BLOB * sizeof(Fr),
-                                            w.d_cells + (size_t)lo * N_CELLS * BYTES_PER_CELL, d_w8192_, w.stream);
+                                            w.d_cells + (size_t)lo * N_CELLS * BYTES_PER_CELL, d_w29_, w.stream);
                 HIPCK(hipEventRecord(w.sub_events[2 * i], w.stream));
                 HIPCK(hipStreamWaitEvent(w.copy, w.sub_events[2 * i], 0));
                 if (side)
                     launch::coeffs_to_cells(nb, (char*)w.coeffs + (size_t)lo * N_BLOB * sizeof(Fr),
-                                            w.d_cells + (size_t)lo * N_CELLS * BYTES_PER_CELL, d_w8192_, w.copy);
+                                            w.d_cells + (size_t)lo * N_CELLS * BYTES_PER_CELL, d_w29_, w.copy);
                 HIPCK(hipMemcpyAsync(w.h_status + lo, w.status + lo, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, w.copy));
                 if (cells)
                     HIPCK(hipMemcpyAsync(w.h_cells + (size_t)lo * N_CELLS * BYTES_PER_CELL, w.d_cells + (size_t)lo * N_CELLS * BYTES_PER_CELL,
@@ -1579,7 +1585,7 @@ int Engine::test_fr_ntt4096(const uint8_t* in_be, uint8_t* out_be, int inverse_d
         HIPCK(hipMalloc(&di, BYTES_PER_BLOB));
         HIPCK(hipMalloc(&dout, BYTES_PER_BLOB));
         HIPCK(hipMemcpy(di, in_be, BYTES_PER_BLOB, hipMemcpyHostToDevice));
-        launch::test_ntt4096(di, dout, d_w8192_, n_inv4096_, inverse_dit, stream_);
+        launch::test_ntt4096(di, dout, d_w29_, n_inv4096_, inverse_dit, stream_);
         HIPCK(hipStreamSynchronize(stream_));
         HIPCK(hipMemcpy(out_be, dout, BYTES_PER_BLOB, hipMemcpyDeviceToHost));
         HIPCK(hipFree(di));

@@ -302,6 +302,7 @@ private:
 
     // constants in HBM
     void* d_w8192_ = nullptr;     // Fr[8192] omega_8192^k, Montgomery
+    void* d_w29_ = nullptr;       // the same in the unsaturated 9 x 29-bit form (36 B each) for the prover's Fr stages
     void* d_naf_ = nullptr;       // u32[128][2][33]: width-w NAF digits (signed bytes) of the GLV halves of omega_128^k
     Fp12w beta_;                  // cube root of unity in Fp: (beta x, y) = [lambda](x, y)
     void* d_srs_ = nullptr;       // G1Affine[4096] monomial SRS

@@ -3,170 +3,194 @@
 // a9 Toeplitz/circulant column FFTs, a11 cell serialisation.
 #include "engine.hpp"
 #include "kcommon.hpp"
+#include "fr29.hpp"
 #include "launch.hpp"
 
 namespace kzg {
 
 // ------------------------------------------------------------------------------------------------
-// LDS-resident 4096-point NTT.  Layout: lds[limb * 4096 + index] (limb-major: a wave touching
-// consecutive indices touches consecutive banks).
-__device__ __forceinline__ Fr lds_load(const uint32_t* s, int idx) {
-    Fr r;
+// LDS-resident 4096-point NTT in the unsaturated 9 x 29-bit form (fr29.hpp).  Layout: lds[limb * 4096 + index] (limb-major: a
+// wave touching consecutive indices touches consecutive banks); 9 limbs = 144 KiB of the CU's 160 KiB.
+// Both networks are Cooley-Tukey -- multiply the second input by the twiddle, then add / subtract -- so a value's bound
+// grows by 2 r per layer and nothing is reduced inside a transform (bounds at every call site).
+__device__ __forceinline__ Fr29 lds_load(const uint32_t* s, int idx) {
+    Fr29 r;
 #pragma unroll
-    for (int l = 0; l < 8; l++) r.v[l] = s[l * N_BLOB + idx];
+    for (int l = 0; l < RL; l++) r.v[l] = s[l * N_BLOB + idx];
     return r;
 }
-__device__ __forceinline__ void lds_store(uint32_t* s, int idx, const Fr& a) {
+__device__ __forceinline__ void lds_store(uint32_t* s, int idx, const Fr29& a) {
 #pragma unroll
-    for (int l = 0; l < 8; l++) s[l * N_BLOB + idx] = a.v[l];
+    for (int l = 0; l < RL; l++) s[l * N_BLOB + idx] = a.v[l];
 }
 
-// w8192[k] = omega_8192^k (Montgomery), k < 8192.  omega_m^j = w8192[j * 8192/m].
-// DIT (input in bit-reversed order -> natural order), inverse twiddles, in LDS, 1024 threads.
-__device__ __forceinline__ void ntt4096_dit_inverse(uint32_t* s, const Fr* __restrict__ w8192) {
+// w29[k] = omega_8192^k in the 9 x 29-bit Montgomery form (canonical), k < 8192.  omega_m^j = w29[j * 8192/m].
+// Inverse transform: input in bit-reversed order -> natural order, inverse twiddles, in LDS, 1024 threads.
+// Bound: in < B  ->  out < B + 24.
+__device__ __forceinline__ void ntt4096_dit_inverse(uint32_t* s, const Fr29* __restrict__ w29) {
     const int tid = threadIdx.x;
     for (int half = 1; half < N_BLOB; half <<= 1) {
         const int tw_step = N_EXT / (2 * half);  // exponent step in units of omega_8192
         for (int q = tid; q < N_BLOB / 2; q += 1024) {
-            int j = q & (half - 1);
-            int i0 = ((q - j) << 1) + j, i1 = i0 + half;
-            Fr a = lds_load(s, i0), b = lds_load(s, i1);
-            int e = (N_EXT - j * tw_step) & (N_EXT - 1);  // omega^-j
-            Fr t = j ? mul(b, w8192[e]) : b;
-            lds_store(s, i0, add(a, t));
-            lds_store(s, i1, sub(a, t));
+            const int j = q & (half - 1);
+            const int i0 = ((q - j) << 1) + j, i1 = i0 + half;
+            const Fr29 a = lds_load(s, i0);
+            const Fr29 t = fr29_mul(lds_load(s, i1), w29[(N_EXT - j * tw_step) & (N_EXT - 1)]);  // omega^-j; < 2r
+            lds_store(s, i0, fr29_add(a, t));
+            lds_store(s, i1, fr29_sub2r(a, t));
         }
         __syncthreads();
     }
 }
-// DIF (natural order -> bit-reversed order), forward twiddles.
-__device__ __forceinline__ void ntt4096_dif_forward(uint32_t* s, const Fr* __restrict__ w8192) {
+// Forward transform: natural order -> bit-reversed order (position q holds X[brp(q)]), Cooley-Tukey butterflies with the
+// twiddles taken in bit-reversed order: at stride `half` the block i = q / half uses omega_4096^(brp(i) * half).
+// (Round 2 used Gentleman-Sande butterflies here, whose sum path doubles the bound per layer.)  Bound: in < B -> out < B + 24.
+__device__ __forceinline__ void ntt4096_ct_forward(uint32_t* s, const Fr29* __restrict__ w29) {
     const int tid = threadIdx.x;
-    for (int half = N_BLOB / 2; half >= 1; half >>= 1) {
-        const int tw_step = N_EXT / (2 * half);
+    int log_m = 0;  // blocks at this stride = 2^log_m
+    for (int half = N_BLOB / 2; half >= 1; half >>= 1, log_m++) {
         for (int q = tid; q < N_BLOB / 2; q += 1024) {
-            int j = q & (half - 1);
-            int i0 = ((q - j) << 1) + j, i1 = i0 + half;
-            Fr a = lds_load(s, i0), b = lds_load(s, i1);
-            Fr d = sub(a, b);
-            lds_store(s, i0, add(a, b));
-            lds_store(s, i1, j ? mul(d, w8192[j * tw_step]) : d);
+            const int j = q & (half - 1), blk = q / half;
+            const int i0 = ((q - j) << 1) + j, i1 = i0 + half;
+            const int e = log_m ? (int)(__brev((unsigned)blk) >> (32 - log_m)) * half * (N_EXT / N_BLOB) : 0;  // omega_4096 = omega_8192^2
+            const Fr29 a = lds_load(s, i0);
+            const Fr29 b = lds_load(s, i1);
+            const Fr29 t = fr29_mul(b, w29[e]);  // e = 0: times one in Montgomery form: brings b below 2r like every other product
+            lds_store(s, i0, fr29_add(a, t));
+            lds_store(s, i1, fr29_sub2r(a, t));
         }
         __syncthreads();
     }
+}
+__device__ __forceinline__ Fr fr_words_of(const Fr29& canonical) {
+    Fr r;
+    fr29_to_words(r.v, canonical);
+    return r;
 }
 
 // Stage A+B of compute_cells_and_kzg_proofs: blob bytes -> monomial coefficients.
 //   coeffs = IFFT_4096(bit_reverse(blob))   (fk20/prover.rs:177-180, domain.rs:199-211)
-// The DIT network wants its input bit-reversed, i.e. exactly the blob as given: no permutation pass.
-// grid = n_blobs, block = 1024, dynamic LDS = 128 KiB.  status[b] |= 1 if any element >= r.
-// If canon_out != nullptr the coefficients are also written out of Montgomery form (MSM scalars).
+// The inverse network wants its input bit-reversed, i.e. exactly the blob as given: no permutation pass.
+// grid = n_blobs, block = 1024, dynamic LDS = 144 KiB.  status[b] |= 1 if any element >= r.
+// Outputs stay in the engine's stored forms: coeffs = saturated Montgomery (8 x 32 bits, canonical), canon_out = the
+// plain integers (MSM scalars), both through the final multiplication by n^-1 with the right constant.
+struct NttConsts {
+    Fr29 to_mont;       // 2^522 mod r: canonical -> this form
+    Fr29 ninv_to_sat;   // n^-1 * 2^256 (an integer): mul(X, .) = x n^-1 2^256 = the saturated Montgomery form of the coefficient
+    Fr29 ninv_plain;    // n^-1 (an integer): mul(X, .) = x n^-1
+};
 __global__ __launch_bounds__(1024) void k_blob_to_coeffs(const uint8_t* __restrict__ blobs, Fr* __restrict__ coeffs,
                                                         Fr* __restrict__ canon_out, int* __restrict__ status,
-                                                        const Fr* __restrict__ w8192, Fr n_inv) {
+                                                        const Fr29* __restrict__ w29, NttConsts K) {
     extern __shared__ uint32_t s[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const uint8_t* blob = blobs + (size_t)b * BYTES_PER_BLOB;
     bool bad = false;
     for (int e = tid; e < N_BLOB; e += 1024) {
-        Fr x = load_fr_be(blob + 32 * e);
+        const Fr x = load_fr_be(blob + 32 * e);
         bad |= geq_mod<FrParams>(x.v);
-        lds_store(s, e, to_mont(x));
+        lds_store(s, e, fr29_mul(fr29_from_plain(x), K.to_mont));  // x < 2^256 < 3r, constant < r -> < 2r
     }
     if (bad) atomicOr(&status[b], 1);
     __syncthreads();
-    ntt4096_dit_inverse(s, w8192);
+    ntt4096_dit_inverse(s, w29);  // < 26 r
     for (int e = tid; e < N_BLOB; e += 1024) {
-        Fr c = mul(lds_load(s, e), n_inv);
-        coeffs[(size_t)b * N_BLOB + e] = c;
-        if (canon_out) canon_out[(size_t)b * N_BLOB + e] = from_mont(c);
+        const Fr29 x = lds_load(s, e);
+        coeffs[(size_t)b * N_BLOB + e] = fr_words_of(fr29_reduce_once(fr29_mul(x, K.ninv_to_sat)));
+        if (canon_out) canon_out[(size_t)b * N_BLOB + e] = fr_words_of(fr29_reduce_once(fr29_mul(x, K.ninv_plain)));
     }
 }
 
 // Stage H+I: cells = bit_reverse(NTT_8192(coeffs || 0)) serialised big-endian
 // (prover.rs:158-165, serialization/src/lib.rs:132-156).  X[2k+h] = NTT_4096(a_i * w8192^(i*h))[k];
-// the DIF network leaves half h bit-reversed in place, which is exactly cells[h*4096 ...].
-// grid = (n_blobs, 2), block = 1024, dynamic LDS = 128 KiB.
+// the forward network leaves half h bit-reversed in place, which is exactly cells[h*4096 ...].
+// grid = (n_blobs, 2), block = 1024, dynamic LDS = 144 KiB.
 __global__ __launch_bounds__(1024) void k_coeffs_to_cells(const Fr* __restrict__ coeffs, uint8_t* __restrict__ cells,
-                                                         const Fr* __restrict__ w8192) {
+                                                         const Fr29* __restrict__ w29) {
     extern __shared__ uint32_t s[];
     const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
     for (int e = tid; e < N_BLOB; e += 1024) {
-        Fr c = coeffs[(size_t)b * N_BLOB + e];
-        if (h && e) c = mul(c, w8192[e]);
+        Fr29 c = fr29_from_fr_mont(coeffs[(size_t)b * N_BLOB + e]);  // < 32 r
+        if (h && e) c = fr29_mul(c, w29[e]);                          // < 2 r
         lds_store(s, e, c);
     }
     __syncthreads();
-    ntt4096_dif_forward(s, w8192);
+    ntt4096_ct_forward(s, w29);  // < 56 r
     uint8_t* out = cells + ((size_t)b * N_EXT + (size_t)h * N_BLOB) * 32;
-    for (int e = tid; e < N_BLOB; e += 1024) store_fr_be(out + 32 * e, from_mont(lds_load(s, e)));
+    const Fr29 one_plain = fr29_const(r29::ONE_PLAIN);
+    for (int e = tid; e < N_BLOB; e += 1024)
+        store_fr_be(out + 32 * e, fr_words_of(fr29_reduce_once(fr29_mul(lds_load(s, e), one_plain))));  // X / 2^261 = the value
 }
-
-// Generic LDS NTT of NPTS (<= 8192/ (threads..)) is not needed: recovery reuses the 4096 kernels through
-// the split X[2k+h] identity; see k_ntt8192_* in engine.hip.
 
 // ------------------------------------------------------------------------------------------------
 // Stage C: the 64 circulant-column NTT_128 of FK20 (h_poly.rs:36-56, toeplitz.rs:132-144,
 // batch_toeplitz.rs:94-106).  For blob b and i < 64 the length-128 vector is
 //   v[0] = a[4095-i];  v[1..64] = 0;  v[64+k] = a[64k-1-i], k = 1..63
 // scalars[b][j][i] = NTT_128(v)[j] * 128^-1  (the 128^-1 of the later G1 inverse FFT, domain.rs:189-191,
-// folded in here because everything downstream is linear), stored OUT of Montgomery form for the
-// MSM's window extraction.  grid = n_blobs * 16, block = 256 (4 vectors per block, one per wave).
+// folded in here because everything downstream is linear), stored as plain integers for the MSM's window extraction.
+// grid = n_blobs * 16, block = 256 (4 vectors per block, one per wave).
 // segs > 1 (tiny batches only): copies of every scalar multiplied by 2^(128 seg / segs) are written as extra "blobs"
 // seg * n + b, so that the MSM stage also delivers 2^32 u, 2^64 u, 2^96 u (four segments; 2^64 u for two) and the
 // doubling chain of k_g1circ.hip splits into `segs` independent shorter chains.
-struct SegShifts { Fr p[3]; };  // Montgomery forms of the segment shifts, p[seg - 1]
+struct SegShifts { Fr29 p[3]; };  // the segment shifts as plain integers times 2^261 (this form), p[seg - 1]
 __global__ __launch_bounds__(256) void k_fk20_scalars(const Fr* __restrict__ coeffs, Fr* __restrict__ scalars,
-                                                      const Fr* __restrict__ w8192, Fr inv128, int n, int segs, SegShifts sh) {
-    __shared__ uint32_t s[4][8][128];
+                                                      const Fr29* __restrict__ w29, Fr29 scale /* 128^-1 or 1/2, this form */, int n,
+                                                      int segs, SegShifts sh) {
+    __shared__ uint32_t s[4][RL][128];
     const int b = blockIdx.x >> 4, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = ((blockIdx.x & 15) << 2) + wv;
     const Fr* a = coeffs + (size_t)b * N_BLOB;
     uint32_t(*sv)[128] = s[wv];
     {
         // element `lane` (0..63) and element 64+lane
-        Fr lo = zero<FrParams>(), hi = zero<FrParams>();
-        if (lane == 0) lo = mul(a[N_BLOB - 1 - i], inv128);
-        else hi = mul(a[64 * lane - 1 - i], inv128);
+        Fr29 lo, hi;
 #pragma unroll
-        for (int l = 0; l < 8; l++) { sv[l][lane] = lo.v[l]; sv[l][64 + lane] = hi.v[l]; }
+        for (int l = 0; l < RL; l++) lo.v[l] = hi.v[l] = 0;
+        if (lane == 0) lo = fr29_mul(fr29_from_fr_mont(a[N_BLOB - 1 - i]), scale);  // (< 32 r) x (< r) -> < 2r
+        else hi = fr29_mul(fr29_from_fr_mont(a[64 * lane - 1 - i]), scale);
+#pragma unroll
+        for (int l = 0; l < RL; l++) { sv[l][lane] = lo.v[l]; sv[l][64 + lane] = hi.v[l]; }
     }
     __syncthreads();
-    // DIF: natural -> bit-reversed
-    for (int half = 64; half >= 1; half >>= 1) {
-        int j = lane & (half - 1);
-        int i0 = ((lane - j) << 1) + j, i1 = i0 + half;
-        Fr x, y;
+    // natural -> bit-reversed, Cooley-Tukey with bit-reversed twiddles (see ntt4096_ct_forward): < 2 + 14 = 16 r
+    int log_m = 0;
+    for (int half = 64; half >= 1; half >>= 1, log_m++) {
+        const int j = lane & (half - 1), blk = lane / half;
+        const int i0 = ((lane - j) << 1) + j, i1 = i0 + half;
+        const int e = log_m ? (int)(__brev((unsigned)blk) >> (32 - log_m)) * half * (N_EXT / 128) : 0;  // omega_128 = omega_8192^64
+        Fr29 x, y;
 #pragma unroll
-        for (int l = 0; l < 8; l++) { x.v[l] = sv[l][i0]; y.v[l] = sv[l][i1]; }
-        Fr d = sub(x, y), sum = add(x, y);
-        if (j) d = mul(d, w8192[j * (N_EXT / (2 * half))]);
+        for (int l = 0; l < RL; l++) { x.v[l] = sv[l][i0]; y.v[l] = sv[l][i1]; }
+        const Fr29 t = fr29_mul(y, w29[e]);
+        const Fr29 sum = fr29_add(x, t), d = fr29_sub2r(x, t);
 #pragma unroll
-        for (int l = 0; l < 8; l++) { sv[l][i0] = sum.v[l]; sv[l][i1] = d.v[l]; }
+        for (int l = 0; l < RL; l++) { sv[l][i0] = sum.v[l]; sv[l][i1] = d.v[l]; }
         __syncthreads();
     }
     // position q holds NTT[brp7(q)]
+    const Fr29 one_plain = fr29_const(r29::ONE_PLAIN);
     for (int q = lane; q < 128; q += 64) {
-        Fr x;
+        Fr29 x;
 #pragma unroll
-        for (int l = 0; l < 8; l++) x.v[l] = sv[l][q];
-        int j = __brev((unsigned)q) >> 25;
-        scalars[((size_t)b * 128 + j) * 64 + i] = from_mont(x);
-        for (int sg = 1; sg < segs; sg++)
-            scalars[((size_t)(sg * n + b) * 128 + j) * 64 + i] = from_mont(mul(x, sh.p[sg - 1]));
+        for (int l = 0; l < RL; l++) x.v[l] = sv[l][q];
+        const int j = __brev((unsigned)q) >> 25;
+        scalars[((size_t)b * 128 + j) * 64 + i] = fr_words_of(fr29_reduce_once(fr29_mul(x, one_plain)));
+        for (int sg = 1; sg < segs; sg++)  // (x sh) is this form again; one more product strips the 2^261
+            scalars[((size_t)(sg * n + b) * 128 + j) * 64 + i] =
+                fr_words_of(fr29_reduce_once(fr29_mul(fr29_mul(x, sh.p[sg - 1]), one_plain)));
     }
 }
 
-__global__ __launch_bounds__(1024) void k_test_ntt4096(const uint8_t* in, uint8_t* out, const Fr* w8192, Fr n_inv, int inverse_dit) {
+__global__ __launch_bounds__(1024) void k_test_ntt4096(const uint8_t* in, uint8_t* out, const Fr29* w29, NttConsts K, int inverse_dit) {
     extern __shared__ uint32_t s[];
-    for (int e = threadIdx.x; e < N_BLOB; e += 1024) lds_store(s, e, to_mont(load_fr_be(in + 32 * e)));
+    for (int e = threadIdx.x; e < N_BLOB; e += 1024) lds_store(s, e, fr29_mul(fr29_from_plain(load_fr_be(in + 32 * e)), K.to_mont));
     __syncthreads();
-    if (inverse_dit) ntt4096_dit_inverse(s, w8192);
-    else ntt4096_dif_forward(s, w8192);
+    if (inverse_dit) ntt4096_dit_inverse(s, w29);
+    else ntt4096_ct_forward(s, w29);
+    const Fr29 one_plain = fr29_const(r29::ONE_PLAIN);
     for (int e = threadIdx.x; e < N_BLOB; e += 1024) {
-        Fr c = lds_load(s, e);
-        if (inverse_dit) c = mul(c, n_inv);
-        store_fr_be(out + 32 * e, from_mont(c));
+        const Fr29 c = lds_load(s, e);
+        store_fr_be(out + 32 * e, fr_words_of(fr29_reduce_once(fr29_mul(c, inverse_dit ? K.ninv_plain : one_plain))));
     }
 }
 __global__ void k_test_scalars_be(const uint8_t* in, Fr* out, size_t n) {
@@ -196,25 +220,46 @@ __global__ void k_test_field_mul(const uint8_t* a, const uint8_t* b, uint8_t* ou
 namespace launch {
 static Fr as_fr(const Fr8& x) { Fr r; for (int i = 0; i < 8; i++) r.v[i] = x.v[i]; return r; }
 
+constexpr size_t LDS_NTT29 = (size_t)N_BLOB * RL * 4;  // 144 KiB: one 4096-point transform of 9-limb elements resident in LDS
 void init_attributes() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_blob_to_coeffs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_NTT);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_coeffs_to_cells), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_NTT);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_test_ntt4096), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_NTT);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_blob_to_coeffs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_NTT29);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_coeffs_to_cells), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_NTT29);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_test_ntt4096), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_NTT29);
 }
-void blob_to_coeffs(int n, const uint8_t* blobs, void* coeffs, void* canon, int* status, const void* w8192, const Fr8& n_inv, hipStream_t st) {
-    k_blob_to_coeffs<<<n, 1024, LDS_NTT, st>>>(blobs, (Fr*)coeffs, (Fr*)canon, status, (const Fr*)w8192, as_fr(n_inv));
+// host-side constants of the 9 x 29-bit form from the engine's saturated Montgomery values (Y = y 2^256 mod r, canonical)
+static Fr29 fr29_of_value(const Fr& plain) { return fr29_from_plain(plain); }            // the integer itself
+// X = y 2^261 mod r = 32 Y mod r: in Fr arithmetic, the Montgomery form of (y * 32) read as a plain integer
+static Fr29 fr29_mont_of(const Fr8& y_mont) {
+    Fr c32 = zero<FrParams>();
+    c32.v[0] = 32;
+    return fr29_from_plain(mul(as_fr(y_mont), to_mont(c32)));
 }
-void coeffs_to_cells(int n, const void* coeffs, uint8_t* cells, const void* w8192, hipStream_t st) {
-    k_coeffs_to_cells<<<dim3(n, 2), 1024, LDS_NTT, st>>>((const Fr*)coeffs, cells, (const Fr*)w8192);
+static NttConsts ntt_consts(const Fr8& n_inv_mont) {
+    NttConsts K;
+    K.to_mont = fr29_const(r29::R2);
+    K.ninv_to_sat = fr29_of_value(as_fr(n_inv_mont));             // the stored Montgomery words ARE n^-1 2^256 mod r as an integer
+    K.ninv_plain = fr29_of_value(from_mont(as_fr(n_inv_mont)));   // n^-1
+    return K;
 }
-void fk20_scalars(int n, const void* coeffs, void* scalars, const void* w8192, const Fr8& inv128, int segs, const Fr8* seg_shifts,
+void ntt_twiddles29(const void* w8192_mont_host /*Fr[8192]*/, void* out_host /*8192 x 9 words*/) {
+    const Fr* w = (const Fr*)w8192_mont_host;
+    Fr29* o = (Fr29*)out_host;
+    for (int k = 0; k < N_EXT; k++) o[k] = fr29_mont_of(*(const Fr8*)&w[k]);
+}
+void blob_to_coeffs(int n, const uint8_t* blobs, void* coeffs, void* canon, int* status, const void* w29, const Fr8& n_inv, hipStream_t st) {
+    k_blob_to_coeffs<<<n, 1024, LDS_NTT29, st>>>(blobs, (Fr*)coeffs, (Fr*)canon, status, (const Fr29*)w29, ntt_consts(n_inv));
+}
+void coeffs_to_cells(int n, const void* coeffs, uint8_t* cells, const void* w29, hipStream_t st) {
+    k_coeffs_to_cells<<<dim3(n, 2), 1024, LDS_NTT29, st>>>((const Fr*)coeffs, cells, (const Fr29*)w29);
+}
+void fk20_scalars(int n, const void* coeffs, void* scalars, const void* w29, const Fr8& inv128, int segs, const Fr8* seg_shifts,
                   hipStream_t st) {
     SegShifts sh;
-    for (int i = 0; i < 3; i++) sh.p[i] = as_fr(seg_shifts[i]);
-    k_fk20_scalars<<<n * 16, 256, 0, st>>>((const Fr*)coeffs, (Fr*)scalars, (const Fr*)w8192, as_fr(inv128), n, segs, sh);
+    for (int i = 0; i < 3; i++) sh.p[i] = fr29_mont_of(seg_shifts[i]);
+    k_fk20_scalars<<<n * 16, 256, 0, st>>>((const Fr*)coeffs, (Fr*)scalars, (const Fr29*)w29, fr29_mont_of(inv128), n, segs, sh);
 }
-void test_ntt4096(const uint8_t* in, uint8_t* out, const void* w8192, const Fr8& n_inv, int inverse_dit, hipStream_t st) {
-    k_test_ntt4096<<<1, 1024, LDS_NTT, st>>>(in, out, (const Fr*)w8192, as_fr(n_inv), inverse_dit);
+void test_ntt4096(const uint8_t* in, uint8_t* out, const void* w29, const Fr8& n_inv, int inverse_dit, hipStream_t st) {
+    k_test_ntt4096<<<1, 1024, LDS_NTT29, st>>>(in, out, (const Fr29*)w29, ntt_consts(n_inv), inverse_dit);
 }
 void test_scalars_be(const uint8_t* in, void* out, size_t n, hipStream_t st) {
     k_test_scalars_be<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(in, (Fr*)out, n);

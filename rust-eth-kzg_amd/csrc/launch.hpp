@@ -13,12 +13,17 @@ namespace launch {
 void init_attributes();  // opt in to 128 KiB dynamic LDS for the NTT kernels
 
 // k_ntt.hip
+// The three Fr stages of the prover compute in the unsaturated 9 x 29-bit form (fr29.hpp): w29 = the twiddle table in that
+// form (8192 x 9 words, built on the host by ntt_twiddles29 from the saturated table); inputs / outputs keep the engine's
+// stored forms (saturated Montgomery coefficients, plain-integer scalars, big-endian bytes).
+constexpr size_t SIZEOF_FR29 = 36;
+void ntt_twiddles29(const void* w8192_mont_host /*Fr[8192]*/, void* out_host /*8192 x 36 B*/);
 void blob_to_coeffs(int n, const uint8_t* blobs, void* coeffs /*Fr*/, void* canon /*Fr or null*/, int* status,
-                    const void* w8192, const Fr8& n_inv, hipStream_t st);
-void coeffs_to_cells(int n, const void* coeffs, uint8_t* cells, const void* w8192, hipStream_t st);
-void fk20_scalars(int n, const void* coeffs, void* scalars, const void* w8192, const Fr8& inv128, int segs, const Fr8* seg_shifts,
+                    const void* w29, const Fr8& n_inv, hipStream_t st);
+void coeffs_to_cells(int n, const void* coeffs, uint8_t* cells, const void* w29, hipStream_t st);
+void fk20_scalars(int n, const void* coeffs, void* scalars, const void* w29, const Fr8& inv128, int segs, const Fr8* seg_shifts,
                   hipStream_t st);
-void test_ntt4096(const uint8_t* in, uint8_t* out, const void* w8192, const Fr8& n_inv, int inverse_dit, hipStream_t st);
+void test_ntt4096(const uint8_t* in, uint8_t* out, const void* w29, const Fr8& n_inv, int inverse_dit, hipStream_t st);
 void test_scalars_be(const uint8_t* in, void* out, size_t n, hipStream_t st);
 void test_field_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, int n, int is_fp, hipStream_t st);
 

@@ -514,7 +514,7 @@ int Engine::recover_cells_and_kzg_proofs_device(int R, const uint8_t* d_cells, c
         int rc = rs_decode(R, d_cells, /*flat_source=*/true, slot, stof, present, status);
         if (rc) return rc;
         hipStream_t st = user_stream ? user_stream : stream_;
-        if (d_out_cells) launch::coeffs_to_cells(R, d_coeffs_, d_out_cells, d_w8192_, st);
+        if (d_out_cells) launch::coeffs_to_cells(R, d_coeffs_, d_out_cells, d_w29_, st);
         if (d_out_proofs) run_proofs_from_coeffs(R, d_out_proofs, st);
         HIPCK(hipEventRecord(work_[0].done, st));  // the next user of the workspace waits for these kernels (ensure_workspace)
         HIPCK(hipGetLastError());
@@ -559,7 +559,7 @@ int Engine::recover_cells_and_kzg_proofs_batch_host(int R, const uint64_t* n_cel
         lap("stage in + RS decode");
         // compute_multi_opening_proofs(Input::PolyCoeff) = stages C..I (prover.rs:164-170) for the whole batch
         PoolBuf d_c(*this, (size_t)R * N_CELLS * BYTES_PER_CELL), d_p(*this, (size_t)R * N_CELLS * 48);
-        launch::coeffs_to_cells(R, d_coeffs_, (uint8_t*)d_c.p, d_w8192_, stream_);
+        launch::coeffs_to_cells(R, d_coeffs_, (uint8_t*)d_c.p, d_w29_, stream_);
         run_proofs_from_coeffs(R, (uint8_t*)d_p.p, stream_);
         PoolBuf hc_buf(*this, (size_t)R * N_CELLS * BYTES_PER_CELL, true), hp_buf(*this, (size_t)R * N_CELLS * 48, true);
         const uint8_t* hc = (const uint8_t*)hc_buf.p;

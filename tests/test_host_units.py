@@ -54,6 +54,16 @@ def test_fk20_proofs_map_compiles_to_its_definition(tmp_path):
 
 
 @pytest.mark.timeout(600)
+def test_unsaturated_fr_matches_saturated_field(tmp_path):
+    """csrc/fr29.hpp (9 x 29-bit Fr of the prover's NTT kernels: no carry instructions, Montgomery factor -1) against the
+    saturated arithmetic of csrc/field.hpp: products at every bound the kernels use (entry 32 r, 56 r after 12 layers), limb
+    re-grouping, the (x << 5) entry from the stored Montgomery form, and the 4096-point Cooley-Tukey network with bit-reversed
+    twiddles against the definition of the DFT, without any reduction inside the transform."""
+    out = _build_and_run(tmp_path, "test_fr29")
+    assert "0 mismatches" in out
+
+
+@pytest.mark.timeout(600)
 def test_glv_split_is_balanced_and_exact(tmp_path):
     """csrc/glv.hpp (the scalar split behind the GLV window table): k1 + k2 lambda == k mod r and |k1|, |k2| <=
     (lambda + 1) / 2 + 1 < 2^127 for 200 k random scalars, small scalars, 0, 1, r - 1, multiples of lambda and the
