@@ -35,7 +35,8 @@ __device__ __forceinline__ void ntt4096_dit_inverse(uint32_t* s, const Fr29* __r
             const int j = q & (half - 1);
             const int i0 = ((q - j) << 1) + j, i1 = i0 + half;
             const Fr29 a = lds_load(s, i0);
-            const Fr29 t = fr29_mul(lds_load(s, i1), w29[(N_EXT - j * tw_step) & (N_EXT - 1)]);  // omega^-j; < 2r
+            const Fr29 b = lds_load(s, i1);
+            const Fr29 t = j ? fr29_mul(b, w29[(N_EXT - j * tw_step) & (N_EXT - 1)]) : fr29_partial_reduce(b);  // omega^-j b; < 2r either way
             lds_store(s, i0, fr29_add(a, t));
             lds_store(s, i1, fr29_sub2r(a, t));
         }
@@ -55,7 +56,7 @@ __device__ __forceinline__ void ntt4096_ct_forward(uint32_t* s, const Fr29* __re
             const int e = log_m ? (int)(__brev((unsigned)blk) >> (32 - log_m)) * half * (N_EXT / N_BLOB) : 0;  // omega_4096 = omega_8192^2
             const Fr29 a = lds_load(s, i0);
             const Fr29 b = lds_load(s, i1);
-            const Fr29 t = fr29_mul(b, w29[e]);  // e = 0: times one in Montgomery form: brings b below 2r like every other product
+            const Fr29 t = e ? fr29_mul(b, w29[e]) : fr29_partial_reduce(b);  // twiddle 1 (block 0 of every layer, 1 butterfly in 6): no product, < 2r all the same
             lds_store(s, i0, fr29_add(a, t));
             lds_store(s, i1, fr29_sub2r(a, t));
         }
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void k_fk20_scalars(const Fr* __restrict__ coe
         Fr29 x, y;
 #pragma unroll
         for (int l = 0; l < RL; l++) { x.v[l] = sv[l][i0]; y.v[l] = sv[l][i1]; }
-        const Fr29 t = fr29_mul(y, w29[e]);
+        const Fr29 t = e ? fr29_mul(y, w29[e]) : fr29_partial_reduce(y);
         const Fr29 sum = fr29_add(x, t), d = fr29_sub2r(x, t);
 #pragma unroll
         for (int l = 0; l < RL; l++) { sv[l][i0] = sum.v[l]; sv[l][i1] = d.v[l]; }

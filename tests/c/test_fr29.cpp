@@ -65,6 +65,22 @@ int main() {
         Fr pa = from_mont(ya);
         if (!same(canon(fr29_mul(fr29_from_plain(pa), fr29_const(r29::R2))), xa1)) { bad++; if (bad < 5) printf("MISMATCH to_mont\n"); }
     }
+    // partial reduction without a multiplication: same residue, below 2r, over the whole range a value can have
+    for (int it = 0; it < 200000; it++) {
+        Fr29 b;
+        for (int i = 0; i < RL; i++) b.v[i] = rnd32() & RMASK;
+        if (it < 64) { b = times(x_of(to_mont(rnd_fr())), it + 1); }                       // multiples of a canonical value: bounds 1 .. 64
+        if (it == 64) for (int i = 0; i < RL; i++) b.v[i] = RMASK;                           // 2^261 - 1
+        if (it == 65) for (int i = 0; i < RL; i++) b.v[i] = 0;
+        const Fr29 red = fr29_partial_reduce(b);
+        for (int i = 0; i < RL - 1; i++) if (red.v[i] > RMASK) { bad++; if (bad < 5) printf("MISMATCH partial_reduce limbs\n"); }
+        // below 2r: one conditional subtraction must reach the canonical form; and the residue is the same (compare plain values)
+        const Fr29 one = fr29_const(r29::ONE_PLAIN);
+        const Fr29 c1 = canon(red);
+        Fr29 chk = fr29_reduce_once(c1);
+        if (!same(chk, c1)) { bad++; if (bad < 5) printf("MISMATCH partial_reduce not below 2r\n"); }
+        if (!same(canon(fr29_mul(red, one)), canon(fr29_mul(b, one)))) { bad++; if (bad < 5) printf("MISMATCH partial_reduce residue\n"); }
+    }
     // Cooley-Tukey natural -> bit-reversed with bit-reversed twiddles, n = 4096 (12 layers, entry bound 32, no reduction)
     {
         const int n = 4096, logn = 12;
@@ -89,7 +105,7 @@ int main() {
                 const int j = q & (half - 1), blk = q / half, i0 = ((q - j) << 1) + j, i1 = i0 + half;
                 int br = 0;
                 for (int b = 0; b < log_m; b++) br |= ((blk >> b) & 1) << (log_m - 1 - b);
-                const Fr29 t = fr29_mul(x[i1], w29[(size_t)br * half]);
+                const Fr29 t = br ? fr29_mul(x[i1], w29[(size_t)br * half]) : fr29_partial_reduce(x[i1]);
                 const Fr29 a = x[i0];
                 x[i0] = fr29_add(a, t);
                 x[i1] = fr29_sub2r(a, t);
