@@ -1097,7 +1097,12 @@ void Engine::release_work(Work& w) {
 // ---------------------------------------------------------------------------------------------
 void Engine::launch_msm(const void* scalars, TableSel which, void* out, int n_groups, int n_slices, int out_stride,
                         int brp_bits, hipStream_t st) {
-    const TableView tv = table_view(which);  // one consistent snapshot: the builder thread may publish a wider table at any time
+    launch_msm(scalars, table_view(which), false, out, n_groups, n_slices, out_stride, brp_bits, st);
+}
+// tv: ONE snapshot of the table view (the builder thread may publish a wider table at any time); scalars_split: the producer
+// has stored the scalars as balanced GLV halves already (only meaningful for a GLV table)
+void Engine::launch_msm(const void* scalars, const TableView& tv, bool scalars_split, void* out, int n_groups, int n_slices,
+                        int out_stride, int brp_bits, hipStream_t st) {
     const void* table = tv.p;
     const int c = tv.c;
     if (tv.glv) {  // GLV table: the scalars are split in place by the launcher (they feed nothing else)
@@ -1115,7 +1120,7 @@ void Engine::launch_msm(const void* scalars, TableSel which, void* out, int n_gr
             // still lose 1-2 %: 16384 short waves dealt out as slots free up balance the SIMDs better than 4096 long ones.
             mode = 2;
         }
-        launch::msm_glv(c, mode, const_cast<void*>(scalars), table, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st);
+        launch::msm_glv(c, mode, const_cast<void*>(scalars), table, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st, scalars_split);
         return;
     }
     if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) {
@@ -1178,13 +1183,14 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         }
         X = w.slp_arena;
     }
+    const TableView tv = table_view(TAB_FK);  // one snapshot for the scalars' form AND the MSM that reads them
     const int mk1 = mark_begin(ST_FK20_SCALARS, st);
-    launch::fk20_scalars(n, w.coeffs, w.scalars, d_w29_, linmap_mode ? half_ : inv128_, segs, segs == 2 ? two_segments : seg_shift_, st);
+    launch::fk20_scalars(n, w.coeffs, w.scalars, d_w29_, linmap_mode ? half_ : inv128_, segs, segs == 2 ? two_segments : seg_shift_, tv.glv, st);
     mark_end(mk1, 1, st);
     launch::g1_set_inf(X, (size_t)128 * bp, st);
     const bool latency_mode = bp <= LATENCY_MODE_MAX_LANES;  // few 64-blob groups: direct 8 x 16 transforms, 4 rounds instead of 14
     const int mk2 = mark_begin(ST_MSM_FIXED, st);
-    launch_msm(w.scalars, TAB_FK, X, 128, segs * n, bp, (latency_mode || linmap_mode) ? 0 : 7, st);
+    launch_msm(w.scalars, tv, tv.glv, X, 128, segs * n, bp, (latency_mode || linmap_mode) ? 0 : 7, st);
     mark_end(mk2, 1, st);
     if (linmap_mode) {
         const int mk3 = mark_begin(ST_G1_LINMAP, st);

@@ -262,6 +262,8 @@ private:
     void set_error(const std::exception& e);
     void launch_msm(const void* scalars, TableSel table, void* out, int n_groups, int n_slices, int out_stride,
                     int brp_bits, hipStream_t st);
+    void launch_msm(const void* scalars, const TableView& tv, bool scalars_split, void* out, int n_groups, int n_slices, int out_stride,
+                    int brp_bits, hipStream_t st);
     void build_final_tables();  // the wide tables: on the helper thread (progressive start) or inline
     void publish(TableSel which, const TableView& v);
     void g1_ifft128_take64(void* X, int stride, hipStream_t st);

@@ -277,8 +277,8 @@ bool glv_width_supported(int c) {
     return false;
 }
 void msm_glv(int c, int mode, void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,
-             int brp_bits, const Fp12w& beta, hipStream_t st) {
-    glv_split(scalars, (size_t)n_groups * n_slices * nb, st);
+             int brp_bits, const Fp12w& beta, hipStream_t st, bool already_split) {
+    if (!already_split) glv_split(scalars, (size_t)n_groups * n_slices * nb, st);
     switch (c) {
         case 8: return msm_glv_w8(mode, scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, beta, st);
         case 12: return msm_glv_w12(mode, scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, beta, st);

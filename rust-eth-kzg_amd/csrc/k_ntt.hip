@@ -4,6 +4,7 @@
 #include "engine.hpp"
 #include "kcommon.hpp"
 #include "fr29.hpp"
+#include "glv.hpp"
 #include "launch.hpp"
 
 namespace kzg {
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(1024) void k_coeffs_to_cells(const Fr* __restrict__
 struct SegShifts { Fr29 p[3]; };  // the segment shifts as plain integers times 2^261 (this form), p[seg - 1]
 __global__ __launch_bounds__(256) void k_fk20_scalars(const Fr* __restrict__ coeffs, Fr* __restrict__ scalars,
                                                       const Fr29* __restrict__ w29, Fr29 scale /* 128^-1 or 1/2, this form */, int n,
-                                                      int segs, SegShifts sh) {
+                                                      int segs, SegShifts sh, int glv /* store the balanced GLV halves (k_msm_glv.inc) instead of the integer */) {
     __shared__ uint32_t s[4][RL][128];
     const int b = blockIdx.x >> 4, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = ((blockIdx.x & 15) << 2) + wv;
@@ -168,17 +169,27 @@ __global__ __launch_bounds__(256) void k_fk20_scalars(const Fr* __restrict__ coe
         for (int l = 0; l < RL; l++) { sv[l][i0] = sum.v[l]; sv[l][i1] = d.v[l]; }
         __syncthreads();
     }
-    // position q holds NTT[brp7(q)]
+    // position q holds NTT[brp7(q)].  For a GLV window table the scalar leaves already split k = k1 + k2 lambda (what the separate
+    // k_glv_split pass of round 2 did in place: 0.19 ms of reading and writing 0.5 GB at 2048 blobs)
     const Fr29 one_plain = fr29_const(r29::ONE_PLAIN);
+    auto emit = [&](size_t at, const Fr29& x_form) {
+        Fr k = fr_words_of(fr29_reduce_once(fr29_mul(x_form, one_plain)));
+        if (glv) {
+            uint32_t h[8];
+            glv_split_balanced(k, h);
+#pragma unroll
+            for (int l = 0; l < 8; l++) k.v[l] = h[l];
+        }
+        scalars[at] = k;
+    };
     for (int q = lane; q < 128; q += 64) {
         Fr29 x;
 #pragma unroll
         for (int l = 0; l < RL; l++) x.v[l] = sv[l][q];
         const int j = __brev((unsigned)q) >> 25;
-        scalars[((size_t)b * 128 + j) * 64 + i] = fr_words_of(fr29_reduce_once(fr29_mul(x, one_plain)));
-        for (int sg = 1; sg < segs; sg++)  // (x sh) is this form again; one more product strips the 2^261
-            scalars[((size_t)(sg * n + b) * 128 + j) * 64 + i] =
-                fr_words_of(fr29_reduce_once(fr29_mul(fr29_mul(x, sh.p[sg - 1]), one_plain)));
+        emit(((size_t)b * 128 + j) * 64 + i, x);
+        for (int sg = 1; sg < segs; sg++)  // (x sh) is this form again
+            emit(((size_t)(sg * n + b) * 128 + j) * 64 + i, fr29_mul(x, sh.p[sg - 1]));
     }
 }
 
@@ -254,10 +265,10 @@ void coeffs_to_cells(int n, const void* coeffs, uint8_t* cells, const void* w29,
     k_coeffs_to_cells<<<dim3(n, 2), 1024, LDS_NTT29, st>>>((const Fr*)coeffs, cells, (const Fr29*)w29);
 }
 void fk20_scalars(int n, const void* coeffs, void* scalars, const void* w29, const Fr8& inv128, int segs, const Fr8* seg_shifts,
-                  hipStream_t st) {
+                  bool glv_split, hipStream_t st) {
     SegShifts sh;
     for (int i = 0; i < 3; i++) sh.p[i] = fr29_mont_of(seg_shifts[i]);
-    k_fk20_scalars<<<n * 16, 256, 0, st>>>((const Fr*)coeffs, (Fr*)scalars, (const Fr29*)w29, fr29_mont_of(inv128), n, segs, sh);
+    k_fk20_scalars<<<n * 16, 256, 0, st>>>((const Fr*)coeffs, (Fr*)scalars, (const Fr29*)w29, fr29_mont_of(inv128), n, segs, sh, glv_split ? 1 : 0);
 }
 void test_ntt4096(const uint8_t* in, uint8_t* out, const void* w29, const Fr8& n_inv, int inverse_dit, hipStream_t st) {
     k_test_ntt4096<<<1, 1024, LDS_NTT29, st>>>(in, out, (const Fr29*)w29, ntt_consts(n_inv), inverse_dit);

@@ -21,8 +21,9 @@ void ntt_twiddles29(const void* w8192_mont_host /*Fr[8192]*/, void* out_host /*8
 void blob_to_coeffs(int n, const uint8_t* blobs, void* coeffs /*Fr*/, void* canon /*Fr or null*/, int* status,
                     const void* w29, const Fr8& n_inv, hipStream_t st);
 void coeffs_to_cells(int n, const void* coeffs, uint8_t* cells, const void* w29, hipStream_t st);
+// glv_split: store every scalar as its balanced GLV halves (what msm_glv's own split pass would make of it)
 void fk20_scalars(int n, const void* coeffs, void* scalars, const void* w29, const Fr8& inv128, int segs, const Fr8* seg_shifts,
-                  hipStream_t st);
+                  bool glv_split, hipStream_t st);
 void test_ntt4096(const uint8_t* in, uint8_t* out, const void* w29, const Fr8& n_inv, int inverse_dit, hipStream_t st);
 void test_scalars_be(const uint8_t* in, void* out, size_t n, hipStream_t st);
 void test_field_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, int n, int is_fp, hipStream_t st);
@@ -35,13 +36,13 @@ void msm_fixed_chunked(int c, const void* scalars, const void* table, void* out 
                        int out_stride, int brp_bits, int S, hipStream_t st);
 // GLV tables (packed 96-B entries, W = glv_windows(c) windows of c bits over the 128-bit half scalars; k_msm_glv.inc, one
 // translation unit per width): mode 0 flat, 1 windowed, 2 four chunks per MSM (width 16), 3 a lane per MSM, 4 a lane per
-// GLV half.  msm_glv splits the scalars in place first (they feed nothing else).
+// GLV half.  msm_glv splits the scalars in place first (they feed nothing else) unless the producer has stored them split.
 constexpr int glv_windows(int c) { return (128 + c - 1) / c; }
 constexpr int GLV_WIDTHS[] = {16, 15, 14, 12, 8};  // widest first: the order the engine tries them in
 bool glv_width_supported(int c);
 void glv_split(void* scalars, size_t n, hipStream_t st);
 void msm_glv(int c, int mode, void* scalars, const void* table, void* out /*JacQ*/, int n_groups, int n_slices, int nb, int out_stride,
-             int brp_bits, const Fp12w& beta, hipStream_t st);
+             int brp_bits, const Fp12w& beta, hipStream_t st, bool already_split = false);
 void msm_fixed_flat(int c, const void* scalars, const void* table, void* out /*G1Jac*/, int n_groups, int n_slices, int nb,
                int out_stride, int brp_bits, hipStream_t st);
 // k_table.hip
