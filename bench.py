@@ -884,7 +884,7 @@ def main():
             "metric": "blobs/sec compute_cells_and_kzg_proofs (4096-pt blob)",
             "value": value, "unit": "blobs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32", "dtype_note": "381-bit Fp as 14x29-bit / 12x32-bit limbs, 255-bit Fr as 8x32-bit limbs, Montgomery integers; exact arithmetic", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u32", "dtype_note": "381-bit Fp as 14x29-bit / 12x32-bit limbs, 255-bit Fr as 8x32-bit (stored) and 9x29-bit (inside the transforms) limbs, Montgomery integers; exact arithmetic", "data": "synthetic",
             "config": {"workload": f"compute_cells_and_kzg_proofs on DEVICE-RESIDENT blobs (inputs and outputs stay in HBM; the "
                                    f"host-pointer ABI rate is configs.abi_host_pointer_batch), batch-saturated: {B} synthetic blobs "
                                    f"per GPU per step (config 2's single blob is reported as single_blob_latency_ms)",
