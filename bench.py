@@ -438,7 +438,15 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
         cold["note"] = "seconds since the creation of a fresh process (no torch): interpreter, dlopen, HIP runtime start (~0.45 s), start tables, one compute_cells_and_kzg_proofs"
     except Exception as e:
         cold = {"error": repr(e)}
-    out["context_creation_s"] = dict(ctx_times, warm_tables_shared=round(warm, 3), fresh_process=cold,
+    try:  # the same from a plain C consumer of the shared library (tools/first_result): no interpreter in front
+        tool = os.path.join(ROOT, "tools", "first_result")
+        subprocess.run(["make", "-C", tool], capture_output=True, timeout=120)
+        r = subprocess.run([os.path.join(tool, "run")], capture_output=True, text=True, timeout=120)
+        cold_c = json.loads(r.stdout.strip().splitlines()[-1])
+        cold_c["note"] = "seconds since main() of a C program linked against libc_eth_kzg.so: HIP runtime start, start tables, one eth_kzg_compute_cells_and_kzg_proofs"
+    except Exception as e:
+        cold_c = {"error": repr(e)}
+    out["context_creation_s"] = dict(ctx_times, warm_tables_shared=round(warm, 3), fresh_process=cold, fresh_c_process=cold_c,
                                      note="first context of the process: eth_kzg_das_context_new returns on the start tables (GLV width 8 + plain "
                                           "width 8, 3.7 GB; HIP runtime start ~0.45 s included), first_result = one compute_cells_and_kzg_proofs "
                                           "on them, wide tables (hipMalloc of ~250 GB: seconds of driver time, + ~0.9 s of build) swapped in by a helper thread")
