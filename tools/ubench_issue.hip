@@ -89,6 +89,17 @@ KERNEL64(k_mix_3to1_chain, M(0) M(0) M(0) Y_AND(8) M(0) M(0) M(0) Y_SHR(9) M(0) 
 // 8 + 8
 KERNEL64(k_mix_1to1, M(0) Y_AND(8) M(1) Y_SHR(9) M(2) Y_ADD(10) M(3) Y_ALIGN(11) M(4) Y_AND(8) M(5) Y_SHR(9) M(6) Y_ADD(10) M(7) Y_ALIGN(11))
 
+// the 64-bit forms around the multiply-add columns: the column shift acc >>= 29 and its two-instruction 32-bit replacement
+#define SHR64(n) "v_lshrrev_b64 %" S_(n) ", 29, %" S_(n) "\n"
+#define LSHLADD64(n) "v_lshl_add_u64 %" S_(n) ", %" S_(n) ", 3, %" S_(n) "\n"
+KERNEL64(k_shr64, SHR64(0) SHR64(1) SHR64(2) SHR64(3) SHR64(4) SHR64(5) SHR64(6) SHR64(7) SHR64(0) SHR64(1) SHR64(2) SHR64(3) SHR64(4) SHR64(5) SHR64(6) SHR64(7))
+KERNEL64(k_lshladd64, LSHLADD64(0) LSHLADD64(1) LSHLADD64(2) LSHLADD64(3) LSHLADD64(4) LSHLADD64(5) LSHLADD64(6) LSHLADD64(7) LSHLADD64(0) LSHLADD64(1) LSHLADD64(2) LSHLADD64(3) LSHLADD64(4) LSHLADD64(5) LSHLADD64(6) LSHLADD64(7))
+// one column of the Montgomery product as the kernels run it: 13 chained multiply-adds, the quotient digit (v_mul_lo + v_and), the shift
+#define Y_MULLO(n) "v_mul_lo_u32 %" S_(n) ", %" S_(n) ", %13\n"
+KERNEL64(k_column, M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) Y_MULLO(8) Y_AND(8) SHR64(0))
+// the same column with s_nop 0 after the multiply-add run (what hipcc emits after an inline-asm statement)
+KERNEL64(k_column_nop, M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) "s_nop 0\n" Y_MULLO(8) Y_AND(8) SHR64(0))
+
 template <class K>
 void run(const char* name, int cus, K kern, uint32_t* out, unsigned long long* d_cyc) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -137,5 +148,9 @@ int main() {
     run("mix 12 mad64 : 4 plain", cus, k_mix_3to1, out, cyc);
     run("mix 12 mad64 (chain) : 4", cus, k_mix_3to1_chain, out, cyc);
     run("mix 8 mad64 : 8 plain", cus, k_mix_1to1, out, cyc);
+    run("v_lshrrev_b64", cus, k_shr64, out, cyc);
+    run("v_lshl_add_u64", cus, k_lshladd64, out, cyc);
+    run("column 13 mad64+mul_lo+and+shr64", cus, k_column, out, cyc);
+    run("column with s_nop 0 (15+1)", cus, k_column_nop, out, cyc);
     return 0;
 }
