@@ -573,9 +573,14 @@ inline Schedule make_schedule(const Plan& p) {
         for (int v : expire[s]) free_list.push_back(slot[v]);
         // emit the launches of this step: the constant multiplications, then ONE launch for the additions, subtractions
         // and doubling runs together (they are independent of each other within a step; half as many small launches)
+        // the cheap operations of a step longest first (a run of k doublings costs k COST_DBL, an addition COST_ADD): the device
+        // deals them out in this order, so the launch ends on short operations instead of a straggling doubling run
+        std::vector<int> ordered = step_ops[s];
+        auto op_cost = [&](int i) { return p.ops[i].kind == OP_DBL ? p.ops[i].b * COST_DBL : p.ops[i].kind == OP_MULC ? COST_MULC : COST_ADD; };
+        std::stable_sort(ordered.begin(), ordered.end(), [&](int x, int y) { return op_cost(x) > op_cost(y); });
         for (int pass = 0; pass < 2; pass++) {
             Launch L{pass == 0 ? OP_MULC : OP_ADD, (int)S.words.size() / 4, 0};
-            for (int i : step_ops[s]) {
+            for (int i : ordered) {
                 const Op& o = p.ops[i];
                 const bool two = o.kind == OP_ADD || o.kind == OP_SUB;
                 if ((pass == 0) != (o.kind == OP_MULC)) continue;

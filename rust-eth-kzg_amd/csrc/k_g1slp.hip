@@ -22,11 +22,14 @@ __global__ __launch_bounds__(64, 2) void k_slp_mulc(JacQ* __restrict__ A, int st
     A[(size_t)dst * stride + lane] = mul_by_recoded(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta);
 }
 // additions, subtractions (flags & 1) and runs of doublings (flags & 2, b = count) of one step, one wave per operation
+// Blocks are dealt in blockIdx order, x fastest: x = lane group, y = operation, and the schedule lists a step's operations
+// longest first (g1_linmap.hpp: runs of up to 7 doublings cost 2.6 additions), so every group's long operations start first
+// and the launch ends on short ones.
 __global__ __launch_bounds__(64) void k_slp_add(JacQ* __restrict__ A, int stride, const uint32_t* __restrict__ words) {
-    const uint32_t* w = words + (size_t)blockIdx.x * 4;
+    const uint32_t* w = words + (size_t)blockIdx.y * 4;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
                    b = __builtin_amdgcn_readfirstlane(w[2]), fl = __builtin_amdgcn_readfirstlane(w[3]);
-    const int lane = blockIdx.y * 64 + threadIdx.x;
+    const int lane = blockIdx.x * 64 + threadIdx.x;
     JacQ r = A[(size_t)a * stride + lane];
     if (fl & 2u) {
 #pragma unroll 1
@@ -150,7 +153,7 @@ void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int
         for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
         k_slp_mulc<<<grid, 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fq_from_fp(b384));
     } else {
-        k_slp_add<<<grid, 64, 0, st>>>((JacQ*)arena, stride, words);
+        k_slp_add<<<dim3((unsigned)(stride / 64), (unsigned)count), 64, 0, st>>>((JacQ*)arena, stride, words);
     }
 }
 size_t g1_slp_walk_sync_ints(int n_groups, int n_levels) { return 32 * 8 + 16 * (size_t)n_groups * n_levels + 32; }
