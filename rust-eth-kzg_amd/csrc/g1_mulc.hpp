@@ -5,6 +5,10 @@
 #include "curve29.hpp"
 #include "launch.hpp"
 
+#ifndef G1_MULC_COZ
+#define G1_MULC_COZ 1  // 0: the table by general additions and a product tree over their Z (round 2's form, kept for A/B builds)
+#endif
+
 namespace kzg {
 
 // Data layout: X[pos * stride + lane], lane = blob index inside the batch (stride = batch padded to a
@@ -27,6 +31,50 @@ __device__ __forceinline__ JacQ mul_by_recoded(const JacQ& p, const uint32_t* __
     AffQ2 A[NT];
     Fq<2> bx[NT];
     Fq<ZB> zc;
+#if G1_MULC_COZ
+    {
+        // The odd multiples by co-Z arithmetic (Meloni's ZADDU: an addition of two points on ONE Z costs 4M + 2S and hands back
+        // its first operand on the sum's Z): the doubling already holds P on the Z of 2P -- (4 X Y^2, 8 Y^4, 2 Y Z) -- and every
+        // step (2j+1)P = 2P + (2j-1)P leaves the sum and 2P on Z_j = Z_(j-1) (X_2P - X_(2j-1)P).  Entry j is then lifted to the
+        // last Z by lambda_j = product of the later differences: 72M + 27S for the table against 153M + 40S for seven general
+        // additions and a product tree over their Z.  X_2P = X_(2j-1)P needs (2j+1)P or (2j-3)P = O: never in the prime-order
+        // group; an identity input (Z = 0) keeps Z = 0 through zc whatever the other coordinates hold.
+        Fq<XB> ex[NT], ey[NT];  // entry j on Z_j
+        Fq<256> dl[NT];         // Z_j = Z_(j-1) dl[j], j >= 1
+        const Fq<2> a = sqr(p.x), b = sqr(p.y), c = sqr(b);
+        const Fq<8> d = dbl2(mul(p.x, b));
+        const Fq<6> e = add(dbl(a), a);
+        const auto x2 = sub2(sqr(e), d);
+        Fq<XB> tx = relax<XB>(x2);                                                 // 2P, kept on the newest Z
+        Fq<XB> ty = relax<XB>(mul_add(e, sub(d, x2), neg2(b), dbl2(b)));
+        const Fq<ZB> z0 = dbl(mul(p.y, p.z));
+        ex[0] = relax<XB>(d);
+        ey[0] = relax<XB>(dbl2(dbl(c)));
+#pragma unroll 1
+        for (int j = 1; j < NT; j++) {
+            const auto dx = sub(tx, ex[j - 1]), dy = sub(ty, ey[j - 1]);
+            const Fq<2> cc = sqr(dx);
+            const Fq<2> w1 = mul(tx, cc), w2 = mul(ex[j - 1], cc);
+            const auto x3 = sub(sub(sqr(dy), w1), w2);
+            const Fq<2> a1 = mul(ty, sub(w1, w2));
+            ex[j] = relax<XB>(x3);
+            ey[j] = relax<XB>(sub(mul(dy, sub(w1, x3)), a1));
+            tx = relax<XB>(w1);
+            ty = relax<XB>(a1);
+            dl[j] = relax<256>(dx);
+        }
+        Fq<256> lam = relax<256>(fq_one());  // Z_(NT-1) / Z_j
+#pragma unroll 1
+        for (int j = NT - 1; j >= 0; j--) {
+            const Fq<2> l2 = sqr(lam);
+            A[j].x = mul(ex[j], l2);
+            A[j].y = mul(ey[j], mul(l2, lam));
+            bx[j] = mul(A[j].x, beta);
+            if (j > 0) lam = relax<256>(mul(lam, dl[j]));
+        }
+        zc = relax<ZB>(mul(z0, lam));
+    }
+#else
     {
         JacQ T[NT];
         Fq<ZB> pre[NT];  // pre[j] = z_0 ... z_j
@@ -50,6 +98,7 @@ __device__ __forceinline__ JacQ mul_by_recoded(const JacQ& p, const uint32_t* __
             suf = relax<ZB>(mul(suf, T[j].z));
         }
     }
+#endif
     JacQ acc = jacq_inf();
     bool started = false;
 #pragma unroll 1
