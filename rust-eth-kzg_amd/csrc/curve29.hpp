@@ -123,6 +123,38 @@ HD JacQ add(const JacQ& p, const JacQ& q, bool negq = false) {
     return r;
 }
 
+// p + q AND p - q: everything of add-2007-bl except rr, X3 and Y3 is shared (the two results have the same Z3), so the
+// second result costs one squaring and one fused product pair on top of the first's 12M + 4S.  In two steps so that a kernel
+// can store one result before it computes the other (both at once would not fit 256 registers).  Degenerate operands (an
+// identity, p = +-q) make the shared Z3 vanish: `degenerate` then sends BOTH results to the exact slow path.
+struct AddSubShared {
+    Fq<2> s1, s2p, j, v, zh;
+    bool degenerate;
+};
+HD AddSubShared add_sub_prepare(const JacQ& p, const JacQ& q) {
+    AddSubShared sh;
+    Fq<2> z1z1 = sqr(p.z), z2z2 = sqr(q.z);
+    Fq<2> u1 = mul(p.x, z2z2), u2 = mul(q.x, z1z1);
+    sh.s1 = mul(mul(p.y, q.z), z2z2);
+    sh.s2p = mul(mul(q.y, p.z), z1z1);
+    auto h = sub(u2, u1);
+    Fq<2> i = sqr(dbl(h));
+    sh.j = mul(h, i);
+    sh.v = mul(u1, i);
+    sh.zh = mul(mul(p.z, q.z), h);
+    sh.degenerate = product_is_zero(sh.zh);
+    return sh;
+}
+HD JacQ add_sub_finish(const AddSubShared& sh, bool negq) {  // p + q, or p - q when negq (not for degenerate operands)
+    auto rr = dbl(signed_sub(negq, sh.s2p, sh.s1));
+    auto x3 = sub_sub2(sqr(rr), sh.j, sh.v);
+    JacQ r;
+    r.x = relax<XB>(x3);
+    r.y = relax<XB>(mul_add(rr, sub(sh.v, x3), neg2(sh.s1), sh.j));
+    r.z = dbl(sh.zh);
+    return r;
+}
+
 // madd-2007-bl with Z3 = 2 Z1 H: 8M + 3S
 HD JacQ add_mixed(const JacQ& p, const AffQ& q, bool negq = false) {
     if (affine_is_inf(q)) return p;  // an affine identity (0,0) does not make Z3 vanish: test it up front

@@ -386,7 +386,7 @@ Engine::~Engine() {
     if (build_stream_) hipStreamDestroy(build_stream_);
     host_pool_.reset();  // joins the helper threads before anything they might touch goes away
     void* ptrs[] = {d_w8192_, d_w29_, d_naf_, d_srs_, d_fk_bases_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_circ_terms_,
-                    d_slp_naf_, d_slp_words_, d_slp_levels_};
+                    d_slp_naf_, d_slp_words_, d_slp_words_small_, d_slp_levels_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (Work& w : work_) {
@@ -543,6 +543,21 @@ void Engine::init_linmap(const Fr8* w8192_mont) {
     HIPCK(hipMemcpy(d_slp_words_, sched.words.data(), sched.words.size() * 4, hipMemcpyHostToDevice));
     slp_launches_.clear();
     for (auto& L : sched.launches) slp_launches_.push_back(SlpLaunch{(int)L.kind, L.first, L.count});
+    {
+        // the same program with every a + b / a - b pair as two operations: for batches that leave the chip part empty a step
+        // lasts as long as its longest operation, and the fused pair is 15 % longer than an addition (64 blobs: 2.65 against
+        // 2.73 ms for the map; 2048 blobs: 16.15 against 16.0 ms -- fewer, fuller rounds win there)
+        const linmap::Schedule plain = linmap::make_schedule(plan, /*fuse_add_sub=*/false);
+        const auto got = linmap::run_schedule_over_fr(plain, plan.consts, 128, 128, std::vector<Fr>(128, lm));
+        const auto want = linmap::run_schedule_over_fr(sched, plan.consts, 128, 128, std::vector<Fr>(128, lm));
+        for (int k = 0; k < 128; k++)
+            if (!eq(got[k], want[k])) throw std::runtime_error("FK20 proofs map: the two schedules differ");
+        if (plain.n_slots != sched.n_slots) throw std::runtime_error("FK20 proofs map: the two schedules need different arenas");
+        HIPCK(hipMalloc(&d_slp_words_small_, plain.words.size() * 4));
+        HIPCK(hipMemcpy(d_slp_words_small_, plain.words.data(), plain.words.size() * 4, hipMemcpyHostToDevice));
+        slp_launches_small_.clear();
+        for (auto& L : plain.launches) slp_launches_small_.push_back(SlpLaunch{(int)L.kind, L.first, L.count});
+    }
     // phases for the ticket walker (k_g1slp.hip: k_slp_walk): every maximal run of cheap launches becomes ONE launch
     {
         std::vector<int> lf, lc;
@@ -1233,8 +1248,10 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
                 n_launches++;
             }
         } else {
-            for (auto& L : slp_launches_)
-                launch::g1_slp_launch(L.kind, w.slp_arena, bp, (const uint32_t*)d_slp_words_ + (size_t)L.first * 4, L.count, d_slp_naf_, beta_, st);
+            const bool fused = bp >= slp_fuse_min_;
+            const void* words = fused ? d_slp_words_ : d_slp_words_small_;
+            for (auto& L : fused ? slp_launches_ : slp_launches_small_)
+                launch::g1_slp_launch(L.kind, w.slp_arena, bp, (const uint32_t*)words + (size_t)L.first * 4, L.count, d_slp_naf_, beta_, st);
             n_launches = (int)slp_launches_.size();
         }
         mark_end(mk3, n_launches, st);

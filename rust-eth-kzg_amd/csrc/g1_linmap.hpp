@@ -499,8 +499,9 @@ struct Schedule {
     std::vector<uint32_t> words;  // per operation: dst slot, a slot, b (slot | doublings | constant id), flags (1 = subtract, 2 = doubling run)
     std::vector<Launch> launches;
     long mulc_total = 0;
+    long fused_pairs = 0;  // (a + b, a - b) pairs emitted as one operation
 };
-inline Schedule make_schedule(const Plan& p) {
+inline Schedule make_schedule(const Plan& p, bool fuse_add_sub = true) {
     const int n_out = (int)p.outputs.size();
     // dead-code elimination
     std::vector<char> live(p.n_values, 0);
@@ -573,10 +574,29 @@ inline Schedule make_schedule(const Plan& p) {
         for (int v : expire[s]) free_list.push_back(slot[v]);
         // emit the launches of this step: the constant multiplications, then ONE launch for the additions, subtractions
         // and doubling runs together (they are independent of each other within a step; half as many small launches)
-        // the cheap operations of a step longest first (a run of k doublings costs k COST_DBL, an addition COST_ADD): the device
-        // deals them out in this order, so the launch ends on short operations instead of a straggling doubling run
+        // a + b and a - b of the same two values are ONE operation on the device (curve29.hpp: add_sub_* share all but the last
+        // squaring and product pair): the subtraction carries the pair, the addition is dropped from the list
+        std::map<std::pair<int, int>, int> add_of;  // unordered operand pair -> index of the step's addition
+        for (int i : step_ops[s])
+            if (p.ops[i].kind == OP_ADD) add_of[{std::min(p.ops[i].a, p.ops[i].b), std::max(p.ops[i].a, p.ops[i].b)}] = i;
+        std::map<int, int> partner;  // subtraction -> its addition
+        std::vector<char> fused_away(p.ops.size(), 0);
+        if (fuse_add_sub)
+            for (int i : step_ops[s]) {
+                if (p.ops[i].kind != OP_SUB) continue;
+                auto it = add_of.find({std::min(p.ops[i].a, p.ops[i].b), std::max(p.ops[i].a, p.ops[i].b)});
+                if (it == add_of.end() || fused_away[it->second]) continue;
+                partner[i] = it->second;
+                fused_away[it->second] = 1;
+            }
+        // the cheap operations of a step longest first (a run of k doublings costs k COST_DBL, an addition COST_ADD, a fused pair
+        // 1.15 of that): the device deals them out in this order, so the launch ends on short operations instead of a straggling
+        // doubling run
         std::vector<int> ordered = step_ops[s];
-        auto op_cost = [&](int i) { return p.ops[i].kind == OP_DBL ? p.ops[i].b * COST_DBL : p.ops[i].kind == OP_MULC ? COST_MULC : COST_ADD; };
+        auto op_cost = [&](int i) {
+            const Op& o = p.ops[i];
+            return o.kind == OP_DBL ? o.b * COST_DBL : o.kind == OP_MULC ? COST_MULC : partner.count(i) ? 1.15 * COST_ADD : COST_ADD;
+        };
         std::stable_sort(ordered.begin(), ordered.end(), [&](int x, int y) { return op_cost(x) > op_cost(y); });
         for (int pass = 0; pass < 2; pass++) {
             Launch L{pass == 0 ? OP_MULC : OP_ADD, (int)S.words.size() / 4, 0};
@@ -584,6 +604,16 @@ inline Schedule make_schedule(const Plan& p) {
                 const Op& o = p.ops[i];
                 const bool two = o.kind == OP_ADD || o.kind == OP_SUB;
                 if ((pass == 0) != (o.kind == OP_MULC)) continue;
+                if (fused_away[i]) continue;
+                if (partner.count(i)) {  // words: slot of a + b, a, b, 4 | slot of a - b << 8
+                    S.words.push_back((uint32_t)slot[p.ops[partner[i]].dst]);
+                    S.words.push_back((uint32_t)slot[o.a]);
+                    S.words.push_back((uint32_t)slot[o.b]);
+                    S.words.push_back(4u | ((uint32_t)slot[o.dst] << 8));
+                    L.count++;
+                    S.fused_pairs++;
+                    continue;
+                }
                 S.words.push_back((uint32_t)slot[o.dst]);
                 S.words.push_back((uint32_t)slot[o.a]);
                 S.words.push_back(two ? (uint32_t)slot[o.b] : (uint32_t)o.b);
@@ -604,15 +634,20 @@ inline std::vector<Fr> run_schedule_over_fr(const Schedule& S, const std::vector
     std::vector<Fr> arena(S.n_slots, zero<FrParams>());
     for (int i = 0; i < n_in; i++) arena[i] = in[i];
     for (auto& L : S.launches) {
-        std::vector<Fr> res(L.count);
+        std::vector<Fr> res(L.count), res2(L.count);
         for (int i = 0; i < L.count; i++) {
             const uint32_t* w = &S.words[(size_t)(L.first + i) * 4];
             const Fr a = arena[w[1]];
             if (L.kind == OP_MULC) res[i] = mul(a, consts[w[2]]);
+            else if (w[3] & 4u) { res[i] = add(a, arena[w[2]]); res2[i] = sub(a, arena[w[2]]); }
             else if (w[3] & 2u) { Fr t = a; for (uint32_t k = 0; k < w[2]; k++) t = add(t, t); res[i] = t; }
             else res[i] = (w[3] & 1u) ? sub(a, arena[w[2]]) : add(a, arena[w[2]]);
         }
-        for (int i = 0; i < L.count; i++) arena[S.words[(size_t)(L.first + i) * 4]] = res[i];
+        for (int i = 0; i < L.count; i++) {
+            const uint32_t* w = &S.words[(size_t)(L.first + i) * 4];
+            arena[w[0]] = res[i];
+            if (L.kind != OP_MULC && (w[3] & 4u)) arena[w[3] >> 8] = res2[i];
+        }
     }
     return std::vector<Fr>(arena.begin() + n_in, arena.begin() + n_in + n_out);
 }

@@ -6,7 +6,7 @@
 // one wave = one operation x 64 blobs, so the operation descriptor and, for multiplications, the digits of the public
 // constant are wave-uniform (scalar loads and scalar branches, no divergence).  Operations of one launch are mutually
 // independent and never write a slot that the same launch reads (linmap::make_schedule).
-// words: 4 per operation: dst slot, a slot, b (slot | number of doublings | constant id), flags (1 = subtract, 2 = doubling run).
+// words: 4 per operation: dst slot, a slot, b (slot | number of doublings | constant id), flags (1 = subtract, 2 = doubling run, 4 = a + b to dst AND a - b to slot flags >> 8).
 #include "engine.hpp"
 #include "g1_mulc.hpp"
 
@@ -25,13 +25,25 @@ __global__ __launch_bounds__(64, 2) void k_slp_mulc(JacQ* __restrict__ A, int st
 // Blocks are dealt in blockIdx order, x fastest: x = lane group, y = operation, and the schedule lists a step's operations
 // longest first (g1_linmap.hpp: runs of up to 7 doublings cost 2.6 additions), so every group's long operations start first
 // and the launch ends on short ones.
-__global__ __launch_bounds__(64) void k_slp_add(JacQ* __restrict__ A, int stride, const uint32_t* __restrict__ words) {
+__global__ __launch_bounds__(64, 2) void k_slp_add(JacQ* __restrict__ A, int stride, const uint32_t* __restrict__ words) {
     const uint32_t* w = words + (size_t)blockIdx.y * 4;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
                    b = __builtin_amdgcn_readfirstlane(w[2]), fl = __builtin_amdgcn_readfirstlane(w[3]);
     const int lane = blockIdx.x * 64 + threadIdx.x;
     JacQ r = A[(size_t)a * stride + lane];
-    if (fl & 2u) {
+    if (fl & 4u) {  // a step's a + b and a - b as one operation (curve29.hpp: add_sub_*); the difference is stored first
+        const JacQ q = A[(size_t)b * stride + lane];
+        const AddSubShared sh = add_sub_prepare(r, q);
+        if (sh.degenerate) {  // rare: the operands are read again instead of being kept in registers across the common path
+            asm volatile("" ::: "memory");
+            const JacQ p2 = A[(size_t)a * stride + lane], q2 = A[(size_t)b * stride + lane];
+            A[(size_t)(fl >> 8) * stride + lane] = add_slow(p2, q2, true);
+            r = add_slow(p2, q2, false);
+        } else {
+            A[(size_t)(fl >> 8) * stride + lane] = add_sub_finish(sh, true);
+            r = add_sub_finish(sh, false);
+        }
+    } else if (fl & 2u) {
 #pragma unroll 1
         for (uint32_t k = 0; k < b; k++) r = dbl(r);
     } else {
@@ -130,7 +142,19 @@ __global__ __launch_bounds__(64) void k_slp_walk(JacQ* __restrict__ A, int strid
                        b = __builtin_amdgcn_readfirstlane(op[2]), fl = __builtin_amdgcn_readfirstlane(op[3]);
         const int lane = group * 64 + threadIdx.x;
         JacQ r = A[(size_t)a * stride + lane];
-        if (fl & 2u) {
+        if (fl & 4u) {
+            const JacQ q = A[(size_t)b * stride + lane];
+            const AddSubShared sh = add_sub_prepare(r, q);
+            if (sh.degenerate) {
+                asm volatile("" ::: "memory");
+                const JacQ p2 = A[(size_t)a * stride + lane], q2 = A[(size_t)b * stride + lane];
+                A[(size_t)(fl >> 8) * stride + lane] = add_slow(p2, q2, true);
+                r = add_slow(p2, q2, false);
+            } else {
+                A[(size_t)(fl >> 8) * stride + lane] = add_sub_finish(sh, true);
+                r = add_sub_finish(sh, false);
+            }
+        } else if (fl & 2u) {
 #pragma unroll 1
             for (uint32_t k = 0; k < b; k++) r = dbl(r);
         } else {
