@@ -552,7 +552,7 @@ void Engine::init_linmap(const Fr8* w8192_mont) {
         const auto want = linmap::run_schedule_over_fr(sched, plan.consts, 128, 128, std::vector<Fr>(128, lm));
         for (int k = 0; k < 128; k++)
             if (!eq(got[k], want[k])) throw std::runtime_error("FK20 proofs map: the two schedules differ");
-        if (plain.n_slots != sched.n_slots) throw std::runtime_error("FK20 proofs map: the two schedules need different arenas");
+        slp_slots_small_ = plain.n_slots;  // the arena is sized for the larger of the two (inputs and outputs sit at the same slots in both)
         HIPCK(hipMalloc(&d_slp_words_small_, plain.words.size() * 4));
         HIPCK(hipMemcpy(d_slp_words_small_, plain.words.data(), plain.words.size() * 4, hipMemcpyHostToDevice));
         slp_launches_small_.clear();
@@ -589,7 +589,7 @@ void Engine::init_linmap(const Fr8* w8192_mont) {
         slp_walk_ = false;
         if (const char* e = getenv("ETH_KZG_AMD_SLP_WALK")) slp_walk_ = atoi(e) != 0;
     }
-    slp_slots_ = sched.n_slots;
+    slp_slots_ = std::max(sched.n_slots, slp_slots_small_);
     slp_mulc_ = (int)sched.mulc_total;
     slp_info_[0] = (int)plan.count(linmap::OP_MULC);
     slp_info_[1] = (int)(plan.count(linmap::OP_ADD) + plan.count(linmap::OP_SUB));
@@ -1250,9 +1250,10 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         } else {
             const bool fused = bp >= slp_fuse_min_;
             const void* words = fused ? d_slp_words_ : d_slp_words_small_;
-            for (auto& L : fused ? slp_launches_ : slp_launches_small_)
+            const auto& launches = fused ? slp_launches_ : slp_launches_small_;
+            for (auto& L : launches)
                 launch::g1_slp_launch(L.kind, w.slp_arena, bp, (const uint32_t*)words + (size_t)L.first * 4, L.count, d_slp_naf_, beta_, st);
-            n_launches = (int)slp_launches_.size();
+            n_launches = (int)launches.size();
         }
         mark_end(mk3, n_launches, st);
         const int mk4 = mark_begin(ST_COMPRESS, st);

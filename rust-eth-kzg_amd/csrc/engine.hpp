@@ -375,7 +375,7 @@ private:
     void* d_slp_words_small_ = nullptr;          // the schedule without fused add / sub pairs (batches below slp_fuse_min_ lanes)
     std::vector<SlpLaunch> slp_launches_small_;
     int slp_fuse_min_ = 1024;  // measured: 512 blobs 5.47 (plain) against 5.55 ms (fused), 2048 blobs 16.13 against 15.93 ms
-    int slp_slots_ = 0, slp_mulc_ = 0;
+    int slp_slots_ = 0, slp_slots_small_ = 0, slp_mulc_ = 0;
     int slp_info_[4] = {0, 0, 0, 0};  // constant multiplications, additions, doublings, launches of the compiled map
     bool use_linmap_ = false;
     Fr8 half_;  // 1/2 in Montgomery form: the scaling folded into the MSM scalars in linear-map mode

@@ -496,12 +496,13 @@ struct Launch {
 };
 struct Schedule {
     int n_slots = 0;             // arena slots; inputs occupy 0 .. n_in-1, outputs n_in .. n_in+n_out-1
-    std::vector<uint32_t> words;  // per operation: dst slot, a slot, b (slot | doublings | constant id), flags (1 = subtract, 2 = doubling run)
+    std::vector<uint32_t> words;  // per operation: dst slot, a slot, b (slot | doublings | constant id), flags (1 = subtract, 2 = doubling run, 4 = a + b to dst and a - b to slot flags >> 16; bits 3-7: doublings of operand a first)
     std::vector<Launch> launches;
     long mulc_total = 0;
     long fused_pairs = 0;  // (a + b, a - b) pairs emitted as one operation
+    long fused_runs = 0;   // doubling runs folded into the operation that consumes them
 };
-inline Schedule make_schedule(const Plan& p, bool fuse_add_sub = true) {
+inline Schedule make_schedule(const Plan& p, bool fuse_add_sub = true, bool fuse_runs = true) {
     const int n_out = (int)p.outputs.size();
     // dead-code elimination
     std::vector<char> live(p.n_values, 0);
@@ -512,6 +513,43 @@ inline Schedule make_schedule(const Plan& p, bool fuse_add_sub = true) {
         live[o.a] = 1;
         if (o.kind == OP_ADD || o.kind == OP_SUB) live[o.b] = 1;
     }
+    // A run of doublings whose only consumer is ONE addition / subtraction (or one a + b / a - b pair that becomes one operation)
+    // is folded into that consumer: the device doubles the operand in registers before it adds.  1544 of the 1552 runs of the
+    // FK20 map qualify: no launch level, no wave, no store and reload of their own (41 -> 25 cheap launches).
+    std::vector<int> run_of(p.n_values, 0);  // value -> number of doublings folded into its consumer (its source is ops[def].a)
+    std::vector<int> run_src(p.n_values, -1);
+    if (fuse_runs) {
+        std::vector<std::vector<int>> users(p.n_values);
+        std::vector<char> is_output(p.n_values, 0);
+        for (auto& r : p.outputs) is_output[r.id] = 1;
+        for (int i = 0; i < (int)p.ops.size(); i++) {
+            const Op& o = p.ops[i];
+            if (!live[o.dst]) continue;
+            users[o.a].push_back(i);
+            if (o.kind == OP_ADD || o.kind == OP_SUB) users[o.b].push_back(i);
+        }
+        for (auto& o : p.ops) {
+            if (!live[o.dst] || o.kind != OP_DBL || is_output[o.dst] || o.b > 31) continue;
+            const auto& u = users[o.dst];
+            auto two = [&](int k) { return p.ops[k].kind == OP_ADD || p.ops[k].kind == OP_SUB; };
+            // the device doubles the FIRST operand only: the run must be the minuend of a subtraction (either side of an addition
+            // will do: it is emitted first), and the other operand must not be a folded run itself
+            auto fits = [&](const Op& c) {
+                const int other = c.a == o.dst ? c.b : c.a;
+                return c.a != c.b && !run_of[other] && (c.kind == OP_ADD || c.a == o.dst);
+            };
+            bool ok = false;
+            if (u.size() == 1 && two(u[0]) && fits(p.ops[u[0]])) ok = true;
+            if (fuse_add_sub && u.size() == 2 && two(u[0]) && two(u[1]) && p.ops[u[0]].kind != p.ops[u[1]].kind) {
+                const Op &x = p.ops[u[0]], &y = p.ops[u[1]];
+                if (std::min(x.a, x.b) == std::min(y.a, y.b) && std::max(x.a, x.b) == std::max(y.a, y.b) && fits(x) && fits(y)) ok = true;
+            }
+            if (!ok) continue;
+            run_of[o.dst] = o.b;
+            run_src[o.dst] = o.a;
+        }
+    }
+    auto eff = [&](int v) { return run_of[v] ? run_src[v] : v; };  // the value an operand is read from
     // multiplication depth and level inside the phase
     std::vector<int> md(p.n_values, 0), lvl(p.n_values, 0);
     int max_md = 0;
@@ -519,6 +557,11 @@ inline Schedule make_schedule(const Plan& p, bool fuse_add_sub = true) {
     for (auto& o : p.ops) {
         if (!live[o.dst]) continue;
         const bool two = o.kind == OP_ADD || o.kind == OP_SUB;
+        if (run_of[o.dst]) {  // folded run: no operation of its own, it sits where its source sits
+            md[o.dst] = md[o.a];
+            lvl[o.dst] = lvl[o.a];
+            continue;
+        }
         if (o.kind == OP_MULC) {
             md[o.dst] = md[o.a] + 1;
             lvl[o.dst] = 0;
@@ -544,12 +587,12 @@ inline Schedule make_schedule(const Plan& p, bool fuse_add_sub = true) {
     std::vector<int> def_step(p.n_values, -1), last_use(p.n_values, -1);
     for (int i = 0; i < (int)p.ops.size(); i++) {
         const Op& o = p.ops[i];
-        if (!live[o.dst]) continue;
+        if (!live[o.dst] || run_of[o.dst]) continue;
         const int s = step_of[{md[o.dst], lvl[o.dst]}];
         step_ops[s].push_back(i);
         def_step[o.dst] = s;
-        last_use[o.a] = std::max(last_use[o.a], s);
-        if (o.kind == OP_ADD || o.kind == OP_SUB) last_use[o.b] = std::max(last_use[o.b], s);
+        last_use[eff(o.a)] = std::max(last_use[eff(o.a)], s);
+        if (o.kind == OP_ADD || o.kind == OP_SUB) last_use[eff(o.b)] = std::max(last_use[eff(o.b)], s);
     }
     // slots: inputs and outputs pinned, temporaries from a free list; a slot freed at step s is reusable from step s+1
     Schedule S;
@@ -595,7 +638,9 @@ inline Schedule make_schedule(const Plan& p, bool fuse_add_sub = true) {
         std::vector<int> ordered = step_ops[s];
         auto op_cost = [&](int i) {
             const Op& o = p.ops[i];
-            return o.kind == OP_DBL ? o.b * COST_DBL : o.kind == OP_MULC ? COST_MULC : partner.count(i) ? 1.15 * COST_ADD : COST_ADD;
+            if (o.kind == OP_DBL) return o.b * COST_DBL;
+            if (o.kind == OP_MULC) return COST_MULC;
+            return (run_of[o.a] + run_of[o.b]) * COST_DBL + (partner.count(i) ? 1.15 * COST_ADD : COST_ADD);  // at most one of the two is a folded run
         };
         std::stable_sort(ordered.begin(), ordered.end(), [&](int x, int y) { return op_cost(x) > op_cost(y); });
         for (int pass = 0; pass < 2; pass++) {
@@ -605,19 +650,24 @@ inline Schedule make_schedule(const Plan& p, bool fuse_add_sub = true) {
                 const bool two = o.kind == OP_ADD || o.kind == OP_SUB;
                 if ((pass == 0) != (o.kind == OP_MULC)) continue;
                 if (fused_away[i]) continue;
-                if (partner.count(i)) {  // words: slot of a + b, a, b, 4 | slot of a - b << 8
+                // an addition / subtraction with a folded run: that operand first, its doublings in bits 3-7 of the flags
+                int first = o.a, second = two ? o.b : 0;
+                if (two && run_of[o.b]) std::swap(first, second);  // additions only (see the folding rule above)
+                const uint32_t shifts = two ? (uint32_t)run_of[first] << 3 : 0u;
+                if (two && run_of[first]) S.fused_runs++;
+                if (partner.count(i)) {  // words: slot of a + b, a, b, 4 | shifts | slot of a - b << 16
                     S.words.push_back((uint32_t)slot[p.ops[partner[i]].dst]);
-                    S.words.push_back((uint32_t)slot[o.a]);
-                    S.words.push_back((uint32_t)slot[o.b]);
-                    S.words.push_back(4u | ((uint32_t)slot[o.dst] << 8));
+                    S.words.push_back((uint32_t)slot[eff(first)]);
+                    S.words.push_back((uint32_t)slot[eff(second)]);
+                    S.words.push_back(4u | shifts | ((uint32_t)slot[o.dst] << 16));
                     L.count++;
                     S.fused_pairs++;
                     continue;
                 }
                 S.words.push_back((uint32_t)slot[o.dst]);
-                S.words.push_back((uint32_t)slot[o.a]);
-                S.words.push_back(two ? (uint32_t)slot[o.b] : (uint32_t)o.b);
-                S.words.push_back(o.kind == OP_SUB ? 1u : o.kind == OP_DBL ? 2u : 0u);
+                S.words.push_back((uint32_t)slot[two ? eff(first) : o.a]);
+                S.words.push_back(two ? (uint32_t)slot[eff(second)] : (uint32_t)o.b);
+                S.words.push_back((o.kind == OP_SUB ? 1u : o.kind == OP_DBL ? 2u : 0u) | shifts);
                 L.count++;
             }
             if (L.count) S.launches.push_back(L);
@@ -639,14 +689,18 @@ inline std::vector<Fr> run_schedule_over_fr(const Schedule& S, const std::vector
             const uint32_t* w = &S.words[(size_t)(L.first + i) * 4];
             const Fr a = arena[w[1]];
             if (L.kind == OP_MULC) res[i] = mul(a, consts[w[2]]);
-            else if (w[3] & 4u) { res[i] = add(a, arena[w[2]]); res2[i] = sub(a, arena[w[2]]); }
             else if (w[3] & 2u) { Fr t = a; for (uint32_t k = 0; k < w[2]; k++) t = add(t, t); res[i] = t; }
-            else res[i] = (w[3] & 1u) ? sub(a, arena[w[2]]) : add(a, arena[w[2]]);
+            else {
+                Fr x = a, y = arena[w[2]];
+                for (uint32_t k = 0; k < ((w[3] >> 3) & 31u); k++) x = add(x, x);
+                if (w[3] & 4u) { res[i] = add(x, y); res2[i] = sub(x, y); }
+                else res[i] = (w[3] & 1u) ? sub(x, y) : add(x, y);
+            }
         }
         for (int i = 0; i < L.count; i++) {
             const uint32_t* w = &S.words[(size_t)(L.first + i) * 4];
             arena[w[0]] = res[i];
-            if (L.kind != OP_MULC && (w[3] & 4u)) arena[w[3] >> 8] = res2[i];
+            if (L.kind != OP_MULC && (w[3] & 4u)) arena[w[3] >> 16] = res2[i];
         }
     }
     return std::vector<Fr>(arena.begin() + n_in, arena.begin() + n_in + n_out);

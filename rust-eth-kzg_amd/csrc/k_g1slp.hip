@@ -21,35 +21,47 @@ __global__ __launch_bounds__(64, 2) void k_slp_mulc(JacQ* __restrict__ A, int st
     const JacQ src = A[(size_t)a * stride + lane];
     A[(size_t)dst * stride + lane] = mul_by_recoded(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta);
 }
-// additions, subtractions (flags & 1) and runs of doublings (flags & 2, b = count) of one step, one wave per operation
-// Blocks are dealt in blockIdx order, x fastest: x = lane group, y = operation, and the schedule lists a step's operations
-// longest first (g1_linmap.hpp: runs of up to 7 doublings cost 2.6 additions), so every group's long operations start first
-// and the launch ends on short ones.
+// one cheap operation of the program on one lane: flags & 2: a run of b doublings; otherwise an addition (flags & 1: subtraction;
+// flags & 4: a + b to dst AND a - b to slot flags >> 16) whose FIRST operand is doubled (flags >> 3) & 31 times in registers
+// before the second one is read -- the schedule folds a doubling run into its only consumer (g1_linmap.hpp: make_schedule)
+__device__ __forceinline__ void slp_cheap_op(JacQ* __restrict__ A, int stride, int lane, uint32_t dst, uint32_t a, uint32_t b, uint32_t fl) {
+    JacQ r = A[(size_t)a * stride + lane];
+    const uint32_t runs = (fl & 2u) ? b : (fl >> 3) & 31u;
+#pragma unroll 1
+    for (uint32_t k = 0; k < runs; k++) r = dbl(r);
+    bool degenerate = false;
+    if (!(fl & 2u)) {
+        if (fl & 4u) {  // the difference is stored before the sum is computed (curve29.hpp: add_sub_*)
+            const AddSubShared sh = add_sub_prepare(r, A[(size_t)b * stride + lane]);
+            degenerate = sh.degenerate;  // (an identity, a = +-b: both results are redone below; what is stored here is overwritten)
+            A[(size_t)(fl >> 16) * stride + lane] = add_sub_finish(sh, true);
+            r = add_sub_finish(sh, false);
+        } else {
+            r = add(r, A[(size_t)b * stride + lane], (fl & 1u) != 0);
+        }
+    }
+    A[(size_t)dst * stride + lane] = r;
+    // The exact slow path of a pair comes LAST, when nothing else is live (inside the branch above its operands cost the common
+    // path 33 spilled registers): the operands are read and doubled again.  Rare: all-zero / constant / two-valued blobs.
+    if (degenerate) {
+        asm volatile("" ::: "memory");
+        JacQ p2 = A[(size_t)a * stride + lane];
+#pragma unroll 1
+        for (uint32_t k = 0; k < runs; k++) p2 = dbl(p2);
+        const JacQ q2 = A[(size_t)b * stride + lane];
+        const JacQ d = add_slow(p2, q2, true);
+        A[(size_t)dst * stride + lane] = add_slow(p2, q2, false);
+        A[(size_t)(fl >> 16) * stride + lane] = d;
+    }
+}
+// additions, subtractions and runs of doublings of one step, one wave per operation.  Blocks are dealt in blockIdx order, x
+// fastest: x = lane group, y = operation, and the schedule lists a step's operations longest first (g1_linmap.hpp), so every
+// group's long operations start first and the launch ends on short ones.
 __global__ __launch_bounds__(64, 2) void k_slp_add(JacQ* __restrict__ A, int stride, const uint32_t* __restrict__ words) {
     const uint32_t* w = words + (size_t)blockIdx.y * 4;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
                    b = __builtin_amdgcn_readfirstlane(w[2]), fl = __builtin_amdgcn_readfirstlane(w[3]);
-    const int lane = blockIdx.x * 64 + threadIdx.x;
-    JacQ r = A[(size_t)a * stride + lane];
-    if (fl & 4u) {  // a step's a + b and a - b as one operation (curve29.hpp: add_sub_*); the difference is stored first
-        const JacQ q = A[(size_t)b * stride + lane];
-        const AddSubShared sh = add_sub_prepare(r, q);
-        if (sh.degenerate) {  // rare: the operands are read again instead of being kept in registers across the common path
-            asm volatile("" ::: "memory");
-            const JacQ p2 = A[(size_t)a * stride + lane], q2 = A[(size_t)b * stride + lane];
-            A[(size_t)(fl >> 8) * stride + lane] = add_slow(p2, q2, true);
-            r = add_slow(p2, q2, false);
-        } else {
-            A[(size_t)(fl >> 8) * stride + lane] = add_sub_finish(sh, true);
-            r = add_sub_finish(sh, false);
-        }
-    } else if (fl & 2u) {
-#pragma unroll 1
-        for (uint32_t k = 0; k < b; k++) r = dbl(r);
-    } else {
-        r = add(r, A[(size_t)b * stride + lane], (fl & 1u) != 0);
-    }
-    A[(size_t)dst * stride + lane] = r;
+    slp_cheap_op(A, stride, blockIdx.x * 64 + threadIdx.x, dst, a, b, fl);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -141,26 +153,7 @@ __global__ __launch_bounds__(64) void k_slp_walk(JacQ* __restrict__ A, int strid
         const uint32_t dst = __builtin_amdgcn_readfirstlane(op[0]), a = __builtin_amdgcn_readfirstlane(op[1]),
                        b = __builtin_amdgcn_readfirstlane(op[2]), fl = __builtin_amdgcn_readfirstlane(op[3]);
         const int lane = group * 64 + threadIdx.x;
-        JacQ r = A[(size_t)a * stride + lane];
-        if (fl & 4u) {
-            const JacQ q = A[(size_t)b * stride + lane];
-            const AddSubShared sh = add_sub_prepare(r, q);
-            if (sh.degenerate) {
-                asm volatile("" ::: "memory");
-                const JacQ p2 = A[(size_t)a * stride + lane], q2 = A[(size_t)b * stride + lane];
-                A[(size_t)(fl >> 8) * stride + lane] = add_slow(p2, q2, true);
-                r = add_slow(p2, q2, false);
-            } else {
-                A[(size_t)(fl >> 8) * stride + lane] = add_sub_finish(sh, true);
-                r = add_sub_finish(sh, false);
-            }
-        } else if (fl & 2u) {
-#pragma unroll 1
-            for (uint32_t k = 0; k < b; k++) r = dbl(r);
-        } else {
-            r = add(r, A[(size_t)b * stride + lane], (fl & 1u) != 0);
-        }
-        A[(size_t)dst * stride + lane] = r;
+        slp_cheap_op(A, stride, lane, dst, a, b, fl);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (threadIdx.x == 0) __hip_atomic_fetch_add(slp_done(w, group, level), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
