@@ -50,9 +50,10 @@ __global__ __launch_bounds__(256, 2) void k_msm_fixed(const Fr* __restrict__ sca
     __shared__ JacQ red[PER_BLOCK * W];
     const int tid = threadIdx.x;
     const int local = tid / W, w = tid % W;
-    const long m = (long)blockIdx.x * PER_BLOCK + local;  // MSM index = slice * n_groups + group
+    const long q_lin = (long)blockIdx.x * PER_BLOCK + local;  // linear index, GROUP-major: consecutive lanes / blocks are slices (blobs) of one group -- the same table rows
+    const long m = (q_lin % n_slices) * (long)n_groups + q_lin / n_slices;  // MSM index = slice * n_groups + group (the scalars' layout)
     const long total = (long)n_groups * n_slices;
-    const bool active = local < PER_BLOCK && m < total;
+    const bool active = local < PER_BLOCK && q_lin < total;
     MsmAcc acc = msm_acc_inf();
     int group = 0, slice = 0;
     if (active) {
@@ -139,8 +140,9 @@ __global__ __launch_bounds__(256, 2) void k_msm_fixed_chunked(const Fr* __restri
     __shared__ JacQ red[256];
     const int tid = threadIdx.x;
     const int chunk = tid & (S - 1);                                      // S is a power of two
-    const long m = ((long)blockIdx.x * 256 + tid) / S;                    // MSM index = slice * n_groups + group
-    const bool active = m < (long)n_groups * n_slices;
+    const long q_lin = ((long)blockIdx.x * 256 + tid) / S;  // linear index, GROUP-major: consecutive lanes / blocks are slices (blobs) of one group -- the same table rows
+    const long m = (q_lin % n_slices) * (long)n_groups + q_lin / n_slices;  // MSM index = slice * n_groups + group (the scalars' layout)
+    const bool active = q_lin < (long)n_groups * n_slices;
     const int Wc = (W + S - 1) / S;
     const int w0 = chunk * Wc, nw = (w0 + Wc <= W ? Wc : W - w0);        // this thread's windows [w0, w0 + nw); nw may be <= 0
     int slice = 0, group = 0;
