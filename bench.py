@@ -41,17 +41,23 @@ FP_MUL_PEAK_G = 78.1             # measured ceiling of the 14x29-bit Montgomery 
                                  # profiles/r1e_ubench_fp29.log (66.0 G/s at the 2 waves/SIMD the point kernels can hold)
 
 
-def fp_mul_eq_per_blob(window_bits, linmap, glv=False):
+def fp_mul_eq_per_blob(window_bits, linmap, glv=False, batch_lanes=2048):
     """Fp multiplication equivalents this build spends per blob, counted in multiply-add passes of 392 MACs
     (M = 1, squaring S = 301/392, fused pair a*b + c*d with one reduction F = 588/392):
     stage D: 128 MSMs x 64 bases x W windows XYZZ mixed additions (6M + 2S + F);
-    stages E+F as one compiled linear map (g1_linmap.hpp): `mulc` constant multiplications x (1 + 128 doublings
-    (2M + 3S + F) + ~43 + 7 additions (10M + 4S + F) + 8 beta-muls) + its additions and doublings."""
+    stages E+F as one compiled linear map (g1_linmap.hpp): `mulc` constant multiplications, each = the co-Z table of 8 odd
+    multiples (a doubling with update 2M + 4S + F, 7 co-Z additions 4M + 2S, 8 lifts to the common Z with the beta multiple
+    5M + S, 1M for the common Z) + 128 doublings (2M + 3S + F) + ~43 mixed additions (6M + 3S + F) + 1M; + its general
+    additions (10M + 4S + F) and doublings.  From 1024 lanes on, every subtraction of the FK20 program shares the work of the
+    addition of the same two values (g1_linmap.hpp: 548 pairs of its 3162 additions and subtractions): the second result of a
+    pair costs S + F."""
     w = 16 if glv else (255 + window_bits) // window_bits  # gathered additions per (scalar, base)
     S, F = 301 / 392, 588 / 392
-    madd, dbl, add = 6 + 2 * S + F, 2 + 3 * S + F, 10 + 4 * S + F
+    madd, dbl, add, madd_jac = 6 + 2 * S + F, 2 + 3 * S + F, 10 + 4 * S + F, 6 + 3 * S + F
     mulc, adds, dbls = linmap
-    return 128 * 64 * w * madd + mulc * (129 * dbl + 50 * add + 8) + adds * add + dbls * dbl
+    table = (dbl + S) + 7 * (4 + 2 * S) + 8 * (5 + S) + 1
+    pairs = 548 if (adds == 3162 and batch_lanes >= 1024) else 0
+    return (128 * 64 * w * madd + mulc * (table + 128 * dbl + 43 * madd_jac + 1) + (adds - pairs) * add + pairs * (S + F) + dbls * dbl)
 
 
 def synth_blobs(n, seed):
@@ -886,7 +892,7 @@ def main():
         # integer-VALU view (the bound that actually binds)
         mac_rate = value * 1.0e9 / 1e9  # reference-algorithm count: ~1.0e9 32x32 MACs per blob
         li = ctx.linmap_info()
-        mul_eq = fp_mul_eq_per_blob(ctx.window_bits(), li[:3] if li[0] else (642, 14 * 64 * 1.5, 0), ctx.glv_table())
+        mul_eq = fp_mul_eq_per_blob(ctx.window_bits(), li[:3] if li[0] else (642, 14 * 64 * 1.5, 0), ctx.glv_table(), args.blobs_per_gpu)
         mul_rate = value * mul_eq / 1e9
         out = {
             "metric": "blobs/sec compute_cells_and_kzg_proofs (4096-pt blob)",
