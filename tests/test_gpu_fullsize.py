@@ -89,9 +89,10 @@ def test_fallback_window_widths_match_oracle(oracle, monkeypatch, width):
         c2.close()
 
 
-@pytest.mark.parametrize("n", [512, 2048])
+@pytest.mark.parametrize("n", [321, 512, 2048])
 def test_compute_full_batches_device_resident(ctx, oracle, n):
-    """The bench step (2048 blobs) and config 4's whole batch (512) through the device entry point: data-in-first-half
+    """The bench step (2048 blobs), config 4's whole batch (512) and a chip-filling batch that is no multiple of the 64-lane
+    groups (321: the last block of every MSM group is one lane wide) through the device entry point: data-in-first-half
     invariant (prover.rs:251-275) on EVERY blob, 16 sampled blobs (first, last, both sides of every 64-lane group
     boundary that the sample hits, the planted edge cases) byte-for-byte against the oracle."""
     blobs = _random_blobs(n, 7000 + n)
