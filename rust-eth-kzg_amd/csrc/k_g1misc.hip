@@ -16,17 +16,49 @@ __global__ void k_g1_set_inf(JacQ* X, size_t n) {
 
 // Stage G+I: normalise and compress (lib.rs:56-104, serialization/src/lib.rs:84-86).
 // X[pos * stride + slice] -> out[(slice * n_pos + pos) * 48]
+// A thread normalises NB = 4 consecutive positions of its slice with ONE inversion (the reference's g1_batch_normalize,
+// lib.rs:56-104, is Montgomery's trick too): z0 z1 z2 z3 inverted once, the four inverses peeled off with 6 multiplications;
+// an identity (z = 0) takes part as z = 1 and is encoded as the identity afterwards.  The binary-GCD inversion is ~80 % of a
+// one-point normalisation, so this is ~3x fewer instructions per point; n_pos not a multiple of 4: the tail takes part as ones.
+// (NB = 1 for batches that leave the chip part empty: there the kernel lasts as long as one thread's chain.)
+template <int NB>
 __global__ __launch_bounds__(64) void k_g1_compress(const JacQ* __restrict__ X, uint8_t* __restrict__ out, int n_pos,
                                                     int stride, int n_slices) {
-    const int pos = blockIdx.x, slice = blockIdx.y * 64 + threadIdx.x;
+    const int pos0 = blockIdx.x * NB, slice = blockIdx.y * 64 + threadIdx.x;
     if (slice >= n_slices) return;
-    G1Affine a = to_affine(jac_from_jacq(X[(size_t)pos * stride + slice]));
-    uint8_t buf[48];
-    g1_compress(buf, a);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(out + ((size_t)slice * n_pos + pos) * 48);
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(buf);
+    G1Jac P[NB];
+    Fp pre[NB];  // pre[i] = z_0 ... z_i (identities and the tail count as 1)
+    bool inf[NB];
+#pragma unroll 1
+    for (int i = 0; i < NB; i++) {
+        inf[i] = true;
+        if (pos0 + i < n_pos) {
+            P[i] = jac_from_jacq(X[(size_t)(pos0 + i) * stride + slice]);
+            inf[i] = is_inf(P[i]);
+        }
+        const Fp z = inf[i] ? one<FpParams>() : P[i].z;
+        pre[i] = i ? mul(pre[i - 1], z) : z;
+    }
+    Fp acc = inv_fast(pre[NB - 1]);  // (z_0 ... z_3)^-1
+#pragma unroll 1
+    for (int i = NB - 1; i >= 0; i--) {
+        const Fp zi = i ? mul(acc, pre[i - 1]) : acc;  // z_i^-1
+        if (i) acc = mul(acc, inf[i] ? one<FpParams>() : P[i].z);
+        if (pos0 + i < n_pos) {
+            G1Affine a = aff_inf();
+            if (!inf[i]) {
+                const Fp zi2 = sqr(zi);
+                a.x = mul(P[i].x, zi2);
+                a.y = mul(P[i].y, mul(zi2, zi));
+            }
+            uint8_t buf[48];
+            g1_compress(buf, a);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(out + ((size_t)slice * n_pos + pos0 + i) * 48);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(buf);
 #pragma unroll
-    for (int i = 0; i < 12; i++) dst[i] = src[i];
+            for (int k = 0; k < 12; k++) dst[k] = src[k];
+        }
+    }
 }
 
 // sum over positions: out[slice] = sum_pos X[pos*stride + slice]   (final fold of the commitment MSM)
@@ -211,7 +243,10 @@ __global__ void k_test_recompress(const G1Affine* in, uint8_t* out, int n) {
 namespace launch {
 void g1_set_inf(void* X, size_t n, hipStream_t st) { k_g1_set_inf<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((JacQ*)X, n); }
 void g1_compress(const void* X, uint8_t* out, int n_pos, int stride, int n_slices, hipStream_t st) {
-    k_g1_compress<<<dim3(n_pos, stride / 64), 64, 0, st>>>((const JacQ*)X, out, n_pos, stride, n_slices);
+    // measured (128 positions): 2048 lanes 0.39 -> 0.22 ms with four positions per thread; 512 lanes 0.155 -> 0.21, 64 lanes 0.15 -> 0.21 ms
+    // (below two rounds of one-point waves the kernel lasts as long as one thread's chain)
+    if ((long)n_pos * stride >= 128L * 2048) k_g1_compress<4><<<dim3((n_pos + 3) / 4, stride / 64), 64, 0, st>>>((const JacQ*)X, out, n_pos, stride, n_slices);
+    else k_g1_compress<1><<<dim3(n_pos, stride / 64), 64, 0, st>>>((const JacQ*)X, out, n_pos, stride, n_slices);
 }
 void g1_sum_positions(void* X, int n_pos, int stride, int n_slices, hipStream_t st) {
     k_g1_sum_positions<<<stride / 64, 64, 0, st>>>((JacQ*)X, n_pos, stride, n_slices);
