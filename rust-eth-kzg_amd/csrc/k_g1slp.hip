@@ -6,7 +6,7 @@
 // one wave = one operation x 64 blobs, so the operation descriptor and, for multiplications, the digits of the public
 // constant are wave-uniform (scalar loads and scalar branches, no divergence).  Operations of one launch are mutually
 // independent and never write a slot that the same launch reads (linmap::make_schedule).
-// words: 4 per operation: dst slot, a slot, b (slot | number of doublings | constant id), flags (1 = subtract, 2 = doubling run, 4 = a + b to dst AND a - b to slot flags >> 8).
+// words: 4 per operation: dst slot, a slot, b (slot | number of doublings | constant id), flags (1 = subtract, 2 = doubling run, 4 = a + b to dst AND a - b to slot flags >> 16; bits 3-7 of an addition: doublings of operand a first).
 #include "engine.hpp"
 #include "g1_mulc.hpp"
 
@@ -65,8 +65,9 @@ __global__ __launch_bounds__(64, 2) void k_slp_add(JacQ* __restrict__ A, int str
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// One launch for a whole PHASE of the program's cheap operations (the 21 dependency levels in front of the constant
-// multiplications, the 20 behind them) instead of one launch per level.  A level-by-level sequence of launches leaves the
+// One launch for a whole PHASE of the program's cheap operations (the dependency levels in front of the constant
+// multiplications -- 11 since the doubling runs are folded into their consumers, 21 before -- and the 14 behind them) instead
+// of one launch per level.  A level-by-level sequence of launches leaves the
 // chip part empty at every level boundary (2,800 waves on 2,048 wave slots: a second round 37 % full, 41 times over) and,
 // for a single 64-blob lane group, pays a launch and a tail per level.  Lanes are blobs, so the dependency structure is
 // PER LANE GROUP: level l + 1 of a group needs level l of THAT group only.  The walker hands out operations by ticket:
