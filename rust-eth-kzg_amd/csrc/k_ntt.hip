@@ -41,7 +41,11 @@ __device__ __forceinline__ void ntt4096_dit_inverse(uint32_t* s, const Fr29* __r
             lds_store(s, i0, fr29_add(a, t));
             lds_store(s, i1, fr29_sub2r(a, t));
         }
-        __syncthreads();
+        // Butterfly q touches elements 2 (q - j) + j and + half: for half <= 64 a wave (q = 64 w .. 64 w + 63, and the same + 1024)
+        // stays inside its own 128 elements, so the layers half = 1 .. 32 need no block barrier -- a wave's LDS operations execute in
+        // program order -- and the first one stands after half = 64, whose results other waves read: 6 barriers instead of 12.
+        if (half >= 64) __syncthreads();
+        else __builtin_amdgcn_wave_barrier();
     }
 }
 // Forward transform: natural order -> bit-reversed order (position q holds X[brp(q)]), Cooley-Tukey butterflies with the
@@ -61,7 +65,10 @@ __device__ __forceinline__ void ntt4096_ct_forward(uint32_t* s, const Fr29* __re
             lds_store(s, i0, fr29_add(a, t));
             lds_store(s, i1, fr29_sub2r(a, t));
         }
-        __syncthreads();
+        // the layers half = 64 .. 1 are wave-local (see ntt4096_dit_inverse): the barrier after half = 128 covers their input, the
+        // one after half = 1 the output that the callers read across waves
+        if (half >= 128 || half == 1) __syncthreads();
+        else __builtin_amdgcn_wave_barrier();
     }
 }
 __device__ __forceinline__ Fr fr_words_of(const Fr29& canonical) {
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(256) void k_fk20_scalars(const Fr* __restrict__ coe
 #pragma unroll
         for (int l = 0; l < RL; l++) { sv[l][lane] = lo.v[l]; sv[l][64 + lane] = hi.v[l]; }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     // natural -> bit-reversed, Cooley-Tukey with bit-reversed twiddles (see ntt4096_ct_forward): < 2 + 14 = 16 r
     int log_m = 0;
     for (int half = 64; half >= 1; half >>= 1, log_m++) {
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(256) void k_fk20_scalars(const Fr* __restrict__ coe
         const Fr29 sum = fr29_add(x, t), d = fr29_sub2r(x, t);
 #pragma unroll
         for (int l = 0; l < RL; l++) { sv[l][i0] = sum.v[l]; sv[l][i1] = d.v[l]; }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();  // a wave owns its whole vector: its LDS operations execute in program order, no block barrier
     }
     // position q holds NTT[brp7(q)].  For a GLV window table the scalar leaves already split k = k1 + k2 lambda (what the separate
     // k_glv_split pass of round 2 did in place: 0.19 ms of reading and writing 0.5 GB at 2048 blobs)
