@@ -78,6 +78,16 @@ int main() {
                 if (!eq(want[k], got[k])) { bad++; if (bad < 5) printf("MISMATCH plan out %d\n", k); }
                 if (!eq(want[k], got2[k])) { bad++; if (bad < 5) printf("MISMATCH schedule out %d\n", k); }
             }
+            // every form of the schedule the engine can pick: with / without the fused a + b, a - b pairs, with / without the
+            // doubling runs folded into their consumers
+            for (int form = 0; form < 4; form++) {
+                const Schedule F = make_schedule(p, (form & 1) != 0, (form & 2) != 0);
+                if (it == 0) printf("  schedule form pairs=%d runs=%d: %zu launches, %ld fused pairs, %ld folded runs, %d slots\n", form & 1, (form >> 1) & 1,
+                                    F.launches.size(), F.fused_pairs, F.fused_runs, F.n_slots);
+                const auto got3 = run_schedule_over_fr(F, p.consts, 128, 128, in);
+                for (int k = 0; k < 128; k++)
+                    if (!eq(want[k], got3[k])) { bad++; if (bad < 5) printf("MISMATCH schedule form %d out %d\n", form, k); }
+            }
         }
     }
     printf("%d mismatches\n", bad);
