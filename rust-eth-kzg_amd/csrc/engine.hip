@@ -385,10 +385,13 @@ Engine::~Engine() {
     }
     if (build_stream_) hipStreamDestroy(build_stream_);
     host_pool_.reset();  // joins the helper threads before anything they might touch goes away
-    void* ptrs[] = {d_w8192_, d_w29_, d_naf_, d_srs_, d_fk_bases_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_circ_terms_,
-                    d_slp_naf_, d_slp_words_, d_slp_words_small_, d_slp_levels_};
+    void* ptrs[] = {d_w8192_, d_w29_, d_naf_, d_srs_, d_fk_bases_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_circ_terms_, d_slp_levels_};
     for (void* p : ptrs)
         if (p) hipFree(p);
+    for (SlpProgram& P : slp_prog_) {
+        if (P.d_words) hipFree(P.d_words);
+        if (P.d_naf && P.owns_naf) hipFree(P.d_naf);
+    }
     for (Work& w : work_) {
         void* dev[] = {w.coeffs, w.canon, w.scalars, w.X, w.status, w.dft_tmp, w.dft_prod, w.circ_table, w.slp_arena, w.slp_sync, w.d_in, w.d_cells, w.d_proofs};
         for (void* p : dev)
@@ -494,16 +497,30 @@ void Engine::init_constants() {
 
 // The two G1 transforms of the prover as one straight-line program of point operations (g1_linmap.hpp): built, checked
 // against the definition of the map over Fr (plan and scheduled slot program), constants recoded, uploaded.
-void Engine::init_linmap(const Fr8* w8192_mont) {
-    static_assert(sizeof(Fr8) == sizeof(Fr), "layout");
-    const Fr* w8192 = reinterpret_cast<const Fr*>(w8192_mont);
-    if (const char* e = getenv("ETH_KZG_AMD_G1FFT")) {  // tuning knob: "radix2" keeps the butterfly network of k_g1fft.hip
-        if (!strcmp(e, "radix2")) { use_linmap_ = false; return; }
+static linmap::Strategy slp_strategy(int id) {
+    linmap::Strategy s;
+    s.allow_toom8 = getenv("ETH_KZG_AMD_NO_TOOM8") == nullptr;
+    auto fixed = [&](int k4, int k8, int k16, int k32) {
+        s.tuned = false;
+        s.balanced_lincomb = true;
+        s.hankel_split = {{2, 2}, {4, k4}, {8, k8}, {16, k16}, {32, k32}};
+    };
+    // (tools/linmap_explore.cpp lists every assignment of splits with its multiplication count and the latency of its cheap
+    // levels; these are points of that Pareto front)
+    switch (id) {
+        case 2: fixed(2, 2, 2, 2); break;  // Karatsuba throughout: 712 multiplications, 13 levels of single additions
+        case 3: fixed(4, 2, 4, 2); break;  // 456 multiplications, 18 levels, at most two doublings in front of an addition
+        case 4: fixed(2, 2, 2, 4); break;  // 606 multiplications, 15 levels
+        case 5: fixed(4, 2, 4, 8); break;  // 372 multiplications, 19 levels (8-way split of the 32-point products only)
+        default: break;                    // tuned by operation count: 350 multiplications
     }
-    std::vector<Fr> w128(128);
-    for (int e = 0; e < 128; e++) w128[e] = w8192[64 * e];
+    return s;
+}
+void Engine::build_slp_program(int id) {
+    const Fr* w128p = reinterpret_cast<const Fr*>(w128_.data());
+    const std::vector<Fr> w128(w128p, w128p + 128);
     const bool verbose = getenv("ETH_KZG_AMD_TRACE") != nullptr;
-    linmap::Plan plan = linmap::build_fk20_proofs_plan(w128, /*allow_toom8=*/getenv("ETH_KZG_AMD_NO_TOOM8") == nullptr, verbose);
+    linmap::Plan plan = linmap::build_fk20_proofs_plan(w128, slp_strategy(id), verbose);
     {   // the executor leaves output p in arena slot 128 + p, and the proofs are wanted in bit-reversed FFT order
         std::vector<linmap::Ref> perm(128);
         for (int p = 0; p < 128; p++) {
@@ -513,9 +530,12 @@ void Engine::init_linmap(const Fr8* w8192_mont) {
         }
         plan.outputs = perm;
     }
-    const linmap::Schedule sched = linmap::make_schedule(plan);
+    // a + b / a - b pairs as ONE operation only in the large-batch schedule: for batches that leave the chip part empty a
+    // step lasts as long as its longest operation, and the fused pair is 15 % longer than an addition (64 blobs: 2.65 against
+    // 2.73 ms for the map; 2048 blobs: 16.15 against 16.0 ms -- fewer, fuller rounds win there)
+    const linmap::Schedule sched = linmap::make_schedule(plan, /*fuse_add_sub=*/id == SLP_TUNED_FUSED);
     // self-check: definition of the map vs the plan vs the scheduled slot program, over Fr
-    uint64_t st = 0x853c49e6748fea9bull;
+    uint64_t st = 0x853c49e6748fea9bull + (uint64_t)id;
     for (int it = 0; it < 2; it++) {
         std::vector<Fr> in(128);
         for (auto& v : in) {
@@ -531,46 +551,83 @@ void Engine::init_linmap(const Fr8* w8192_mont) {
             if (!eq(want[k], got1[p]) || !eq(want[k], got2[p])) throw std::runtime_error("FK20 proofs map: compiled program differs from its definition");
         }
     }
-    Fr lam = zero<FrParams>();
-    for (int i = 0; i < 4; i++) lam.v[i] = (uint32_t)(GLV_LAMBDA >> (32 * i));
-    const Fr lm = to_mont(lam);
-    constexpr int TWW = launch::TWIDDLE_WORDS;
-    std::vector<uint32_t> naf(plan.consts.size() * 2 * TWW);
-    for (size_t c = 0; c < plan.consts.size(); c++) recode_glv_wnaf(plan.consts[c], lm, &naf[c * 2 * TWW]);
-    HIPCK(hipMalloc(&d_slp_naf_, naf.size() * 4));
-    HIPCK(hipMemcpy(d_slp_naf_, naf.data(), naf.size() * 4, hipMemcpyHostToDevice));
-    HIPCK(hipMalloc(&d_slp_words_, sched.words.size() * 4));
-    HIPCK(hipMemcpy(d_slp_words_, sched.words.data(), sched.words.size() * 4, hipMemcpyHostToDevice));
-    slp_launches_.clear();
-    for (auto& L : sched.launches) slp_launches_.push_back(SlpLaunch{(int)L.kind, L.first, L.count});
-    {
-        // the same program with every a + b / a - b pair as two operations: for batches that leave the chip part empty a step
-        // lasts as long as its longest operation, and the fused pair is 15 % longer than an addition (64 blobs: 2.65 against
-        // 2.73 ms for the map; 2048 blobs: 16.15 against 16.0 ms -- fewer, fuller rounds win there)
-        const linmap::Schedule plain = linmap::make_schedule(plan, /*fuse_add_sub=*/false);
-        const auto got = linmap::run_schedule_over_fr(plain, plan.consts, 128, 128, std::vector<Fr>(128, lm));
-        const auto want = linmap::run_schedule_over_fr(sched, plan.consts, 128, 128, std::vector<Fr>(128, lm));
-        for (int k = 0; k < 128; k++)
-            if (!eq(got[k], want[k])) throw std::runtime_error("FK20 proofs map: the two schedules differ");
-        slp_slots_small_ = plain.n_slots;  // the arena is sized for the larger of the two (inputs and outputs sit at the same slots in both)
-        HIPCK(hipMalloc(&d_slp_words_small_, plain.words.size() * 4));
-        HIPCK(hipMemcpy(d_slp_words_small_, plain.words.data(), plain.words.size() * 4, hipMemcpyHostToDevice));
-        slp_launches_small_.clear();
-        for (auto& L : plain.launches) slp_launches_small_.push_back(SlpLaunch{(int)L.kind, L.first, L.count});
+    SlpProgram& P = slp_prog_[id];
+    if (id == SLP_TUNED && slp_prog_[SLP_TUNED_FUSED].ready) {  // same plan, same constants
+        P.d_naf = slp_prog_[SLP_TUNED_FUSED].d_naf;
+    } else {
+        Fr lam = zero<FrParams>();
+        for (int i = 0; i < 4; i++) lam.v[i] = (uint32_t)(GLV_LAMBDA >> (32 * i));
+        const Fr lm = to_mont(lam);
+        constexpr int TWW = launch::TWIDDLE_WORDS;
+        std::vector<uint32_t> naf(plan.consts.size() * 2 * TWW);
+        for (size_t c = 0; c < plan.consts.size(); c++) recode_glv_wnaf(plan.consts[c], lm, &naf[c * 2 * TWW]);
+        HIPCK(hipMalloc(&P.d_naf, naf.size() * 4));
+        P.owns_naf = true;
+        HIPCK(hipMemcpy(P.d_naf, naf.data(), naf.size() * 4, hipMemcpyHostToDevice));
+    }
+    HIPCK(hipMalloc(&P.d_words, sched.words.size() * 4));
+    HIPCK(hipMemcpy(P.d_words, sched.words.data(), sched.words.size() * 4, hipMemcpyHostToDevice));
+    P.launches.clear();
+    for (auto& L : sched.launches) P.launches.push_back(SlpLaunch{(int)L.kind, L.first, L.count});
+    P.n_slots = sched.n_slots;
+    P.info[0] = (int)plan.count(linmap::OP_MULC);
+    P.info[1] = (int)(plan.count(linmap::OP_ADD) + plan.count(linmap::OP_SUB));
+    P.info[2] = (int)plan.doublings();
+    P.info[3] = (int)sched.launches.size();
+    if (verbose) fprintf(stderr, "[linmap] program %d: %d multiplications, %d additions, %d doublings, %d launches, %d slots\n", id, P.info[0], P.info[1], P.info[2], P.info[3], P.n_slots);
+    P.ready = true;
+}
+const Engine::SlpProgram& Engine::slp_program(int id) {
+    std::lock_guard<std::mutex> lk(slp_build_mu_);
+    if (!slp_prog_[id].ready) build_slp_program(id);
+    return slp_prog_[id];
+}
+// Which compilation of the map serves a batch of `lanes` (a multiple of 64).  A constant multiplication is one wave per 64-blob
+// lane group and lasts 1.3 ms with a SIMD to itself, 2.3 ms when two share one (the chip has wave_slots_ / 2 SIMDs), and from
+// two waves per SIMD on the launch is throughput (1.2 us per wave): so the multiplication count M is chosen so that M x groups
+// stays within the SIMDs (<= 2 groups) or the wave slots (<= 5 groups), and within that the program with the shallowest cheap
+// levels wins (tools/linmap_explore.cpp; measured per group count in profiles/r4_linmap_variants.log).
+int Engine::pick_slp_program(int lanes) const {
+    if (slp_force_ >= 0) return slp_force_;
+    const int groups = lanes / 64, simds = wave_slots_ / 2;
+    if (712 * groups <= simds) return SLP_KARATSUBA;
+    if (456 * groups <= simds) return SLP_DEPTH_456;
+    if (606 * groups <= wave_slots_) return SLP_DEPTH_606;
+    if (456 * groups <= wave_slots_) return SLP_DEPTH_456;
+    if (372 * groups <= wave_slots_) return SLP_DEPTH_372;
+    return lanes >= slp_fuse_min_ ? SLP_TUNED_FUSED : SLP_TUNED;
+}
+void Engine::init_linmap(const Fr8* w8192_mont) {
+    static_assert(sizeof(Fr8) == sizeof(Fr), "layout");
+    if (const char* e = getenv("ETH_KZG_AMD_G1FFT")) {  // tuning knob: "radix2" keeps the butterfly network of k_g1fft.hip
+        if (!strcmp(e, "radix2")) { use_linmap_ = false; return; }
+    }
+    if (const char* e = getenv("ETH_KZG_AMD_SLP_PROGRAM")) {  // tuning knob / tests: one compilation of the map at every batch size
+        const int v = atoi(e);
+        if (v >= 0 && v < SLP_COUNT) slp_force_ = v;
+    }
+    w128_.resize(128);
+    for (int e = 0; e < 128; e++) w128_[e] = w8192_mont[64 * e];
+    build_slp_program(SLP_TUNED_FUSED);
+    build_slp_program(SLP_TUNED);
+    const SlpProgram& fused = slp_prog_[SLP_TUNED_FUSED];
+    {   // the two schedules of the tuned plan must agree (the arena is sized per program; inputs and outputs sit at the same slots in all)
+        if (fused.info[0] != slp_prog_[SLP_TUNED].info[0]) throw std::runtime_error("FK20 proofs map: the two schedules differ");
     }
     // phases for the ticket walker (k_g1slp.hip: k_slp_walk): every maximal run of cheap launches becomes ONE launch
     {
+        const auto& launches = fused.launches;
         std::vector<int> lf, lc;
         slp_phases_.clear();
-        for (size_t i = 0; i < slp_launches_.size();) {
-            if (slp_launches_[i].kind == (int)linmap::OP_MULC) { slp_phases_.push_back(SlpPhase{(int)i, -1, 0, 0, 0}); i++; continue; }
+        for (size_t i = 0; i < launches.size();) {
+            if (launches[i].kind == (int)linmap::OP_MULC) { slp_phases_.push_back(SlpPhase{(int)i, -1, 0, 0, 0}); i++; continue; }
             SlpPhase ph{(int)i, (int)lf.size(), 0, 0, 0};
-            while (i < slp_launches_.size() && slp_launches_[i].kind != (int)linmap::OP_MULC) {
-                lf.push_back(slp_launches_[i].first);
-                lc.push_back(slp_launches_[i].count);
+            while (i < launches.size() && launches[i].kind != (int)linmap::OP_MULC) {
+                lf.push_back(launches[i].first);
+                lc.push_back(launches[i].count);
                 ph.n_levels++;
-                ph.max_count = std::max(ph.max_count, slp_launches_[i].count);
-                ph.total_ops += slp_launches_[i].count;
+                ph.max_count = std::max(ph.max_count, launches[i].count);
+                ph.total_ops += launches[i].count;
                 i++;
             }
             slp_phases_.push_back(ph);
@@ -589,12 +646,8 @@ void Engine::init_linmap(const Fr8* w8192_mont) {
         slp_walk_ = false;
         if (const char* e = getenv("ETH_KZG_AMD_SLP_WALK")) slp_walk_ = atoi(e) != 0;
     }
-    slp_slots_ = std::max(sched.n_slots, slp_slots_small_);
-    slp_mulc_ = (int)sched.mulc_total;
-    slp_info_[0] = (int)plan.count(linmap::OP_MULC);
-    slp_info_[1] = (int)(plan.count(linmap::OP_ADD) + plan.count(linmap::OP_SUB));
-    slp_info_[2] = (int)plan.doublings();
-    slp_info_[3] = slp_walk_ ? (int)slp_phases_.size() : (int)sched.launches.size();
+    for (int i = 0; i < 3; i++) slp_info_[i] = fused.info[i];
+    slp_info_[3] = slp_walk_ ? (int)slp_phases_.size() : fused.info[3];
     const Fr h = inv(fr_from_u64(2));
     memcpy(&half_, &h, 32);
     use_linmap_ = true;
@@ -1189,8 +1242,10 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
     // the MSM outputs halved instead of divided by 128 and in natural Fourier order in the first 128 arena slots
     const bool linmap_mode = use_linmap_ && n > circ_max_;
     void* X = w.X;
+    const SlpProgram* prog = nullptr;
     if (linmap_mode) {
-        const size_t need = (size_t)slp_slots_ * bp * launch::SIZEOF_JACQ;
+        prog = &slp_program(slp_walk_ ? (int)SLP_TUNED_FUSED : pick_slp_program(bp));
+        const size_t need = (size_t)prog->n_slots * bp * launch::SIZEOF_JACQ;
         if (need > w.slp_arena_bytes) {
             if (w.slp_arena) { HIPCK(hipStreamSynchronize(st)); HIPCK(hipFree(w.slp_arena)); w.slp_arena = nullptr; }
             HIPCK(hipMalloc(&w.slp_arena, need));
@@ -1221,10 +1276,10 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
             int walk = 0;
             for (auto& ph : slp_phases_) {
                 if (ph.level0 < 0) {
-                    const SlpLaunch& L = slp_launches_[ph.launch0];
-                    launch::g1_slp_launch(L.kind, w.slp_arena, bp, (const uint32_t*)d_slp_words_ + (size_t)L.first * 4, L.count, d_slp_naf_, beta_, st);
+                    const SlpLaunch& L = prog->launches[ph.launch0];
+                    launch::g1_slp_launch(L.kind, w.slp_arena, bp, (const uint32_t*)prog->d_words + (size_t)L.first * 4, L.count, prog->d_naf, beta_, st);
                 } else {
-                    launch::g1_slp_walk(w.slp_arena, bp, (const uint32_t*)d_slp_words_, (const int*)d_slp_levels_ + ph.level0,
+                    launch::g1_slp_walk(w.slp_arena, bp, (const uint32_t*)prog->d_words, (const int*)d_slp_levels_ + ph.level0,
                                         (const int*)d_slp_levels_ + slp_level_total_ + ph.level0, ph.n_levels, ph.max_count, ph.total_ops,
                                         w.slp_sync + (size_t)(walk & 1) * w.slp_sync_ints, wave_slots_, st);
                     if (getenv("ETH_KZG_AMD_SLP_DEBUG")) {  // debugging aid: the walker's counters after the phase
@@ -1248,12 +1303,9 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
                 n_launches++;
             }
         } else {
-            const bool fused = bp >= slp_fuse_min_;
-            const void* words = fused ? d_slp_words_ : d_slp_words_small_;
-            const auto& launches = fused ? slp_launches_ : slp_launches_small_;
-            for (auto& L : launches)
-                launch::g1_slp_launch(L.kind, w.slp_arena, bp, (const uint32_t*)words + (size_t)L.first * 4, L.count, d_slp_naf_, beta_, st);
-            n_launches = (int)launches.size();
+            for (auto& L : prog->launches)
+                launch::g1_slp_launch(L.kind, w.slp_arena, bp, (const uint32_t*)prog->d_words + (size_t)L.first * 4, L.count, prog->d_naf, beta_, st);
+            n_launches = (int)prog->launches.size();
         }
         mark_end(mk3, n_launches, st);
         const int mk4 = mark_begin(ST_COMPRESS, st);

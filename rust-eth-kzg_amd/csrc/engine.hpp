@@ -362,21 +362,37 @@ private:
     int pip_shift_min_ = 1;
     int circ_T_ = 0, circ_per_lane_ = 0, circ_max_ = 8;  // measured cross-over with the compiled linear map (2.8 ms flat up to 64 blobs): 8 blobs 2.5 vs 2.9 ms, 12 blobs 3.2 vs 2.9
     Fr8 seg_shift_[3];  // 2^32, 2^64, 2^96 in Montgomery form
-    // the two G1 transforms as one compiled linear map (g1_linmap.hpp, k_g1slp.hip): launches, constants, slot arena
+    // the two G1 transforms as one compiled linear map (g1_linmap.hpp, k_g1slp.hip).  SEVERAL compilations of the same map:
+    // the throughput optimum (fewest point operations: 350 constant multiplications, 8-way Toom-Cook) for batches that fill
+    // the chip, and depth-optimised ones for batches that do not -- there a dependency level lasts as long as its longest
+    // operation and a constant multiplication has a SIMD to itself as long as waves <= SIMDs, so more multiplications with
+    // shallower, doubling-free evaluation / interpolation trees (Karatsuba: 712 multiplications, 13 levels of single
+    // additions instead of 25 levels with runs of up to 7 doublings) are faster.  Picked per launch by the number of 64-blob
+    // lane groups (pick_slp_program); built on first use except the two tuned schedules.
     struct SlpLaunch { int kind, first, count; };
-    std::vector<SlpLaunch> slp_launches_;
+    enum SlpProgramId { SLP_TUNED_FUSED = 0, SLP_TUNED = 1, SLP_KARATSUBA = 2, SLP_DEPTH_456 = 3, SLP_DEPTH_606 = 4, SLP_DEPTH_372 = 5, SLP_COUNT = 6 };
+    struct SlpProgram {
+        std::vector<SlpLaunch> launches;
+        void *d_words = nullptr, *d_naf = nullptr;  // d_naf may be shared with another program of the same plan (owns_naf)
+        bool owns_naf = false, ready = false;
+        int n_slots = 0;
+        int info[4] = {0, 0, 0, 0};  // constant multiplications, additions, doublings, launches
+    };
+    SlpProgram slp_prog_[SLP_COUNT];
+    std::mutex slp_build_mu_;
+    std::vector<Fr8> w128_;                       // omega_128^e, kept for the programs built on first use
+    const SlpProgram& slp_program(int id);        // builds it if need be (engine.hip: build_slp_program)
+    void build_slp_program(int id);
+    int pick_slp_program(int lanes) const;        // lanes = blobs rounded up to 64
+    int slp_force_ = -1;                          // ETH_KZG_AMD_SLP_PROGRAM: this program at every batch size (tests, A/B runs)
     // a phase = one multiplication launch (level0 < 0) or a run of cheap dependency levels executed by ONE ticket-walking launch
     struct SlpPhase { int launch0, level0, n_levels, max_count, total_ops; };
     std::vector<SlpPhase> slp_phases_;
     void* d_slp_levels_ = nullptr;  // int[2][slp_level_total_]: first operation / operation count of every cheap level
     int slp_level_total_ = 0, slp_max_levels_ = 0;
     bool slp_walk_ = true;
-    void *d_slp_words_ = nullptr, *d_slp_naf_ = nullptr;
-    void* d_slp_words_small_ = nullptr;          // the schedule without fused add / sub pairs (batches below slp_fuse_min_ lanes)
-    std::vector<SlpLaunch> slp_launches_small_;
     int slp_fuse_min_ = 1024;  // measured: 512 blobs 5.47 (plain) against 5.55 ms (fused), 2048 blobs 16.13 against 15.93 ms
-    int slp_slots_ = 0, slp_slots_small_ = 0, slp_mulc_ = 0;
-    int slp_info_[4] = {0, 0, 0, 0};  // constant multiplications, additions, doublings, launches of the compiled map
+    int slp_info_[4] = {0, 0, 0, 0};  // constant multiplications, additions, doublings, launches of the tuned program
     bool use_linmap_ = false;
     Fr8 half_;  // 1/2 in Montgomery form: the scaling folded into the MSM scalars in linear-map mode
 

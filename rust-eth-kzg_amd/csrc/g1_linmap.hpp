@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <map>
 #include <stdexcept>
 #include <tuple>
@@ -147,6 +148,32 @@ public:
         if (pending) acc = dbl(acc, pending);
         return acc;
     }
+    // the same sum as a balanced tree when every coefficient is +-2^e: the terms sorted by exponent, halves summed relative to
+    // their own lowest exponent, joined by ONE run of doublings and one addition per tree level -- depth log2(terms) instead
+    // of one dependent (run + addition) per term (the Horner form above).  For batches that leave the chip part empty, where
+    // a dependency level lasts as long as its longest operation.  Other coefficients fall back to the bit-plane form.
+    Ref lincomb_balanced(const std::vector<std::pair<Ref, int64_t>>& terms) {
+        struct T { Ref r; int e; };
+        std::vector<T> t;
+        for (auto& pr : terms) {
+            if (pr.first.zero() || pr.second == 0) continue;
+            const uint64_t m = pr.second < 0 ? (uint64_t)(-pr.second) : (uint64_t)pr.second;
+            if (m & (m - 1)) return lincomb(terms);
+            int e = 0;
+            while (!((m >> e) & 1)) e++;
+            t.push_back(T{pr.second < 0 ? negate(pr.first) : pr.first, e});
+        }
+        if (t.empty()) return Ref{};
+        std::stable_sort(t.begin(), t.end(), [](const T& a, const T& b) { return a.e < b.e; });
+        // sum of t[lo..hi) divided by 2^(t[lo].e)
+        std::function<Ref(int, int)> rec = [&](int lo, int hi) -> Ref {
+            if (hi - lo == 1) return t[lo].r;
+            const int mid = (lo + hi) / 2;
+            const Ref a = rec(lo, mid), b = rec(mid, hi);
+            return add(dbl(b, t[mid].e - t[lo].e), a);
+        };
+        return dbl(rec(0, (int)t.size()), t[0].e);
+    }
     Plan take(const std::vector<Ref>& outputs) {
         plan_.outputs = outputs;
         return std::move(plan_);
@@ -224,6 +251,8 @@ public:
     std::map<int, int> hankel_split;
     std::map<int, bool> root_split;
     bool allow_toom8 = true;
+    bool balanced_lincomb = false;  // evaluation / interpolation sums as balanced trees (Builder::lincomb_balanced)
+    Ref sum(Builder& B, const std::vector<std::pair<Ref, int64_t>>& t) const { return balanced_lincomb ? B.lincomb_balanced(t) : B.lincomb(t); }
 
     // y_i = sum_j h[i + j] x[j],  i, j < n;  h has 2n - 1 entries
     std::vector<Ref> hankel(Builder& B, const std::vector<Ref>& x, const std::vector<Fr>& h) {
@@ -247,11 +276,11 @@ public:
                 if (partner[r] < 0) {
                     std::vector<std::pair<Ref, int64_t>> t;
                     for (int J = 0; J < k; J++) t.emplace_back(x[J * m + i], ipow(pts[r].a, J) * ipow(pts[r].b, k - 1 - J));
-                    X[r][i] = B.lincomb(t);
+                    X[r][i] = sum(B, t);
                 } else {
                     std::vector<std::pair<Ref, int64_t>> ev, od;
                     for (int J = 0; J < k; J++) (J & 1 ? od : ev).emplace_back(x[J * m + i], ipow(pts[r].a, J) * ipow(pts[r].b, k - 1 - J));
-                    const Ref e = B.lincomb(ev), o = B.lincomb(od);
+                    const Ref e = sum(B, ev), o = sum(B, od);
                     X[r][i] = B.add(e, o);
                     X[partner[r]][i] = B.sub(e, o);
                 }
@@ -284,7 +313,7 @@ public:
                     if (partner[r] < 0) t.emplace_back(Z[r][i], coef);
                     else t.emplace_back((I & 1) ? Dm[r] : S[r], coef);
                 }
-                y[I * m + i] = B.lincomb(t);
+                y[I * m + i] = sum(B, t);
             }
         }
         return y;
@@ -426,9 +455,18 @@ inline std::vector<Fr> run_over_fr(const Plan& p, const std::vector<Fr>& in) {
     return out;
 }
 
+// How a plan is built: the split of a Hankel product per size, whether a twisted-cyclic product is first split over Fr, and the
+// shape of the small-integer sums.  tuned = false: the tables below are used as given (sizes without an entry: 2-way, no root
+// split); tuned = true: Compiler::tune fills them by operation count (the throughput optimum for batches that fill the chip).
+struct Strategy {
+    bool tuned = true, allow_toom8 = true;
+    std::map<int, int> hankel_split;
+    std::map<int, bool> root_split;
+    bool balanced_lincomb = false;
+};
 // The FK20 map: in[j] = y_j / 2 (Fourier index j < 128, natural order), out[k] = proof at FFT index k (natural order).
 // w128[e] = omega_128^e in Montgomery form, e < 128.
-inline Plan build_fk20_proofs_plan(const std::vector<Fr>& w128, bool allow_toom8 = true, bool verbose = false) {
+inline Plan build_fk20_proofs_plan(const std::vector<Fr>& w128, const Strategy& strat, bool verbose = false) {
     if (w128.size() != 128) throw std::runtime_error("w128: need the 128 powers");
     auto sqrt_of = [&](const Fr& z, Fr& s) {  // z = w^e with e even  ->  s = w^(e/2)
         for (int e = 0; e < 128; e += 2)
@@ -436,8 +474,10 @@ inline Plan build_fk20_proofs_plan(const std::vector<Fr>& w128, bool allow_toom8
         return false;
     };
     Compiler C;
-    C.allow_toom8 = allow_toom8;
-    C.tune(32);
+    C.allow_toom8 = strat.allow_toom8;
+    C.balanced_lincomb = strat.balanced_lincomb;
+    if (strat.tuned) C.tune(32);
+    else { C.hankel_split = strat.hankel_split; C.root_split = strat.root_split; }
     Builder B(128);
     const Fr one_ = one<FrParams>(), inv32 = inv(fr_small(32));
     auto m_of = [&](int e) {  // (1/32) / (1 - w^e), e odd
@@ -467,6 +507,11 @@ inline Plan build_fk20_proofs_plan(const std::vector<Fr>& w128, bool allow_toom8
                 p.count(OP_ADD) + p.count(OP_SUB), p.doublings());
     }
     return p;
+}
+inline Plan build_fk20_proofs_plan(const std::vector<Fr>& w128, bool allow_toom8 = true, bool verbose = false) {
+    Strategy s;
+    s.allow_toom8 = allow_toom8;
+    return build_fk20_proofs_plan(w128, s, verbose);
 }
 
 // the definition the plan is checked against: h = first 64 of IDFT_128(2 in) (with 1/128), out = DFT_128(h || 0)

@@ -90,6 +90,33 @@ int main() {
             }
         }
     }
+    // the depth-optimised compilations the engine uses for batches that do not fill the chip (engine.hip: slp_strategy): fixed
+    // splits per size, small-integer sums as balanced trees.  Each against the definition, as a plan and as its slot program.
+    const int fixed_splits[][4] = {{2, 2, 2, 2}, {4, 2, 4, 2}, {2, 2, 2, 4}, {4, 2, 4, 8}, {4, 4, 4, 4}, {4, 8, 8, 8}};
+    for (auto& f : fixed_splits) {
+        for (int balanced = 0; balanced < 2; balanced++) {
+            Strategy st_;
+            st_.tuned = false;
+            st_.balanced_lincomb = balanced != 0;
+            st_.hankel_split = {{2, 2}, {4, f[0]}, {8, f[1]}, {16, f[2]}, {32, f[3]}};
+            Plan p = build_fk20_proofs_plan(w, st_);
+            Schedule S = make_schedule(p, false);
+            if (balanced) printf("fixed splits 4->%d 8->%d 16->%d 32->%d, balanced sums: %ld mulc, %ld add/sub, %ld doublings, %zu launches, %d slots\n", f[0], f[1], f[2], f[3],
+                                 p.count(OP_MULC), p.count(OP_ADD) + p.count(OP_SUB), p.doublings(), S.launches.size(), S.n_slots);
+            for (int it = 0; it < 2; it++) {
+                std::vector<Fr> in(128);
+                for (auto& v : in) v = rnd_fr();
+                if (it == 1) for (int j = 0; j < 128; j++) in[j] = j == 77 ? one<FrParams>() : zero<FrParams>();
+                auto want = fk20_proofs_map_by_definition(w, in);
+                auto got = run_over_fr(p, in);
+                auto got2 = run_schedule_over_fr(S, p.consts, 128, 128, in);
+                for (int k = 0; k < 128; k++) {
+                    if (!eq(want[k], got[k])) { bad++; if (bad < 5) printf("MISMATCH fixed plan out %d\n", k); }
+                    if (!eq(want[k], got2[k])) { bad++; if (bad < 5) printf("MISMATCH fixed schedule out %d\n", k); }
+                }
+            }
+        }
+    }
     printf("%d mismatches\n", bad);
     return bad != 0;
 }

@@ -274,6 +274,7 @@ def test_ticket_walking_executor_matches_oracle(oracle, monkeypatch):
     per-(lane group, level) completion counters, agent-scope release / acquire) instead of one launch per dependency level.
     A measured negative (profiles/r3_slp_walk_ab.log) kept as an option: same bytes at one lane group, several, and a ragged count."""
     monkeypatch.setenv("ETH_KZG_AMD_SLP_WALK", "1")
+    _torch_first()
     c2 = kzg.DASContext(use_precomp=True)
     try:
         assert c2.linmap_info()[3] == 3  # two walks around the one multiplication launch
@@ -287,10 +288,31 @@ def test_ticket_walking_executor_matches_oracle(oracle, monkeypatch):
         c2.close()
 
 
+@pytest.mark.parametrize("program", [0, 1, 2, 3, 4, 5])
+def test_every_compilation_of_the_linear_map_matches_oracle(oracle, monkeypatch, program):
+    """ETH_KZG_AMD_SLP_PROGRAM forces ONE compilation of the FK20 proofs map at every batch size (the engine picks by the number
+    of 64-blob lane groups: the operation-count optimum with 350 constant multiplications when the chip is full, depth-optimised
+    ones with 372 / 456 / 606 / 712 multiplications and shallower cheap levels when it is not; g1_linmap.hpp: Strategy).
+    Same bytes from each of them at one lane group, two, and a ragged count, incl. the all-zero blob (identity everywhere)."""
+    monkeypatch.setenv("ETH_KZG_AMD_SLP_PROGRAM", str(program))
+    _torch_first()
+    c2 = kzg.DASContext(use_precomp=True)
+    try:
+        for n in (9, 64, 130):
+            blobs = _random_blobs(n, 900 + n)
+            blobs[2] = 0
+            st, cells, proofs = _compute_on_device(c2, blobs)
+            assert st == [0] * n
+            _check_sample_against_oracle(oracle, blobs, cells, proofs, [0, 2, min(63, n - 1), n - 1])
+    finally:
+        c2.close()
+
+
 def test_radix2_transform_schedule_still_matches_oracle(oracle, monkeypatch):
     """ETH_KZG_AMD_G1FFT=radix2 keeps the butterfly network (and the direct 8 x 16 form below 129 blobs) instead of the
     compiled linear map: same bytes."""
     monkeypatch.setenv("ETH_KZG_AMD_G1FFT", "radix2")
+    _torch_first()
     c2 = kzg.DASContext(use_precomp=True)
     try:
         for n in (70, 200):
