@@ -267,6 +267,8 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
     _mark("side configs: device rates")
     r64, ms64, _ = dev_rate(min(64, B))
     out["config4_per_gpu_share_64_blobs"] = {"blobs_per_s": round(r64), "ms": round(ms64, 2), "form": "device-resident"}
+    r256, ms256, _ = dev_rate(min(256, B))
+    out["batch_256_blobs_on_one_gpu"] = {"blobs_per_s": round(r256), "ms": round(ms256, 2), "form": "device-resident"}
     r512, ms512, _ = dev_rate(min(512, B))
     out["config4_512_blobs_on_one_gpu"] = {"blobs_per_s": round(r512), "ms": round(ms512, 2), "form": "device-resident"}
     rc, msc, _ = dev_rate(B, "cells")
@@ -598,6 +600,17 @@ def strong_configs(ctx, sharding, torch, dist, dev, world, rank, lib_comm, strea
     return out
 
 
+def kernel_sources_hash():
+    """SHA-256 over the sources of the dominant kernel (the GLV MSM and the field / curve headers it is made of): the key that
+    ties a committed PMC profile to the build it was collected on (tools/pmc_summary.py stores it, bench.py compares it)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("k_msm_glv.inc", "k_msm_glv16.hip", "curve29.hpp", "fp29.hpp", "fp29_mac.hpp", "fp29_consts.hpp", "glv.hpp", "Makefile"):
+        with open(os.path.join(ROOT, "rust-eth-kzg_amd", "csrc", f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def _free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
@@ -705,6 +718,11 @@ def main():
     record_fd = os.dup(1)
     os.dup2(2, 1)
 
+    rccl_log = None
+    if world > 1:  # RCCL's own warnings go to a file per rank, so that a failed communicator can be explained in the record
+        rccl_log = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"kzg_bench_rccl_rank{rank}_{os.getpid()}.log")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
     import torch
     import torch.distributed as dist
 
@@ -734,12 +752,32 @@ def main():
     first_out = ctx.compute_cells_and_kzg_proofs(first_blob)
     t_ctx_first = time.perf_counter() - t_ctx0
     _mark("first result computed")
+    # While the helper thread allocates (pieces of < 1 GB) and builds the wide tables, a caller keeps working: one
+    # compute_cells_and_kzg_proofs through the reference's entry point every 5 ms.  How long the slowest of them took is the
+    # stall a service sees during start-up (round 3: one 206 GB hipMalloc froze every HIP call of the process for 2-4.4 s).
+    waits, half_s, all_groups_s = [], None, None
+    while ctx.tables_ready(0) == 0:
+        t1 = time.perf_counter()
+        out_k = ctx.compute_cells_and_kzg_proofs(first_blob)
+        waits.append(time.perf_counter() - t1)
+        assert out_k == first_out, "a call made while the wide tables were being built returned different bytes"
+        g = ctx.table_groups_ready()
+        if half_s is None and (g >= 64 or ctx.window_bits() != start_width):
+            half_s = time.perf_counter() - t_ctx0
+        time.sleep(0.005)
     tables_state = ctx.tables_ready(-1)
     t_ctx = time.perf_counter() - t_ctx0
     _mark("wide tables ready")
     assert ctx.compute_cells_and_kzg_proofs(first_blob) == first_out, "start tables and wide tables disagree"
+    ws = sorted(waits)
     ctx_times = {"constructor_returns_s": round(t_ctx_new, 3), "first_result_s": round(t_ctx_first, 3), "wide_tables_in_use_s": round(t_ctx, 2),
-                 "start_table_window_bits": start_width, "final_state": tables_state}
+                 "half_of_the_fk20_groups_on_the_wide_table_s": round(half_s, 2) if half_s is not None else None,
+                 "start_table_window_bits": start_width, "final_state": tables_state,
+                 "calls_during_build": {"calls": len(ws), "calls_per_s": round(len(ws) / max(1e-9, t_ctx - t_ctx_first), 1) if ws else None,
+                                        "longest_ms": round(ws[-1] * 1e3, 2) if ws else None, "p99_ms": round(ws[int(0.99 * (len(ws) - 1))] * 1e3, 2) if ws else None,
+                                        "median_ms": round(ws[len(ws) // 2] * 1e3, 2) if ws else None,
+                                        "what": "eth_kzg_compute_cells_and_kzg_proofs of one blob every 5 ms from the calling thread while the helper thread "
+                                                "allocates and builds ~250 GB of window tables; bytes checked against the first result every time"}}
 
     B = args.blobs_per_gpu
     blobs_h = synth_blobs(B, seed=0x4B5A47 + rank)
@@ -765,6 +803,13 @@ def main():
             if args.exchange == "library-required":
                 raise
             comm_error = str(e)  # never silent: stderr now, config.exchange / config.library_communicator_error in the record
+            try:  # what RCCL itself had to say (NCCL_DEBUG=WARN into NCCL_DEBUG_FILE, set above)
+                with open(os.environ.get("NCCL_DEBUG_FILE", rccl_log or ""), "r", errors="replace") as fh:
+                    tail = fh.read()[-1500:].strip()
+                if tail:
+                    comm_error += " | RCCL log: " + " / ".join(tail.splitlines()[-8:])
+            except OSError:
+                pass
             if rank == 0:
                 print(f"bench.py: the library's RCCL communicator is unavailable ({comm_error}); the all-gather runs on torch.distributed's",
                       file=sys.stderr, flush=True)
@@ -823,10 +868,41 @@ def main():
     dt = time.perf_counter() - t0
     stages = ctx.get_stage_times()
     ctx.set_profiling(False)
+    dt_rank = dt
+    per_rank_ms, gather_ms = None, None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         hz.all_reduce(t, dist.ReduceOp.MAX)
         dt = float(t.item())
+        # one line must be enough to diagnose a bad scaling curve: every rank's own time per step, and the all-gather alone
+        mine = torch.tensor([dt_rank / args.steps * 1e3], dtype=torch.float64, device=dev)
+        allr = torch.empty(world, dtype=torch.float64, device=dev)
+        hz.all_gather_into(allr, mine)
+        per_rank_ms = [round(float(v), 3) for v in allr.cpu()]
+        fence()
+        tg = time.perf_counter()
+        for _ in range(args.steps):
+            with torch.cuda.stream(stream):
+                if lib_comm:
+                    sharding.all_gather_proofs(ctx, d_proofs, d_all_proofs, stream)
+                else:
+                    hz.all_gather_into(d_all_proofs, d_proofs)
+        fence()
+        tgm = torch.tensor([(time.perf_counter() - tg) / args.steps * 1e3], dtype=torch.float64, device=dev)
+        hz.all_reduce(tgm, dist.ReduceOp.MAX)
+        gather_ms = round(float(tgm.item()), 3)
+    # the same K steps once more WITHOUT the per-stage events (they also keep the small-batch cells kernel on the main stream):
+    # what the instrumentation of the timed region costs, stated instead of assumed
+    fence()
+    t0u = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt_plain = time.perf_counter() - t0u
+    if world > 1:
+        t = torch.tensor([dt_plain], dtype=torch.float64, device=dev)
+        hz.all_reduce(t, dist.ReduceOp.MAX)
+        dt_plain = float(t.item())
 
     # single-blob latency (BASELINE.json config 2), outside the timed region
     lat = []
@@ -855,6 +931,10 @@ def main():
         dom = max(stages, key=lambda s: stages[s][0])
         dom_ms, dom_launches = stages[dom]
         per_launch_s = dom_ms * 1e-3 / max(1, dom_launches)
+        # gathered additions per (scalar, base) of the FK20 table IN USE: 2 ceil(128 / w) for a GLV table of width w (both 128-bit
+        # halves over the same windows), ceil(255 / w) for a plain one
+        wbits = ctx.window_bits()
+        msm_adds = 2 * -(-128 // wbits) if ctx.glv_table() else -(-255 // wbits)
         # algorithmic bytes per launch of each kernel family (DESIGN.md "kernels"):
         alg_bytes = {
             "blob_to_coeffs": B * (BYTES_PER_BLOB + 4096 * 32),
@@ -862,7 +942,7 @@ def main():
             "fk20_scalars": B * (4096 * 32 + 128 * 64 * 32),
             # scalars in + one 96-B table entry per (scalar, window) + 128 Jacobian sums out
             # (GLV table: 16 packed 96-B entries per scalar; plain table of width c: ceil(256/c) entries of 112 B)
-            "msm_fixed": B * (128 * 64 * 32 + 128 * 64 * (16 * 96 if ctx.glv_table() else ((255 + ctx.window_bits()) // ctx.window_bits()) * 112) + 128 * 168),
+            "msm_fixed": B * (128 * 64 * 32 + 128 * 64 * msm_adds * (96 if ctx.glv_table() else 112) + 128 * 168),
             # one radix-2 layer: 64 butterflies x (2 points in, 2 points out) x 168 B per blob
             "g1_ifft": B * 64 * 4 * 168,
             "g1_fft": B * 64 * 4 * 168,
@@ -878,7 +958,12 @@ def main():
         try:
             import glob
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_pmc_b2048*.json")))
-            pm = json.load(open(files[-1]))["kernels"]
+            pmc_doc = json.load(open(files[-1]))
+            pm = pmc_doc["kernels"]
+            # the counters are only quoted for the build they were collected on: the profile records a hash of the dominant
+            # kernel's sources (tools/pmc_summary.py); a build whose sources differ gets traffic = null instead of stale numbers
+            if pmc_doc.get("msm_kernel_sources_sha256") != kernel_sources_hash():
+                raise RuntimeError("committed PMC profile belongs to another build of the kernel")
             want = {"msm_fixed": ("k_msm_glv_chunked", "k_msm_glv_lane<1>") if ctx.glv_table() else ("k_msm_fixed_chunked<14>",), "g1_linmap": ("k_slp_mulc",)}.get(dom, ())
             key = next((k for w_ in want for k in pm if w_ in k), None)  # the newest profile names the kernel the default schedule runs
             if key in pm and B == 2048 and ctx.glv_table() and ctx.window_bits() == 16:
@@ -898,13 +983,15 @@ def main():
             "metric": "blobs/sec compute_cells_and_kzg_proofs (4096-pt blob)",
             "value": value, "unit": "blobs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step_without_stage_events": round(dt_plain / args.steps * 1e3, 3),
+            "ms_per_step_per_rank": per_rank_ms, "all_gather_ms_per_step": gather_ms,
             "vs_baseline": None, "dtype": "u32", "dtype_note": "381-bit Fp as 14x29-bit / 12x32-bit limbs, 255-bit Fr as 8x32-bit (stored) and 9x29-bit (inside the transforms) limbs, Montgomery integers; exact arithmetic", "data": "synthetic",
             "config": {"workload": f"compute_cells_and_kzg_proofs on DEVICE-RESIDENT blobs (inputs and outputs stay in HBM; the "
                                    f"host-pointer ABI rate is configs.abi_host_pointer_batch), batch-saturated: {B} synthetic blobs "
                                    f"per GPU per step (config 2's single blob is reported as single_blob_latency_ms)",
                        "blobs_per_gpu": B, "use_precomp": True, "window_bits": ctx.window_bits(),
-                       "fk20_table": "GLV: 8 windows of 16 bits per 128-bit half scalar, packed 96-B entries, 16 gathered additions per base" if ctx.glv_table()
-                                     else f"plain: width {ctx.window_bits()}, {(255 + ctx.window_bits()) // ctx.window_bits()} gathered additions per base",
+                       "fk20_table": f"GLV: {msm_adds // 2} windows of {wbits} bits per 128-bit half scalar, packed 96-B entries, {msm_adds} gathered additions per base" if ctx.glv_table()
+                                     else f"plain: width {wbits}, {msm_adds} gathered additions per base",
                        "table_GB": round(ctx.table_bytes() / 1e9, 2),
                        "g1_transforms": f"compiled linear map: {li[0]} constant multiplications, {li[1]} additions, {li[2]} doublings per blob, {li[3]} launches" if li[0] else "radix-2 network",
                        "exchange": ("ncclAllGather of the proof vectors per step inside libc_eth_kzg.so (eth_kzg_amd_all_gather)" if lib_comm
@@ -976,6 +1063,12 @@ def main():
                         os.environ.pop(k, None)
             out["configs"]["blobs_per_s_vs_table_memory"] = {"batch": B, "note": "table_GB = FK20 table + commitment table (43 GB at its default width 13); same resident batch, median of 3 steps", "points": curve}
         os.write(record_fd, (json.dumps(out) + "\n").encode())
+    if world > 1 and getattr(sharding.attach_library_comm, "stuck", False):
+        # a thread of this rank is still inside ncclCommInitRank (the watchdog gave up on it): the record is out, leave without
+        # running destructors that would wait for it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     if world > 1:
         dist.destroy_process_group()
     if ctx is not None:

@@ -48,7 +48,8 @@ typedef struct DASContext DASContext;
  * 206 GB, and a width-13 table for commitments, 43 GB, on an otherwise empty MI355X; narrower automatically when memory
  * is short or $ETH_KZG_AMD_TABLE_GB bounds them), false the 0.8 GB width-4 tables; results are identical.
  * Progressive start: the call returns as soon as small start tables are up (about 0.5 s) and every entry point works from
- * then on; the wide tables are built by a helper thread and swapped in when ready (eth_kzg_amd_tables_ready;
+ * then on; the wide tables are built by a helper thread, in pieces of under a gigabyte so that no other HIP call of the process
+ * waits long, and taken into use group by group (eth_kzg_amd_tables_ready, eth_kzg_amd_table_groups_ready;
  * $ETH_KZG_AMD_PROGRESSIVE=0 builds them before returning).  The embedded mainnet trusted setup is loaded; GPU 0 (or the
  * ordinal in $ETH_KZG_AMD_DEVICE) is used.  Aborts if no MI355X-class GPU is usable: there is no CPU fallback. */
 DASContext *eth_kzg_das_context_new(bool use_precomp);
@@ -216,6 +217,10 @@ int eth_kzg_amd_glv_table(const DASContext *ctx);
  * milliseconds for the switch; negative: until it happened), 2 if the wide tables could not be built (memory) and the
  * context stays on what it has.  Results never depend on the table in use. */
 int eth_kzg_amd_tables_ready(const DASContext *ctx, int wait_ms);
+/* The wide FK20 table is allocated in pieces of under a gigabyte and used GROUP BY GROUP while the helper thread builds it (the
+ * 128 MSM groups of a blob: the groups already built run on the wide table, the rest on the start table): this returns how
+ * many of the 128 groups of the table under construction are in use (128 once it is complete or when nothing is being built). */
+int eth_kzg_amd_table_groups_ready(const DASContext *ctx);
 /* The compiled linear map that replaces the two G1 transforms of the prover: out4 = constant multiplications, point
  * additions, point doublings per blob, kernel launches per call (all 0 when ETH_KZG_AMD_G1FFT=radix2 keeps the butterfly network). */
 void eth_kzg_amd_linmap_info(const DASContext *ctx, int32_t *out4);

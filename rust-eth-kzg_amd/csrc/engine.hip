@@ -262,21 +262,32 @@ Engine::SerialLease Engine::lease_serial() {
         L.e = this;
         return L;
     }
+    bool create = false;
     {
         std::lock_guard<std::mutex> lk(lanes_mu_);
         for (auto& a : aux_) {
             L.busy = std::unique_lock<std::mutex>(a->lane_busy_, std::try_to_lock);
             if (L.busy.owns_lock()) { L.e = a.get(); return L; }
         }
-        if ((int)aux_.size() + 1 < max_lanes_) {
-            try {
-                aux_.emplace_back(new Engine(use_precomp_, dev_, /*auxiliary=*/true));
-                L.busy = std::unique_lock<std::mutex>(aux_.back()->lane_busy_);
-                L.e = aux_.back().get();
-                return L;
-            } catch (const std::exception&) {
-                (void)hipGetLastError();  // no room for another lane: queue on an existing one
-            }
+        if ((int)aux_.size() + lanes_pending_ + 1 < max_lanes_) { lanes_pending_++; create = true; }
+    }
+    if (create) {
+        // a new lane is built OUTSIDE lanes_mu_ (0.1 s of set-up kernels): callers that find the existing lanes busy meanwhile
+        // queue on one of those instead of behind this constructor; the lane shares this engine's window tables (no registry
+        // look-up, no lock a table build could hold)
+        std::unique_ptr<Engine> fresh;
+        try {
+            fresh.reset(new Engine(use_precomp_, dev_, /*primary=*/this));
+        } catch (const std::exception&) {
+            (void)hipGetLastError();  // no room for another lane: queue on an existing one
+        }
+        std::lock_guard<std::mutex> lk(lanes_mu_);
+        lanes_pending_--;
+        if (fresh) {
+            L.busy = std::unique_lock<std::mutex>(fresh->lane_busy_);
+            L.e = fresh.get();
+            aux_.push_back(std::move(fresh));
+            return L;
         }
     }
     // all lanes busy: wait on one of them, round-robin
@@ -291,7 +302,7 @@ Engine::SerialLease Engine::lease_serial() {
     return L;
 }
 
-Engine::Engine(bool use_precomp, int device, bool auxiliary) : dev_(device), use_precomp_(use_precomp), auxiliary_(auxiliary) {
+Engine::Engine(bool use_precomp, int device, const Engine* primary) : dev_(device), use_precomp_(use_precomp), primary_(primary), auxiliary_(primary != nullptr) {
     if (const char* s = getenv("ETH_KZG_AMD_SERIAL_LANES")) {
         const int v = atoi(s);
         if (v >= 1 && v <= 16) max_lanes_ = v;
@@ -338,7 +349,11 @@ Engine::Engine(bool use_precomp, int device, bool auxiliary) : dev_(device), use
         }
     }
     HIPCK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    HIPCK(hipStreamCreateWithFlags(&build_stream_, hipStreamNonBlocking));
+    {   // the table builder runs at the lowest stream priority: callers' kernels are dispatched ahead of its waves
+        int prio_low = 0, prio_high = 0;
+        HIPCK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        HIPCK(hipStreamCreateWithPriority(&build_stream_, hipStreamNonBlocking, prio_low));
+    }
     HIPCK(hipStreamCreateWithFlags(&v_side_, hipStreamNonBlocking));
     HIPCK(hipEventCreateWithFlags(&v_decoded_, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&v_checked_, hipEventDisableTiming));
@@ -586,7 +601,13 @@ const Engine::SlpProgram& Engine::slp_program(int id) {
 // lane group and lasts 1.3 ms with a SIMD to itself, 2.3 ms when two share one (the chip has wave_slots_ / 2 SIMDs), and from
 // two waves per SIMD on the launch is throughput (1.2 us per wave): so the multiplication count M is chosen so that M x groups
 // stays within the SIMDs (<= 2 groups) or the wave slots (<= 5 groups), and within that the program with the shallowest cheap
-// levels wins (tools/linmap_explore.cpp; measured per group count in profiles/r4_linmap_variants.log).
+// levels wins (tools/linmap_explore.cpp).  Measured per group count on one box (profiles/r4_linmap_programs.log; g1_linmap ms):
+//   blobs           32    64    128   192   256   320   384   448   512   768   1024  1536
+//   350 (tuned)    2.50  2.55  2.71  3.82  3.87  3.98  5.14  5.19  5.36  7.72  8.98* 13.2*      (* with fused a + b / a - b pairs)
+//   712 Karatsuba  1.70  1.77  3.04  4.29  4.43  5.56  6.91        8.30
+//   456            1.92  1.98  2.14  3.28  3.38  4.60  4.81  5.85  6.07  8.59  10.9
+//   606            1.78  1.85  3.08  3.20  4.43  4.56  5.83        7.16
+//   372            2.21  2.22  2.35  3.54  3.61  3.72  4.96  4.95  5.16  7.64  9.05  13.4
 int Engine::pick_slp_program(int lanes) const {
     if (slp_force_ >= 0) return slp_force_;
     const int groups = lanes / 64, simds = wave_slots_ / 2;
@@ -595,6 +616,8 @@ int Engine::pick_slp_program(int lanes) const {
     if (606 * groups <= wave_slots_) return SLP_DEPTH_606;
     if (456 * groups <= wave_slots_) return SLP_DEPTH_456;
     if (372 * groups <= wave_slots_) return SLP_DEPTH_372;
+    if (456 * groups <= wave_slots_ * 3 / 2) return SLP_DEPTH_456;  // 6 groups: 1.34 rounds of shorter levels beat 1.03 rounds of the tuned program's
+    if (groups <= 12) return SLP_DEPTH_372;
     return lanes >= slp_fuse_min_ ? SLP_TUNED_FUSED : SLP_TUNED;
 }
 void Engine::init_linmap(const Fr8* w8192_mont) {
@@ -696,170 +719,113 @@ void Engine::init_srs() {
 // Window tables are immutable once built and depend only on (device, which bases, width), so the contexts of one
 // process share them: the second DASContext on a GPU costs neither another 206 GB nor another build
 // (the reference's Java test creates several contexts, LibEthKZGTest.java:32).  The last context to go frees the table.
-// Optional piecewise backing of a large table (ETH_KZG_AMD_VMM=1; see build_table_glv for why it is not the default): mapping
-// 200+ GB with one hipMalloc takes the driver seconds during which every other HIP call of the process waits (measured: a
-// 214 GB hipMalloc on the helper thread stalled the caller's launches for 4.3 s) and cannot be abandoned.  With the virtual
-// memory API the address range is reserved and backed PIECE BY PIECE (hipMemCreate / hipMemMap / hipMemSetAccess, 2 GB at a
-// time, a few tens of milliseconds each), just ahead of the builder kernels: other threads' calls slip in between the
-// pieces and a cancellation is honoured within one piece.
+//
+// A table is NOT one allocation.  Mapping 200+ GB with one hipMalloc takes the driver seconds during which every other HIP
+// call of the process waits (measured in round 3: a 214 GB hipMalloc on the helper thread stalled the caller's launches for
+// 4.3 s; the virtual-memory API that would back one address range piece by piece produced GPU memory faults on ROCm 7.0.2 and
+// is gone).  Instead the kernels reach a table through a device array of BLOCK pointers -- one block per group for a plain
+// table, two for a GLV table (its lower and upper windows; launch::TabBlocks) -- and the blocks live in PIECES of at most
+// ~0.85 GB (one 0.8 GB block of the widest table; many blocks of a small one), each its own hipMalloc of a few milliseconds:
+//   * other threads' HIP calls slip in between the pieces (tests/test_gpu_tables.py: a caller every 5 ms never waits long),
+//   * a build is abandoned within one piece,
+//   * the table is usable GROUP BY GROUP while it is built: ready_groups counts the leading groups whose entries are final,
+//     an MSM stage runs those on the new table and the rest on the table the context started on (Engine::launch_msm).
 struct Engine::SharedTable {
-    void* p = nullptr;
-    size_t bytes = 0;
-    int dev = 0;
-    // VMM backing (empty for a hipMalloc'ed table)
-    size_t reserved = 0, mapped = 0, piece = 0;
-    std::vector<hipMemGenericAllocationHandle_t> handles;
-    std::string why;  // the HIP call that failed in map_until
-    bool vmm() const { return reserved != 0; }
-    // reserve the address range; false -> use hipMalloc instead
-    bool reserve(size_t n) {
-        hipMemAllocationProp prop{};
-        prop.type = hipMemAllocationTypePinned;
-        prop.location.type = hipMemLocationTypeDevice;
-        prop.location.id = dev;
-        size_t gran = 0;
-        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) { (void)hipGetLastError(); return false; }
-        piece = ((size_t)(2ull << 30) + gran - 1) / gran * gran;
-        // whole pieces only: hipMemSetAccess rejected a smaller last piece ("invalid argument", ROCm 7.0.2); the price is < 2 GB of slack
-        const size_t total = (n + piece - 1) / piece * piece;
-        void* base = nullptr;
-        if (hipMemAddressReserve(&base, total, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
-        p = base;
-        reserved = total;
-        return true;
-    }
-    // back the range up to byte offset `end` (rounded up to whole pieces); false on failure (out of memory) or cancellation
-    bool map_until(size_t end, const std::atomic<bool>* cancel) {
-        if (end > reserved) end = reserved;
-        hipMemAllocationProp prop{};
-        prop.type = hipMemAllocationTypePinned;
-        prop.location.type = hipMemLocationTypeDevice;
-        prop.location.id = dev;
-        hipMemAccessDesc acc{};
-        acc.location = prop.location;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        while (mapped < end) {
-            if (cancel && cancel->load()) return false;
-            const size_t sz = std::min(piece, reserved - mapped);
-            hipMemGenericAllocationHandle_t h;
-            hipError_t e;
-            if ((e = hipMemCreate(&h, sz, &prop, 0)) != hipSuccess) { why = std::string("hipMemCreate: ") + hipGetErrorString(e); (void)hipGetLastError(); return false; }
-            if ((e = hipMemMap((char*)p + mapped, sz, 0, h, 0)) != hipSuccess) { why = std::string("hipMemMap: ") + hipGetErrorString(e); (void)hipGetLastError(); (void)hipMemRelease(h); return false; }
-            handles.push_back(h);
-            if ((e = hipMemSetAccess((char*)p + mapped, sz, &acc, 1)) != hipSuccess) { why = std::string("hipMemSetAccess: ") + hipGetErrorString(e); (void)hipGetLastError(); mapped += sz; return false; }
-            mapped += sz;
-        }
-        return true;
-    }
-    void release() {
-        if (!p) return;
-        (void)hipSetDevice(dev);
-        if (vmm()) {
-            size_t off = 0;
-            for (auto h : handles) {
-                const size_t sz = std::min(piece, reserved - off);
-                (void)hipMemUnmap((char*)p + off, sz);
-                (void)hipMemRelease(h);
-                off += sz;
-            }
-            (void)hipMemAddressFree(p, reserved);
-            handles.clear();
-            reserved = mapped = 0;
+    int dev = 0, kind = 0, c = 0;  // kind: 0 = commitments (plain, monomial SRS as [64][64]), 1 = FK20 plain, 2 = FK20 GLV
+    bool glv = false;
+    int n_groups = 0, nb = 64, halves = 1;
+    size_t bytes = 0;                      // of all blocks
+    size_t block_entries[2] = {0, 0};      // entries of a group's block(s)
+    std::vector<void*> pieces;
+    std::vector<void*> h_blocks;           // host copy of the pointer array (entries of unallocated blocks are null)
+    void** d_blocks = nullptr;             // device: [n_groups * halves]
+    int blocks_allocated = 0;
+    std::atomic<int> ready_groups{0};      // leading groups whose entries are final and whose pointers are on the device
+    std::atomic<int> state{0};             // 0 under construction, 1 complete, 2 abandoned (cancelled / out of memory): what is ready stays usable
+    std::string why;                       // of state 2
+    size_t entry_bytes() const { return glv ? launch::SIZEOF_TABP : launch::SIZEOF_TABQ; }
+    size_t block_bytes(int b) const { return block_entries[b % halves] * entry_bytes(); }
+    void shape(int device, int kind_, int width, int groups) {
+        dev = device; kind = kind_; c = width; glv = kind_ == 2; n_groups = groups;
+        halves = glv ? 2 : 1;
+        if (glv) {
+            const size_t per_window = (size_t)nb << (c - 1);
+            block_entries[0] = per_window * launch::glv_lower_windows(c);
+            block_entries[1] = per_window * (launch::glv_windows(c) - launch::glv_lower_windows(c));
         } else {
-            (void)hipFree(p);
+            block_entries[0] = launch::table_entries(c, 1, nb);
         }
-        p = nullptr;
+        bytes = 0;
+        for (int b = 0; b < halves; b++) bytes += block_bytes(b) * (size_t)n_groups;
+        h_blocks.assign((size_t)n_groups * halves, nullptr);
     }
-    ~SharedTable() { release(); }
+    double alloc_ms = 0, alloc_ms_max = 0;  // time spent in hipMalloc for the pieces: total and the longest single call (trace)
+    // allocate pieces until blocks [0, block_end) exist; false: out of memory (why is set) or cancelled
+    bool alloc_until(int block_end, const std::atomic<bool>* cancel) {
+        constexpr size_t PIECE = 850ull << 20;
+        const int total = n_groups * halves;
+        if (block_end > total) block_end = total;
+        if (!d_blocks) {
+            if (hipMalloc((void**)&d_blocks, (size_t)total * sizeof(void*)) != hipSuccess) { (void)hipGetLastError(); d_blocks = nullptr; why = "hipMalloc of the block pointer array failed"; return false; }
+            (void)hipMemset(d_blocks, 0, (size_t)total * sizeof(void*));
+        }
+        while (blocks_allocated < block_end) {
+            if (cancel && cancel->load()) { why = "cancelled"; return false; }
+            int n = 0;
+            size_t sz = 0;
+            while (blocks_allocated + n < total && (n == 0 || sz + block_bytes(blocks_allocated + n) <= PIECE)) { sz += block_bytes(blocks_allocated + n); n++; }
+            void* p = nullptr;
+            const auto a0 = std::chrono::steady_clock::now();
+            const hipError_t e = hipMalloc(&p, sz);
+            const double dt = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count();
+            alloc_ms += dt;
+            alloc_ms_max = std::max(alloc_ms_max, dt);
+            if (e != hipSuccess) { (void)hipGetLastError(); why = std::string("hipMalloc of a table piece: ") + hipGetErrorString(e); return false; }
+            pieces.push_back(p);
+            char* q = (char*)p;
+            for (int k = 0; k < n; k++) { h_blocks[blocks_allocated + k] = q; q += block_bytes(blocks_allocated + k); }
+            blocks_allocated += n;
+        }
+        return true;
+    }
+    ~SharedTable() {
+        (void)hipSetDevice(dev);
+        for (void* p : pieces) (void)hipFree(p);
+        if (d_blocks) (void)hipFree(d_blocks);
+    }
 };
 struct BuildCancelled {};  // thrown out of a table build when its context (or the process) is going away
-static std::mutex g_tables_mu;
+static std::mutex g_tables_mu;  // the registry below: held for look-ups and inserts only, never across a build
 static std::map<std::tuple<int, int, int>, std::weak_ptr<Engine::SharedTable>> g_tables;  // (device, kind, width)
+static std::mutex g_build_mu;   // one builder of WIDE tables at a time per process (the helper threads of several contexts queue here)
 
-// returns false (and leaves *table null) if the device cannot hold the table + scratch
-static bool build_table(int c, const void* bases, void** table, size_t* bytes, int n_groups, int nb, hipStream_t st) {
-    // groups are built in chunks so that the scratch stays small: 56 B per entry for the wave-wide builder (widths >= 10),
-    // 144 B per entry (Jacobian) for the thread-per-window builder that serves widths 4 and 8
-    const bool fast = c >= 10;  // width 8 (128 entries per window = two wave steps) is quicker with the simple builder
-    const size_t per_group = launch::table_entries(c, 1, nb);
-    const size_t scratch_per_entry = fast ? 56 : sizeof(G1Jac);
-    int chunk = (int)((fast ? (9ull << 30) : (24ull << 30)) / (per_group * scratch_per_entry));
-    if (chunk < 1) chunk = 1;
-    if (chunk > n_groups) chunk = n_groups;
-    const size_t entries = per_group * n_groups;
-    const size_t side_bytes = fast ? launch::table_fast_side_bytes(c, chunk, nb) : 0;
-    void *scratch = nullptr, *side = nullptr;
-    int* d_err = nullptr;
-    *table = nullptr;
-    size_t free_b = 0, total_b = 0;
-    HIPCK(hipMemGetInfo(&free_b, &total_b));
-    const size_t need = entries * launch::SIZEOF_TABQ + per_group * chunk * scratch_per_entry + side_bytes + (8ull << 30);  // + head-room for batches
-    if (need > free_b) return false;
+static size_t plain_table_bytes(int c, int n_groups) { return launch::table_entries(c, n_groups, 64) * launch::SIZEOF_TABQ; }
+static size_t glv_table_bytes(int c) { return launch::table_glv_entries(c, 128, 64) * launch::SIZEOF_TABP; }
+
+// Fill a table the caller has just created: pieces are allocated a chunk of groups ahead of the builder kernels, every
+// finished chunk is published through ready_groups.  Returns false (state 2, `why` set) if the device cannot hold it;
+// throws BuildCancelled when `cancel` is raised (state 2 as well).  The groups that are ready stay usable either way.
+// gentle: the build shares the GPU with callers on the start tables (progressive start): one group per launch -- 512 waves, one
+// per SIMD on half the chip's SIMDs, so a caller's kernels find free SIMDs at once instead of waiting for 1,500 builder
+// waves that run 17 ms -- at twice the build time, which the allocation of the pieces hides anyway.
+static bool fill_table(Engine::SharedTable& t, const void* bases, hipStream_t st, const std::atomic<bool>* cancel, bool gentle = false) {
     const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-    if (hipMalloc(table, entries * launch::SIZEOF_TABQ) != hipSuccess) { (void)hipGetLastError(); *table = nullptr; return false; }
-    if (hipMalloc(&scratch, per_group * chunk * scratch_per_entry) != hipSuccess ||
-        (fast && (hipMalloc(&side, side_bytes) != hipSuccess || hipMalloc(&d_err, sizeof(int)) != hipSuccess))) {
-        (void)hipGetLastError();
-        if (scratch) (void)hipFree(scratch);
-        if (side) (void)hipFree(side);
-        HIPCK(hipFree(*table));
-        *table = nullptr;
-        return false;
-    }
-    if (trace) fprintf(stderr, "[context]   table c=%d: hipMalloc %.1f GB  %8.1f ms\n", c,
-                       (entries * launch::SIZEOF_TABQ + per_group * chunk * scratch_per_entry + side_bytes) / 1e9, ms());
-    if (fast) HIPCK(hipMemsetAsync(d_err, 0, sizeof(int), st));
-    for (int g0 = 0; g0 < n_groups; g0 += chunk) {
-        int g = n_groups - g0 < chunk ? n_groups - g0 : chunk;
-        const char* b = (const char*)bases + (size_t)g0 * nb * sizeof(G1Affine);
-        char* t = (char*)*table + (size_t)g0 * per_group * launch::SIZEOF_TABQ;
-        if (fast) launch::build_table_fast(c, b, t, scratch, side, g, nb, d_err, st);
-        else launch::build_table(c, b, t, scratch, g, nb, st);
-        HIPCK(hipStreamSynchronize(st));
-    }
-    if (fast) {
-        int err = 0;
-        HIPCK(hipMemcpy(&err, d_err, sizeof(int), hipMemcpyDeviceToHost));
-        HIPCK(hipFree(d_err));
-        HIPCK(hipFree(side));
-        if (err) throw std::runtime_error("window table: a base point of small order");
-    }
-    if (trace) fprintf(stderr, "[context]   table c=%d: built            %8.1f ms\n", c, ms());
-    HIPCK(hipFree(scratch));
-    *bytes = entries * launch::SIZEOF_TABQ;
-    return true;
-}
-
-// a GLV table of width c (k_table.hip: build_table_glv): packed 96-B entries, built in chunks of groups with 168 B of scratch per
-// entry; the table memory is backed piece by piece just ahead of the builder kernels (SharedTable::map_until).
-// false: the device cannot hold it.  Throws BuildCancelled when `cancel` is raised.
-static bool build_table_glv(int c, const void* bases, Engine::SharedTable& t, int n_groups, int nb, hipStream_t st,
-                            const std::atomic<bool>* cancel) {
-    const size_t per_group = launch::table_glv_entries(c, 1, nb), entries = per_group * n_groups;
-    const size_t table_bytes = entries * launch::SIZEOF_TABP;
-    int chunk = (int)((9ull << 30) / (per_group * 168));
+    const int c = t.c, nb = t.nb;
+    const bool fast = t.glv || c >= 10;  // plain width 8 (128 entries per window = two wave steps) is quicker with the simple builder
+    const size_t per_group = t.glv ? launch::table_glv_entries(c, 1, nb) : launch::table_entries(c, 1, nb);
+    const size_t scratch_per_entry = t.glv ? 168 : fast ? 56 : sizeof(G1Jac);
+    int chunk = (int)((t.glv || fast ? (9ull << 30) : (24ull << 30)) / (per_group * scratch_per_entry));
     if (chunk < 1) chunk = 1;
-    if (chunk > n_groups) chunk = n_groups;
-    const size_t side_bytes = launch::table_glv_side_bytes(c, chunk, nb);
-    size_t free_b = 0, total_b = 0;
-    HIPCK(hipMemGetInfo(&free_b, &total_b));
-    const size_t need = table_bytes + per_group * chunk * 168 + side_bytes + (8ull << 30);  // + head-room for batches
-    if (need > free_b) return false;
-    const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
-    auto t0 = std::chrono::steady_clock::now();
-    auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    if (chunk > t.n_groups) chunk = t.n_groups;
+    if (gentle) {  // <= ~512 builder waves in flight (a wave per (base, window): 64 x W per group)
+        const int W = t.glv ? launch::glv_windows(c) : (255 + c) / c;
+        chunk = std::max(1, std::min(chunk, 512 / (nb * W)));
+    }
+    const size_t side_bytes = t.glv ? launch::table_glv_side_bytes(c, chunk, nb) : fast ? launch::table_fast_side_bytes(c, chunk, nb) : 0;
     void *scratch = nullptr, *side = nullptr;
     int* d_err = nullptr;
-    // Piecewise backing is OPT-IN (ETH_KZG_AMD_VMM=1).  It keeps other threads' calls flowing during the build (22 prover calls
-    // completed during a build against 1 with a single hipMalloc, which blocks the process's HIP calls for ~4 s) and makes the
-    // build cancellable within 2 GB, but on ROCm 7.0.2 two GPU memory faults were seen with it in ~10 runs (a builder kernel
-    // hit "write access to a read-only page" while a later piece was given its access rights; one bench process died of a
-    // fault of unknown reason while calls overlapped the mapping), none without it.  Correctness first: one hipMalloc by default.
-    const char* vmm_env = getenv("ETH_KZG_AMD_VMM");
-    const bool piecewise = table_bytes > (8ull << 30) && vmm_env && atoi(vmm_env) != 0 && t.reserve(table_bytes);
-    if (!piecewise && hipMalloc(&t.p, table_bytes) != hipSuccess) { (void)hipGetLastError(); t.p = nullptr; return false; }
     auto cleanup = [&] {
         (void)hipStreamSynchronize(st);
         if (scratch) (void)hipFree(scratch);
@@ -868,84 +834,135 @@ static bool build_table_glv(int c, const void* bases, Engine::SharedTable& t, in
         scratch = side = nullptr;
         d_err = nullptr;
     };
-    if (hipMalloc(&scratch, per_group * chunk * 168) != hipSuccess || hipMalloc(&side, side_bytes) != hipSuccess ||
+    auto give_up = [&](const std::string& why) {
+        cleanup();
+        t.why = why;
+        t.state.store(2);
+        return false;
+    };
+    size_t free_b = 0, total_b = 0;
+    HIPCK(hipMemGetInfo(&free_b, &total_b));
+    const size_t need = t.bytes + per_group * chunk * scratch_per_entry + side_bytes + (8ull << 30);  // + head-room for batches
+    if (need > free_b) return give_up("not enough free device memory");
+    if (hipMalloc(&scratch, per_group * chunk * scratch_per_entry) != hipSuccess || (side_bytes && hipMalloc(&side, side_bytes) != hipSuccess) ||
         hipMalloc(&d_err, sizeof(int)) != hipSuccess) {
         (void)hipGetLastError();
-        cleanup();
-        t.release();
-        return false;
+        return give_up("hipMalloc of the builder's scratch failed");
     }
-    if (trace) fprintf(stderr, "[context]   GLV table (%d x %d-bit windows): %.1f GB %s, scratch allocated  %8.1f ms\n", launch::glv_windows(c), c,
-                       table_bytes / 1e9, piecewise ? "reserved (backed piece by piece)" : "hipMalloc'ed", ms());
+    if (trace) fprintf(stderr, "[context]   table kind %d width %d: %.1f GB in pieces, scratch %.1f GB allocated  %8.1f ms\n", t.kind, c, t.bytes / 1e9,
+                       (per_group * chunk * scratch_per_entry + side_bytes) / 1e9, ms());
     try {
         HIPCK(hipMemsetAsync(d_err, 0, sizeof(int), st));
-        for (int g0 = 0; g0 < n_groups; g0 += chunk) {
-            const int g = n_groups - g0 < chunk ? n_groups - g0 : chunk;
+        for (int g0 = 0; g0 < t.n_groups; g0 += chunk) {
+            const int g = std::min(chunk, t.n_groups - g0);
             if (cancel && cancel->load()) throw BuildCancelled{};
-            // The previous chunk must have left the table before more of it is backed: hipMemSetAccess on a later piece was
-            // seen to fault a builder kernel still writing an earlier one ("write access to a read-only page", ROCm 7.0.2),
-            // so mapping and building alternate instead of overlapping.  Other streams (callers on the start tables) go on.
-            HIPCK(hipStreamSynchronize(st));
-            if (piecewise && !t.map_until((size_t)(g0 + g) * per_group * launch::SIZEOF_TABP, cancel)) {
+            // the pieces of this chunk are allocated while the previous chunk's kernels still run
+            if (!t.alloc_until((g0 + g) * t.halves, cancel)) {
                 if (cancel && cancel->load()) throw BuildCancelled{};
-                if (trace) fprintf(stderr, "[context]   GLV table width %d: backing failed at %.1f of %.1f GB (%s)\n", c, t.mapped / 1e9, table_bytes / 1e9, t.why.c_str());
-                cleanup();
-                t.release();
-                return false;  // out of memory after all (another process took it meanwhile)
+                if (trace) fprintf(stderr, "[context]   table kind %d width %d: stopped at group %d of %d (%s)\n", t.kind, c, g0, t.n_groups, t.why.c_str());
+                return give_up(t.why);
             }
-            HIPCK(hipStreamSynchronize(st));  // the previous chunk has left the scratch
-            if (!launch::build_table_glv(c, (const char*)bases + (size_t)g0 * nb * sizeof(G1Affine),
-                                         (char*)t.p + (size_t)g0 * per_group * launch::SIZEOF_TABP, scratch, side, g, nb, d_err, st))
-                throw std::runtime_error("GLV table width not built in");
+            HIPCK(hipStreamSynchronize(st));  // the previous chunk has left the scratch: its groups are final
+            t.ready_groups.store(g0, std::memory_order_release);
+            HIPCK(hipMemcpyAsync(t.d_blocks + (size_t)g0 * t.halves, t.h_blocks.data() + (size_t)g0 * t.halves, (size_t)g * t.halves * sizeof(void*),
+                                 hipMemcpyHostToDevice, st));
+            const char* b = (const char*)bases + (size_t)g0 * nb * sizeof(G1Affine);
+            void* const* blocks = t.d_blocks + (size_t)g0 * t.halves;
+            if (t.glv) {
+                if (!launch::build_table_glv(c, b, blocks, scratch, side, g, nb, d_err, st)) throw std::runtime_error("GLV table width not built in");
+            } else if (fast) {
+                if (!launch::build_table_fast(c, b, blocks, scratch, side, g, nb, d_err, st)) throw std::runtime_error("table width not built in");
+            } else {
+                launch::build_table(c, b, blocks, scratch, g, nb, st);
+            }
         }
         HIPCK(hipStreamSynchronize(st));
         int err = 0;
         HIPCK(hipMemcpy(&err, d_err, sizeof(int), hipMemcpyDeviceToHost));
         if (err) throw std::runtime_error("window table: a base point of small order");
-    } catch (...) {
-        cleanup();
-        t.release();
+    } catch (const BuildCancelled&) {
+        give_up("cancelled: the context is being freed");
+        throw;
+    } catch (const std::exception& e) {
+        give_up(e.what());
         throw;
     }
     cleanup();
-    if (trace) fprintf(stderr, "[context]   GLV table width %d: built            %8.1f ms\n", c, ms());
-    t.bytes = table_bytes;
+    t.ready_groups.store(t.n_groups, std::memory_order_release);
+    t.state.store(1);
+    if (trace) fprintf(stderr, "[context]   table kind %d width %d: built            %8.1f ms (%zu pieces: hipMalloc %.1f ms in all, longest %.1f ms)\n", t.kind, c, ms(),
+                       t.pieces.size(), t.alloc_ms, t.alloc_ms_max);
     return true;
 }
 
-// shared tables of a device: (kind, width) -> table; kind 0 = commitments (plain, over the monomial SRS as [64][64]),
-// 1 = FK20 plain, 2 = FK20 GLV.  Callers hold g_tables_mu.
-static std::shared_ptr<Engine::SharedTable> obtain_table(int dev, int kind, int w, const void* bases, int n_groups, hipStream_t st,
-                                                         bool only_if_live = false, const std::atomic<bool>* cancel = nullptr) {
-    auto key = std::make_tuple(dev, kind, w);
-    if (auto live = g_tables[key].lock()) return live;
-    if (only_if_live) return nullptr;
-    if (cancel && cancel->load()) throw BuildCancelled{};
-    auto t = std::make_shared<Engine::SharedTable>();
-    t->dev = dev;
-    const bool ok = kind == 2 ? build_table_glv(w, bases, *t, n_groups, 64, st, cancel)
-                              : build_table(w, bases, &t->p, &t->bytes, n_groups, 64, st);
-    if (!ok) return nullptr;
-    g_tables[key] = t;
+// the live table of (device, kind, width) in the registry, whatever its state (null: none, or only an abandoned one)
+static std::shared_ptr<Engine::SharedTable> find_table(int dev, int kind, int w) {
+    std::lock_guard<std::mutex> lk(g_tables_mu);
+    auto it = g_tables.find(std::make_tuple(dev, kind, w));
+    if (it == g_tables.end()) return nullptr;
+    auto t = it->second.lock();
+    if (!t || t->state.load() == 2) return nullptr;
     return t;
 }
-static size_t plain_table_bytes(int c, int n_groups) { return launch::table_entries(c, n_groups, 64) * launch::SIZEOF_TABQ; }
-static size_t glv_table_bytes(int c) { return launch::table_glv_entries(c, 128, 64) * launch::SIZEOF_TABP; }
+// find_table, or a new (empty, state 0) table registered under the key; *created tells which
+static std::shared_ptr<Engine::SharedTable> find_or_create_table(int dev, int kind, int w, int n_groups, bool* created) {
+    std::lock_guard<std::mutex> lk(g_tables_mu);
+    auto& slot = g_tables[std::make_tuple(dev, kind, w)];
+    auto t = slot.lock();
+    *created = false;
+    if (t && t->state.load() != 2) return t;
+    t = std::make_shared<Engine::SharedTable>();
+    t->shape(dev, kind, w, n_groups);
+    slot = t;
+    *created = true;
+    return t;
+}
+// a COMPLETE table of (device, kind, width): found, awaited (another thread is building it) or built here; null if it does not fit
+static std::shared_ptr<Engine::SharedTable> obtain_table(int dev, int kind, int w, const void* bases, int n_groups, hipStream_t st,
+                                                         bool only_if_live = false, const std::atomic<bool>* cancel = nullptr) {
+    if (only_if_live) {
+        auto t = find_table(dev, kind, w);
+        return t && t->state.load() == 1 ? t : nullptr;
+    }
+    if (cancel && cancel->load()) throw BuildCancelled{};
+    bool created = false;
+    auto t = find_or_create_table(dev, kind, w, n_groups, &created);
+    if (created) return fill_table(*t, bases, st, cancel) ? t : nullptr;
+    while (t->state.load() == 0) {  // another context's thread is building it
+        if (cancel && cancel->load()) throw BuildCancelled{};
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    return t->state.load() == 1 ? t : nullptr;
+}
 
 Engine::TableView Engine::table_view(TableSel which) const {
+    if (primary_) return primary_->table_view(which);  // an engine lane reads through to the context's engine
     std::lock_guard<std::mutex> lk(tab_mu_);
     return views_[which];
 }
-void Engine::publish(TableSel which, const TableView& v) {
+// main: the complete table calls run on; next: a wider one under construction whose ready groups are used already
+void Engine::publish(TableSel which, const std::shared_ptr<SharedTable>& main, const std::shared_ptr<SharedTable>& next) {
     std::lock_guard<std::mutex> lk(tab_mu_);
-    if (views_[which].owner && views_[which].owner != v.owner) retired_.push_back(views_[which].owner);  // kernels in flight may still read it
-    views_[which] = v;
+    TableView& v = views_[which];
+    if (v.main && v.main != main) retired_.push_back(v.main);  // kernels in flight may still read it
+    if (v.next && v.next != next && v.next != main) retired_.push_back(v.next);
+    v.main = main;
+    v.next = next;
+    v.c = main ? main->c : 0;
+    v.glv = main ? main->glv : false;
+    v.bytes = main ? main->bytes : 0;
 }
 int Engine::tables_ready(int wait_ms) {
+    if (primary_) return const_cast<Engine*>(primary_)->tables_ready(wait_ms);
     std::unique_lock<std::mutex> lk(tab_mu_);
     if (wait_ms < 0) tab_cv_.wait(lk, [&] { return tables_state_ != 0; });
     else if (wait_ms > 0) tab_cv_.wait_for(lk, std::chrono::milliseconds(wait_ms), [&] { return tables_state_ != 0; });
     return tables_state_;
+}
+int Engine::table_groups_ready(TableSel which) const {
+    const TableView v = table_view(which);
+    if (v.next) return v.next->ready_groups.load(std::memory_order_acquire);
+    return v.main ? v.main->n_groups : 0;
 }
 
 void Engine::init_fk20() {
@@ -958,12 +975,12 @@ void Engine::init_fk20() {
     launch::fk20_gather_bases(X, d_fk_bases_, stream_);
     HIPCK(hipStreamSynchronize(stream_));
     HIPCK(hipFree(X));
+    if (primary_) return;  // an engine lane: the tables are the context's (table_view reads through)
     if (!use_precomp_) {  // UsePrecomp::No: the 0.8 GB width-4 tables, nothing else to build
-        std::lock_guard<std::mutex> lk(g_tables_mu);
         auto srs = obtain_table(dev_, 0, 4, d_srs_, 64, stream_), fk = obtain_table(dev_, 1, 4, d_fk_bases_, 128, stream_);
         if (!srs || !fk) throw std::runtime_error("not enough device memory for the window tables");
-        publish(TAB_SRS, TableView{srs->p, 4, false, srs->bytes, srs});
-        publish(TAB_FK, TableView{fk->p, 4, false, fk->bytes, fk});
+        publish(TAB_SRS, srs, nullptr);
+        publish(TAB_FK, fk, nullptr);
         std::lock_guard<std::mutex> lk2(tab_mu_);
         tables_state_ = 1;
         return;
@@ -972,25 +989,23 @@ void Engine::init_fk20() {
     if (const char* e = getenv("ETH_KZG_AMD_PROGRESSIVE")) progressive = atoi(e) != 0;
     if (!progressive) {
         build_final_tables();
-        if (!table_view(TAB_FK).p || !table_view(TAB_SRS).p) throw std::runtime_error("not enough device memory for the window tables: " + tables_error_);
+        if (!table_view(TAB_FK).main || !table_view(TAB_SRS).main) throw std::runtime_error("not enough device memory for the window tables: " + tables_error_);
         return;
     }
     // Progressive start (the reference's "Initialize context" bench, benchmark-mt.rs:103-113): serve from small tables at once --
     // or from whatever wider table another context of this process already holds -- and build the wide ones on a helper thread.
     {
-        std::lock_guard<std::mutex> lk(g_tables_mu);
         std::shared_ptr<SharedTable> fk, srs;
-        int fk_c = 0, srs_c = 0;
         if (!want_plain_c_)
             for (int w : launch::GLV_WIDTHS)
-                if (!fk && (fk = obtain_table(dev_, 2, w, nullptr, 128, stream_, /*only_if_live=*/true))) fk_c = w;
-        if (!fk && (fk = obtain_table(dev_, 2, 8, d_fk_bases_, 128, stream_))) fk_c = 8;
+                if (!fk) fk = obtain_table(dev_, 2, w, nullptr, 128, stream_, /*only_if_live=*/true);
+        if (!fk) fk = obtain_table(dev_, 2, 8, d_fk_bases_, 128, stream_);
         for (int w : {13, 12, 10, 8})
-            if (!srs && (srs = obtain_table(dev_, 0, w, nullptr, 64, stream_, true))) srs_c = w;
-        if (!srs && (srs = obtain_table(dev_, 0, 8, d_srs_, 64, stream_))) srs_c = 8;
+            if (!srs) srs = obtain_table(dev_, 0, w, nullptr, 64, stream_, true);
+        if (!srs) srs = obtain_table(dev_, 0, 8, d_srs_, 64, stream_);
         if (!fk || !srs) throw std::runtime_error("not enough device memory for the start window tables");
-        publish(TAB_FK, TableView{fk->p, fk_c, true, fk->bytes, fk});
-        publish(TAB_SRS, TableView{srs->p, srs_c, false, srs->bytes, srs});
+        publish(TAB_FK, fk, nullptr);
+        publish(TAB_SRS, srs, nullptr);
     }
     {
         std::lock_guard<std::mutex> lk(g_engines_mu);
@@ -998,63 +1013,85 @@ void Engine::init_fk20() {
         if (!registered) { atexit(stop_all_builders_at_exit); registered = true; }
         g_engines.push_back(this);
     }
+    progressive_build_ = true;
     builder_ = std::thread([this] {
         (void)hipSetDevice(dev_);
         build_final_tables();
     });
 }
 
-// The wide tables, widest first, each taken from the process-wide map if another context of this GPU holds it already:
+// The wide tables, widest first, each taken from the process-wide registry if another context of this GPU holds it already:
 //   commitments: plain width 13 (43 GB; 20 windows), 12, 10, 8
 //   FK20: GLV width 16 (206 GB; 16 gathered additions per base), 15 (116 GB; 18), 14 (64 GB; 20), 12 (18 GB; 22), 8 (1.6 GB; 32)
 //         -- GLV first at every size: the endomorphism halves the memory per window bit (a plain width-14 table costs
 //         163 GB for 19 additions) -- or the plain width ETH_KZG_AMD_WINDOW names;
 // bounded by what the HBM still holds (another process may own part of it) and by ETH_KZG_AMD_TABLE_GB (both tables
-// together; the commitment table gets at most 18 % of it).  Never throws: a failure leaves the context on the tables it has.
+// together; the commitment table gets at most 18 % of it).  A table this thread creates is published as the view's `next`
+// BEFORE it is filled, so the MSMs use its groups as they become ready.  Never throws: a failure leaves the context on the
+// tables it has.
 void Engine::build_final_tables() {
     int state = 1;
     std::string why;
+    // wider than `now`, from the registry or built here; attach = publish as `next` while it is filled
+    auto widen = [&](TableSel sel, int kind, int w, const void* bases, int n_groups) -> std::shared_ptr<SharedTable> {
+        if (cancel_build_.load()) throw BuildCancelled{};
+        bool created = false;
+        auto t = find_or_create_table(dev_, kind, w, n_groups, &created);
+        const TableView cur = table_view(sel);
+        const bool same_form = cur.main && cur.main->glv == t->glv && cur.main->n_groups == t->n_groups;
+        if (t->state.load() == 0 && same_form) publish(sel, cur.main, t);  // its ready groups serve at once
+        if (created) {
+            if (!fill_table(*t, bases, build_stream_, &cancel_build_, /*gentle=*/progressive_build_)) {
+                if (t->ready_groups.load() == 0) publish(sel, cur.main, nullptr);
+                return nullptr;
+            }
+        } else {
+            while (t->state.load() == 0) {  // another context's helper thread is filling it
+                if (cancel_build_.load()) throw BuildCancelled{};
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            }
+            if (t->state.load() != 1) return nullptr;
+        }
+        return t;
+    };
     try {
-        std::lock_guard<std::mutex> lk(g_tables_mu);  // one builder at a time per process
+        std::lock_guard<std::mutex> lk(g_build_mu);  // one builder of wide tables at a time per process
         if (cancel_build_.load()) throw BuildCancelled{};
         const double budget = table_budget_gb_ > 0 ? table_budget_gb_ * 1e9 : 1e18;
         const TableView srs_now = table_view(TAB_SRS), fk_now = table_view(TAB_FK);
         std::shared_ptr<SharedTable> srs;
-        int srs_c = 0;
         for (int w : {13, 12, 10, 8}) {
             if (srs) break;
-            if (srs_now.p && w <= srs_now.c) break;  // nothing wider than what is in use fits
+            if (srs_now.main && w <= srs_now.c) break;  // nothing wider than what is in use fits
             if ((double)plain_table_bytes(w, 64) > std::max(0.18 * budget, 2.2e9)) continue;
-            if ((srs = obtain_table(dev_, 0, w, d_srs_, 64, build_stream_, false, &cancel_build_))) srs_c = w;
+            srs = widen(TAB_SRS, 0, w, d_srs_, 64);
         }
-        if (srs) publish(TAB_SRS, TableView{srs->p, srs_c, false, srs->bytes, srs});
+        if (srs) publish(TAB_SRS, srs, nullptr);
         const double left = budget - (double)table_view(TAB_SRS).bytes;
         std::shared_ptr<SharedTable> fk;
-        int fk_c = 0;
-        bool fk_glv = true;
         if (want_plain_c_) {
             static const int widths[] = {14, 13, 12, 10, 8};
             for (int w : widths) {
                 if (fk || w > want_plain_c_) continue;
-                if ((fk = obtain_table(dev_, 1, w, d_fk_bases_, 128, build_stream_, false, &cancel_build_))) { fk_c = w; fk_glv = false; }
+                fk = widen(TAB_FK, 1, w, d_fk_bases_, 128);
             }
         } else {
             for (int w : launch::GLV_WIDTHS) {
                 if (fk) break;
                 if (want_glv_c_ && w != want_glv_c_) continue;
-                if (fk_now.p && fk_now.glv && w <= fk_now.c) break;
+                if (fk_now.main && fk_now.glv && w <= fk_now.c) break;
                 if ((double)glv_table_bytes(w) > std::max(left, 1.7e9)) continue;
-                if ((fk = obtain_table(dev_, 2, w, d_fk_bases_, 128, build_stream_, false, &cancel_build_))) fk_c = w;
+                fk = widen(TAB_FK, 2, w, d_fk_bases_, 128);
             }
         }
-        if (fk) publish(TAB_FK, TableView{fk->p, fk_c, fk_glv, fk->bytes, fk});
-        if (!table_view(TAB_FK).p) {  // not even the narrowest GLV table fits: the plain width-4 tables (0.8 GB)
+        if (fk) publish(TAB_FK, fk, nullptr);
+        if (!table_view(TAB_FK).main) {  // not even the narrowest GLV table fits: the plain width-4 tables (0.8 GB)
             auto f4 = obtain_table(dev_, 1, 4, d_fk_bases_, 128, build_stream_);
-            if (f4) publish(TAB_FK, TableView{f4->p, 4, false, f4->bytes, f4});
+            if (f4) publish(TAB_FK, f4, nullptr);
         }
-        if (!table_view(TAB_SRS).p) {
+        if (!table_view(TAB_SRS).main) {
             auto s4 = obtain_table(dev_, 0, 4, d_srs_, 64, build_stream_);
-            if (s4) publish(TAB_SRS, TableView{s4->p, 4, false, s4->bytes, s4});
+            if (s4) publish(TAB_SRS, s4, nullptr);
         }
     } catch (const BuildCancelled&) {
         state = 2;
@@ -1168,13 +1205,25 @@ void Engine::launch_msm(const void* scalars, TableSel which, void* out, int n_gr
     launch_msm(scalars, table_view(which), false, out, n_groups, n_slices, out_stride, brp_bits, st);
 }
 // tv: ONE snapshot of the table view (the builder thread may publish a wider table at any time); scalars_split: the producer
-// has stored the scalars as balanced GLV halves already (only meaningful for a GLV table)
+// has stored the scalars as balanced GLV halves already (only meaningful for a GLV table).  While a wider table is under
+// construction its leading ready groups run on it and the rest on the complete table: two launches, one MSM stage.
 void Engine::launch_msm(const void* scalars, const TableView& tv, bool scalars_split, void* out, int n_groups, int n_slices,
                         int out_stride, int brp_bits, hipStream_t st) {
-    const void* table = tv.p;
-    const int c = tv.c;
-    if (tv.glv) {  // GLV table: the scalars are split in place by the launcher (they feed nothing else)
-        const long msms = (long)n_groups * n_slices;
+    const SharedTable* main = tv.main.get();
+    const SharedTable* next = tv.next.get();
+    int ready = 0;
+    if (next && next->glv == main->glv) ready = std::min(n_groups, next->ready_groups.load(std::memory_order_acquire));
+    if (main->glv && !scalars_split) launch::glv_split(const_cast<void*>(scalars), (size_t)n_groups * n_slices * 64, st);  // in place: they feed nothing else
+    if (ready > 0) launch_msm_range(scalars, *next, 0, ready, out, n_groups, n_slices, out_stride, brp_bits, st);
+    if (ready < n_groups) launch_msm_range(scalars, *main, ready, n_groups - ready, out, n_groups, n_slices, out_stride, brp_bits, st);
+}
+// groups [g0, g0 + gcnt) of every slice on table t
+void Engine::launch_msm_range(const void* scalars, const SharedTable& t, int g0, int gcnt, void* out, int n_groups, int n_slices,
+                              int out_stride, int brp_bits, hipStream_t st) {
+    const launch::TabBlocks tb{(const void* const*)t.d_blocks, g0, gcnt};
+    const int c = t.c;
+    const long msms = (long)gcnt * n_slices;
+    if (t.glv) {
         int mode = 1;
         if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) mode = 0;
         else if (msm_chunks_ >= 0) mode = msm_chunks_ == 0 ? 1 : msm_chunks_ == 1 ? 3 : msm_chunks_ == 2 ? 4 : 2;  // tuning knob / tests
@@ -1188,23 +1237,22 @@ void Engine::launch_msm(const void* scalars, const TableView& tv, bool scalars_s
             // still lose 1-2 %: 16384 short waves dealt out as slots free up balance the SIMDs better than 4096 long ones.
             mode = 2;
         }
-        launch::msm_glv(c, mode, const_cast<void*>(scalars), table, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st, scalars_split);
+        launch::msm_glv(c, mode, scalars, tb, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st);
         return;
     }
     if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) {
-        launch::msm_fixed_flat(c, scalars, table, out, n_groups, n_slices, 64, out_stride, brp_bits, st);
+        launch::msm_fixed_flat(c, scalars, tb, out, n_groups, n_slices, 64, out_stride, brp_bits, st);
         return;
     }
     // Large batches: threads own a chunk of the windows of an MSM (S = 4 chunks: the fold is two additions per ~300, and
     // the waves are short enough for the tail of a launch not to matter; measured equal or better than S = 1, 2 at every
     // batch that fills the chip).  Below one round of the chip's 2-per-SIMD wave slots the windowed kernel (one thread
     // per window) has more parallelism.
-    const long msms = (long)n_groups * n_slices;
     int S = 0;
     if (msm_chunks_ >= 0) S = msm_chunks_;  // tuning knob ETH_KZG_AMD_MSM_CHUNKS: 0 = windowed kernel, 1/2/4 = chunked
     else if ((msms * 4 + 63) / 64 >= (long)wave_slots_) S = 4;
-    if (S) launch::msm_fixed_chunked(c, scalars, table, out, n_groups, n_slices, 64, out_stride, brp_bits, S, st);
-    else launch::msm_fixed(c, scalars, table, out, n_groups, n_slices, 64, out_stride, brp_bits, st);
+    if (S) launch::msm_fixed_chunked(c, scalars, tb, out, n_groups, n_slices, 64, out_stride, brp_bits, S, st);
+    else launch::msm_fixed(c, scalars, tb, out, n_groups, n_slices, 64, out_stride, brp_bits, st);
 }
 
 // inverse FFT_128, DIT, input at bit-reversed positions, only outputs 0..63 produced (domain.rs:172-194;

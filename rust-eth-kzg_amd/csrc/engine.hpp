@@ -106,7 +106,9 @@ public:
     // use_precomp: true -> the widest FK20 window table that fits in HBM (width 14 = 163 GB on an otherwise empty
     //              MI355X; the reference's UsePrecomp::Yes uses width 8 on the CPU), false -> width-4 tables (0.8 GB,
     //              ~3.4x the additions).  Results identical.  Tables are shared by the contexts of a device.
-    Engine(bool use_precomp, int device, bool auxiliary = false);
+    // primary: the context's engine when this one is an auxiliary lane of it (lease_serial): the lane shares the primary's
+    // window tables by reading through to its view -- no registry look-up, no builder thread, no lock shared with a build
+    Engine(bool use_precomp, int device, const Engine* primary = nullptr);
     ~Engine();
     Engine(const Engine&) = delete;
 
@@ -213,18 +215,20 @@ public:
     // built by a helper thread and published with one pointer swap: every MSM launch takes a snapshot of the view, results
     // are identical for every table (tests), only the speed changes.  ETH_KZG_AMD_PROGRESSIVE=0 builds them before the
     // constructor returns.
-    struct TableView {  // immutable once published
-        const void* p = nullptr;
+    struct TableView {  // a snapshot: main = the complete table calls run on, next = a wider one under construction (its
+                        // leading ready groups are used already; launch_msm); c / glv / bytes describe main
+        std::shared_ptr<SharedTable> main, next;
         int c = 0;          // window width
         bool glv = false;   // packed GLV table (k_msm_glv.inc) or plain (k_msm.hip)
         size_t bytes = 0;
-        std::shared_ptr<SharedTable> owner;
     };
     enum TableSel { TAB_FK = 0, TAB_SRS = 1 };
     TableView table_view(TableSel which) const;
     // 1 = final tables in place, 0 = still on the start tables (waits up to wait_ms; < 0: until done), 2 = the wide build
     // failed (out of memory ...) and the context stays on what it has
     int tables_ready(int wait_ms);
+    // groups of the table under construction that MSMs already run on (all of them once it is complete)
+    int table_groups_ready(TableSel which) const;
     void stop_builder();  // abandon an unfinished build of the wide tables and join the helper thread
     size_t table_bytes() const { return table_view(TAB_FK).bytes + table_view(TAB_SRS).bytes; }
     int window_bits() const { return table_view(TAB_FK).c; }  // of the FK20 table in use
@@ -264,8 +268,10 @@ private:
                     int brp_bits, hipStream_t st);
     void launch_msm(const void* scalars, const TableView& tv, bool scalars_split, void* out, int n_groups, int n_slices, int out_stride,
                     int brp_bits, hipStream_t st);
+    void launch_msm_range(const void* scalars, const SharedTable& t, int g0, int gcnt, void* out, int n_groups, int n_slices, int out_stride,
+                          int brp_bits, hipStream_t st);
     void build_final_tables();  // the wide tables: on the helper thread (progressive start) or inline
-    void publish(TableSel which, const TableView& v);
+    void publish(TableSel which, const std::shared_ptr<SharedTable>& main, const std::shared_ptr<SharedTable>& next);
     void g1_ifft128_take64(void* X, int stride, hipStream_t st);
     void g1_fft128_from64(void* X, int stride, hipStream_t st);
     void g1_fft128_full(void* X, int stride, int inverse, hipStream_t st);
@@ -292,6 +298,7 @@ private:
     std::string tables_error_;
     std::thread builder_;
     std::atomic<bool> cancel_build_{false};
+    bool progressive_build_ = false;  // the wide tables are built next to callers on the start tables: the builder leaves room on the GPU
     hipStream_t build_stream_ = nullptr;
     int wave_slots_ = 2048;  // CUs x 4 SIMDs x 2 waves: what one round of a ~240-VGPR point kernel occupies
     int msm_chunks_ = -1;    // -1: pick per launch (launch_msm); otherwise forced by ETH_KZG_AMD_MSM_CHUNKS
@@ -328,7 +335,9 @@ private:
     hipEvent_t v_decoded_ = nullptr, v_checked_ = nullptr;
 
     // serial-path lanes (lease_serial)
+    const Engine* primary_ = nullptr;   // set in an auxiliary lane
     bool auxiliary_ = false;
+    int lanes_pending_ = 0;             // lanes under construction (outside lanes_mu_)
     std::mutex lane_busy_;              // held while a leased call runs on THIS engine
     std::mutex lanes_mu_;               // guards aux_
     std::vector<std::unique_ptr<Engine>> aux_;

@@ -19,7 +19,9 @@ __device__ __forceinline__ JacQ msm_acc_to_jacq(const MsmAcc& a) { return to_jac
 // The table holds, for every base P and every window w, the multiples d * 2^(c*w) * P, d = 1..2^(c-1),
 // so an MSM is a pure sum of table entries selected by the signed Booth digits of the scalars
 // (booth_encoding.rs:4-46): no doublings at run time.
-//   table index: (((group * W + w) * NB + i) << (c-1)) + (|d| - 1)
+//   table index inside a group's block: (((w * NB + i) << (c-1)) + (|d| - 1); the groups' blocks are reached through a device
+//   array of pointers (launch::TabBlocks: blocks[group]) -- the table is allocated and published piece by piece -- and
+//   every kernel takes a group range [g0, g0 + gcnt) of the n_groups MSMs per slice
 // Thread (m, w) accumulates the NB entries of MSM m = (slice, group) for window w; the W partial
 // sums of an MSM sit in adjacent lanes and are folded through LDS.
 // scalars: [msm][NB] canonical Fr.  out[(perm(group)) * out_stride + slice] Jacobian.
@@ -42,7 +44,7 @@ __device__ __forceinline__ int booth_digit(const uint32_t* sc, int w, int c) {
 }
 
 template <int C>
-__global__ __launch_bounds__(256, 2) void k_msm_fixed(const Fr* __restrict__ scalars, const TabQ* __restrict__ table,
+__global__ __launch_bounds__(256, 2) void k_msm_fixed(const Fr* __restrict__ scalars, launch::TabBlocks table,
                                                    JacQ* __restrict__ out, int n_groups, int n_slices, int nb,
                                                    int out_stride, int brp_bits) {
     constexpr int W = (255 + C) / C;  // number of Booth windows
@@ -51,8 +53,8 @@ __global__ __launch_bounds__(256, 2) void k_msm_fixed(const Fr* __restrict__ sca
     const int tid = threadIdx.x;
     const int local = tid / W, w = tid % W;
     const long q_lin = (long)blockIdx.x * PER_BLOCK + local;  // linear index, GROUP-major: consecutive lanes / blocks are slices (blobs) of one group -- the same table rows
-    const long m = (q_lin % n_slices) * (long)n_groups + q_lin / n_slices;  // MSM index = slice * n_groups + group (the scalars' layout)
-    const long total = (long)n_groups * n_slices;
+    const long m = (q_lin % n_slices) * (long)n_groups + table.g0 + q_lin / n_slices;  // MSM index = slice * n_groups + group (the scalars' layout)
+    const long total = (long)table.gcnt * n_slices;
     const bool active = local < PER_BLOCK && q_lin < total;
     MsmAcc acc = msm_acc_inf();
     int group = 0, slice = 0;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void k_msm_fixed(const Fr* __restrict__ sca
         slice = (int)(m / n_groups);
         group = (int)(m % n_groups);
         const Fr* sc = scalars + (size_t)m * nb;
-        const TabQ* tb = table + (((size_t)group * W + w) * nb << (C - 1));
+        const TabQ* tb = reinterpret_cast<const TabQ*>(table.blocks[group]) + ((size_t)w * nb << (C - 1));
         for (int i = 0; i < nb; i++) {
             int d = booth_digit(sc[i].v, w, C);
             if (d != 0) {
@@ -133,7 +135,7 @@ __device__ __forceinline__ int take_booth(Fr& s) {
     return (x >> C) ? t - (1 << C) : t;
 }
 template <int C>
-__global__ __launch_bounds__(256, 2) void k_msm_fixed_chunked(const Fr* __restrict__ scalars, const TabQ* __restrict__ table,
+__global__ __launch_bounds__(256, 2) void k_msm_fixed_chunked(const Fr* __restrict__ scalars, launch::TabBlocks table,
                                                               JacQ* __restrict__ out, int n_groups, int n_slices, int nb,
                                                               int out_stride, int brp_bits, int S) {
     constexpr int W = (255 + C) / C;
@@ -141,8 +143,8 @@ __global__ __launch_bounds__(256, 2) void k_msm_fixed_chunked(const Fr* __restri
     const int tid = threadIdx.x;
     const int chunk = tid & (S - 1);                                      // S is a power of two
     const long q_lin = ((long)blockIdx.x * 256 + tid) / S;  // linear index, GROUP-major: consecutive lanes / blocks are slices (blobs) of one group -- the same table rows
-    const long m = (q_lin % n_slices) * (long)n_groups + q_lin / n_slices;  // MSM index = slice * n_groups + group (the scalars' layout)
-    const bool active = q_lin < (long)n_groups * n_slices;
+    const long m = (q_lin % n_slices) * (long)n_groups + table.g0 + q_lin / n_slices;  // MSM index = slice * n_groups + group (the scalars' layout)
+    const bool active = q_lin < (long)table.gcnt * n_slices;
     const int Wc = (W + S - 1) / S;
     const int w0 = chunk * Wc, nw = (w0 + Wc <= W ? Wc : W - w0);        // this thread's windows [w0, w0 + nw); nw may be <= 0
     int slice = 0, group = 0;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void k_msm_fixed_chunked(const Fr* __restri
         slice = (int)(m / n_groups);
         group = (int)(m % n_groups);
         const Fr* sc = scalars + (size_t)m * nb;
-        const TabQ* tb = table + ((((size_t)group * W + w0) * nb) << (C - 1));  // entry (w, i, a): tb[(((w - w0) * nb + i) << (C-1)) + a]
+        const TabQ* tb = reinterpret_cast<const TabQ*>(table.blocks[group]) + (((size_t)w0 * nb) << (C - 1));  // entry (w, i, a): tb[(((w - w0) * nb + i) << (C-1)) + a]
         // The scalar sits in registers shifted left by one bit (window 0 is padded with a zero bit,
         // booth_encoding.rs:4-46; r < 2^255 so nothing is lost); each window reads its c+1 low bits and shifts the
         // scalar right by c: static register indexing only.
@@ -206,14 +208,15 @@ __global__ __launch_bounds__(256, 2) void k_msm_fixed_chunked(const Fr* __restri
 // to all 256 lanes (5 additions each for W = 19, nb = 64) and folded by an 8-level tree in LDS.  ~30 % more field
 // work than the kernel above, but the dependent chain drops from 64 + 5 additions to 5 + 8.
 template <int C>
-__global__ __launch_bounds__(256) void k_msm_fixed_flat(const Fr* __restrict__ scalars, const TabQ* __restrict__ table,
+__global__ __launch_bounds__(256) void k_msm_fixed_flat(const Fr* __restrict__ scalars, launch::TabBlocks table,
                                                         JacQ* __restrict__ out, int n_groups, int nb, int out_stride,
                                                         int brp_bits) {
     constexpr int W = (255 + C) / C;
     __shared__ JacQ red[256];
     const int tid = threadIdx.x;
-    const long m = blockIdx.x;  // MSM index = slice * n_groups + group
-    const int slice = (int)(m / n_groups), group = (int)(m % n_groups);
+    const int slice = (int)(blockIdx.x / table.gcnt), group = table.g0 + (int)(blockIdx.x % table.gcnt);
+    const long m = (long)slice * n_groups + group;  // MSM index = slice * n_groups + group
+    const TabQ* tb = reinterpret_cast<const TabQ*>(table.blocks[group]);
     const Fr* sc = scalars + (size_t)m * nb;
     MsmAcc xacc = msm_acc_inf();
     for (int e = tid; e < W * nb; e += 256) {
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(256) void k_msm_fixed_flat(const Fr* __restrict__ s
         const int d = booth_digit(sc[i].v, w, C);
         if (d != 0) {
             const int ad = d < 0 ? -d : d;
-            const AffQ p = table[((((size_t)group * W + w) * nb + i) << (C - 1)) + (ad - 1)].a;
+            const AffQ p = tb[(((size_t)w * nb + i) << (C - 1)) + (ad - 1)].a;
             xacc = add_mixed(xacc, p, d < 0);
         }
     }
@@ -252,12 +255,13 @@ __global__ void k_glv_split(Fr* __restrict__ scalars, size_t n) {
 }
 namespace launch {
 template <int C>
-static void msm_flat_c(const void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,
+static void msm_flat_c(const void* scalars, const TabBlocks& table, void* out, int n_groups, int n_slices, int nb, int out_stride,
                        int brp_bits, hipStream_t st) {
-    k_msm_fixed_flat<C><<<(unsigned)(n_groups * n_slices), 256, 0, st>>>((const Fr*)scalars, (const TabQ*)table, (JacQ*)out,
-                                                                        n_groups, nb, out_stride, brp_bits);
+    if (table.gcnt <= 0 || n_slices <= 0) return;
+    k_msm_fixed_flat<C><<<(unsigned)(table.gcnt * n_slices), 256, 0, st>>>((const Fr*)scalars, table, (JacQ*)out,
+                                                                          n_groups, nb, out_stride, brp_bits);
 }
-void msm_fixed_flat(int c, const void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,
+void msm_fixed_flat(int c, const void* scalars, const TabBlocks& table, void* out, int n_groups, int n_slices, int nb, int out_stride,
                     int brp_bits, hipStream_t st) {
     if (c == 8) msm_flat_c<8>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
     else if (c == 12) msm_flat_c<12>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
@@ -270,7 +274,7 @@ void msm_fixed_flat(int c, const void* scalars, const void* table, void* out, in
 void glv_split(void* scalars, size_t n, hipStream_t st) {
     k_glv_split<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((Fr*)scalars, n);
 }
-#define GLV_DECL(w) void msm_glv_w##w(int, const void*, const void*, void*, int, int, int, int, int, const Fp12w&, hipStream_t);
+#define GLV_DECL(w) void msm_glv_w##w(int, const void*, const TabBlocks&, void*, int, int, int, int, int, const Fp12w&, hipStream_t);
 GLV_DECL(8) GLV_DECL(12) GLV_DECL(14) GLV_DECL(15) GLV_DECL(16)
 #undef GLV_DECL
 bool glv_width_supported(int c) {
@@ -278,9 +282,8 @@ bool glv_width_supported(int c) {
         if (w == c) return true;
     return false;
 }
-void msm_glv(int c, int mode, void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,
-             int brp_bits, const Fp12w& beta, hipStream_t st, bool already_split) {
-    if (!already_split) glv_split(scalars, (size_t)n_groups * n_slices * nb, st);
+void msm_glv(int c, int mode, const void* scalars, const TabBlocks& table, void* out, int n_groups, int n_slices, int nb, int out_stride,
+             int brp_bits, const Fp12w& beta, hipStream_t st) {
     switch (c) {
         case 8: return msm_glv_w8(mode, scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, beta, st);
         case 12: return msm_glv_w12(mode, scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, beta, st);
@@ -290,13 +293,14 @@ void msm_glv(int c, int mode, void* scalars, const void* table, void* out, int n
     }
 }
 template <int C>
-static void msm_chunked_c(const void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,
+static void msm_chunked_c(const void* scalars, const TabBlocks& table, void* out, int n_groups, int n_slices, int nb, int out_stride,
                           int brp_bits, int S, hipStream_t st) {
-    const long threads = (long)n_groups * n_slices * S;
-    k_msm_fixed_chunked<C><<<(unsigned)((threads + 255) / 256), 256, 0, st>>>((const Fr*)scalars, (const TabQ*)table, (JacQ*)out,
+    const long threads = (long)table.gcnt * n_slices * S;
+    if (threads <= 0) return;
+    k_msm_fixed_chunked<C><<<(unsigned)((threads + 255) / 256), 256, 0, st>>>((const Fr*)scalars, table, (JacQ*)out,
                                                                                n_groups, n_slices, nb, out_stride, brp_bits, S);
 }
-void msm_fixed_chunked(int c, const void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,
+void msm_fixed_chunked(int c, const void* scalars, const TabBlocks& table, void* out, int n_groups, int n_slices, int nb, int out_stride,
                        int brp_bits, int S, hipStream_t st) {
     if (c == 8) msm_chunked_c<8>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, S, st);
     else if (c == 12) msm_chunked_c<12>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, S, st);
@@ -306,14 +310,15 @@ void msm_fixed_chunked(int c, const void* scalars, const void* table, void* out,
     else msm_chunked_c<4>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, S, st);
 }
 template <int C>
-static void msm_c(const void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,
+static void msm_c(const void* scalars, const TabBlocks& table, void* out, int n_groups, int n_slices, int nb, int out_stride,
                   int brp_bits, hipStream_t st) {
     constexpr int PB = 256 / ((255 + C) / C);
-    long total = (long)n_groups * n_slices;
-    k_msm_fixed<C><<<(unsigned)((total + PB - 1) / PB), 256, 0, st>>>((const Fr*)scalars, (const TabQ*)table, (JacQ*)out,
+    long total = (long)table.gcnt * n_slices;
+    if (total <= 0) return;
+    k_msm_fixed<C><<<(unsigned)((total + PB - 1) / PB), 256, 0, st>>>((const Fr*)scalars, table, (JacQ*)out,
                                                                      n_groups, n_slices, nb, out_stride, brp_bits);
 }
-void msm_fixed(int c, const void* scalars, const void* table, void* out, int n_groups, int n_slices, int nb, int out_stride,
+void msm_fixed(int c, const void* scalars, const TabBlocks& table, void* out, int n_groups, int n_slices, int nb, int out_stride,
                int brp_bits, hipStream_t st) {
     if (c == 8) msm_c<8>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
     else if (c == 12) msm_c<12>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);

@@ -9,7 +9,7 @@ namespace kzg {
 // normalised to affine with one inversion per thread (Montgomery's trick over the thread's entries).
 // bases: [n_groups][nb] affine.  scratch: one Fp per table entry (prefix products of the Z's).
 template <int C>
-__global__ __launch_bounds__(64) void k_build_table(const G1Affine* __restrict__ bases, TabQ* __restrict__ table,
+__global__ __launch_bounds__(64) void k_build_table(const G1Affine* __restrict__ bases, void* const* __restrict__ blocks,
                                                     G1Jac* __restrict__ scratch, int n_groups, int nb) {
     constexpr int W = (255 + C) / C;
     constexpr int T = 1 << (C - 1);
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(64) void k_build_table(const G1Affine* __restrict__
     long bi = t / W;
     int i = (int)(bi % nb), group = (int)(bi / nb);
     G1Affine P = bases[bi];
-    TabQ* dst = table + ((((size_t)group * W + w) * nb + i) << (C - 1));
+    TabQ* dst = reinterpret_cast<TabQ*>(blocks[group]) + ((((size_t)w * nb + i) << (C - 1)));  // the group's block: [window][base][digit]
     G1Jac* scr = scratch + ((((size_t)group * W + w) * nb + i) << (C - 1));
     if (is_inf(P)) {
         for (int d = 0; d < T; d++) dst[d].a = affq_from_affine(aff_inf());
@@ -125,7 +125,7 @@ __global__ void k_table_windows(const G1Affine* __restrict__ bases, AffQ* __rest
 }
 
 template <int C>
-__global__ __launch_bounds__(64) void k_table_fill(const AffQ* __restrict__ qw, TabQ* __restrict__ table, Fq<260>* __restrict__ scratch,
+__global__ __launch_bounds__(64) void k_table_fill(const AffQ* __restrict__ qw, void* const* __restrict__ blocks, Fq<260>* __restrict__ scratch,
                                                    int nb, int* __restrict__ err) {
     constexpr int W = (255 + C) / C;
     constexpr int T = 1 << (C - 1), K = T / 64;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64) void k_table_fill(const AffQ* __restrict__ qw, 
     const long group = blk / ((long)nb * W);
     const long base = group * nb + i;
     const AffQ Q = qw[(size_t)base * 2 * W + w], S = qw[(size_t)base * 2 * W + W + w];
-    TabQ* dst = table + ((size_t)blk << (C - 1));
+    TabQ* dst = reinterpret_cast<TabQ*>(blocks[group]) + (((size_t)w * nb + i) << (C - 1));  // the group's block: [window][base][digit]
     Fq<260>* scr = scratch + ((size_t)blk << (C - 1));
     if (is_inf(Q)) {  // identity base (wave-uniform): an all-identity block
         for (int k = 0; k < K; k++) dst[k * 64 + lane].a = Q;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64) void k_table_fill(const AffQ* __restrict__ qw, 
 // window be 16 bits wide at all.  Entries are packed canonical coordinates (2 x 48 B): at 128 B they would not fit in HBM.
 // Same wave-per-(base, window) walk as k_table_fill; the un-normalised X, Y wait in a scratch (the 96-B entry cannot hold them).
 template <int C, int W>
-__global__ __launch_bounds__(64) void k_table_fill_packed(const AffQ* __restrict__ qw, TabP* __restrict__ table,
+__global__ __launch_bounds__(64) void k_table_fill_packed(const AffQ* __restrict__ qw, void* const* __restrict__ blocks,
                                                           Fq<260>* __restrict__ scratch_f, Fq<XB>* __restrict__ scratch_xy,
                                                           int nb, int* __restrict__ err) {
     constexpr int T = 1 << (C - 1), K = T / 64;
@@ -197,7 +197,10 @@ __global__ __launch_bounds__(64) void k_table_fill_packed(const AffQ* __restrict
     const long group = blk / ((long)nb * W);
     const long base = group * nb + i;
     const AffQ Q = qw[(size_t)base * 2 * W + w], S = qw[(size_t)base * 2 * W + W + w];
-    TabP* dst = table + ((size_t)blk << (C - 1));
+    // a group's lower WL = ceil(W / 2) windows and its upper W - WL windows are two blocks (k_msm_glv.inc: tab_window)
+    constexpr int WL = (W + 1) / 2;
+    const int upper = w >= WL ? 1 : 0;
+    TabP* dst = reinterpret_cast<TabP*>(blocks[2 * group + upper]) + (((size_t)(w - (upper ? WL : 0)) * nb + i) << (C - 1));
     Fq<260>* scr = scratch_f + ((size_t)blk << (C - 1));
     Fq<XB>* raw = scratch_xy + ((size_t)blk << C);  // 2 per entry
     if (is_inf(Q)) {  // identity base (wave-uniform): an all-identity block
@@ -244,19 +247,19 @@ __global__ __launch_bounds__(64) void k_table_fill_packed(const AffQ* __restrict
 
 namespace launch {
 template <int C>
-static void table_fast_c(const void* bases, void* table, void* scratch, void* qw, void* tmp, void* pre, int n_groups, int nb, int* err,
+static void table_fast_c(const void* bases, void* const* table, void* scratch, void* qw, void* tmp, void* pre, int n_groups, int nb, int* err,
                          hipStream_t st) {
     const int n_bases = n_groups * nb;
     constexpr int W = (255 + C) / C;
     k_table_windows<C><<<(n_bases + 63) / 64, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)qw, (JacQ*)tmp, (Fq<2>*)pre, n_bases);
-    k_table_fill<C><<<(unsigned)((long)n_bases * W), 64, 0, st>>>((const AffQ*)qw, (TabQ*)table, (Fq<260>*)scratch, nb, err);
+    k_table_fill<C><<<(unsigned)((long)n_bases * W), 64, 0, st>>>((const AffQ*)qw, table, (Fq<260>*)scratch, nb, err);
 }
 // side buffers of the fast builder, in bytes, for a chunk of n_groups groups
 size_t table_fast_side_bytes(int c, int n_groups, int nb) {
     const size_t W = (255 + c) / c, n = (size_t)n_groups * nb;
     return n * 2 * W * (SIZEOF_AFFQ + SIZEOF_JACQ + 56) + 256;
 }
-bool build_table_fast(int c, const void* bases, void* table, void* scratch /*56 B per entry*/, void* side, int n_groups, int nb,
+bool build_table_fast(int c, const void* bases, void* const* table, void* scratch /*56 B per entry*/, void* side, int n_groups, int nb,
                       int* err, hipStream_t st) {
     const size_t W = (255 + c) / c, n = (size_t)n_groups * nb;
     char* qw = (char*)side;
@@ -278,7 +281,7 @@ size_t table_glv_side_bytes(int c, int n_groups, int nb) {
     return n * 2 * glv_windows(c) * (SIZEOF_AFFQ + SIZEOF_JACQ + 56) + 256;
 }
 template <int C>
-static void table_glv_c(const void* bases, void* table, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st) {
+static void table_glv_c(const void* bases, void* const* table, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st) {
     constexpr int W = glv_windows(C);
     const size_t n = (size_t)n_groups * nb, entries = table_glv_entries(C, n_groups, nb);
     char* qw = (char*)side;
@@ -287,9 +290,9 @@ static void table_glv_c(const void* bases, void* table, void* scratch, void* sid
     char* scr_f = (char*)scratch;
     char* scr_xy = scr_f + entries * 56;
     k_table_windows<C, W><<<((int)n + 63) / 64, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)qw, (JacQ*)tmp, (Fq<2>*)pre, (int)n);
-    k_table_fill_packed<C, W><<<(unsigned)(n * W), 64, 0, st>>>((const AffQ*)qw, (TabP*)table, (Fq<260>*)scr_f, (Fq<XB>*)scr_xy, nb, err);
+    k_table_fill_packed<C, W><<<(unsigned)(n * W), 64, 0, st>>>((const AffQ*)qw, table, (Fq<260>*)scr_f, (Fq<XB>*)scr_xy, nb, err);
 }
-bool build_table_glv(int c, const void* bases, void* table, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st) {
+bool build_table_glv(int c, const void* bases, void* const* table, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st) {
     if (c == 16) table_glv_c<16>(bases, table, scratch, side, n_groups, nb, err, st);
     else if (c == 15) table_glv_c<15>(bases, table, scratch, side, n_groups, nb, err, st);
     else if (c == 14) table_glv_c<14>(bases, table, scratch, side, n_groups, nb, err, st);
@@ -302,16 +305,16 @@ size_t table_entries(int c, int n_groups, int nb) {
     int W = (255 + c) / c;
     return ((size_t)n_groups * nb * W) << (c - 1);
 }
-void build_table(int c, const void* bases, void* table, void* scratch, int n_groups, int nb, hipStream_t st) {
+void build_table(int c, const void* bases, void* const* table, void* scratch, int n_groups, int nb, hipStream_t st) {
     int W = (255 + c) / c;
     long threads = (long)n_groups * nb * W;
     unsigned blocks = (unsigned)((threads + 63) / 64);
-    if (c == 8) k_build_table<8><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (TabQ*)table, (G1Jac*)scratch, n_groups, nb);
-    else if (c == 12) k_build_table<12><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (TabQ*)table, (G1Jac*)scratch, n_groups, nb);
-    else if (c == 13) k_build_table<13><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (TabQ*)table, (G1Jac*)scratch, n_groups, nb);
-    else if (c == 14) k_build_table<14><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (TabQ*)table, (G1Jac*)scratch, n_groups, nb);
-    else if (c == 10) k_build_table<10><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (TabQ*)table, (G1Jac*)scratch, n_groups, nb);
-    else k_build_table<4><<<blocks, 64, 0, st>>>((const G1Affine*)bases, (TabQ*)table, (G1Jac*)scratch, n_groups, nb);
+    if (c == 8) k_build_table<8><<<blocks, 64, 0, st>>>((const G1Affine*)bases, table, (G1Jac*)scratch, n_groups, nb);
+    else if (c == 12) k_build_table<12><<<blocks, 64, 0, st>>>((const G1Affine*)bases, table, (G1Jac*)scratch, n_groups, nb);
+    else if (c == 13) k_build_table<13><<<blocks, 64, 0, st>>>((const G1Affine*)bases, table, (G1Jac*)scratch, n_groups, nb);
+    else if (c == 14) k_build_table<14><<<blocks, 64, 0, st>>>((const G1Affine*)bases, table, (G1Jac*)scratch, n_groups, nb);
+    else if (c == 10) k_build_table<10><<<blocks, 64, 0, st>>>((const G1Affine*)bases, table, (G1Jac*)scratch, n_groups, nb);
+    else k_build_table<4><<<blocks, 64, 0, st>>>((const G1Affine*)bases, table, (G1Jac*)scratch, n_groups, nb);
 }
 }  // namespace launch
 }  // namespace kzg

@@ -29,33 +29,45 @@ void test_scalars_be(const uint8_t* in, void* out, size_t n, hipStream_t st);
 void test_field_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, int n, int is_fp, hipStream_t st);
 
 // k_msm.hip
-void msm_fixed(int c, const void* scalars, const void* table, void* out /*G1Jac*/, int n_groups, int n_slices, int nb,
+// A window table as the kernels see it: a device array of block pointers -- one block per group for a plain table
+// (blocks[group]: [window][base][digit]), two per group for a GLV table (blocks[2 group + upper]: the lower ceil(W / 2) windows,
+// the upper rest) -- and the range [g0, g0 + gcnt) of groups this launch covers (of the n_groups MSMs per slice the scalars hold).
+// Tables are allocated in pieces and published group by group while they are built (engine.hip: SharedTable): a launch over
+// the groups already built on the new table and one over the rest on the old table make one MSM stage.
+struct TabBlocks {
+    const void* const* blocks;
+    int g0, gcnt;
+};
+void msm_fixed(int c, const void* scalars, const TabBlocks& table, void* out /*G1Jac*/, int n_groups, int n_slices, int nb,
                int out_stride, int brp_bits, hipStream_t st);
 // S = 1, 2 or 4 threads per MSM, each summing a chunk of the windows (large batches: no window-sum fold to speak of)
-void msm_fixed_chunked(int c, const void* scalars, const void* table, void* out /*JacQ*/, int n_groups, int n_slices, int nb,
+void msm_fixed_chunked(int c, const void* scalars, const TabBlocks& table, void* out /*JacQ*/, int n_groups, int n_slices, int nb,
                        int out_stride, int brp_bits, int S, hipStream_t st);
 // GLV tables (packed 96-B entries, W = glv_windows(c) windows of c bits over the 128-bit half scalars; k_msm_glv.inc, one
 // translation unit per width): mode 0 flat, 1 windowed, 2 four chunks per MSM (width 16), 3 a lane per MSM, 4 a lane per
-// GLV half.  msm_glv splits the scalars in place first (they feed nothing else) unless the producer has stored them split.
+// GLV half.  The scalars must be stored as balanced GLV halves (glv_split, or k_fk20_scalars' fused split).
 constexpr int glv_windows(int c) { return (128 + c - 1) / c; }
+constexpr int glv_lower_windows(int c) { return (glv_windows(c) + 1) / 2; }  // windows in the lower block of a group
 constexpr int GLV_WIDTHS[] = {16, 15, 14, 12, 8};  // widest first: the order the engine tries them in
 bool glv_width_supported(int c);
 void glv_split(void* scalars, size_t n, hipStream_t st);
-void msm_glv(int c, int mode, void* scalars, const void* table, void* out /*JacQ*/, int n_groups, int n_slices, int nb, int out_stride,
-             int brp_bits, const Fp12w& beta, hipStream_t st, bool already_split = false);
-void msm_fixed_flat(int c, const void* scalars, const void* table, void* out /*G1Jac*/, int n_groups, int n_slices, int nb,
+void msm_glv(int c, int mode, const void* scalars, const TabBlocks& table, void* out /*JacQ*/, int n_groups, int n_slices, int nb, int out_stride,
+             int brp_bits, const Fp12w& beta, hipStream_t st);
+void msm_fixed_flat(int c, const void* scalars, const TabBlocks& table, void* out /*G1Jac*/, int n_groups, int n_slices, int nb,
                int out_stride, int brp_bits, hipStream_t st);
 // k_table.hip
 constexpr size_t SIZEOF_TABP = 96;    // a packed GLV table entry
 size_t table_glv_entries(int c, int n_groups, int nb);
 size_t table_glv_side_bytes(int c, int n_groups, int nb);
-// scratch: 168 B per entry of the chunk; side: table_glv_side_bytes; false if the width is not built in
-bool build_table_glv(int c, const void* bases, void* table, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st);
+// scratch: 168 B per entry of the chunk; side: table_glv_side_bytes; false if the width is not built in.
+// blocks: device array of 2 * n_groups block pointers of THIS chunk's groups (lower / upper windows of each)
+bool build_table_glv(int c, const void* bases, void* const* blocks, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st);
 size_t table_entries(int c, int n_groups, int nb);
 size_t table_fast_side_bytes(int c, int n_groups, int nb);
-// widths >= 8: wave-per-(base, window) builder; scratch = 56 B per entry of the chunk, side = table_fast_side_bytes; false if c unsupported
-bool build_table_fast(int c, const void* bases, void* table, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st);
-void build_table(int c, const void* bases /*G1Affine*/, void* table /*G1Affine*/, void* scratch /*G1Jac*/, int n_groups,
+// widths >= 8: wave-per-(base, window) builder; scratch = 56 B per entry of the chunk, side = table_fast_side_bytes; false if c unsupported.
+// blocks: device array of n_groups block pointers of THIS chunk's groups
+bool build_table_fast(int c, const void* bases, void* const* blocks, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st);
+void build_table(int c, const void* bases /*G1Affine*/, void* const* blocks, void* scratch /*G1Jac*/, int n_groups,
                  int nb, hipStream_t st);
 
 // k_g1fft.hip

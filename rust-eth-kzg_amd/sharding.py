@@ -27,7 +27,7 @@ def all_gather_flat(local, out=None, dist=None):
     return out
 
 
-def attach_library_comm(ctx, dist, required=False) -> bool:
+def attach_library_comm(ctx, dist, required=False, timeout_s=None) -> bool:
     """Give `ctx` the library's own RCCL communicator (eth_kzg_amd_comm_init): rank 0 draws the id, torch.distributed
     only carries its 128 bytes to the other ranks.  After this, all_gather_proofs runs ncclAllGather inside
     libc_eth_kzg.so, which is also what a C / Go / Java host would call.
@@ -35,8 +35,19 @@ def attach_library_comm(ctx, dist, required=False) -> bool:
     comm_init is itself a collective (ncclCommInitRank), so no rank may enter it unless all do: every rank first runs the
     local probe (RCCL bindable, no communicator attached yet; rank 0 also draws the id) and the ranks agree on the MIN of
     those flags BEFORE anyone calls comm_init.  All ranks or none.  Returns False -- with the reason in
-    `attach_library_comm.last_error` -- if some rank cannot take part; raises instead when `required`."""
+    `attach_library_comm.last_error` -- if some rank cannot take part; raises instead when `required`.
+
+    Watchdog: comm_init runs on a helper thread and is given `timeout_s` seconds ($KZG_COMM_INIT_TIMEOUT_S, default 60).  A
+    rank whose ncclCommInitRank has not returned by then reports that as its failure; the ranks then agree (over torch's
+    communicator, which is independent of the library's) that the library communicator is unusable and every one of them takes
+    the failure path -- nobody waits for ever, the caller falls back to torch.distributed's all-gather and says so.  The stuck
+    thread is left behind (`attach_library_comm.stuck` is set: the caller should leave with os._exit when it is done)."""
+    import os
+    import threading
     attach_library_comm.last_error = ""
+    attach_library_comm.stuck = False
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("KZG_COMM_INIT_TIMEOUT_S", "60"))
     if dist is None or not dist.is_initialized():
         attach_library_comm.last_error = "torch.distributed is not initialised"
         if required:
@@ -64,23 +75,35 @@ def attach_library_comm(ctx, dist, required=False) -> bool:
     dist.broadcast_object_list(box, src=0)
     # from here on every rank is known to be able to enter the collective
     ok, why = 1, ""
-    try:
-        ctx.comm_init(box[0], rank, world)
-        got = ctx.comm_info()
-        if got != (rank, world):
-            ok, why = 0, f"rank {rank}: communicator reports (rank, world) = {got}, expected {(rank, world)}"
-    except Exception as e:
-        ok, why = 0, f"rank {rank}: {e}"
+    result = {}
+
+    def enter():
+        try:
+            ctx.comm_init(box[0], rank, world)
+            result["info"] = ctx.comm_info()
+        except Exception as e:  # reported below
+            result["error"] = e
+    th = threading.Thread(target=enter, name="kzg-comm-init", daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        attach_library_comm.stuck = True
+        ok, why = 0, f"rank {rank}: ncclCommInitRank did not return within {timeout_s:g} s (watchdog)"
+    elif "error" in result:
+        ok, why = 0, f"rank {rank}: {result['error']}"
+    elif result.get("info") != (rank, world):
+        ok, why = 0, f"rank {rank}: communicator reports (rank, world) = {result.get('info')}, expected {(rank, world)}"
     flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if on_cpu else "cuda")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if not int(flag.item()):
         reasons = [None] * world
         dist.all_gather_object(reasons, why)
         attach_library_comm.last_error = "; ".join(r for r in reasons if r)
-        try:
-            ctx.comm_destroy()
-        except Exception:
-            pass
+        if not attach_library_comm.stuck:  # (a communicator another thread is still building is left alone)
+            try:
+                ctx.comm_destroy()
+            except Exception:
+                pass
         if required:
             raise RuntimeError("library communicator could not be built: " + attach_library_comm.last_error)
         return False
@@ -88,6 +111,7 @@ def attach_library_comm(ctx, dist, required=False) -> bool:
 
 
 attach_library_comm.last_error = ""
+attach_library_comm.stuck = False
 
 
 def all_gather_proofs(ctx, local, out, stream=None):

@@ -108,8 +108,12 @@ def test_table_budget_picks_the_widest_glv_table_that_fits(oracle, monkeypatch):
 
 
 def test_progressive_start_serves_at_once_and_switches_tables(oracle, monkeypatch):
-    """eth_kzg_das_context_new returns on the start tables (GLV width 8 / plain width 8); calls made before, during and
-    after the switch to the wide tables give identical bytes (and match the oracle)."""
+    """eth_kzg_das_context_new returns on the start tables (GLV width 8 / plain width 8).  The wide tables are allocated in pieces
+    of under a gigabyte and taken into use GROUP BY GROUP while the helper thread builds them (an MSM stage = the ready groups on
+    the wide table + the rest on the start table): calls made before, during -- at every mix of the two tables the loop happens
+    to meet -- and after the switch give identical bytes (and match the oracle), and a commitment / a verification issued from
+    other threads during the build come back right.  How long a call waits during the build is a measurement: bench.py records it
+    (configs.context_creation_s.calls_during_build); nothing here compares clocks."""
     import torch
     full._torch_first()
     monkeypatch.delenv("ETH_KZG_AMD_PROGRESSIVE", raising=False)
@@ -126,22 +130,52 @@ def test_progressive_start_serves_at_once_and_switches_tables(oracle, monkeypatc
         comm0 = c.blob_to_kzg_commitment(blobs[5].tobytes())
         full._check_sample_against_oracle(oracle, blobs, cells0, proofs0, [0, 1, 39])
         assert comm0 == oracle.blob_to_kzg_commitment(blobs[5].tobytes())
-        # keep calling while the helper thread builds and publishes the wide tables
-        widths_seen, n_calls = {first_w}, 0
-        while c.tables_ready(0) == 0 and n_calls < 4000:
-            st, cells, proofs = full._compute_on_device(c, blobs)
-            assert st == [0] * 40 and np.array_equal(cells, cells0) and np.array_equal(proofs, proofs0)
-            widths_seen.add(c.window_bits())
-            n_calls += 1
+        # other threads use the serial paths (commitment on the SRS table that is being widened too, verification) meanwhile
+        side_errors, stop = [], threading.Event()
+        cl = [cells0[5][k * 2048:(k + 1) * 2048].tobytes() for k in range(128)]
+        pl = [proofs0[5][k * 48:(k + 1) * 48].tobytes() for k in range(128)]
+
+        def side():
+            try:
+                while not stop.is_set():
+                    assert c.blob_to_kzg_commitment(blobs[5].tobytes()) == comm0
+                    assert c.verify_cell_kzg_proof_batch([comm0] * 128, list(range(128)), cl, pl) is True
+            except Exception as e:  # pragma: no cover
+                side_errors.append(e)
+        th = threading.Thread(target=side)
+        th.start()
+        # keep calling (one call every ~5 ms) while the helper thread builds and publishes the wide tables
+        widths_seen, groups_seen, n_calls, waits = {first_w}, [c.table_groups_ready()], 0, []
+        try:
+            while c.tables_ready(0) == 0 and n_calls < 20000:
+                t1 = time.perf_counter()
+                st, cells, proofs = full._compute_on_device(c, blobs)
+                waits.append(time.perf_counter() - t1)
+                assert st == [0] * 40 and np.array_equal(cells, cells0) and np.array_equal(proofs, proofs0), (n_calls, groups_seen[-1])
+                widths_seen.add(c.window_bits())
+                g = c.table_groups_ready()
+                if c.tables_ready(0) == 0 and c.window_bits() == first_w:
+                    assert g >= groups_seen[-1] or groups_seen[-1] == 128, (g, groups_seen[-5:])  # groups only ever become ready
+                groups_seen.append(g)
+                n_calls += 1
+                time.sleep(0.005)
+        finally:
+            stop.set()
+            th.join()
+        assert not side_errors, side_errors
         assert c.tables_ready(-1) == 1
-        assert c.glv_table() and c.window_bits() == 16
+        assert c.glv_table() and c.window_bits() == 16 and c.table_groups_ready() == 128
         st, cells, proofs = full._compute_on_device(c, blobs)
         assert np.array_equal(cells, cells0) and np.array_equal(proofs, proofs0)
         assert c.blob_to_kzg_commitment(blobs[5].tobytes()) == comm0
+        mixed = sorted({g for g in groups_seen if 0 < g < 128})
         print(f"progressive start: context_new {t_new:.2f} s, first 40-blob result after {t_first:.2f} s, start state {first_state} "
-              f"on width {first_w}, {n_calls} calls during the build, widths seen {sorted(widths_seen)}")
+              f"on width {first_w}, {n_calls} calls during the build (longest {max(waits) * 1e3 if waits else 0:.0f} ms, median "
+              f"{sorted(waits)[len(waits) // 2] * 1e3 if waits else 0:.1f} ms), widths seen {sorted(widths_seen)}, "
+              f"{len(mixed)} distinct mixes of start and wide table met (groups ready: {mixed[:6]} ... {mixed[-3:]})")
         if first_state == 0:
             assert first_w == 8
+            assert n_calls == 0 or mixed, "the wide table was never used before it was complete"
     finally:
         c.close()
 

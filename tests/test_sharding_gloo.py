@@ -67,8 +67,8 @@ def _worker(rank, world, port, n_blobs, q):
         """Stands in for the context's communicator calls.  comm_init is a collective in the real library, so the fake
         records whether it was ever entered: when one rank's probe fails, NO rank may enter it (a rank inside
         ncclCommInitRank would wait for the missing one for ever)."""
-        def __init__(self, probe_fails_on=None, init_fails_on=None):
-            self.probe_fails_on, self.init_fails_on = probe_fails_on, init_fails_on
+        def __init__(self, probe_fails_on=None, init_fails_on=None, init_hangs_on=None):
+            self.probe_fails_on, self.init_fails_on, self.init_hangs_on = probe_fails_on, init_fails_on, init_hangs_on
             self.attached, self.destroyed, self.entered_init = None, False, False
 
         def comm_probe(self):
@@ -81,6 +81,9 @@ def _worker(rank, world, port, n_blobs, q):
 
         def comm_init(self, uid, r, w):
             self.entered_init = True
+            if self.init_hangs_on == r:  # a rank stuck inside ncclCommInitRank (the watchdog's case)
+                import time
+                time.sleep(30)
             if self.init_fails_on == r:
                 raise RuntimeError("no RCCL here")
             self.attached = (uid, r, w)
@@ -106,6 +109,12 @@ def _worker(rank, world, port, n_blobs, q):
         except RuntimeError:
             loud = True
         assert loud  # bench.py asks for required=True: no silent fall-back
+    # the watchdog: one rank never comes back from comm_init -> after the timeout ALL ranks report failure with the reason, none
+    # waits for the sleeper, and the stuck communicator is not destroyed under the thread that is still inside it
+    fc = FakeComm(init_hangs_on=1)
+    assert sh.attach_library_comm(fc, dist, timeout_s=1.5) is False
+    assert "did not return within 1.5 s" in sh.attach_library_comm.last_error
+    assert sh.attach_library_comm.stuck == (rank == 1) and (fc.destroyed == (rank != 1))
     if rank == 0:
         q.put(res)
     dist.barrier()

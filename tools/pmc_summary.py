@@ -16,5 +16,12 @@ for d in dirs:
             k = kern.setdefault(name, {})
             k[ctr + "_per_launch_max"] = max(k.get(ctr + "_per_launch_max", 0.0), v)
             k[ctr + "_launches"] = k.get(ctr + "_launches", 0) + 1
-json.dump({"note": note, "kernels": kern}, open(out, "w"), indent=1)
+# the key bench.py uses to decide whether these counters belong to the build it is running (bench.py: kernel_sources_hash)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+try:
+    from bench import kernel_sources_hash
+    src_hash = kernel_sources_hash()
+except Exception as e:  # pragma: no cover
+    src_hash = None
+json.dump({"note": note, "msm_kernel_sources_sha256": src_hash, "kernels": kern}, open(out, "w"), indent=1)
 print(out, len(kern), "kernels")
