@@ -382,11 +382,27 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
         t0 = time.perf_counter()
         run_bad()
         tb.append(time.perf_counter() - t0)
+    # ... and with EIGHT tampered problems spread over the call
+    bad_at = [3, 77, 200, 201, 512, 700, 901, 1023]
+    many_bad8 = list(many)
+    for j in bad_at:
+        pj = list(many[j][3]); pj[9] = many[(j + 1) % nb][3][9]
+        many_bad8[j] = (many[j][0], many[j][1], many[j][2], pj)
+    run_bad8 = ctx.prepare_verify_cell_kzg_proof_batch_many(many_bad8)
+    ver, stt = run_bad8()
+    assert stt == [0] * 1024 and ver == [j not in bad_at for j in range(1024)], "verify_many verdicts (eight tampered problems)"
+    tb8 = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        run_bad8()
+        tb8.append(time.perf_counter() - t0)
     out["verify_many_1024_x_128_cells"] = {"ms": round(_median(ts) * 1e3, 2), "verifications_per_s": round(1024 / _median(ts)), "cells_per_s": round(1024 * CELLS / _median(ts)),
                                            "with_one_invalid_proof_ms": round(_median(tb) * 1e3, 2), "with_one_invalid_proof_verifications_per_s": round(1024 / _median(tb)),
+                                           "with_eight_invalid_proofs_ms": round(_median(tb8) * 1e3, 2), "with_eight_invalid_proofs_verifications_per_s": round(1024 / _median(tb8)),
                                            "entry": "eth_kzg_amd_verify_cell_kzg_proof_batch_many (host pointers: 275 MB of input per call, staging and 1024 transcript hashes on the "
-                                                    "host threads included; all problems valid: ONE folded pairing check per pass; with an invalid proof in the call: "
-                                                    "1024 pairing checks on the host threads, verdicts checked)"}
+                                                    "host threads included; all problems valid: ONE folded pairing check per pass; with invalid proofs in the call: "
+                                                    "the wrong problems are searched by folding sub-ranges of the resident weighted sums, one pairing per probe "
+                                                    "on the host threads; verdicts checked)"}
     _mark("side configs: single verifications from many threads")
     import threading
     for n_thr, key in ((4, "verify_128_cells_from_4_threads"), (32, "verify_128_cells_from_32_threads")):
@@ -755,11 +771,12 @@ def main():
     # While the helper thread allocates (pieces of < 1 GB) and builds the wide tables, a caller keeps working: one
     # compute_cells_and_kzg_proofs through the reference's entry point every 5 ms.  How long the slowest of them took is the
     # stall a service sees during start-up (round 3: one 206 GB hipMalloc froze every HIP call of the process for 2-4.4 s).
-    waits, half_s, all_groups_s = [], None, None
+    waits, wait_at, half_s = [], [], None
     while ctx.tables_ready(0) == 0:
         t1 = time.perf_counter()
         out_k = ctx.compute_cells_and_kzg_proofs(first_blob)
         waits.append(time.perf_counter() - t1)
+        wait_at.append(t1 - t_ctx0)
         assert out_k == first_out, "a call made while the wide tables were being built returned different bytes"
         g = ctx.table_groups_ready()
         if half_s is None and (g >= 64 or ctx.window_bits() != start_width):
@@ -776,6 +793,7 @@ def main():
                  "calls_during_build": {"calls": len(ws), "calls_per_s": round(len(ws) / max(1e-9, t_ctx - t_ctx_first), 1) if ws else None,
                                         "longest_ms": round(ws[-1] * 1e3, 2) if ws else None, "p99_ms": round(ws[int(0.99 * (len(ws) - 1))] * 1e3, 2) if ws else None,
                                         "median_ms": round(ws[len(ws) // 2] * 1e3, 2) if ws else None,
+                                        "slowest_three_at_s_ms": [[round(a, 2), round(w * 1e3, 1)] for w, a in sorted(zip(waits, wait_at), reverse=True)[:3]],
                                         "what": "eth_kzg_compute_cells_and_kzg_proofs of one blob every 5 ms from the calling thread while the helper thread "
                                                 "allocates and builds ~250 GB of window tables; bytes checked against the first result every time"}}
 

@@ -322,6 +322,7 @@ Engine::Engine(bool use_precomp, int device, const Engine* primary) : dev_(devic
             if (g > 0) table_budget_gb_ = g;
         }
     }
+    if (const char* s = getenv("ETH_KZG_AMD_VM_SEARCH")) vm_search_ = atoi(s) != 0;  // tests: the per-problem re-check of round 3 as the cross-check
     if (const char* s = getenv("ETH_KZG_AMD_PIP_SHIFT_MIN")) {  // tuning knob: smallest cell count verified with byte-shifted point copies
         const int v = atoi(s);
         if (v >= 1) pip_shift_min_ = v;
@@ -782,6 +783,9 @@ struct Engine::SharedTable {
             alloc_ms_max = std::max(alloc_ms_max, dt);
             if (e != hipSuccess) { (void)hipGetLastError(); why = std::string("hipMalloc of a table piece: ") + hipGetErrorString(e); return false; }
             pieces.push_back(p);
+            // the HIP runtime serialises allocations and other calls on locks that are not fair: a thread that allocates piece
+            // after piece without a pause can keep another thread's launch waiting for many pieces in a row
+            std::this_thread::sleep_for(std::chrono::microseconds(300));
             char* q = (char*)p;
             for (int k = 0; k < n; k++) { h_blocks[blocks_allocated + k] = q; q += block_bytes(blocks_allocated + k); }
             blocks_allocated += n;
@@ -960,9 +964,11 @@ int Engine::tables_ready(int wait_ms) {
     return tables_state_;
 }
 int Engine::table_groups_ready(TableSel which) const {
+    if (primary_) return primary_->table_groups_ready(which);
     const TableView v = table_view(which);
     if (v.next) return v.next->ready_groups.load(std::memory_order_acquire);
-    return v.main ? v.main->n_groups : 0;
+    std::lock_guard<std::mutex> lk(tab_mu_);
+    return tables_state_ != 0 && v.main ? v.main->n_groups : 0;  // nothing wider under construction yet (or ever): 0 until the builder is done
 }
 
 void Engine::init_fk20() {

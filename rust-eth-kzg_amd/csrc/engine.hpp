@@ -24,6 +24,11 @@ struct G1Affine;  // curve.hpp
 struct Fr8 { uint32_t v[8]; };
 struct Fp12w { uint32_t v[12]; };
 
+// A verification problem's cell list is bounded: the powers of the Fiat-Shamir challenge come from a 24-entry table r^(2^i)
+// (k_verify.hip: k_verify_scalars, k_verify_many.hip: k_vm_scalars) and positions are 32-bit on the device.  2^24 cells are 34 GB
+// of input; longer lists are rejected as invalid input by every verification entry point.
+constexpr uint64_t MAX_CELLS_PER_VERIFICATION = (1u << 24) - 1;
+
 enum Status : int {
     OK = 0,
     ERR_SCALAR = 1,    // a field element >= r   (SerializationError::CouldNotDeserializeScalar)
@@ -355,6 +360,7 @@ private:
 
     // many-verification path (verify_many.hip): its own lock, stream, device arena and pinned slab
     std::mutex vm_mu_;
+    bool vm_search_ = true;  // ETH_KZG_AMD_VM_SEARCH=0: a pass whose folded check fails is re-checked problem by problem (round 3's form)
     hipStream_t vm_stream_ = nullptr;
     void* vm_dev_ = nullptr;
     size_t vm_dev_cap_ = 0;

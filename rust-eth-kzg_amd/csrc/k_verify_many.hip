@@ -235,6 +235,26 @@ __global__ __launch_bounds__(256) void k_vm_fold_sum(const JacQ* __restrict__ pr
     if (l == 0) out2[job] = acc;
 }
 
+// sums of the weighted per-problem pairs over RANGES of problems: out[r][j] = sum of prod[b][j], ranges[r][0] <= b < ranges[r][1]
+// (the probes of the search for the wrong proofs of a pass whose folded check failed; the products rho_b * sum_b are resident)
+__global__ __launch_bounds__(256) void k_vm_fold_ranges(const JacQ* __restrict__ prod, const int* __restrict__ ranges, JacQ* __restrict__ out) {
+    __shared__ JacQ red[256];
+    const int t = threadIdx.x, job = t >> 7, l = t & 127;
+    const int lo = ranges[2 * blockIdx.x], hi = ranges[2 * blockIdx.x + 1];
+    JacQ acc = jacq_inf();
+    for (int b = lo + l; b < hi; b += 128) acc = add(acc, prod[2 * (size_t)b + job]);
+    const int width = hi - lo < 128 ? hi - lo : 128;  // lanes that hold anything
+#pragma unroll 1
+    for (int span = 64; span >= 1; span >>= 1) {
+        if (span >= width) continue;  // (block-uniform) nothing to fold at this distance
+        red[t] = acc;
+        __syncthreads();
+        if (l < span) acc = add(acc, red[t + span]);
+        __syncthreads();
+    }
+    if (l == 0) out[2 * (size_t)blockIdx.x + job] = acc;
+}
+
 namespace launch {
 static Fr vm_fr(const Fr8& x) { Fr r; for (int i = 0; i < 8; i++) r.v[i] = x.v[i]; return r; }
 void vm_scalars(const void* pow_tables /*[B][24] Fr, device*/, const int* batch_of, const int* pos_in_batch, const int* cell_idx,
@@ -261,6 +281,9 @@ void vm_fold(const void* sums, const uint32_t* rho, void* prod, void* out2, int 
     for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
     k_vm_fold_mul<<<(2 * n_batches + 63) / 64, 64, 0, st>>>((const JacQ*)sums, rho, (JacQ*)prod, n_batches, fq_from_fp(b384));
     k_vm_fold_sum<<<1, 256, 0, st>>>((const JacQ*)prod, (JacQ*)out2, n_batches);
+}
+void vm_fold_ranges(const void* prod, const int* ranges, void* out, int n_ranges, hipStream_t st) {
+    if (n_ranges > 0) k_vm_fold_ranges<<<n_ranges, 256, 0, st>>>((const JacQ*)prod, ranges, (JacQ*)out);
 }
 void vm_reduce(const void* prod, const void* icommit, const int* cell_start, const int* row_start, void* out, int n, int n_batches,
                hipStream_t st) {

@@ -153,6 +153,8 @@ void vm_reduce(const void* prod, const void* icommit, const int* cell_start, con
                int n_batches, hipStream_t st);
 // out2[j] = sum_b rho_b sums[b][j] (rho: 4 words per problem, 0 excludes it); prod: scratch of 2 B JacQ
 void vm_fold(const void* sums, const uint32_t* rho, void* prod, void* out2, int n_batches, const Fp12w& beta, hipStream_t st);
+// out[r][2] = the weighted pairs summed over problems ranges[r][0] .. ranges[r][1] - 1 (prod as vm_fold left it)
+void vm_fold_ranges(const void* prod, const int* ranges /*[n_ranges][2], device*/, void* out /*[n_ranges][2] JacQ*/, int n_ranges, hipStream_t st);
 
 // k_4844.hip
 void quotient_by_linear(int n, const void* coeffs, const void* z_mont, void* quotient, void* y_out, hipStream_t st);

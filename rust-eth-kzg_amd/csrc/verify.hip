@@ -118,6 +118,7 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
     }
     // validation (verifier.rs:123-164)
     if (!(n_commitments == n_indices && n_commitments == n_cells && n_commitments == n_proofs)) return ERR_INPUT;
+    if (n_cells > MAX_CELLS_PER_VERIFICATION) return ERR_INPUT;  // (engine.hpp: the 24-entry power table, 32-bit positions)
     for (uint64_t i = 0; i < n_indices; i++)
         if (cell_indices[i] >= (uint64_t)N_CELLS) return ERR_INPUT;
     if (lo > hi || hi > n_cells) return ERR_INPUT;

@@ -116,7 +116,7 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
         std::vector<Problem> pr(B);
         parallel_for(B, T, dev_, [&](int b) {
             const uint64_t nc = n_commitments[b];
-            if (!(nc == n_indices[b] && nc == n_cells[b] && nc == n_proofs[b])) { status[b] = ERR_INPUT; return; }
+            if (!(nc == n_indices[b] && nc == n_cells[b] && nc == n_proofs[b]) || nc > MAX_CELLS_PER_VERIFICATION) { status[b] = ERR_INPUT; return; }
             for (uint64_t i = 0; i < nc; i++)
                 if (cell_indices[b][i] >= (uint64_t)N_CELLS) { status[b] = ERR_INPUT; return; }
             if (nc == 0) { verified[b] = 1; return; }  // verifier.rs:90-93
@@ -176,12 +176,17 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
             const size_t off_out = o; o += up((size_t)2 * Bc * launch::SIZEOF_JACQ);
             const size_t off_fprod = o; o += up((size_t)2 * Bc * launch::SIZEOF_JACQ);
             const size_t off_fold = o; o += up((size_t)2 * launch::SIZEOF_JACQ);
+            const int max_ranges = std::min(Bc, 2048);  // probes per level of the search for wrong proofs
+            const size_t off_rng = o; o += up((size_t)max_ranges * 8);
+            const size_t off_rsum = o; o += up((size_t)2 * max_ranges * launch::SIZEOF_JACQ);
             const size_t dev_bytes = o;
             // pinned read-backs behind the inputs
             size_t po = in2_bytes;
             const size_t poff_st = po; po += up((size_t)(n + m + Bc) * 4);
             const size_t poff_out = po; po += up((size_t)2 * Bc * launch::SIZEOF_JACQ);
             const size_t poff_fold = po; po += up((size_t)2 * launch::SIZEOF_JACQ);
+            const size_t poff_rng = po; po += up((size_t)max_ranges * 8);
+            const size_t poff_rsum = po; po += up((size_t)2 * max_ranges * launch::SIZEOF_JACQ);
             const size_t pin_bytes = po;
             if (dev_bytes > vm_dev_cap_) {
                 if (vm_dev_) { HIPCK(hipStreamSynchronize(st)); HIPCK(hipFree(vm_dev_)); vm_dev_ = nullptr; vm_dev_cap_ = 0; }
@@ -337,22 +342,84 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
                 G1Affine pts[2] = {to_affine(jac_from_jacq(f2[0])), to_affine(jac_from_jacq(f2[1]))};
                 all_true = verify_cells_pairing(pts);
             }
+            auto check_single = [&](int i) {  // one problem's own pairing check on the sums read back
+                G1Affine pts[2];
+                for (int j = 0; j < 2; j++) {
+                    const JacQ& s = sums[2 * (size_t)i + j];
+                    if (poisoned(s)) { device_fault.store(1); return; }
+                    pts[j] = to_affine(jac_from_jacq(s));
+                }
+                verified[b0 + i] = verify_cells_pairing(pts) ? 1 : 0;
+            };
             if (all_true) {
                 for (int i = 0; i < Bc; i++)
                     if (live[i]) {
                         if (poisoned(sums[2 * (size_t)i]) || poisoned(sums[2 * (size_t)i + 1])) { device_fault.store(1); break; }
                         verified[b0 + i] = 1;
                     }
+            } else if (folded && vm_search_) {
+                // Some proof of the pass is wrong.  The weighted pairs rho_b * sum_b are still in HBM: SEARCH for the wrong ones by
+                // folding sub-ranges (k_vm_fold_ranges: one small launch per level) and checking each with one pairing on a host
+                // thread -- a range whose fold passes holds only valid proofs (the same 2^-127 argument, the weights were fixed
+                // after every input byte), a single problem whose weighted pair fails is wrong EXACTLY (rho_b != 0 and the
+                // pairing group has prime order).  Ranges are split K ways with K chosen so that a level's probes fill the
+                // host threads once: one wrong proof among 1024 costs ~36 pairings in 3 rounds instead of 1024 in 64 (round 3:
+                // 85 ms per call against 29.6 ms for an all-valid one).  When wrong proofs are many the search stops paying:
+                // from a quarter of the live problems suspect, the rest is checked one by one as before.
+                std::vector<std::pair<int, int>> suspects{{0, Bc}};
+                int* h_rng = (int*)(hb + poff_rng);
+                const JacQ* h_rsum = (const JacQ*)(hb + poff_rsum);
+                while (!suspects.empty()) {
+                    long suspect_problems = 0;
+                    for (auto& sr : suspects) suspect_problems += sr.second - sr.first;
+                    if ((long)suspects.size() * 4 >= n_live || suspect_problems <= 2 * T) {  // few problems left, or wrong proofs everywhere
+                        std::vector<int> todo;
+                        for (auto& sr : suspects)
+                            for (int i = sr.first; i < sr.second; i++)
+                                if (live[i]) todo.push_back(i);
+                        parallel_for((int)todo.size(), T, dev_, [&](int q) { check_single(todo[q]); });
+                        break;
+                    }
+                    int K = T / (int)suspects.size();
+                    K = K < 2 ? 2 : K > 16 ? 16 : K;
+                    std::vector<std::pair<int, int>> probes;
+                    for (auto& sr : suspects) {
+                        const int len = sr.second - sr.first, parts = std::min(K, len);
+                        for (int q = 0; q < parts; q++) probes.emplace_back(sr.first + (int)((long)len * q / parts), sr.first + (int)((long)len * (q + 1) / parts));
+                    }
+                    if ((int)probes.size() > max_ranges) throw std::runtime_error("many-verification search: too many probes");
+                    for (size_t q = 0; q < probes.size(); q++) { h_rng[2 * q] = probes[q].first; h_rng[2 * q + 1] = probes[q].second; }
+                    memset(hb + poff_rsum, 0xff, probes.size() * 2 * launch::SIZEOF_JACQ);
+                    HIPCK(hipMemcpyAsync(db + off_rng, h_rng, probes.size() * 8, hipMemcpyHostToDevice, st));
+                    launch::vm_fold_ranges(db + off_fprod, (const int*)(db + off_rng), db + off_rsum, (int)probes.size(), st);
+                    HIPCK(hipMemcpyAsync(hb + poff_rsum, db + off_rsum, probes.size() * 2 * launch::SIZEOF_JACQ, hipMemcpyDeviceToHost, st));
+                    SYNC_CHECKED(st);
+                    std::vector<char> fails(probes.size(), 0);
+                    parallel_for((int)probes.size(), T, dev_, [&](int q) {
+                        G1Affine pts[2];
+                        for (int j = 0; j < 2; j++) {
+                            const JacQ& sj = h_rsum[2 * (size_t)q + j];
+                            if (poisoned(sj)) { device_fault.store(1); return; }
+                            pts[j] = to_affine(jac_from_jacq(sj));
+                        }
+                        fails[q] = verify_cells_pairing(pts) ? 0 : 1;
+                    });
+                    if (device_fault.load()) break;
+                    suspects.clear();
+                    for (size_t q = 0; q < probes.size(); q++) {
+                        const int lo = probes[q].first, hi = probes[q].second;
+                        if (!fails[q]) {
+                            for (int i = lo; i < hi; i++) if (live[i]) verified[b0 + i] = 1;
+                        } else if (hi - lo == 1) {
+                            verified[b0 + lo] = 0;  // exact: its own weighted pair fails the check
+                        } else {
+                            suspects.emplace_back(lo, hi);
+                        }
+                    }
+                }
             } else {
                 parallel_for(Bc, T, dev_, [&](int i) {
-                    if (!live[i]) return;
-                    G1Affine pts[2];
-                    for (int j = 0; j < 2; j++) {
-                        const JacQ& s = sums[2 * (size_t)i + j];
-                        if (poisoned(s)) { device_fault.store(1); return; }
-                        pts[j] = to_affine(jac_from_jacq(s));
-                    }
-                    verified[b0 + i] = verify_cells_pairing(pts) ? 1 : 0;
+                    if (live[i]) check_single(i);
                 });
             }
             if (device_fault.load()) throw std::runtime_error("many-verification pass left no result");
@@ -409,22 +476,36 @@ int Engine::verify_cell_kzg_proof_batch_combined(uint64_t n_commitments, const u
         const size_t B = batch.size();
         static const bool trace = getenv("ETH_KZG_AMD_TRACE_COMBINE") != nullptr;
         if (trace) fprintf(stderr, "[combine] leader %p runs %zu problems\n", (void*)&me, B);
-        std::vector<uint64_t> l0(B), l1(B), l2(B), l3(B);
-        std::vector<const uint8_t* const*> pc(B), pl(B), pp(B);
-        std::vector<const uint64_t*> pi(B);
-        std::vector<int> ver(B), st(B);
-        for (size_t i = 0; i < B; i++) {
-            l0[i] = batch[i]->n[0]; l1[i] = batch[i]->n[1]; l2[i] = batch[i]->n[2]; l3[i] = batch[i]->n[3];
-            pc[i] = batch[i]->commitments; pi[i] = batch[i]->cell_indices; pl[i] = batch[i]->cells; pp[i] = batch[i]->proofs;
+        // whatever happens in here (an allocation failure included) the followers must be released with a verdict: a leader that
+        // left with comb_running_ set would leave every queued and every later caller waiting for ever
+        int rc = ERR_DEVICE;
+        std::string why;
+        std::vector<int> ver, st;
+        try {
+            std::vector<uint64_t> l0(B), l1(B), l2(B), l3(B);
+            std::vector<const uint8_t* const*> pc(B), pl(B), pp(B);
+            std::vector<const uint64_t*> pi(B);
+            ver.assign(B, 0);
+            st.assign(B, (int)ERR_DEVICE);
+            for (size_t i = 0; i < B; i++) {
+                l0[i] = batch[i]->n[0]; l1[i] = batch[i]->n[1]; l2[i] = batch[i]->n[2]; l3[i] = batch[i]->n[3];
+                pc[i] = batch[i]->commitments; pi[i] = batch[i]->cell_indices; pl[i] = batch[i]->cells; pp[i] = batch[i]->proofs;
+            }
+            rc = verify_cell_kzg_proof_batch_many_host(B, l0.data(), pc.data(), l1.data(), pi.data(), l2.data(), pl.data(), l3.data(),
+                                                       pp.data(), ver.data(), st.data());
+            if (rc == ERR_DEVICE) why = last_error();
+        } catch (const std::exception& e) {
+            rc = ERR_DEVICE;
+            why = std::string("combined verification pass: ") + e.what();
+        } catch (...) {
+            rc = ERR_DEVICE;
+            why = "combined verification pass: unknown failure";
         }
-        const int rc = verify_cell_kzg_proof_batch_many_host(B, l0.data(), pc.data(), l1.data(), pi.data(), l2.data(), pl.data(), l3.data(),
-                                                             pp.data(), ver.data(), st.data());
-        const std::string why = rc == ERR_DEVICE ? last_error() : std::string();
         if (trace) fprintf(stderr, "[combine] leader %p done rc=%d\n", (void*)&me, rc);
         lk.lock();
         for (size_t i = 0; i < B; i++) {
-            batch[i]->status = rc == ERR_DEVICE ? (int)ERR_DEVICE : st[i];
-            batch[i]->verified = ver[i];
+            batch[i]->status = (rc == ERR_DEVICE || i >= st.size()) ? (int)ERR_DEVICE : st[i];
+            batch[i]->verified = i < ver.size() ? ver[i] : 0;
             batch[i]->error = why;
             batch[i]->done = true;
         }

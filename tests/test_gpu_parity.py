@@ -724,6 +724,46 @@ def test_verify_many_without_folding_gives_the_same_verdicts(ctx, monkeypatch):
     assert ctx.verify_cell_kzg_proof_batch_many(all_good) == ([True] * len(all_good), [0] * len(all_good))
 
 
+def test_verify_many_finds_wrong_proofs_by_searching_folded_ranges(ctx, monkeypatch):
+    """A many-verification call that contains wrong proofs: the folded pairing check of the pass fails, and the wrong problems are
+    found by folding sub-ranges of the resident weighted sums (k_vm_fold_ranges) with one pairing per probe -- not by 1024
+    pairings.  Verdicts must be exact per problem for one wrong proof (first, last, middle), neighbours, a cluster, every third
+    problem (the search gives up and checks one by one), wrong proofs next to malformed problems -- and equal to what the
+    per-problem re-check of round 3 says (ETH_KZG_AMD_VM_SEARCH=0 on a second context)."""
+    blobs = [synth.seeded_blob(150 + i) for i in range(3)]
+    st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs)
+    _, comms = ctx.blob_to_kzg_commitment_batch(blobs)
+    n_prob, n_cells = 300, 16
+
+    def problem(j, wrong=False, malformed=None):
+        b = j % 3
+        ks = [(j + 5 * t) % 128 for t in range(n_cells)]
+        P = [proofs[b][k] for k in ks]
+        L = [cells[b][k] for k in ks]
+        I = list(ks)
+        if wrong:
+            P[j % n_cells] = proofs[(b + 1) % 3][ks[j % n_cells]]
+        if malformed == "index":
+            I[0] = 128
+        if malformed == "cell":
+            L[1] = b"\xff" * 2048
+        return ([comms[b]] * n_cells, I, L, P)
+    monkeypatch.setenv("ETH_KZG_AMD_VM_SEARCH", "0")
+    plain_ctx = kzg.DASContext(use_precomp=True)
+    monkeypatch.delenv("ETH_KZG_AMD_VM_SEARCH")
+    try:
+        for wrong in ([0], [n_prob - 1], [137], [40, 41], [7, 8, 9, 10, 11, 200], list(range(0, n_prob, 3)), list(range(n_prob)), []):
+            ws = set(wrong)
+            probs = [problem(j, wrong=j in ws, malformed="index" if j == 20 else "cell" if j == 260 else None) for j in range(n_prob)]
+            got = ctx.verify_cell_kzg_proof_batch_many(probs)
+            want_ver = [False if j in (20, 260) else j not in ws for j in range(n_prob)]
+            want_st = [3 if j == 20 else 1 if j == 260 else 0 for j in range(n_prob)]
+            assert got == (want_ver, want_st), (wrong[:8], [j for j in range(n_prob) if got[0][j] != want_ver[j]][:8])
+            assert plain_ctx.verify_cell_kzg_proof_batch_many(probs) == got
+    finally:
+        plain_ctx.close()
+
+
 def test_serial_paths_overlap_across_threads(ctx):
     """The verification / recovery / commitment entry points run on engine lanes created on demand (c_eth_kzg.h, "Threading"):
     four threads calling at once all get correct answers (the overlap itself is measured by bench.py, not asserted here)."""
