@@ -790,6 +790,9 @@ def main():
     ctx_times = {"constructor_returns_s": round(t_ctx_new, 3), "first_result_s": round(t_ctx_first, 3), "wide_tables_in_use_s": round(t_ctx, 2),
                  "half_of_the_fk20_groups_on_the_wide_table_s": round(half_s, 2) if half_s is not None else None,
                  "start_table_window_bits": start_width, "final_state": tables_state,
+                 "table_allocation": dict(ctx.table_build_info(), note="hipMalloc of the wide tables' pieces (< 1 GB each). On an idle GPU a piece takes ~2 ms (206 GB: 0.4 s); "
+                                          "a piece that takes seconds is the driver wiping memory another process has just freed, and this process's GPU queues "
+                                          "stand still meanwhile -- that, not the library, is what the longest call during the build then shows"),
                  "calls_during_build": {"calls": len(ws), "calls_per_s": round(len(ws) / max(1e-9, t_ctx - t_ctx_first), 1) if ws else None,
                                         "longest_ms": round(ws[-1] * 1e3, 2) if ws else None, "p99_ms": round(ws[int(0.99 * (len(ws) - 1))] * 1e3, 2) if ws else None,
                                         "median_ms": round(ws[len(ws) // 2] * 1e3, 2) if ws else None,

@@ -221,6 +221,11 @@ int eth_kzg_amd_tables_ready(const DASContext *ctx, int wait_ms);
  * 128 MSM groups of a blob: the groups already built run on the wide table, the rest on the start table): this returns how
  * many of the 128 groups of the table under construction are in use (128 once it is complete or when nothing is being built). */
 int eth_kzg_amd_table_groups_ready(const DASContext *ctx);
+/* How the window tables in use were allocated: out4[0] = milliseconds spent in hipMalloc for their pieces, out4[1] = the longest
+ * single allocation (ms), out4[2] = number of pieces, out4[3] = bytes.  On an idle GPU a piece takes 2 ms; a piece that takes
+ * seconds is the driver waiting for memory that another process has just freed to be wiped, and the calling process's GPU
+ * queues stand still for as long (tools/alloc_test/probe_stall.cpp): the one start-up stall the library cannot remove. */
+void eth_kzg_amd_table_build_info(const DASContext *ctx, double *out4);
 /* The compiled linear map that replaces the two G1 transforms of the prover: out4 = constant multiplications, point
  * additions, point doublings per blob, kernel launches per call (all 0 when ETH_KZG_AMD_G1FFT=radix2 keeps the butterfly network). */
 void eth_kzg_amd_linmap_info(const DASContext *ctx, int32_t *out4);

@@ -53,7 +53,7 @@ EXPORTED_SYMBOLS = [
     "eth_kzg_amd_verify_cell_kzg_proof_batch_partial", "eth_kzg_amd_verify_cell_kzg_proof_batch_combine",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_device", "eth_kzg_amd_blob_to_kzg_commitment_device",
     "eth_kzg_amd_verify_cell_kzg_proof_batch_device", "eth_kzg_amd_verify_cell_kzg_proof_batch_many",
-    "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits", "eth_kzg_amd_glv_table", "eth_kzg_amd_tables_ready", "eth_kzg_amd_table_groups_ready", "eth_kzg_amd_linmap_info",
+    "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits", "eth_kzg_amd_glv_table", "eth_kzg_amd_tables_ready", "eth_kzg_amd_table_groups_ready", "eth_kzg_amd_table_build_info", "eth_kzg_amd_linmap_info",
     "eth_kzg_amd_set_profiling", "eth_kzg_amd_get_stage_times",
     "eth_kzg_amd_comm_probe", "eth_kzg_amd_comm_unique_id", "eth_kzg_amd_comm_init", "eth_kzg_amd_comm_info",
     "eth_kzg_amd_all_gather", "eth_kzg_amd_comm_destroy",
@@ -129,6 +129,8 @@ def load_library():
     lib.eth_kzg_amd_glv_table.argtypes = [P]
     lib.eth_kzg_amd_tables_ready.argtypes = [P, C.c_int]
     lib.eth_kzg_amd_tables_ready.restype = C.c_int
+    lib.eth_kzg_amd_table_build_info.argtypes = [P, C.POINTER(C.c_double)]
+    lib.eth_kzg_amd_table_build_info.restype = None
     lib.eth_kzg_amd_table_groups_ready.argtypes = [P]
     lib.eth_kzg_amd_table_groups_ready.restype = C.c_int
     lib.eth_kzg_amd_linmap_info.argtypes = [P, P]
@@ -232,6 +234,12 @@ class DASContext:
     def tables_ready(self, wait_ms=0):
         """1 = final window tables in use, 0 = still on the start tables, 2 = the wide build failed (stays on what it has)."""
         return int(self._lib.eth_kzg_amd_tables_ready(self._ctx, int(wait_ms)))
+
+    def table_build_info(self):
+        """{'hipmalloc_ms', 'longest_hipmalloc_ms', 'pieces', 'bytes'} of the window tables in use (eth_kzg_amd_table_build_info)."""
+        out = (C.c_double * 4)()
+        self._lib.eth_kzg_amd_table_build_info(self._ctx, out)
+        return {"hipmalloc_ms": round(out[0], 1), "longest_hipmalloc_ms": round(out[1], 1), "pieces": int(out[2]), "bytes": int(out[3])}
 
     def table_groups_ready(self):
         """How many of the 128 MSM groups already run on the wide FK20 table under construction (128: complete / nothing being built)."""

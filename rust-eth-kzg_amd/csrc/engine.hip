@@ -146,6 +146,11 @@ static void recode_glv_wnaf(const Fr& k_mont, const Fr& lambda_mont, uint32_t* o
         if (!eq(back, fr_of(cand[best][h]))) throw std::runtime_error("constant recoding failed");
     }
 }
+// milliseconds since the library first asked (ETH_KZG_AMD_TRACE lines of different threads on one time line)
+static double trace_clock_ms() {
+    static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
 // The text of a device error belongs to the call that failed, and calls run concurrently: keep it per thread.
 static thread_local std::string t_last_error;
 const std::string& Engine::last_error() const { return t_last_error; }
@@ -350,12 +355,13 @@ Engine::Engine(bool use_precomp, int device, const Engine* primary) : dev_(devic
         }
     }
     HIPCK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    {   // the table builder runs at the lowest stream priority: callers' kernels are dispatched ahead of its waves
+    if (!primary_) {  // the table builder runs at the lowest stream priority: callers' kernels are dispatched ahead of its waves
         int prio_low = 0, prio_high = 0;
         HIPCK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
         HIPCK(hipStreamCreateWithPriority(&build_stream_, hipStreamNonBlocking, prio_low));
     }
-    HIPCK(hipStreamCreateWithFlags(&v_side_, hipStreamNonBlocking));
+    if (const char* s = getenv("ETH_KZG_AMD_VERIFY_SIDE_STREAM")) v_two_streams_ = atoi(s) != 0;
+    if (v_two_streams_) HIPCK(hipStreamCreateWithFlags(&v_side_, hipStreamNonBlocking));
     HIPCK(hipEventCreateWithFlags(&v_decoded_, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&v_checked_, hipEventDisableTiming));
     for (Work& w : work_) {
@@ -367,6 +373,7 @@ Engine::Engine(bool use_precomp, int device, const Engine* primary) : dev_(devic
         HIPCK(hipEventCreateWithFlags(&w.ev_coeffs, hipEventDisableTiming));
         HIPCK(hipEventCreateWithFlags(&w.ev_side, hipEventDisableTiming));
         if (&w == &work_[0]) continue;  // the paths under mu_ run on stream_
+        if (primary_) continue;         // an engine lane serves the serial paths only: no prover streams (HIP maps all of a process's streams onto four hardware queues)
         // ROCm multiplexes streams onto a few hardware queues per priority level and a queue runs in order: a copy stream
         // that shares its queue with a compute stream delivers the cells only after the MSMs.  Copy streams get the high
         // priority level, i.e. queues of their own.
@@ -781,6 +788,7 @@ struct Engine::SharedTable {
             const double dt = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count();
             alloc_ms += dt;
             alloc_ms_max = std::max(alloc_ms_max, dt);
+            if (dt > 100 && getenv("ETH_KZG_AMD_TRACE")) fprintf(stderr, "[context] @%.0f ms: hipMalloc of table piece %zu (%.2f GB) took %.0f ms\n", trace_clock_ms(), pieces.size(), sz / 1e9, dt);
             if (e != hipSuccess) { (void)hipGetLastError(); why = std::string("hipMalloc of a table piece: ") + hipGetErrorString(e); return false; }
             pieces.push_back(p);
             // the HIP runtime serialises allocations and other calls on locks that are not fair: a thread that allocates piece
@@ -853,7 +861,7 @@ static bool fill_table(Engine::SharedTable& t, const void* bases, hipStream_t st
         (void)hipGetLastError();
         return give_up("hipMalloc of the builder's scratch failed");
     }
-    if (trace) fprintf(stderr, "[context]   table kind %d width %d: %.1f GB in pieces, scratch %.1f GB allocated  %8.1f ms\n", t.kind, c, t.bytes / 1e9,
+    if (trace) fprintf(stderr, "[context] @%.0f ms:  table kind %d width %d: %.1f GB in pieces, scratch %.1f GB allocated  %8.1f ms\n", trace_clock_ms(), t.kind, c, t.bytes / 1e9,
                        (per_group * chunk * scratch_per_entry + side_bytes) / 1e9, ms());
     try {
         HIPCK(hipMemsetAsync(d_err, 0, sizeof(int), st));
@@ -971,6 +979,20 @@ int Engine::table_groups_ready(TableSel which) const {
     return tables_state_ != 0 && v.main ? v.main->n_groups : 0;  // nothing wider under construction yet (or ever): 0 until the builder is done
 }
 
+void Engine::table_build_info(double* out4) const {
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    for (TableSel sel : {TAB_FK, TAB_SRS}) {
+        const TableView v = table_view(sel);
+        for (const SharedTable* t : {v.main.get(), v.next.get()}) {
+            if (!t) continue;
+            out4[0] += t->alloc_ms;
+            out4[1] = std::max(out4[1], t->alloc_ms_max);
+            out4[2] += (double)t->pieces.size();
+            out4[3] += (double)t->bytes;
+        }
+    }
+}
+
 void Engine::init_fk20() {
     // 64 G1-FFT_128 of the SRS vectors: the 64 vectors ride on the 64 lanes of the FFT kernel.
     void* X;
@@ -1061,6 +1083,9 @@ void Engine::build_final_tables() {
         return t;
     };
     try {
+        const double p0 = trace_clock_ms();
+        launch::preload_code_objects();  // before the first piece is allocated: no caller's first launch of a kernel waits behind a hipMalloc
+        if (getenv("ETH_KZG_AMD_TRACE")) fprintf(stderr, "[context] @%.0f ms: code objects preloaded in %.0f ms\n", trace_clock_ms(), trace_clock_ms() - p0);
         std::lock_guard<std::mutex> lk(g_build_mu);  // one builder of wide tables at a time per process
         if (cancel_build_.load()) throw BuildCancelled{};
         const double budget = table_budget_gb_ > 0 ? table_budget_gb_ * 1e9 : 1e18;
@@ -1495,6 +1520,20 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
     const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    // ETH_KZG_AMD_TRACE_SLOW=<ms>: report the steps of a call that took longer (which HIP call waited, and for how long)
+    static const double slow_ms = [] { const char* e = getenv("ETH_KZG_AMD_TRACE_SLOW"); return e ? atof(e) : 0.0; }();
+    double step_at[8] = {0};
+    int n_steps = 0;
+    auto step = [&]() { if (slow_ms > 0 && n_steps < 8) step_at[n_steps++] = now_ms(); };
+    struct SlowReport {
+        const double& limit; double* at; int& n; std::function<double()> now;
+        ~SlowReport() {
+            if (limit <= 0 || now() < limit) return;
+            fprintf(stderr, "[host-batch] @%.0f ms: slow call, %.1f ms; steps (lease, enqueue sub-batches, enqueue proofs, events recorded, cells back, all back):", trace_clock_ms(), now());
+            for (int i = 0; i < n; i++) fprintf(stderr, " %.1f", at[i]);
+            fprintf(stderr, "\n");
+        }
+    } slow_report{slow_ms, step_at, n_steps, now_ms};
     Work* held = nullptr;
     std::atomic<int> failed{0};
     std::mutex err_mu;
@@ -1520,6 +1559,7 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
             });
         Work& w = lease_work(1, NW - 1);
         held = &w;
+        step();
         for (int s0 = 0; s0 < n && !failed.load(); s0 += SUPER) {
             const int ns = std::min(SUPER, n - s0), n_sub = (ns + SUB - 1) / SUB;
             ensure_workspace(w, ns);
@@ -1609,13 +1649,16 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
                 }
                 if (trace) fprintf(stderr, "[host-batch] sub-batch %d (%d blobs) enqueued at %.2f ms\n", i, nb, now_ms());
             }
+            step();
             if (proofs) {
                 run_proofs_from_coeffs(w, ns, w.d_proofs, w.stream);
                 HIPCK(hipMemcpyAsync(w.h_proofs, w.d_proofs, (size_t)ns * N_CELLS * 48, hipMemcpyDeviceToHost, w.stream));
             }
+            step();
             HIPCK(hipEventRecord(w.ev_done, w.stream));
             HIPCK(hipEventRecord(w.done, w.stream));
             HIPCK(hipGetLastError());
+            step();
             if (!threaded) {  // small call: status and cells as soon as they are back, proofs at the end, all on this thread
                 HIPCK(hipEventSynchronize(w.sub_events[1]));
                 for (int b = 0; b < ns; b++) {
@@ -1625,8 +1668,10 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
                     for (int k = 0; k < N_CELLS; k++) memcpy(cells[s0 + b][k], src + (size_t)k * BYTES_PER_CELL, BYTES_PER_CELL);
                 }
             }
+            step();
             HIPCK(hipEventSynchronize(w.ev_done));
             HIPCK(hipStreamSynchronize(w.copy));
+            step();
             if (trace) fprintf(stderr, "[host-batch] proofs of %d blobs back at %.2f ms\n", ns, now_ms());
             if (proofs) {
                 scatter_proofs = [&, s0](int lo, int hi) {

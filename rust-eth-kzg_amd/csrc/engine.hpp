@@ -234,6 +234,10 @@ public:
     int tables_ready(int wait_ms);
     // groups of the table under construction that MSMs already run on (all of them once it is complete)
     int table_groups_ready(TableSel which) const;
+    // how the tables in use were allocated: out[0] = milliseconds spent in hipMalloc for their pieces (both tables), out[1] = the
+    // longest single hipMalloc (ms), out[2] = pieces, out[3] = bytes.  A long single allocation is the driver waiting for memory
+    // another process freed to be wiped: the process's GPU queues stand still meanwhile (tools/alloc_test/probe_stall.cpp)
+    void table_build_info(double* out4) const;
     void stop_builder();  // abandon an unfinished build of the wide tables and join the helper thread
     size_t table_bytes() const { return table_view(TAB_FK).bytes + table_view(TAB_SRS).bytes; }
     int window_bits() const { return table_view(TAB_FK).c; }  // of the FK20 table in use
@@ -336,7 +340,8 @@ private:
     size_t v_dev_cap_ = 0;
     uint8_t* v_pin_ = nullptr;
     size_t v_pin_cap_ = 0;
-    hipStream_t v_side_ = nullptr;  // verification: the subgroup tests run here next to the point shifts on stream_
+    hipStream_t v_side_ = nullptr;  // verification, round 3's form: the subgroup tests run here next to the point shifts on stream_
+    bool v_two_streams_ = false;    // ETH_KZG_AMD_VERIFY_SIDE_STREAM=1 (default: both chains in ONE launch on stream_, k_pip_shift_subgroup)
     hipEvent_t v_decoded_ = nullptr, v_checked_ = nullptr;
 
     // serial-path lanes (lease_serial)

@@ -57,6 +57,12 @@ __global__ __launch_bounds__(64) void k_quotient_by_linear(const Fr* __restrict_
 }
 
 namespace launch {
+// the code object of this translation unit is loaded now (HIP loads a code object on the first launch of one of its kernels, and
+// that load is an allocation: it would wait behind a table piece the builder thread is allocating)
+void preload_k_4844() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_quotient_by_linear));
+}
 void quotient_by_linear(int n, const void* coeffs, const void* z_mont, void* quotient, void* y_out, hipStream_t st) {
     k_quotient_by_linear<<<n, 64, 0, st>>>((const Fr*)coeffs, (const Fr*)z_mont, (Fr*)quotient, (Fr*)y_out);
 }

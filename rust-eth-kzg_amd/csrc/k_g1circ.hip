@@ -81,6 +81,12 @@ __global__ __launch_bounds__(CIRC_LANES) void k_g1_circ_sum(const JacQ* __restri
 }
 
 namespace launch {
+// the code object of this translation unit is loaded now (HIP loads a code object on the first launch of one of its kernels, and
+// that load is an allocation: it would wait behind a table piece the builder thread is allocating)
+void preload_k_g1circ() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_g1_dbl_table));
+}
 size_t g1_circ_table_bytes(int n, int T) { return (size_t)n * N_CELLS * 2 * T * sizeof(JacQ); }
 // X: [128][stride] MSM outputs (natural order) -> X: proofs (bit-reversed), for blobs 0 .. n-1
 void g1_circ128(void* X, int stride, int n, int segs, void* D, int T, const void* terms, int per_lane, const Fp12w& beta, hipStream_t st) {

@@ -94,6 +94,12 @@ __global__ __launch_bounds__(256) void k_g1_dft_sum(const JacQ* __restrict__ pro
 }
 
 namespace launch {
+// the code object of this translation unit is loaded now (HIP loads a code object on the first launch of one of its kernels, and
+// that load is an allocation: it would wait behind a table piece the builder thread is allocating)
+void preload_k_g1fft() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_g1_butterfly));
+}
 // mode 0: DIT butterfly (a, b) -> (a + w b, a - w b);  mode 1: DIF butterfly (a, b) -> (a + b, (a - b) w);
 // mode 2: DIF first layer with b == identity: b <- a w;  mode 3: DIT last layer keeping only a <- a + w b.
 void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int mode, const void* tw, const Fp12w& beta,

@@ -4,6 +4,7 @@
 #include "engine.hpp"
 #include "kcommon.hpp"
 #include "curve29.hpp"
+#include "g1_subgroup.hpp"
 #include "launch.hpp"
 
 namespace kzg {
@@ -97,28 +98,6 @@ __device__ __forceinline__ Fq<2> fq_sqrt_candidate(const Fq<2>& a) {
         }
     }
     return acc;
-}
-// [|z|] P for a general Jacobian P (|z| = 0xd201000000010000: 63 doublings + 5 additions)
-__device__ __forceinline__ JacQ mul_by_z_abs_q(const JacQ& p) {
-    constexpr uint64_t Z = 0xd201000000010000ULL;
-    JacQ acc = p;
-#pragma unroll 1
-    for (int i = 62; i >= 0; i--) {
-        acc = dbl(acc);
-        if ((Z >> i) & 1) acc = add(acc, p);
-    }
-    return acc;
-}
-// Scott's test for a curve point P != O: [z^2]P - P == phi(P) = (beta x, y)
-__device__ __forceinline__ bool g1_in_subgroup_q(const AffQ& pa, const Fq<1>& beta) {
-    const JacQ p = to_jacq(pa);
-    const JacQ q = mul_by_z_abs_q(mul_by_z_abs_q(p));
-    const JacQ r = add_mixed(q, pa, true);
-    if (is_inf(r)) return false;
-    const Fq<2> zz = sqr(r.z);
-    if (!is_zero_slow(sub(r.x, mul(mul(pa.x, beta), zz)))) return false;
-    if (!is_zero_slow(sub(r.y, mul(pa.y, mul(zz, r.z))))) return false;
-    return true;
 }
 // rc 0 ok (out = affine Montgomery-384 point), 1 bad encoding / x >= p / not on the curve, 2 not in the subgroup
 __device__ __forceinline__ int g1_decompress_q(G1Affine& out, const uint8_t* in, bool subgroup_check, const Fq<1>& beta) {
@@ -241,6 +220,12 @@ __global__ void k_test_recompress(const G1Affine* in, uint8_t* out, int n) {
 }
 
 namespace launch {
+// the code object of this translation unit is loaded now (HIP loads a code object on the first launch of one of its kernels, and
+// that load is an allocation: it would wait behind a table piece the builder thread is allocating)
+void preload_k_g1misc() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_g1_set_inf));
+}
 void g1_set_inf(void* X, size_t n, hipStream_t st) { k_g1_set_inf<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((JacQ*)X, n); }
 void g1_compress(const void* X, uint8_t* out, int n_pos, int stride, int n_slices, hipStream_t st) {
     // measured (128 positions): 2048 lanes 0.39 -> 0.22 ms with four positions per thread; 512 lanes 0.155 -> 0.21, 64 lanes 0.15 -> 0.21 ms

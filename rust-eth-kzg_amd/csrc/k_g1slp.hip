@@ -162,6 +162,12 @@ __global__ __launch_bounds__(64) void k_slp_walk(JacQ* __restrict__ A, int strid
 }
 
 namespace launch {
+// the code object of this translation unit is loaded now (HIP loads a code object on the first launch of one of its kernels, and
+// that load is an allocation: it would wait behind a table piece the builder thread is allocating)
+void preload_k_g1slp() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_slp_add));
+}
 // kind: 3 multiplication by a constant, anything else the mixed addition / subtraction / doubling launch (linmap::OpKind)
 void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int count, const void* naf, const Fp12w& beta,
                    hipStream_t st) {

@@ -254,6 +254,12 @@ __global__ void k_glv_split(Fr* __restrict__ scalars, size_t n) {
     scalars[i] = o;
 }
 namespace launch {
+// the code object of this translation unit is loaded now (HIP loads a code object on the first launch of one of its kernels, and
+// that load is an allocation: it would wait behind a table piece the builder thread is allocating)
+void preload_k_msm() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_glv_split));
+}
 template <int C>
 static void msm_flat_c(const void* scalars, const TabBlocks& table, void* out, int n_groups, int n_slices, int nb, int out_stride,
                        int brp_bits, hipStream_t st) {
@@ -274,9 +280,16 @@ void msm_fixed_flat(int c, const void* scalars, const TabBlocks& table, void* ou
 void glv_split(void* scalars, size_t n, hipStream_t st) {
     k_glv_split<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((Fr*)scalars, n);
 }
-#define GLV_DECL(w) void msm_glv_w##w(int, const void*, const TabBlocks&, void*, int, int, int, int, int, const Fp12w&, hipStream_t);
+#define GLV_DECL(w) void msm_glv_w##w(int, const void*, const TabBlocks&, void*, int, int, int, int, int, const Fp12w&, hipStream_t); void preload_k_msm_glv##w();
 GLV_DECL(8) GLV_DECL(12) GLV_DECL(14) GLV_DECL(15) GLV_DECL(16)
 #undef GLV_DECL
+void preload_k_ntt(); void preload_k_g1fft(); void preload_k_g1circ(); void preload_k_g1misc(); void preload_k_verify();
+void preload_k_verify_many(); void preload_k_4844(); void preload_k_g1slp(); void preload_k_table();
+void preload_code_objects() {
+    preload_k_msm(); preload_k_msm_glv8(); preload_k_msm_glv12(); preload_k_msm_glv14(); preload_k_msm_glv15(); preload_k_msm_glv16();
+    preload_k_ntt(); preload_k_g1fft(); preload_k_g1circ(); preload_k_g1misc(); preload_k_verify(); preload_k_verify_many();
+    preload_k_4844(); preload_k_g1slp(); preload_k_table();
+}
 bool glv_width_supported(int c) {
     for (int w : GLV_WIDTHS)
         if (w == c) return true;

@@ -237,6 +237,12 @@ __global__ void k_test_field_mul(const uint8_t* a, const uint8_t* b, uint8_t* ou
 }
 
 namespace launch {
+// the code object of this translation unit is loaded now (HIP loads a code object on the first launch of one of its kernels, and
+// that load is an allocation: it would wait behind a table piece the builder thread is allocating)
+void preload_k_ntt() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_blob_to_coeffs));
+}
 static Fr as_fr(const Fr8& x) { Fr r; for (int i = 0; i < 8; i++) r.v[i] = x.v[i]; return r; }
 
 constexpr size_t LDS_NTT29 = (size_t)N_BLOB * RL * 4;  // 144 KiB: one 4096-point transform of 9-limb elements resident in LDS

@@ -246,6 +246,12 @@ __global__ __launch_bounds__(64) void k_table_fill_packed(const AffQ* __restrict
 }
 
 namespace launch {
+// the code object of this translation unit is loaded now (HIP loads a code object on the first launch of one of its kernels, and
+// that load is an allocation: it would wait behind a table piece the builder thread is allocating)
+void preload_k_table() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>((&k_build_table<4>)));
+}
 template <int C>
 static void table_fast_c(const void* bases, void* const* table, void* scratch, void* qw, void* tmp, void* pre, int n_groups, int nb, int* err,
                          hipStream_t st) {

@@ -6,6 +6,7 @@
 #include "engine.hpp"
 #include "kcommon.hpp"
 #include "curve29.hpp"
+#include "g1_subgroup.hpp"
 #include "launch.hpp"
 #include "glv.hpp"
 
@@ -339,10 +340,8 @@ __global__ __launch_bounds__(64) void k_pip_final(const JacQ* __restrict__ wsum,
 // k_pip_window; the host normalises the two sums.  No doubling at all: 3.4 -> 0.8 ms of GPU time behind the hash.
 //   pts32[(phi * 16 + p) * n_max + i] = phi^phi(2^(8p) P_i)
 constexpr int PS_P = 16, PS_SLICES = 64;
-__global__ __launch_bounds__(64) void k_pip_shift(const G1Affine* __restrict__ in, AffQ* __restrict__ pts32, JacQ* __restrict__ jac,
-                                                  Fq<2>* __restrict__ pre, int n, int n_max, Fq<1> beta) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__device__ __forceinline__ void pip_shift_point(int i, const G1Affine* __restrict__ in, AffQ* __restrict__ pts32, JacQ* __restrict__ jac,
+                                                Fq<2>* __restrict__ pre, int n_max, const Fq<1>& beta) {
     auto put = [&](int p, const AffQ& a) {
         pts32[(size_t)p * n_max + i] = a;
         AffQ b = a;
@@ -376,6 +375,37 @@ __global__ __launch_bounds__(64) void k_pip_shift(const G1Affine* __restrict__ i
         a.y = reduce_once(mul(q.y, mul(zi2, zi)));
         put(p, a);
     }
+}
+__global__ __launch_bounds__(64) void k_pip_shift(const G1Affine* __restrict__ in, AffQ* __restrict__ pts32, JacQ* __restrict__ jac,
+                                                  Fq<2>* __restrict__ pre, int n, int n_max, Fq<1> beta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pip_shift_point(i, in, pts32, jac, pre, n_max, beta);
+}
+// The two challenge-free chains of a verification -- the byte-shifted copies (120 dependent doublings per point) and the
+// subgroup tests of the decoded proofs and commitments (126 dependent doublings per point) -- in ONE launch: the first
+// shift_blocks blocks shift, the rest test.  They used to be two launches on two streams so as to run side by side; HIP maps a
+// process's streams onto four hardware queues, and with several verifications in flight on several engine lanes one lane's
+// side stream landed on another lane's queue and the lanes took turns (rocprofv3 trace of two callers: 5.0 ms per round of
+// two instead of 3.3).  One launch needs one stream per verification, and the waves of the two halves still run side by side.
+// status: 0 -> 0 or 2; other values are kept (k_g1misc.hip: k_g1_subgroup does the same on its own).
+__global__ __launch_bounds__(64) void k_pip_shift_subgroup(const G1Affine* __restrict__ in, AffQ* __restrict__ pts32, JacQ* __restrict__ jac,
+                                                           Fq<2>* __restrict__ pre, int n, int n_max, int shift_blocks,
+                                                           const G1Affine* __restrict__ pts0, int* __restrict__ status0, int n0,
+                                                           const G1Affine* __restrict__ pts1, int* __restrict__ status1, int n1, Fq<1> beta) {
+    if ((int)blockIdx.x < shift_blocks) {
+        const int i = blockIdx.x * 64 + threadIdx.x;
+        if (i < n) pip_shift_point(i, in, pts32, jac, pre, n_max, beta);
+        return;
+    }
+    int i = ((int)blockIdx.x - shift_blocks) * 64 + threadIdx.x;
+    if (i >= n0 + n1) return;
+    const bool second = i >= n0;
+    if (second) i -= n0;
+    int* st = second ? status1 : status0;
+    if (st[i] != 0) return;
+    const G1Affine a = (second ? pts1 : pts0)[i];
+    if (is_inf(a)) return;
+    if (!g1_in_subgroup_q(affq_from_affine(a), beta)) st[i] = 2;
 }
 // counting sort of the 32 n items of a job by their byte.  Half-scalar entry e < 2n (k1 of scalar e, or k2 of scalar e - n)
 // carries 16 items; slice s of PS_SLICES owns a contiguous range of entries.
@@ -587,6 +617,12 @@ __global__ __launch_bounds__(1024) void k_rec_dif_half(const Fr* __restrict__ U,
 }
 
 namespace launch {
+// the code object of this translation unit is loaded now (HIP loads a code object on the first launch of one of its kernels, and
+// that load is an allocation: it would wait behind a table piece the builder thread is allocating)
+void preload_k_verify() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_cells_to_fr));
+}
 static Fr as_fr2(const Fr8& x) { Fr r; for (int i = 0; i < 8; i++) r.v[i] = x.v[i]; return r; }
 void init_attributes_verify() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_rec_dit_half), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_NTT);
@@ -675,6 +711,15 @@ void pip_shift_prepare(const void* points, int n_pts, int n_max, void* workspace
     for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
     const PsLayout L = ps_layout(workspace, n_max);
     k_pip_shift<<<(n_pts + 63) / 64, 64, 0, st>>>((const G1Affine*)points, L.pts32, L.jac, L.pre, n_pts, n_max, fq_from_fp(b384));
+}
+void pip_shift_prepare_and_subgroup(const void* points, int n_pts, int n_max, void* workspace, const void* pts0, int* status0, int n0,
+                                    const void* pts1, int* status1, int n1, const Fp12w& beta, hipStream_t st) {
+    Fp b384;
+    for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
+    const PsLayout L = ps_layout(workspace, n_max);
+    const int shift_blocks = (n_pts + 63) / 64, sub_blocks = (n0 + n1 + 63) / 64;
+    k_pip_shift_subgroup<<<shift_blocks + sub_blocks, 64, 0, st>>>((const G1Affine*)points, L.pts32, L.jac, L.pre, n_pts, n_max, shift_blocks,
+                                                                   (const G1Affine*)pts0, status0, n0, (const G1Affine*)pts1, status1, n1, fq_from_fp(b384));
 }
 void msm_pippenger2_shifted(const void* sc0, int n0, const void* sc1, int n1, int n_max, void* workspace, void* out_jacq2,
                             hipStream_t st) {

@@ -256,6 +256,12 @@ __global__ __launch_bounds__(256) void k_vm_fold_ranges(const JacQ* __restrict__
 }
 
 namespace launch {
+// the code object of this translation unit is loaded now (HIP loads a code object on the first launch of one of its kernels, and
+// that load is an allocation: it would wait behind a table piece the builder thread is allocating)
+void preload_k_verify_many() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_vm_scalars));
+}
 static Fr vm_fr(const Fr8& x) { Fr r; for (int i = 0; i < 8; i++) r.v[i] = x.v[i]; return r; }
 void vm_scalars(const void* pow_tables /*[B][24] Fr, device*/, const int* batch_of, const int* pos_in_batch, const int* cell_idx,
                 const void* w8192, void* rp_mont, void* s1, void* s2, int n, hipStream_t st) {

@@ -11,6 +11,11 @@ struct Fp12w;  // 12 x u32, Montgomery
 namespace launch {
 
 void init_attributes();  // opt in to 128 KiB dynamic LDS for the NTT kernels
+// Load every code object of the library now (k_msm.hip).  HIP loads a translation unit's code object when one of its kernels
+// is first launched, and that load allocates device memory: a caller whose first recovery / first wide-table MSM happens while
+// the table builder thread sits in a hipMalloc (seconds, when the driver is still wiping memory another process freed) would
+// wait for it -- kernel launches, copies and events themselves do not (tools/alloc_test/probe_stall.cpp).
+void preload_code_objects();
 
 // k_ntt.hip
 // The three Fr stages of the prover compute in the unsaturated 9 x 29-bit form (fr29.hpp): w29 = the twiddle table in that
@@ -131,6 +136,9 @@ void interp_sum(const void* coef, const void* rp_mont, void* partial, int nblock
 // large verification batches: byte-shifted point copies built before the challenge is known (k_verify.hip)
 size_t pip_shift_workspace_bytes(int n_max);
 void pip_shift_prepare(const void* points, int n_pts, int n_max, void* workspace, const Fp12w& beta, hipStream_t st);
+// the same and, in the same launch, the subgroup tests of two point segments (status 0 -> 0 / 2): one stream per verification
+void pip_shift_prepare_and_subgroup(const void* points, int n_pts, int n_max, void* workspace, const void* pts0, int* status0, int n0,
+                                    const void* pts1, int* status1, int n1, const Fp12w& beta, hipStream_t st);
 void msm_pippenger2_shifted(const void* sc0, int n0, const void* sc1, int n1, int n_max, void* workspace, void* out_jacq2,
                             hipStream_t st);  // out: two JacQ (SIZEOF_JACQ each)
 size_t pip_workspace_bytes(int n_max);

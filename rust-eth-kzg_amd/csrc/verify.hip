@@ -218,15 +218,20 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
                     // everything that needs only the coordinates and not the challenge: the byte-shifted point copies (120
                     // dependent doublings per point) and the per-cell interpolation polynomials
                     launch::g1_decode2((const uint8_t*)d_pb.p, d_prf_p, (int*)d_stp.p, n, (const uint8_t*)d_cb.p, d_comm_p, (int*)d_stc.p, m, beta_, st);
-                    HIPCK(hipEventRecord(v_decoded_, st));
-                    HIPCK(hipStreamWaitEvent(v_side_, v_decoded_, 0));
-                    launch::g1_subgroup2(d_prf_p, (int*)d_stp.p, n, d_comm_p, (int*)d_stc.p, m, beta_, v_side_);
-                    HIPCK(hipEventRecord(v_checked_, v_side_));
                     launch::copy_affine(d_srs_, d_comm_p + m, 64, st);  // vk.g1s: the first 64 SRS points (verification_key.rs:66-70)
                     launch::cells_to_fr((const uint8_t*)d_cellb.p, d_evals.p, nullptr, (int*)d_ste.p, nullptr, nullptr, n, st);
-                    launch::pip_shift_prepare(d_pts.p, (int)npts, (int)npts, db + off_ws, beta_, st);
+                    if (v_two_streams_) {  // round 3's form: the subgroup tests on a second stream (ETH_KZG_AMD_VERIFY_SIDE_STREAM=1)
+                        HIPCK(hipEventRecord(v_decoded_, st));
+                        HIPCK(hipStreamWaitEvent(v_side_, v_decoded_, 0));
+                        launch::g1_subgroup2(d_prf_p, (int*)d_stp.p, n, d_comm_p, (int*)d_stc.p, m, beta_, v_side_);
+                        HIPCK(hipEventRecord(v_checked_, v_side_));
+                        launch::pip_shift_prepare(d_pts.p, (int)npts, (int)npts, db + off_ws, beta_, st);
+                    } else {
+                        launch::pip_shift_prepare_and_subgroup(d_pts.p, (int)npts, (int)npts, db + off_ws, d_prf_p, (int*)d_stp.p, n, d_comm_p,
+                                                               (int*)d_stc.p, m, beta_, st);
+                    }
                     launch::interp_cells(d_evals.p, (const int*)d_idx.p, d_w8192_, inv64_, db + off_coef, n, st);
-                    HIPCK(hipStreamWaitEvent(st, v_checked_, 0));
+                    if (v_two_streams_) HIPCK(hipStreamWaitEvent(st, v_checked_, 0));
                 } else {
                     launch::g1_decompress2((const uint8_t*)d_pb.p, d_prf_p, (int*)d_stp.p, n, (const uint8_t*)d_cb.p, d_comm_p, (int*)d_stc.p, m, beta_, st);
                     launch::copy_affine(d_srs_, d_comm_p + m, 64, st);  // vk.g1s: the first 64 SRS points (verification_key.rs:66-70)
