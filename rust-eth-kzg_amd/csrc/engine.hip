@@ -327,6 +327,8 @@ Engine::Engine(bool use_precomp, int device, const Engine* primary) : dev_(devic
             if (g > 0) table_budget_gb_ = g;
         }
     }
+    if (const char* s = getenv("ETH_KZG_AMD_VERIFY_LANES")) { const int v = atoi(s); if (v >= 0 && v <= 16) verify_lanes_ = v; }
+    if (const char* s = getenv("ETH_KZG_AMD_VM_SMALL")) vm_small_max_ = atoi(s);  // 0 disables the short-chain form of small passes
     if (const char* s = getenv("ETH_KZG_AMD_VM_SEARCH")) vm_search_ = atoi(s) != 0;  // tests: the per-problem re-check of round 3 as the cross-check
     if (const char* s = getenv("ETH_KZG_AMD_PIP_SHIFT_MIN")) {  // tuning knob: smallest cell count verified with byte-shifted point copies
         const int v = atoi(s);
@@ -408,6 +410,7 @@ Engine::~Engine() {
     }
     if (build_stream_) hipStreamDestroy(build_stream_);
     host_pool_.reset();  // joins the helper threads before anything they might touch goes away
+    vm_pool_.reset();
     void* ptrs[] = {d_w8192_, d_w29_, d_naf_, d_srs_, d_fk_bases_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_circ_terms_, d_slp_levels_};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -431,10 +434,11 @@ Engine::~Engine() {
     }
     if (v_dev_) hipFree(v_dev_);
     if (v_pin_) hipHostFree(v_pin_);
-    if (vm_dev_) hipFree(vm_dev_);
-    if (vm_pin_) hipHostFree(vm_pin_);
+    for (VmSlot& v : vm_slot_) {
+        if (v.dev) hipFree(v.dev);
+        if (v.pin) hipHostFree(v.pin);
+    }
     if (vd_pin_) hipHostFree(vd_pin_);
-    if (vm_stream_) hipStreamDestroy(vm_stream_);
     if (v_side_) hipStreamDestroy(v_side_);
     if (v_decoded_) hipEventDestroy(v_decoded_);
     if (v_checked_) hipEventDestroy(v_checked_);

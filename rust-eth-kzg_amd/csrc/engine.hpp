@@ -359,18 +359,29 @@ private:
     std::mutex comb_mu_;
     std::condition_variable comb_cv_;
     std::vector<VerifyRequest*> comb_queue_;
-    bool comb_running_ = false;
+    int comb_running_ = 0;                 // leaders running a pass right now (at most VM_SLOTS)
     std::atomic<int> verify_inflight_{0};  // single verifications on the latency path right now
+    int verify_lanes_ = 1;                 // concurrent single verifications on the latency path (ETH_KZG_AMD_VERIFY_LANES); the others are combined
     int comb_max_cells_ = 1024;            // larger problems always take the single path (their transcript hash is the bound)
 
     // many-verification path (verify_many.hip): its own lock, stream, device arena and pinned slab
-    std::mutex vm_mu_;
+    // THREE pass slots, each with its own lock, stream, device arena and pinned slab: while one pass is on the GPU the other one's
+    // staging, transcript hashes and pairing checks run on the host threads (concurrent single calls are combined into passes:
+    // verify_cell_kzg_proof_batch_combined lets two leaders run at a time)
+    static constexpr int VM_SLOTS = 3;
+    struct VmSlot {
+        std::mutex mu;
+        void* dev = nullptr;
+        size_t dev_cap = 0;
+        uint8_t* pin = nullptr;
+        size_t pin_cap = 0;
+    };
+    VmSlot vm_slot_[VM_SLOTS];
+    std::unique_ptr<HostPool> vm_pool_;  // the host threads of the many-verification passes (hashes, staging, pairing checks)
+    std::once_flag vm_pool_once_;
+    std::atomic<unsigned> vm_rr_{0};
     bool vm_search_ = true;  // ETH_KZG_AMD_VM_SEARCH=0: a pass whose folded check fails is re-checked problem by problem (round 3's form)
-    hipStream_t vm_stream_ = nullptr;
-    void* vm_dev_ = nullptr;
-    size_t vm_dev_cap_ = 0;
-    uint8_t* vm_pin_ = nullptr;
-    size_t vm_pin_cap_ = 0;
+    int vm_small_max_ = -1;  // passes of at most this many problems take the short-chain form (verify_many.hip); -1: 2 x host threads; ETH_KZG_AMD_VM_SMALL
     uint8_t* vd_pin_ = nullptr;  // device-resident verification: the bytes come down here once (grow-only, guarded by mu_)
     size_t vd_pin_cap_ = 0;
 

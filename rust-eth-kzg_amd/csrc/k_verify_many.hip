@@ -19,6 +19,7 @@
 #include "engine.hpp"
 #include "kcommon.hpp"
 #include "curve29.hpp"
+#include "g1_subgroup.hpp"
 #include "launch.hpp"
 #include "glv.hpp"
 
@@ -182,6 +183,62 @@ __global__ __launch_bounds__(64, 2) void k_vm_mul(const G1Affine* __restrict__ p
     glv_split_balanced(k, split);
     prod[e] = vm_mul_by_scalar(affq_from_affine(pts[pi]), split, beta);
 }
+// SMALL passes (a handful of problems: concurrent single calls combined, verify_many.hip) are a chain of latencies, so the chain
+// is cut: ONE launch holds every scalar multiplication of the pass -- the 2 n + m products above and, as 64 more lanes per
+// problem, the terms isc[b][j] SRS_j of the interpolation commitments (one more 255-bit multiplication each instead of a
+// window-table MSM launch of its own: 25 % more lanes, nothing on a chip that is empty anyway) -- AND the subgroup tests of the
+// decoded points in further blocks (their 126 dependent doublings run beside the multiplications' 128 instead of in front).
+//   products: e < n: s1[e] pi_e | n <= e < 2n: s2 pi | 2n <= e < 2n + m: w C | 2n + m <= e < 2n + m + 64 B: isc[b][j] SRS_j
+__global__ __launch_bounds__(64, 2) void k_vm_mul_small(const G1Affine* __restrict__ pts, const Fr* __restrict__ s1, const Fr* __restrict__ s2,
+                                                        const Fr* __restrict__ wts, const Fr* __restrict__ isc, const G1Affine* __restrict__ srs,
+                                                        JacQ* __restrict__ prod, int n, int m, int n_batches, int mul_blocks,
+                                                        int* __restrict__ status /*[n + m]*/, Fq<1> beta) {
+    if ((int)blockIdx.x >= mul_blocks) {  // subgroup tests of [proofs n | commitments m]: status 0 -> 0 / 2, others kept
+        const int i = ((int)blockIdx.x - mul_blocks) * 64 + threadIdx.x;
+        if (i >= n + m || status[i] != 0) return;
+        const G1Affine a = pts[i];
+        if (is_inf(a)) return;
+        if (!g1_in_subgroup_q(affq_from_affine(a), beta)) status[i] = 2;
+        return;
+    }
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    const int base = 2 * n + m;
+    if (e >= base + 64 * n_batches) return;
+    G1Affine P;
+    Fr k;
+    if (e < base) {
+        P = pts[e < n ? e : e < 2 * n ? e - n : n + (e - 2 * n)];
+        k = e < n ? s1[e] : e < 2 * n ? s2[e - n] : wts[e - 2 * n];
+    } else {
+        P = srs[(e - base) & 63];
+        k = isc[e - base];
+    }
+    uint32_t split[8];
+    glv_split_balanced(k, split);
+    prod[e] = vm_mul_by_scalar(affq_from_affine(P), split, beta);
+}
+// the sums of a small pass: as k_vm_reduce, with the 64 interpolation terms of the problem in place of icommit[b]
+__global__ __launch_bounds__(256) void k_vm_reduce_small(const JacQ* __restrict__ prod, const int* __restrict__ cell_start,
+                                                         const int* __restrict__ row_start, JacQ* __restrict__ out, int n, int m) {
+    __shared__ JacQ red[256];
+    const int b = blockIdx.x, t = threadIdx.x, job = t >> 7, l = t & 127;
+    const int lo = cell_start[b], hi = cell_start[b + 1], rlo = row_start[b], rhi = row_start[b + 1];
+    JacQ acc = jacq_inf();
+    const JacQ* src = prod + (job ? n : 0);
+    for (int k = lo + l; k < hi; k += 128) acc = add(acc, src[k]);
+    if (job) {
+        for (int r = rlo + l; r < rhi; r += 128) acc = add(acc, prod[2 * (size_t)n + r]);
+        if (l < 64) acc = add(acc, prod[2 * (size_t)n + m + 64 * (size_t)b + l]);
+    }
+#pragma unroll 1
+    for (int span = 64; span >= 1; span >>= 1) {
+        red[t] = acc;
+        __syncthreads();
+        if (l < span) acc = add(acc, red[t + span]);
+        __syncthreads();
+    }
+    if (l == 0) out[2 * (size_t)b + job] = acc;
+}
 // per problem b: out[2b] = sum of prod[cells of b], out[2b + 1] = sum of prod[n + cells of b] + sum of prod[2n + rows of b]
 // + icommit[b]; threads 0-127 take the first sum, 128-255 the second, 7-level trees in LDS
 __global__ __launch_bounds__(256) void k_vm_reduce(const JacQ* __restrict__ prod, const JacQ* __restrict__ icommit,
@@ -280,6 +337,17 @@ void vm_mul(const void* pts, const void* s1, const void* s2, const void* wts, vo
     const int total = 2 * n + m;
     if (total > 0)
         k_vm_mul<<<(total + 63) / 64, 64, 0, st>>>((const G1Affine*)pts, (const Fr*)s1, (const Fr*)s2, (const Fr*)wts, (JacQ*)prod, n, m, fq_from_fp(b384));
+}
+void vm_mul_small(const void* pts, const void* s1, const void* s2, const void* wts, const void* isc, const void* srs, void* prod, int n, int m,
+                  int n_batches, int* status, const Fp12w& beta, hipStream_t st) {
+    Fp b384;
+    for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
+    const int mul_blocks = (2 * n + m + 64 * n_batches + 63) / 64, sub_blocks = (n + m + 63) / 64;
+    k_vm_mul_small<<<mul_blocks + sub_blocks, 64, 0, st>>>((const G1Affine*)pts, (const Fr*)s1, (const Fr*)s2, (const Fr*)wts, (const Fr*)isc,
+                                                           (const G1Affine*)srs, (JacQ*)prod, n, m, n_batches, mul_blocks, status, fq_from_fp(b384));
+}
+void vm_reduce_small(const void* prod, const int* cell_start, const int* row_start, void* out, int n, int m, int n_batches, hipStream_t st) {
+    if (n_batches > 0) k_vm_reduce_small<<<n_batches, 256, 0, st>>>((const JacQ*)prod, cell_start, row_start, (JacQ*)out, n, m);
 }
 void vm_fold(const void* sums, const uint32_t* rho, void* prod, void* out2, int n_batches, const Fp12w& beta, hipStream_t st) {
     if (n_batches <= 0) return;

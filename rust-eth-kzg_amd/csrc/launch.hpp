@@ -157,6 +157,11 @@ void vm_weights(const void* rp_mont, const int* row, const int* row_batch, const
 void vm_interp_sum(const void* coef, const void* rp_mont, const int* cell_start, void* out_neg_canon, int n_batches, hipStream_t st);
 // pts = [proofs n | commitments m] (G1Affine); prod[2n + m] JacQ: s1[e] pi_e | s2[e] pi_e | w[j] C_j
 void vm_mul(const void* pts, const void* s1, const void* s2, const void* wts, void* prod, int n, int m, const Fp12w& beta, hipStream_t st);
+// small passes: every scalar multiplication of the pass (incl. the 64 interpolation terms isc[b][j] SRS_j per problem, prod[2n + m + 64 b + j])
+// and the subgroup tests of [proofs n | commitments m] (status: 0 -> 0 / 2) in ONE launch; then the per-problem sums
+void vm_mul_small(const void* pts, const void* s1, const void* s2, const void* wts, const void* isc, const void* srs, void* prod, int n, int m,
+                  int n_batches, int* status, const Fp12w& beta, hipStream_t st);
+void vm_reduce_small(const void* prod, const int* cell_start, const int* row_start, void* out, int n, int m, int n_batches, hipStream_t st);
 void vm_reduce(const void* prod, const void* icommit, const int* cell_start, const int* row_start, void* out /*[B][2] JacQ*/, int n,
                int n_batches, hipStream_t st);
 // out2[j] = sum_b rho_b sums[b][j] (rho: 4 words per problem, 0 excludes it); prod: scratch of 2 B JacQ

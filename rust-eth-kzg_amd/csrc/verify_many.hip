@@ -19,6 +19,9 @@
 #include "sha256.hpp"
 
 #include <atomic>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,30 +50,47 @@ namespace kzg {
 static constexpr int N_BLOB = 4096, N_CELLS = 128, CELL_LEN = 64, BYTES_PER_CELL = 2048;
 
 namespace {
-// fork-join over [0, n) on `threads` host threads (work stealing by an atomic counter); the first exception is rethrown
+// fork-join over [0, n) on the calling thread and up to `threads` - 1 workers of a persistent pool (work stealing by an atomic
+// counter; the first exception is rethrown).  Round 3 started fresh std::threads here, five times per pass: ~0.5 ms of thread
+// churn on a pass that should last 4.
 template <class F>
-void parallel_for(int n, int threads, int device, F fn) {
+void parallel_for(int n, int threads, HostPool* pool, F fn) {
     if (n <= 0) return;
     if (threads > n) threads = n;
-    if (threads <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
-    std::atomic<int> next{0};
-    std::exception_ptr err;
-    std::mutex err_mu;
-    auto body = [&] {
-        (void)hipSetDevice(device);
+    if (threads <= 1 || !pool) { for (int i = 0; i < n; i++) fn(i); return; }
+    struct Shared {
+        std::atomic<int> next{0};
+        std::atomic<unsigned> state{0};  // helpers inside body | CLOSED: the caller has left its own share and admits no more
+        std::exception_ptr err;
+        std::mutex mu;
+        std::condition_variable cv;
+    };
+    constexpr unsigned CLOSED = 0x80000000u;
+    auto sh = std::make_shared<Shared>();  // outlives this frame: a helper the pool gets to late finds the door closed and leaves
+    auto body = [sh, n, &fn] {
         try {
-            for (int i; (i = next.fetch_add(1)) < n;) fn(i);
+            for (int i; (i = sh->next.fetch_add(1)) < n;) fn(i);
         } catch (...) {
-            std::lock_guard<std::mutex> lk(err_mu);
-            if (!err) err = std::current_exception();
-            next.store(n);
+            std::lock_guard<std::mutex> lk(sh->mu);
+            if (!sh->err) sh->err = std::current_exception();
+            sh->next.store(n);
         }
     };
-    std::vector<std::thread> th;
-    for (int t = 1; t < threads; t++) th.emplace_back(body);
+    for (int t = 0; t < threads - 1; t++)
+        pool->submit([sh, body, CLOSED] {
+            unsigned s = sh->state.load();
+            do {
+                if (s & CLOSED) return;  // too late: nothing of the caller's frame may be touched any more
+            } while (!sh->state.compare_exchange_weak(s, s + 1));
+            body();
+            if (sh->state.fetch_sub(1) == (CLOSED | 1u)) { std::lock_guard<std::mutex> lk(sh->mu); sh->cv.notify_all(); }
+        });
     body();
-    for (auto& t : th) t.join();
-    if (err) std::rethrow_exception(err);
+    {   // no new helper may enter; those inside are waited for (fn and the caller's captures die with this frame)
+        std::unique_lock<std::mutex> lk(sh->mu);
+        if (sh->state.fetch_or(CLOSED) != 0) sh->cv.wait(lk, [&] { return sh->state.load() == CLOSED; });
+    }
+    if (sh->err) std::rethrow_exception(sh->err);
 }
 int host_threads() {
     int t = 16;
@@ -107,14 +127,30 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
     for (int b = 0; b < B; b++) { verified[b] = 0; status[b] = OK; }
     if (B == 0) return OK;
     const int T = host_threads();
-    std::lock_guard<std::mutex> lk(vm_mu_);
+    std::call_once(vm_pool_once_, [&] { vm_pool_.reset(new HostPool(T > 1 ? T - 1 : 1, dev_)); });
+    HostPool* pool = vm_pool_.get();
+    // a free pass slot (lock, stream, arena, pinned slab); when both are taken, queue on one of them in turn
+    VmSlot* slot = nullptr;
+    std::unique_lock<std::mutex> lk;
+    for (int k = 0; k < VM_SLOTS && !slot; k++) {
+        std::unique_lock<std::mutex> t(vm_slot_[k].mu, std::try_to_lock);
+        if (t.owns_lock()) { lk = std::move(t); slot = &vm_slot_[k]; }
+    }
+    if (!slot) {
+        slot = &vm_slot_[vm_rr_.fetch_add(1) % VM_SLOTS];
+        lk = std::unique_lock<std::mutex>(slot->mu);
+    }
     try {
         HIPCK(hipSetDevice(dev_));
-        if (!vm_stream_) HIPCK(hipStreamCreateWithFlags(&vm_stream_, hipStreamNonBlocking));
-        hipStream_t st = vm_stream_;
+        // A slot runs on the stream of one of the prover's three work sets instead of a stream of its own: HIP maps a process's
+        // streams onto FOUR hardware queues per priority, and the context's stream + the three work-set streams are exactly four --
+        // a fifth stream would share a queue with one of them and the two would take turns (seen in the rocprofv3 trace of four
+        // concurrent callers).  A prover call that happens to hold that work set shares the (in-order) stream with the pass.
+        const int slot_index = (int)(slot - vm_slot_);
+        hipStream_t st = work_[1 + slot_index % (NW - 1)].stream ? work_[1 + slot_index % (NW - 1)].stream : stream_;
         // ---- per problem: validation (verifier.rs:123-164) and de-duplication
         std::vector<Problem> pr(B);
-        parallel_for(B, T, dev_, [&](int b) {
+        parallel_for(B, T, pool, [&](int b) {
             const uint64_t nc = n_commitments[b];
             if (!(nc == n_indices[b] && nc == n_cells[b] && nc == n_proofs[b]) || nc > MAX_CELLS_PER_VERIFICATION) { status[b] = ERR_INPUT; return; }
             for (uint64_t i = 0; i < nc; i++)
@@ -141,6 +177,11 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
             while (b1 < B && (b1 == b0 || nn + pr[b1].n <= CHUNK_CELLS)) { nn += pr[b1].n; mm += pr[b1].m; b1++; }
             const int Bc = b1 - b0, n = nn, m = mm;
             if (n == 0) { b0 = b1; continue; }
+            // A pass of a few problems (concurrent single calls combined) is a chain of latencies, not work: it takes the SHORT-CHAIN
+            // form -- subgroup tests and the interpolation commitments' terms inside the ONE launch of all scalar multiplications
+            // (k_vm_mul_small), no fold (its 128-bit multiplication per problem is a 1.4 ms chain; <= 2 T pairing checks are one or
+            // two rounds of the host threads) -- decode 0.45 + products 1.7 + sums 0.2 ms of GPU instead of ~6
+            const bool small = vm_small_max_ != 0 && Bc <= (vm_small_max_ > 0 ? vm_small_max_ : 2 * T);
             std::vector<int> cell_start(Bc + 1, 0), row_start(Bc + 1, 0);
             for (int i = 0; i < Bc; i++) { cell_start[i + 1] = cell_start[i] + pr[b0 + i].n; row_start[i + 1] = row_start[i] + pr[b0 + i].m; }
             // ---- layout: [inputs, uploaded in one copy][device-only]; pinned slab = inputs + read-backs
@@ -172,7 +213,7 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
             const size_t off_w = o; o += up((size_t)m * sizeof(Fr));
             const size_t off_isc = o; o += up((size_t)Bc * 64 * sizeof(Fr));
             const size_t off_icm = o; o += up((size_t)Bc * launch::SIZEOF_JACQ);
-            const size_t off_prod = o; o += up((size_t)(2 * n + m) * launch::SIZEOF_JACQ);
+            const size_t off_prod = o; o += up((size_t)(2 * n + m + (small ? 64 * Bc : 0)) * launch::SIZEOF_JACQ);
             const size_t off_out = o; o += up((size_t)2 * Bc * launch::SIZEOF_JACQ);
             const size_t off_fprod = o; o += up((size_t)2 * Bc * launch::SIZEOF_JACQ);
             const size_t off_fold = o; o += up((size_t)2 * launch::SIZEOF_JACQ);
@@ -188,18 +229,18 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
             const size_t poff_rng = po; po += up((size_t)max_ranges * 8);
             const size_t poff_rsum = po; po += up((size_t)2 * max_ranges * launch::SIZEOF_JACQ);
             const size_t pin_bytes = po;
-            if (dev_bytes > vm_dev_cap_) {
-                if (vm_dev_) { HIPCK(hipStreamSynchronize(st)); HIPCK(hipFree(vm_dev_)); vm_dev_ = nullptr; vm_dev_cap_ = 0; }
-                HIPCK(hipMalloc(&vm_dev_, dev_bytes + (dev_bytes >> 2)));
-                vm_dev_cap_ = dev_bytes + (dev_bytes >> 2);
+            if (dev_bytes > slot->dev_cap) {
+                if (slot->dev) { HIPCK(hipStreamSynchronize(st)); HIPCK(hipFree(slot->dev)); slot->dev = nullptr; slot->dev_cap = 0; }
+                HIPCK(hipMalloc(&slot->dev, dev_bytes + (dev_bytes >> 2)));
+                slot->dev_cap = dev_bytes + (dev_bytes >> 2);
             }
-            if (pin_bytes > vm_pin_cap_) {
-                if (vm_pin_) { HIPCK(hipHostFree(vm_pin_)); vm_pin_ = nullptr; vm_pin_cap_ = 0; }
-                HIPCK(hipHostMalloc((void**)&vm_pin_, pin_bytes + (pin_bytes >> 2), hipHostMallocDefault));
-                vm_pin_cap_ = pin_bytes + (pin_bytes >> 2);
+            if (pin_bytes > slot->pin_cap) {
+                if (slot->pin) { HIPCK(hipHostFree(slot->pin)); slot->pin = nullptr; slot->pin_cap = 0; }
+                HIPCK(hipHostMalloc((void**)&slot->pin, pin_bytes + (pin_bytes >> 2), hipHostMallocDefault));
+                slot->pin_cap = pin_bytes + (pin_bytes >> 2);
             }
-            uint8_t* hb = vm_pin_;
-            uint8_t* db = (uint8_t*)vm_dev_;
+            uint8_t* hb = slot->pin;
+            uint8_t* db = (uint8_t*)slot->dev;
             int* h_idx = (int*)(hb + off_idx);
             int* h_row = (int*)(hb + off_row);
             int* h_bat = (int*)(hb + off_bat);
@@ -208,7 +249,7 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
             memcpy(hb + off_cs, cell_start.data(), (size_t)(Bc + 1) * 4);
             memcpy(hb + off_rs, row_start.data(), (size_t)(Bc + 1) * 4);
             // ---- staging (parallel over problems)
-            parallel_for(Bc, T, dev_, [&](int i) {
+            parallel_for(Bc, T, pool, [&](int i) {
                 const int b = b0 + i;
                 const Problem& p = pr[b];
                 const int c0 = cell_start[i], r0 = row_start[i];
@@ -236,7 +277,7 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
             G1Affine* d_pts = (G1Affine*)(db + off_pts);
             int* d_stp = (int*)(db + off_stp);
             launch::g1_decode2(db + off_p, d_pts, d_stp, n, db + off_c, d_pts + n, d_stp + n, m, beta_, st);
-            launch::g1_subgroup2(d_pts, d_stp, n, d_pts + n, d_stp + n, m, beta_, st);
+            if (!small) launch::g1_subgroup2(d_pts, d_stp, n, d_pts + n, d_stp + n, m, beta_, st);  // (small: inside k_vm_mul_small)
             launch::cells_to_fr(db + off_cells, db + off_evals, nullptr, (int*)(db + off_ste), (const int*)(db + off_bat), nullptr, n, st);
             launch::interp_cells(db + off_evals, (const int*)(db + off_idx), d_w8192_, inv64_, db + off_coef, n, st);
             HIPCK(hipMemcpyAsync(h_st, d_stp, (size_t)(n + m) * 4, hipMemcpyDeviceToHost, st));
@@ -246,7 +287,7 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
             // encodings, so the transcript is the input bytes themselves; then the table r^(2^i) per problem
             Fr* h_pow = (Fr*)(hb + off_pow);
             std::vector<uint8_t> digests((size_t)Bc * 32, 0);
-            parallel_for(Bc, T, dev_, [&](int i) {
+            parallel_for(Bc, T, pool, [&](int i) {
                 const int b = b0 + i;
                 const Problem& p = pr[b];
                 Fr* tab = h_pow + (size_t)i * 24;
@@ -273,24 +314,30 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
             // ---- decoding verdicts per problem (order of the reference: commitments, proofs, cells): the challenge-free GPU work
             // has long finished under the hashes, so this wait is short; a problem with an error takes no part in what follows
             SYNC_CHECKED(st);
+            // (order of the reference: commitments, proofs, cells)
             std::vector<char> live(Bc, 0);
-            for (int i = 0; i < Bc; i++) {
-                const int b = b0 + i;
-                const Problem& p = pr[b];
-                if (p.n == 0) continue;
-                const int c0 = cell_start[i], r0 = row_start[i];
-                int bad = OK;
-                for (int j = 0; j < p.m && !bad; j++) if (h_st[n + r0 + j]) bad = ERR_G1;
-                for (int k = 0; k < p.n && !bad; k++) if (h_st[c0 + k]) bad = ERR_G1;
-                if (!bad && h_st[n + m + i]) bad = ERR_SCALAR;
-                if (bad) status[b] = bad; else live[i] = 1;
-            }
+            auto judge = [&]() {
+                for (int i = 0; i < Bc; i++) {
+                    const int b = b0 + i;
+                    const Problem& p = pr[b];
+                    live[i] = 0;
+                    if (p.n == 0) continue;
+                    const int c0 = cell_start[i], r0 = row_start[i];
+                    int bad = OK;
+                    for (int j = 0; j < p.m && !bad; j++) if (h_st[n + r0 + j]) bad = ERR_G1;
+                    for (int k = 0; k < p.n && !bad; k++) if (h_st[c0 + k]) bad = ERR_G1;
+                    if (!bad && h_st[n + m + i]) bad = ERR_SCALAR;
+                    status[b] = bad;
+                    if (!bad) live[i] = 1;
+                }
+            };
+            judge();  // (a small pass judges again once its subgroup tests are in)
             // ---- folding weights: rho_b = SHA-256(seed || b) truncated to 127 bits, seed = SHA-256 over ALL challenges' digests of the
             // pass (so no weight can be predicted before every input byte is fixed); 0 for problems that are out
             uint32_t* h_rho = (uint32_t*)(hb + off_rho);
             int n_live = 0;
             for (int i = 0; i < Bc; i++) n_live += live[i];
-            const bool folded = fold && n_live >= 2;
+            const bool folded = fold && n_live >= 2 && !small;
             if (folded) {
                 uint8_t seed[32];
                 {
@@ -299,7 +346,7 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
                     sh.update(digests.data(), digests.size());
                     sh.finish(seed);
                 }
-                parallel_for(Bc, T, dev_, [&](int i) {
+                parallel_for(Bc, T, pool, [&](int i) {
                     uint32_t* r4 = h_rho + 4 * (size_t)i;
                     if (!live[i]) { r4[0] = r4[1] = r4[2] = r4[3] = 0; return; }
                     Sha256 sh;
@@ -321,16 +368,23 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
                                db + off_rp, db + off_s1, db + off_s2, n, st);
             launch::vm_weights(db + off_rp, (const int*)(db + off_row), (const int*)(db + off_rowb), d_cs, db + off_w, m, st);
             launch::vm_interp_sum(db + off_coef, db + off_rp, d_cs, db + off_isc, Bc, st);
-            launch::vm_mul(d_pts, db + off_s1, db + off_s2, db + off_w, db + off_prod, n, m, beta_, st);
-            // - commit(interpolation polynomial): 64 fixed bases = group 0 of the commitment window table (verification_key.rs:66-70)
-            launch_msm(db + off_isc, TAB_SRS, db + off_icm, 1, Bc, Bc, 0, st);
-            launch::vm_reduce(db + off_prod, db + off_icm, d_cs, d_rs, db + off_out, n, Bc, st);
+            if (small) {
+                launch::vm_mul_small(d_pts, db + off_s1, db + off_s2, db + off_w, db + off_isc, d_srs_, db + off_prod, n, m, Bc, d_stp, beta_, st);
+                launch::vm_reduce_small(db + off_prod, d_cs, d_rs, db + off_out, n, m, Bc, st);
+                HIPCK(hipMemcpyAsync(h_st, d_stp, (size_t)(n + m) * 4, hipMemcpyDeviceToHost, st));  // with the subgroup verdicts now
+            } else {
+                launch::vm_mul(d_pts, db + off_s1, db + off_s2, db + off_w, db + off_prod, n, m, beta_, st);
+                // - commit(interpolation polynomial): 64 fixed bases = group 0 of the commitment window table (verification_key.rs:66-70)
+                launch_msm(db + off_isc, TAB_SRS, db + off_icm, 1, Bc, Bc, 0, st);
+                launch::vm_reduce(db + off_prod, db + off_icm, d_cs, d_rs, db + off_out, n, Bc, st);
+            }
             if (folded) {
                 launch::vm_fold(db + off_out, (const uint32_t*)(db + off_rho), db + off_fprod, db + off_fold, Bc, beta_, st);
                 HIPCK(hipMemcpyAsync(hb + poff_fold, db + off_fold, (size_t)2 * launch::SIZEOF_JACQ, hipMemcpyDeviceToHost, st));
             }
             HIPCK(hipMemcpyAsync(hb + poff_out, db + off_out, (size_t)2 * Bc * launch::SIZEOF_JACQ, hipMemcpyDeviceToHost, st));
             SYNC_CHECKED(st);
+            if (small) judge();
             // ---- verdicts: ONE pairing check of the folded sums; only if that fails (some problem's proof is wrong) one per problem
             const JacQ* sums = (const JacQ*)(hb + poff_out);
             std::atomic<int> device_fault{0};
@@ -377,7 +431,7 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
                         for (auto& sr : suspects)
                             for (int i = sr.first; i < sr.second; i++)
                                 if (live[i]) todo.push_back(i);
-                        parallel_for((int)todo.size(), T, dev_, [&](int q) { check_single(todo[q]); });
+                        parallel_for((int)todo.size(), T, pool, [&](int q) { check_single(todo[q]); });
                         break;
                     }
                     int K = T / (int)suspects.size();
@@ -395,7 +449,7 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
                     HIPCK(hipMemcpyAsync(hb + poff_rsum, db + off_rsum, probes.size() * 2 * launch::SIZEOF_JACQ, hipMemcpyDeviceToHost, st));
                     SYNC_CHECKED(st);
                     std::vector<char> fails(probes.size(), 0);
-                    parallel_for((int)probes.size(), T, dev_, [&](int q) {
+                    parallel_for((int)probes.size(), T, pool, [&](int q) {
                         G1Affine pts[2];
                         for (int j = 0; j < 2; j++) {
                             const JacQ& sj = h_rsum[2 * (size_t)q + j];
@@ -418,7 +472,7 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
                     }
                 }
             } else {
-                parallel_for(Bc, T, dev_, [&](int i) {
+                parallel_for(Bc, T, pool, [&](int i) {
                     if (live[i]) check_single(i);
                 });
             }
@@ -441,6 +495,7 @@ struct Engine::VerifyRequest {
     const uint8_t* const* proofs;
     int verified = 0, status = OK;
     bool done = false;
+    bool taken = false;  // a leader has this request in its pass (its owner then only waits)
     std::string error;  // of a device failure of the pass that carried this request
 };
 
@@ -449,10 +504,12 @@ int Engine::verify_cell_kzg_proof_batch_combined(uint64_t n_commitments, const u
                                                  uint64_t n_proofs, const uint8_t* const* proofs, int* verified) {
     *verified = 0;
     static const bool enabled = [] { const char* e = getenv("ETH_KZG_AMD_VERIFY_COMBINE"); return !e || atoi(e) != 0; }();
-    // up to one caller per engine lane, a large batch, or the feature switched off: the latency-optimised single path on a lane
-    // (measured at 4 threads: 8.6 ms per round of four on lanes against 12.7 ms through passes of 1-3 problems, whose
-    // floor is one scalar multiplication's dependent chain; at 32 threads the passes carry ~26 problems: 1.7 k/s against 0.4 k/s)
-    if (!enabled || n_cells > (uint64_t)comb_max_cells_ || verify_inflight_.fetch_add(1) < max_lanes_) {
+    // ONE caller at a time (verify_lanes_), a large batch, or the feature switched off: the latency-optimised single path (3.3 ms);
+    // callers that arrive while it is taken are combined into passes on the three pass slots (a pass of 1-8 problems: 3.7-4.1 ms
+    // in the short-chain form).  Round 3 sent the first four callers to four engine lanes; their streams shared hardware queues
+    // with each other (HIP has four per process), and lanes cannot share launches the way a pass does: measured this round,
+    // verifications/s at 2 / 4 / 8 / 16 / 32 threads: four lanes 450 / 650 / 906 / 1997 / 3703, one lane 523 / 681 / 1284 / 2291 / 4323
+    if (!enabled || n_cells > (uint64_t)comb_max_cells_ || verify_inflight_.fetch_add(1) < verify_lanes_) {
         struct Leave { std::atomic<int>* c; bool on; ~Leave() { if (on) c->fetch_sub(1); } } leave{&verify_inflight_, enabled && n_cells <= (uint64_t)comb_max_cells_};
         auto lane = lease_serial();
         const int st = lane.e->verify_cell_kzg_proof_batch_host(n_commitments, commitments, n_indices, cell_indices, n_cells, cells, n_proofs,
@@ -467,11 +524,12 @@ int Engine::verify_cell_kzg_proof_batch_combined(uint64_t n_commitments, const u
     std::unique_lock<std::mutex> lk(comb_mu_);
     comb_queue_.push_back(&me);
     while (!me.done) {
-        if (comb_running_) { comb_cv_.wait(lk); continue; }
-        // become the leader: run everything queued so far (this request included) as ONE many-verification pass
-        comb_running_ = true;
+        if (me.taken || comb_running_ >= VM_SLOTS) { comb_cv_.wait(lk); continue; }
+        // become a leader (one per pass slot): run everything queued so far (this request included) as ONE many-verification pass
+        comb_running_++;
         std::vector<VerifyRequest*> batch;
         batch.swap(comb_queue_);
+        for (VerifyRequest* r : batch) r->taken = true;
         lk.unlock();
         const size_t B = batch.size();
         static const bool trace = getenv("ETH_KZG_AMD_TRACE_COMBINE") != nullptr;
@@ -509,7 +567,7 @@ int Engine::verify_cell_kzg_proof_batch_combined(uint64_t n_commitments, const u
             batch[i]->error = why;
             batch[i]->done = true;
         }
-        comb_running_ = false;
+        comb_running_--;
         comb_cv_.notify_all();
     }
     lk.unlock();
