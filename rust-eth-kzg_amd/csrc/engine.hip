@@ -33,6 +33,7 @@ namespace kzg {
 
 // batches up to this many lanes (blobs rounded up to 64) use the direct 8 x 16 G1 transforms (k_g1fft.hip)
 static constexpr int FLAT_MSM_MAX_SLICES = 8;  // measured: 1 blob 0.23 ms (vs 1.0), 16 blobs 1.6 ms (vs 1.06): one block per MSM pays while the chip is not full
+static constexpr int SIDE_CELLS_MAX = 256;  // batches up to this size compute their cells on the work set's second stream, next to the proof stages (64 blobs: 0.08 of 3.7 ms)
 static constexpr int LATENCY_MODE_MAX_LANES = 128;  // direct 8 x 16 transforms up to two 64-blob groups (128 blobs: 14.6 ms; the radix-2 network needs 17 ms at any batch below ~1000)
 static constexpr int N_BLOB = 4096, N_EXT = 8192, N_CELLS = 128, CELL_LEN = 64, BYTES_PER_BLOB = 131072, BYTES_PER_CELL = 2048;
 static_assert(sizeof(Fr) == launch::SIZEOF_FR && sizeof(G1Affine) == launch::SIZEOF_G1AFFINE && sizeof(G1Jac) == launch::SIZEOF_G1JAC, "layout");
@@ -774,7 +775,8 @@ struct Engine::SharedTable {
     double alloc_ms = 0, alloc_ms_max = 0;  // time spent in hipMalloc for the pieces: total and the longest single call (trace)
     // allocate pieces until blocks [0, block_end) exist; false: out of memory (why is set) or cancelled
     bool alloc_until(int block_end, const std::atomic<bool>* cancel) {
-        constexpr size_t PIECE = 850ull << 20;
+        // (ETH_KZG_AMD_TABLE_PIECE_MB: experiments only -- one piece for the whole table is round 3's single hipMalloc)
+        static const size_t PIECE = [] { const char* e = getenv("ETH_KZG_AMD_TABLE_PIECE_MB"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 850) << 20; }();
         const int total = n_groups * halves;
         if (block_end > total) block_end = total;
         if (!d_blocks) {
@@ -1315,7 +1317,9 @@ void Engine::g1_fft128_full(void* X, int stride, int inverse, hipStream_t st) {
 }
 
 // stages C..G of SURVEY 3.2 from coefficients already in w.coeffs
-void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream_t st) {
+// tv_pre: the scalars of all n blobs are in w.scalars already, computed in the form of THIS view (the host-pointer path does it
+// sub-batch by sub-batch under the uploads)
+void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream_t st, const TableView* tv_pre) {
     const int bp = ((n + 63) / 64) * 64;
     // one or two blobs: the MSM also delivers 2^32 u, 2^64 u, 2^96 u (scaled copies of the scalars, same tables), which
     // cuts the doubling chain of the circulant form into four parallel quarters (needs 32 * 4 >= T - 1 doublings)
@@ -1336,10 +1340,12 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         }
         X = w.slp_arena;
     }
-    const TableView tv = table_view(TAB_FK);  // one snapshot for the scalars' form AND the MSM that reads them
-    const int mk1 = mark_begin(ST_FK20_SCALARS, st);
-    launch::fk20_scalars(n, w.coeffs, w.scalars, d_w29_, linmap_mode ? half_ : inv128_, segs, segs == 2 ? two_segments : seg_shift_, tv.glv, st);
-    mark_end(mk1, 1, st);
+    const TableView tv = tv_pre ? *tv_pre : table_view(TAB_FK);  // one snapshot for the scalars' form AND the MSM that reads them
+    if (!tv_pre) {
+        const int mk1 = mark_begin(ST_FK20_SCALARS, st);
+        launch::fk20_scalars(n, w.coeffs, w.scalars, d_w29_, linmap_mode ? half_ : inv128_, segs, segs == 2 ? two_segments : seg_shift_, tv.glv, st);
+        mark_end(mk1, 1, st);
+    }
     launch::g1_set_inf(X, (size_t)128 * bp, st);
     const bool latency_mode = bp <= LATENCY_MODE_MAX_LANES;  // few 64-blob groups: direct 8 x 16 transforms, 4 rounds instead of 14
     const int mk2 = mark_begin(ST_MSM_FIXED, st);
@@ -1436,7 +1442,7 @@ void Engine::enqueue_compute(Work& w, int n, const uint8_t* d_blobs, uint8_t* d_
     mark_end(mk11, 1, st);
     // a handful of blobs is a chain of latencies: the cells (one 8192-point transform, 0.08 ms) then run on the set's second
     // stream next to the proof stages instead of in front of them
-    const bool side = d_cells && d_proofs && n <= circ_max_ && w.copy && !profiling_;
+    const bool side = d_cells && d_proofs && n <= SIDE_CELLS_MAX && w.copy && !profiling_;
     if (side) {
         HIPCK(hipEventRecord(w.ev_coeffs, st));
         HIPCK(hipStreamWaitEvent(w.copy, w.ev_coeffs, 0));
@@ -1565,10 +1571,16 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
         held = &w;
         step();
         for (int s0 = 0; s0 < n && !failed.load(); s0 += SUPER) {
-            const int ns = std::min(SUPER, n - s0), n_sub = (ns + SUB - 1) / SUB;
+            const int ns = std::min(SUPER, n - s0);
+            // sub-batch boundaries: 256 blobs each, but the first one short (64) so that the link starts carrying blobs 0.15 ms into
+            // the call instead of 0.6 ms (the gather of 256 blobs)
+            std::vector<int> cut{0};
+            if (ns > SUB) cut.push_back(SUB / 4);
+            while (cut.back() < ns) cut.push_back(std::min(ns, cut.back() + SUB));
+            const int n_sub = (int)cut.size() - 1;
             ensure_workspace(w, ns);
             ensure_staging(w, ns);
-            while ((int)w.sub_events.size() < 2 * n_sub) {
+            while ((int)w.sub_events.size() < 3 * n_sub) {
                 hipEvent_t e;
                 HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
                 w.sub_events.push_back(e);
@@ -1586,7 +1598,7 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
             } drain_on_exit{drain};
             // gather tasks for the whole super-batch, in order
             for (int i = 0; i < n_sub; i++) {
-                const int lo = i * SUB, hi = std::min(ns, lo + SUB), parts = (hi - lo + PART - 1) / PART;
+                const int lo = cut[i], hi = cut[i + 1], parts = (hi - lo + PART - 1) / PART;
                 gathered[i].store(threaded ? parts : 0, std::memory_order_relaxed);
                 if (!threaded) {
                     for (int b = lo; b < hi; b++) memcpy(w.h_in + (size_t)b * BYTES_PER_BLOB, blobs[s0 + b], BYTES_PER_BLOB);
@@ -1622,19 +1634,38 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
                 } catch (const std::exception& e) { fail(e); }
                 outstanding.fetch_sub(1, std::memory_order_release);
             };
+            // a handful of blobs: the cells are computed on the copy stream, next to the proof stages (enqueue_compute does the same)
+            const bool side = cells && proofs && ns <= circ_max_;
+            // batches that take the compiled linear map: the MSM scalars are computed sub-batch by sub-batch under the uploads
+            // (0.77 ms per 2048 blobs that used to sit between the last upload and the MSMs)
+            const bool early_scalars = proofs && use_linmap_ && ns > circ_max_;
+            const TableView tv_call = table_view(TAB_FK);
+            // The uploads run back to back on the copy stream (its own hardware queue), the light per-blob stages follow on the compute
+            // stream sub-batch by sub-batch: in one stream the copy engine idled during the kernels and the kernels during the copies
+            // (rocprofv3 --memory-copy-trace: 7.6 ms until the MSMs could start, for 5.2 ms of link time)
             for (int i = 0; i < n_sub; i++) {
-                const int lo = i * SUB, hi = std::min(ns, lo + SUB), nb = hi - lo;
+                const int lo = cut[i], hi = cut[i + 1], nb = hi - lo;
                 while (gathered[i].load(std::memory_order_acquire) > 0) std::this_thread::yield();  // a few hundred microseconds: the gather of 32 MB
                 HIPCK(hipMemcpyAsync(w.d_in + (size_t)lo * BYTES_PER_BLOB, w.h_in + (size_t)lo * BYTES_PER_BLOB, (size_t)nb * BYTES_PER_BLOB,
-                                     hipMemcpyHostToDevice, w.stream));
+                                     hipMemcpyHostToDevice, w.copy));
+                HIPCK(hipEventRecord(w.sub_events[2 * n_sub + i], w.copy));
+                HIPCK(hipStreamWaitEvent(w.stream, w.sub_events[2 * n_sub + i], 0));
                 launch::blob_to_coeffs(nb, w.d_in + (size_t)lo * BYTES_PER_BLOB, (char*)w.coeffs + (size_t)lo * N_BLOB * sizeof(Fr), nullptr,
                                        w.status + lo, d_w29_, n_inv4096_, w.stream);
-                // a handful of blobs: the cells are computed on the copy stream, next to the proof stages (enqueue_compute does the same)
-                const bool side = cells && proofs && ns <= circ_max_;
                 if (cells && !side)
                     launch::coeffs_to_cells(nb, (char*)w.coeffs + (size_t)lo * N_BLOB * sizeof(Fr),
                                             w.d_cells + (size_t)lo * N_CELLS * BYTES_PER_CELL, d_w29_, w.stream);
                 HIPCK(hipEventRecord(w.sub_events[2 * i], w.stream));
+                if (early_scalars)
+                    launch::fk20_scalars(nb, (char*)w.coeffs + (size_t)lo * N_BLOB * sizeof(Fr), (char*)w.scalars + (size_t)lo * 128 * 64 * sizeof(Fr),
+                                         d_w29_, half_, 1, seg_shift_, tv_call.glv, w.stream);
+                if (trace) fprintf(stderr, "[host-batch] sub-batch %d (%d blobs) enqueued at %.2f ms\n", i, nb, now_ms());
+            }
+            // The cells go back on the same copy stream, i.e. behind the LAST upload: the fixed-base MSMs run once over the whole batch
+            // and cannot start before every blob is up, so until then the PCIe link belongs to the uploads; the 537 MB of cells then
+            // have the 50 ms of the heavy stages to come down.
+            for (int i = 0; i < n_sub; i++) {
+                const int lo = cut[i], hi = cut[i + 1], nb = hi - lo;
                 HIPCK(hipStreamWaitEvent(w.copy, w.sub_events[2 * i], 0));
                 if (side)
                     launch::coeffs_to_cells(nb, (char*)w.coeffs + (size_t)lo * N_BLOB * sizeof(Fr),
@@ -1651,11 +1682,10 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
                         host_pool_->submit([&, i, p0, p1] { scatter_cells(i, p0, p1); });
                     }
                 }
-                if (trace) fprintf(stderr, "[host-batch] sub-batch %d (%d blobs) enqueued at %.2f ms\n", i, nb, now_ms());
             }
             step();
             if (proofs) {
-                run_proofs_from_coeffs(w, ns, w.d_proofs, w.stream);
+                run_proofs_from_coeffs(w, ns, w.d_proofs, w.stream, early_scalars ? &tv_call : nullptr);
                 HIPCK(hipMemcpyAsync(w.h_proofs, w.d_proofs, (size_t)ns * N_CELLS * 48, hipMemcpyDeviceToHost, w.stream));
             }
             step();
@@ -1686,7 +1716,7 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
                     }
                 };
                 if (threaded && ns >= 256) {
-                    const int parts = 4;
+                    const int parts = 8;
                     for (int t = 1; t < parts; t++) {
                         outstanding.fetch_add(1, std::memory_order_relaxed);
                         host_pool_->submit([&, t] { scatter_proofs(t * ns / parts, (t + 1) * ns / parts); outstanding.fetch_sub(1, std::memory_order_release); });

@@ -265,7 +265,7 @@ private:
     void ensure_workspace(Work& w, int n);
     void ensure_staging(Work& w, int n);
     void run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st) { run_proofs_from_coeffs(work_[0], n, d_proofs, st); }
-    void run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream_t st);
+    void run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream_t st, const TableView* tv_pre = nullptr);
     void enqueue_compute(Work& w, int n, const uint8_t* d_blobs, uint8_t* d_cells, uint8_t* d_proofs, hipStream_t st,
                          hipEvent_t after_cells);
     Work& lease_work(int first, int last);  // locks and returns a free set among work_[first..last] (waits for whichever frees first)

@@ -450,6 +450,31 @@ def test_sparse_polynomials_hit_the_degenerate_point_operations(ctx, oracle):
     assert st == [0] * 70 and cells2[:12] == cells and proofs2[:12] == proofs
 
 
+def test_degenerate_blobs_inside_a_batch_that_fills_the_chip(ctx, oracle):
+    """The large-batch forms of the point kernels have their own handling of identity / equal / opposite operands: k_g1_compress<4>
+    (four positions share one inversion from 128 x 2048 lanes on; an identity takes part as Z = 1) and the fused a + b / a - b pair
+    of the linear map with its exact slow path (from 1024 lanes on).  Zero, constant and one- / two-term polynomials embedded at
+    scattered places of a 2112-blob device-resident batch (33 lane groups, a ragged count for the four-position compressor) must
+    give the oracle's bytes, and their random neighbours too."""
+    def poly(*terms):
+        c = [0] * 4096
+        for idx, val in terms:
+            c[idx] = val
+        return c
+    special = {0: [0] * 4096, 1: poly((0, 7)), 63: poly((0, 1), (5, 3)), 64: poly((64, 1), (128, synth.R - 1)), 1000: poly((4095, 1)),
+               1023: [1] * 4096, 1024: poly((64, 1), (128, 1)), 2047: poly(*[(64 * m, 1) for m in range(64)]), 2048: poly((63, 5)), 2111: [0] * 4096}
+    n = 2112
+    blobs = _random_blobs(n, 77077)
+    for b, c in special.items():
+        blobs[b] = np.frombuffer(_blob_from_coefficients(c), dtype=np.uint8).reshape(4096, 32)
+    st, cells, proofs = _compute_on_device(ctx, blobs)
+    assert st == [0] * n
+    _check_sample_against_oracle(oracle, blobs, cells, proofs, sorted(special) + [2, 62, 65, 1001, 2110])
+    inf = np.frombuffer((b"\xc0" + bytes(47)) * 128, dtype=np.uint8)
+    for b in (0, 1, 2111):  # zero and constant polynomials: every proof is the identity
+        assert np.array_equal(proofs[b], inf)
+
+
 def test_verify_device_resident_matches_the_host_form(ctx, oracle):
     """eth_kzg_amd_verify_cell_kzg_proof_batch_device on the prover's own device buffers (config 3 at full size: cells
     and proofs never leave HBM before the call): true; a flipped proof byte pair, a swapped cell, a wrong commitment:
