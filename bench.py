@@ -286,6 +286,25 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
         ts.append(time.perf_counter() - t0)
     out["abi_host_pointer_batch"] = {"blobs_per_s": round(B / _median(ts)), "ms": round(_median(ts) * 1e3, 2), "blobs": B,
                                      "entry": "eth_kzg_amd_compute_cells_and_kzg_proofs_batch (PCIe both ways, gather and scatter included)"}
+    # the same entry point from TWO caller threads, each with its own batch and buffers: one call's gather and upload run under the
+    # other call's MSMs (the context has three independent work sets) -- what a host that pipelines its calls gets
+    import threading as _th
+    bufs2 = ctx.host_batch_buffers(B)
+    ctx.compute_cells_and_kzg_proofs_batch_np(blobs_h, bufs2)
+
+    def _caller(bf, k):
+        for _ in range(k):
+            ctx.compute_cells_and_kzg_proofs_batch_np(blobs_h, bf)
+    tt = [_th.Thread(target=_caller, args=(bf, 3)) for bf in (bufs, bufs2)]
+    t0 = time.perf_counter()
+    for t in tt:
+        t.start()
+    for t in tt:
+        t.join()
+    dt2 = time.perf_counter() - t0
+    out["abi_host_pointer_batch_two_callers"] = {"blobs_per_s": round(6 * B / dt2), "ms_per_call": round(dt2 / 6 * 1e3, 2), "blobs": B,
+                                                 "entry": "eth_kzg_amd_compute_cells_and_kzg_proofs_batch from two threads, three calls each"}
+    del bufs2
     one = blobs_h[0].tobytes()
     ctx.compute_cells_and_kzg_proofs(one)
     ts = []
@@ -321,6 +340,24 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
     assert ctx.verify_cell_kzg_proof_batch(C_, I_, L_, P2) is False
     out["config3_verify_64x128_cells"] = {"ms": round(_median(ts) * 1e3, 2), "cells": len(L_), "cells_per_s": round(len(L_) / _median(ts)),
                                           "entry": "eth_kzg_verify_cell_kzg_proof_batch (host pointers, 17.6 MB of input; tampered proof -> false checked)"}
+    # the same batch with cells and proofs where the prover left them, in HBM (eth_kzg_amd_verify_cell_kzg_proof_batch_device): the GPU's part
+    # reads them in place, only the transcript's bytes come down (in chunks, under the hash)
+    try:
+        d_comm = torch.frombuffer(bytearray(b"".join(comms)), dtype=torch.uint8).to(dev).view(nb, 1, 48).expand(nb, CELLS, 48).contiguous().view(-1)
+        d_idx = torch.arange(CELLS, dtype=torch.int64, device=dev).repeat(nb)
+        torch.cuda.synchronize(dev)
+        tsd = []
+        for it in range(7):
+            t0 = time.perf_counter()
+            okd = ctx.verify_cell_kzg_proof_batch_device(nb * CELLS, d_comm.data_ptr(), d_idx.data_ptr(), d_c.data_ptr(), d_p.data_ptr())
+            if it >= 1:
+                tsd.append(time.perf_counter() - t0)
+            assert okd is True
+        out["config3_verify_64x128_cells_device_resident"] = {"ms": round(_median(tsd) * 1e3, 2), "cells": nb * CELLS,
+                                                              "entry": "eth_kzg_amd_verify_cell_kzg_proof_batch_device (cells and proofs stay in HBM for the GPU's part; "
+                                                                       "17.6 MB come down in chunks for the SHA-256 transcript, 7.2 ms of one host core = the floor)"}
+    except Exception as e:  # a side figure must not cost the record
+        out["config3_verify_64x128_cells_device_resident"] = {"error": repr(e)}
     # config 5: recover 256 blobs at 50 % erasure, device-resident form; and its per-GPU share on 8 GPUs (32 blobs)
     _mark("side configs: config 5")
     for nb, key in ((min(256, B), "config5_recover_256_blobs_half_erased"), (32, "config5_per_gpu_share_32_blobs")):
@@ -407,13 +444,19 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
     import threading
     for n_thr, key in ((4, "verify_128_cells_from_4_threads"), (32, "verify_128_cells_from_32_threads")):
         runs_t = [ctx.prepare_verify_cell_kzg_proof_batch(*probs[b % nb]) for b in range(n_thr)]
-        reps = 25
+        reps = 60
 
         def hammer(r):
             for _ in range(reps):
                 assert r()
         for r in runs_t[:2]:
             r()
+        # an untimed round first: the pass slots get their arenas, the host pool its threads, on first use
+        warm = [threading.Thread(target=lambda r=r: [r() for _ in range(4)]) for r in runs_t]
+        for t in warm:
+            t.start()
+        for t in warm:
+            t.join()
         ths = [threading.Thread(target=hammer, args=(r,)) for r in runs_t]
         t0 = time.perf_counter()
         for t in ths:
@@ -422,8 +465,8 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
             t.join()
         dtt = time.perf_counter() - t0
         out[key] = {"verifications_per_s": round(n_thr * reps / dtt),
-                    "entry": f"eth_kzg_verify_cell_kzg_proof_batch from {n_thr} host threads on one context: up to one caller per engine lane (4) takes the "
-                             "latency path, callers beyond that are combined into many-verification passes"}
+                    "entry": f"eth_kzg_verify_cell_kzg_proof_batch from {n_thr} host threads on one context: one caller at a time takes the latency "
+                             "path, callers that arrive meanwhile are combined into many-verification passes (three pass slots, short-chain form)"}
     _mark("side configs: recover one")
     half_idx, half_cells = list(range(CELLS // 2)), L_[:CELLS // 2]
     ts = []

@@ -440,6 +440,8 @@ Engine::~Engine() {
         if (v.pin) hipHostFree(v.pin);
     }
     if (vd_pin_) hipHostFree(vd_pin_);
+    for (hipEvent_t e : vd_events_)
+        if (e) hipEventDestroy(e);
     if (v_side_) hipStreamDestroy(v_side_);
     if (v_decoded_) hipEventDestroy(v_decoded_);
     if (v_checked_) hipEventDestroy(v_checked_);

@@ -253,9 +253,18 @@ private:
     int open_blobs_at(int n, const uint8_t* const* blobs, const Fr8* z_mont, bool want_proofs, uint8_t* h_proofs, Fr8* h_y_canon,
                       int* h_status);
     int pairing_check_4844(const void* d_points, const std::vector<Fr8>& sc0, const std::vector<Fr8>& sc1);
+    // dsrc (device-resident form): the cells and proofs already sit in HBM -- they are copied device to device into the arena
+    // instead of being gathered on the host and uploaded; the pointer arrays then address their pinned host mirror, which the
+    // transcript hash reads, and whose cells arrive in chunks (an event per chunk)
+    struct VerifyDeviceSource {
+        const uint8_t *d_cells, *d_proofs;  // flat [n][2048] / [n][48] in this GPU's memory
+        hipEvent_t* chunk_events;           // chunk j = cells [j * chunk_cells, (j + 1) * chunk_cells) of the mirror
+        int chunk_cells, n_chunks;
+    };
     int verify_cells_partial(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,
                              const uint64_t* cell_indices, uint64_t n_cells, const uint8_t* const* cells, uint64_t n_proofs,
-                             const uint8_t* const* proofs, uint64_t lo, uint64_t hi, G1Affine* out2, bool* empty);
+                             const uint8_t* const* proofs, uint64_t lo, uint64_t hi, G1Affine* out2, bool* empty,
+                             const VerifyDeviceSource* dsrc = nullptr);
     bool verify_cells_pairing(const G1Affine* pts2) const;
     int rs_decode(int R, const uint8_t* d_cells, bool flat_source, const std::vector<int>& slot, const std::vector<int>& stof,
                   const std::vector<uint32_t>& present, int* st_out);
@@ -382,8 +391,10 @@ private:
     std::atomic<unsigned> vm_rr_{0};
     bool vm_search_ = true;  // ETH_KZG_AMD_VM_SEARCH=0: a pass whose folded check fails is re-checked problem by problem (round 3's form)
     int vm_small_max_ = -1;  // passes of at most this many problems take the short-chain form (verify_many.hip); -1: 2 x host threads; ETH_KZG_AMD_VM_SMALL
-    uint8_t* vd_pin_ = nullptr;  // device-resident verification: the bytes come down here once (grow-only, guarded by mu_)
+    uint8_t* vd_pin_ = nullptr;  // device-resident verification: the host mirror the transcript hash reads (grow-only, guarded by mu_)
     size_t vd_pin_cap_ = 0;
+    static constexpr int VD_CHUNKS = 8;
+    hipEvent_t vd_events_[VD_CHUNKS] = {};
 
     // small-batch circulant form of the two G1 transforms: term list, doubling tables (allocated on first use)
     void *d_circ_terms_ = nullptr;

@@ -101,7 +101,7 @@ static Fr reduce_be32(const uint8_t* b) {
 int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,
                                  const uint64_t* cell_indices, uint64_t n_cells, const uint8_t* const* cells,
                                  uint64_t n_proofs, const uint8_t* const* proofs, uint64_t lo, uint64_t hi,
-                                 G1Affine* out, bool* empty) {
+                                 G1Affine* out, bool* empty, const VerifyDeviceSource* dsrc) {
     *empty = false;
     out[0] = out[1] = aff_inf();
     // deduplicate_with_indices (verifier.rs:49-65): byte equality, first-occurrence order
@@ -199,8 +199,10 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
                 HIPCK(hipSetDevice(dev_));
                 for (int i = 0; i < m; i++) memcpy(hc + (size_t)i * 48, uniq[i], 48);
                 for (int k = 0; k < n; k++) {
-                    memcpy(hp + (size_t)k * 48, proofs[k0 + k], 48);
-                    memcpy(hcells + (size_t)k * BYTES_PER_CELL, cells[k0 + k], BYTES_PER_CELL);
+                    if (!dsrc) {
+                        memcpy(hp + (size_t)k * 48, proofs[k0 + k], 48);
+                        memcpy(hcells + (size_t)k * BYTES_PER_CELL, cells[k0 + k], BYTES_PER_CELL);
+                    }
                     hidx[k] = (int)cell_indices[k0 + k];
                     hrow[k] = row[k0 + k];
                 }
@@ -210,7 +212,14 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
                 HIPCK(hipMemsetAsync(d_stc.p, 0xff, (size_t)m * sizeof(int), st));
                 HIPCK(hipMemsetAsync(d_stp.p, 0xff, (size_t)n * sizeof(int), st));
                 HIPCK(hipMemsetAsync(db + off_out, 0xff, 512, st));
-                HIPCK(hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, st));
+                if (!dsrc) {
+                    HIPCK(hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, st));
+                } else {  // device-resident form: only the small host-made parts go up; cells and proofs move inside HBM
+                    HIPCK(hipMemcpyAsync(db + off_c, hb + off_c, sz_c, hipMemcpyHostToDevice, st));
+                    HIPCK(hipMemcpyAsync(db + off_idx, hb + off_idx, in_bytes - off_idx, hipMemcpyHostToDevice, st));
+                    HIPCK(hipMemcpyAsync(db + off_p, dsrc->d_proofs + (size_t)k0 * 48, sz_p, hipMemcpyDeviceToDevice, st));
+                    HIPCK(hipMemcpyAsync(db + off_cells, dsrc->d_cells + (size_t)k0 * BYTES_PER_CELL, sz_cells, hipMemcpyDeviceToDevice, st));
+                }
                 HIPCK(hipMemsetAsync(d_ste.p, 0, sizeof(int), st));
                 // deserialisation with on-curve + subgroup checks (serialization/src/lib.rs:69-99), on the GPU
                 if (shifted) {
@@ -255,7 +264,9 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
         be64(N_BLOB, hdr + 16); be64(CELL_LEN, hdr + 24); be64((uint64_t)m, hdr + 32); be64((uint64_t)n_all, hdr + 40);
         sh.update(hdr, sizeof hdr);
         for (int i = 0; i < m; i++) sh.update(uniq[i], 48);
+        int chunks_in = 0;  // (device-resident form) chunks of the cells' host mirror that have arrived
         for (int k = 0; k < n_all; k++) {  // the transcript always covers the whole batch, whatever the shard
+            while (dsrc && chunks_in < dsrc->n_chunks && k >= chunks_in * dsrc->chunk_cells) HIPCK(hipEventSynchronize(dsrc->chunk_events[chunks_in++]));
             uint8_t ix[16];
             be64((uint64_t)row[k], ix); be64(cell_indices[k], ix + 8);
             sh.update(ix, 16);
@@ -321,14 +332,21 @@ bool Engine::verify_cells_pairing(const G1Affine* pts) const {
 }
 
 // Device-resident form of the same check: the four flat arrays already sit in this GPU's HBM (cells straight from a prover or
-// recovery call, for instance).  The Fiat-Shamir transcript is a sequential SHA-256 over all of it, which belongs on a host
-// core, so the bytes come down once over PCIe into pinned memory (17.6 MB at config 3: 0.4 ms) and the host-pointer path
-// runs on them; what is saved is the caller's own round trip and its 3 n pointers.
+// recovery call, for instance) and STAY there for the GPU's part: decoding, subgroup tests, shifted copies and interpolation
+// read them after a device-to-device copy into the arena, at once.  What has to come down is what the Fiat-Shamir transcript
+// hashes -- a sequential SHA-256 over every byte, which belongs on a host core (2 cycles per byte with SHA-NI: 7.2 ms for
+// config 3's 17.6 MB, the floor of this call): commitments, indices and proofs first (0.9 MB; the host de-duplicates the
+// commitments), then the cells in eight chunks that the hash consumes as they land (PCIe delivers 20x faster than it reads).
+// Round 3 copied everything down, gathered it on the host and uploaded it again.
 int Engine::verify_cell_kzg_proof_batch_device(uint64_t n, const uint8_t* d_commitments, const uint64_t* d_cell_indices,
                                                const uint8_t* d_cells, const uint8_t* d_proofs, int* verified, hipStream_t user_stream) {
     *verified = 0;
     if (n == 0) { *verified = 1; return OK; }  // verifier.rs:90-93
-    std::lock_guard<std::recursive_mutex> lk(mu_);  // the pinned landing buffer is the context's (grow-only, reused by every call)
+    if (n > MAX_CELLS_PER_VERIFICATION) return ERR_INPUT;
+    std::lock_guard<std::recursive_mutex> lk(mu_);  // the pinned mirror is the context's (grow-only, reused by every call)
+    G1Affine pts[2];
+    bool empty = false;
+    int rc = OK;
     try {
         std::vector<const uint8_t*> cp(n), lp(n), pp(n);  // inside the try: a bogus n must not unwind through the C ABI
         HIPCK(hipSetDevice(dev_));
@@ -339,23 +357,41 @@ int Engine::verify_cell_kzg_proof_batch_device(uint64_t n, const uint8_t* d_comm
             HIPCK(hipHostMalloc((void**)&vd_pin_, need + (need >> 2), hipHostMallocDefault));
             vd_pin_cap_ = need + (need >> 2);
         }
+        for (hipEvent_t& e : vd_events_)
+            if (!e) HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         uint8_t* pin = vd_pin_;
-        hipStream_t s = user_stream ? user_stream : stream_;
-        HIPCK(hipMemcpyAsync(pin, d_commitments, sz_c, hipMemcpyDeviceToHost, s));
-        HIPCK(hipMemcpyAsync(pin + sz_c, d_cell_indices, sz_i, hipMemcpyDeviceToHost, s));
-        HIPCK(hipMemcpyAsync(pin + sz_c + sz_i, d_cells, sz_l, hipMemcpyDeviceToHost, s));
-        HIPCK(hipMemcpyAsync(pin + sz_c + sz_i + sz_l, d_proofs, sz_p, hipMemcpyDeviceToHost, s));
-        SYNC_CHECKED(s);
-        for (uint64_t k = 0; k < n; k++) {
-            cp[k] = pin + k * 48;
-            lp[k] = pin + sz_c + sz_i + k * (size_t)BYTES_PER_CELL;
-            pp[k] = pin + sz_c + sz_i + sz_l + k * 48;
+        uint8_t *pin_c = pin, *pin_i = pin + sz_c, *pin_p = pin + sz_c + sz_i, *pin_l = pin + sz_c + sz_i + sz_p;
+        hipStream_t st = stream_;
+        if (user_stream && user_stream != st) {  // what the caller has queued on its stream produces the inputs
+            HIPCK(hipEventRecord(v_decoded_, user_stream));
+            HIPCK(hipStreamWaitEvent(st, v_decoded_, 0));
         }
-        return verify_cell_kzg_proof_batch_host(n, cp.data(), n, reinterpret_cast<const uint64_t*>(pin + n * 48), n, lp.data(), n, pp.data(), verified);
+        HIPCK(hipMemcpyAsync(pin_c, d_commitments, sz_c, hipMemcpyDeviceToHost, st));
+        HIPCK(hipMemcpyAsync(pin_i, d_cell_indices, sz_i, hipMemcpyDeviceToHost, st));
+        HIPCK(hipMemcpyAsync(pin_p, d_proofs, sz_p, hipMemcpyDeviceToHost, st));
+        HIPCK(hipEventRecord(v_checked_, st));
+        const int n_chunks = n >= 64 * VD_CHUNKS ? VD_CHUNKS : 1, chunk_cells = (int)((n + n_chunks - 1) / n_chunks);
+        for (int j = 0; j < n_chunks; j++) {
+            const size_t c0 = (size_t)j * chunk_cells, c1 = std::min<size_t>(n, c0 + chunk_cells);
+            if (c1 > c0) HIPCK(hipMemcpyAsync(pin_l + c0 * BYTES_PER_CELL, d_cells + c0 * BYTES_PER_CELL, (c1 - c0) * BYTES_PER_CELL, hipMemcpyDeviceToHost, st));
+            HIPCK(hipEventRecord(vd_events_[j], st));
+        }
+        HIPCK(hipEventSynchronize(v_checked_));  // commitments, indices, proofs are down: validation and de-duplication can start
+        for (uint64_t k = 0; k < n; k++) {
+            cp[k] = pin_c + k * 48;
+            lp[k] = pin_l + k * (size_t)BYTES_PER_CELL;
+            pp[k] = pin_p + k * 48;
+        }
+        const VerifyDeviceSource src{d_cells, d_proofs, vd_events_, chunk_cells, n_chunks};
+        rc = verify_cells_partial(n, cp.data(), n, reinterpret_cast<const uint64_t*>(pin_i), n, lp.data(), n, pp.data(), 0, n, pts, &empty, &src);
+        if (rc != OK) (void)hipStreamSynchronize(st);  // (an early error return: the copies into the mirror must not outlive the call)
     } catch (const std::exception& e) {
         set_error(e);
         return ERR_DEVICE;
     }
+    if (rc) return rc;
+    *verified = (empty || verify_cells_pairing(pts)) ? 1 : 0;
+    return OK;
 }
 
 int Engine::verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,

@@ -19,5 +19,12 @@ python3 "$REPO/tools/pmc_summary.py" "$OUT/${TAG}_pmc_b2048_${SUFFIX}.json" "roc
 # single-blob (latency) regime
 rocprofv3 --kernel-trace --stats -d "$OUT/trace_b1" -o t --output-format csv -- python3 "$REPO/bench.py" --blobs-per-gpu 1 --steps 20 --warmup 2 --no-cpu-baseline --no-latency-probe --no-configs > "$OUT/bench_b1.json" 2> "$OUT/trace_b1.err"
 cp "$(find "$OUT/trace_b1" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats_bench_b1.csv"
+# the batches that do not fill the chip (BASELINE configs 4 and 5 per GPU, round 4's subject): 64 and 256 blobs
+for B in 64 256; do
+  rocprofv3 --kernel-trace --stats -d "$OUT/trace_b$B" -o t --output-format csv -- python3 "$REPO/bench.py" --blobs-per-gpu $B --steps 20 --warmup 2 --no-cpu-baseline --no-latency-probe --no-configs > "$OUT/bench_b$B.json" 2> "$OUT/trace_b$B.err"
+  cp "$(find "$OUT/trace_b$B" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats_bench_b$B.csv"
+  grep '^{' "$OUT/bench_b$B.json" > "$OUT/${TAG}_bench_b${B}_under_rocprof.json"
+  rm -rf "$OUT/trace_b$B"
+done
 rm -rf "$OUT"/trace "$OUT"/trace_b1 "$OUT"/pmc_*/ 2>/dev/null
 ls -la "$OUT"
