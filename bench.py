@@ -749,6 +749,9 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the side configurations (BASELINE configs 3-5, ABI, context creation)")
     ap.add_argument("--no-latency-probe", action="store_true",
                     help="skip the 1-blob latency launches (profiling runs: keeps rocprofv3's per-kernel averages to full-batch launches)")
+    ap.add_argument("--no-build-probe", action="store_true",
+                    help="do not issue single-blob calls while the wide tables are built (profiling runs: keeps those launches, slowed by the "
+                         "table builder next to them, out of rocprofv3's per-kernel averages)")
     ap.add_argument("--strong-configs", action="store_true",
                     help="also run the strong-scaling legs (configs 4 and 5 as written) at N = 1; they always run at N > 1")
     ap.add_argument("--launcher-selftest", action="store_true", help="CPU only: check the --gpus N launcher and the rendezvous, then exit")
@@ -815,7 +818,7 @@ def main():
     # compute_cells_and_kzg_proofs through the reference's entry point every 5 ms.  How long the slowest of them took is the
     # stall a service sees during start-up (round 3: one 206 GB hipMalloc froze every HIP call of the process for 2-4.4 s).
     waits, wait_at, half_s = [], [], None
-    while ctx.tables_ready(0) == 0:
+    while ctx.tables_ready(0) == 0 and not args.no_build_probe:
         t1 = time.perf_counter()
         out_k = ctx.compute_cells_and_kzg_proofs(first_blob)
         waits.append(time.perf_counter() - t1)

@@ -13,9 +13,10 @@
  * caller-allocated memory; only `CResult.error_msg` and the context are library-allocated
  * (free with eth_kzg_free_error_message / eth_kzg_das_context_free).
  * Threading: a context may be used from many threads at once.  Prover calls take one of several scratch sets; the
- * verification / recovery / commitment / EIP-4844 calls run on up to $ETH_KZG_AMD_SERIAL_LANES (default 4) engine lanes
- * that the context creates on demand, so calls from different threads overlap on the GPU; eth_kzg_verify_cell_kzg_proof_batch
- * callers beyond one per lane are combined into many-verification passes behind the ABI (same verdicts and error split).
+ * recovery / commitment / EIP-4844 calls run on up to $ETH_KZG_AMD_SERIAL_LANES (default 4) engine lanes that the context
+ * creates on demand, so calls from different threads overlap on the GPU; of concurrent eth_kzg_verify_cell_kzg_proof_batch
+ * callers one at a time takes the latency path and those that arrive meanwhile are combined into many-verification passes
+ * behind the ABI (three pass slots; same verdicts and error split).
  */
 #ifndef C_ETH_KZG_H
 #define C_ETH_KZG_H
@@ -169,8 +170,9 @@ CResult eth_kzg_amd_verify_cell_kzg_proof_batch_combine(const DASContext *ctx, u
  * commitments[b] / cell_indices[b] / cells[b] / proofs[b] with the four lengths *_lengths[b], exactly as one call of the
  * single form; the problems share every GPU launch (one lane per scalar multiplication), their transcripts are hashed on host
  * threads in parallel, and the pairing checks of a pass are folded into one with 127-bit weights derived from all the
- * challenges (error 2^-127, the argument of the powers of r inside one batch); a pass that contains a wrong proof is
- * re-checked problem by problem, so a false verdict is always exact and per problem.  Per problem: status[b] = 0 and verified[b] = the verdict, or
+ * challenges (error 2^-127, the argument of the powers of r inside one batch); in a pass that contains wrong proofs they are
+ * found by folding sub-ranges of the resident weighted sums (a handful of pairings per wrong proof instead of one per problem)
+ * down to single problems, so a false verdict is always exact and per problem.  A problem may hold at most 2^24 - 1 cells.  Per problem: status[b] = 0 and verified[b] = the verdict, or
  * status[b] = 1 (a cell holds a non-canonical field element), 2 (bad G1 encoding / not in the subgroup), 3 (invalid lengths
  * or indices) and verified[b] = false -- what the single form reports as Err (status may be NULL).  The CResult is Err only
  * for a call-level (device) failure.  An empty problem verifies (verifier.rs:90-93). */

@@ -792,7 +792,9 @@ struct Engine::SharedTable {
             while (blocks_allocated + n < total && (n == 0 || sz + block_bytes(blocks_allocated + n) <= PIECE)) { sz += block_bytes(blocks_allocated + n); n++; }
             void* p = nullptr;
             const auto a0 = std::chrono::steady_clock::now();
-            const hipError_t e = hipMalloc(&p, sz);
+            // (ETH_KZG_AMD_TABLE_CONTIGUOUS=1: experiments -- physically contiguous pieces, in the hope of larger page-table fragments)
+            static const bool contiguous = [] { const char* e = getenv("ETH_KZG_AMD_TABLE_CONTIGUOUS"); return e && atoi(e) != 0; }();
+            const hipError_t e = contiguous ? hipExtMallocWithFlags(&p, sz, hipDeviceMallocContiguous) : hipMalloc(&p, sz);
             const double dt = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count();
             alloc_ms += dt;
             alloc_ms_max = std::max(alloc_ms_max, dt);
