@@ -335,6 +335,10 @@ Engine::Engine(bool use_precomp, int device, const Engine* primary) : dev_(devic
         const int v = atoi(s);
         if (v >= 1) pip_shift_min_ = v;
     }
+    // largest batch on the circulant form: its cost grows by 0.3 ms per blob (1 blob 1.48 ms, 4: 2.33, 5: 3.0, 8: 3.5), the compiled
+    // map in its Karatsuba compilation is flat (5 - 8 blobs: 2.5 - 2.7 ms with the flat MSM) -- round 3's cross-over, against the
+    // tuned program, was 8
+    circ_max_ = 4;
     if (const char* s = getenv("ETH_KZG_AMD_CIRC_MAX")) {  // tuning knob: largest batch served by the circulant form (0 disables it)
         int v = atoi(s);
         if (v >= 0 && v <= 64) circ_max_ = v;
