@@ -1084,6 +1084,8 @@ def main():
         }
         if strong is not None:
             out["configs_strong"] = strong
+        if world > 1:
+            out["omitted_at_n_gpus_above_1"] = ["cpu_baseline", "configs (single-GPU side figures)", "blobs_per_s_vs_table_memory"]
         extra = None
         if not args.no_configs and world == 1:
             out["configs"], extra = side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times)

@@ -1075,8 +1075,22 @@ void Engine::build_final_tables() {
     int state = 1;
     std::string why;
     // wider than `now`, from the registry or built here; attach = publish as `next` while it is filled
+    // A table this context had attached as `next` may have been ABANDONED by the context that was filling it (freed mid-build):
+    // its pieces must go before another 206 GB can be allocated.  Nothing refers to it once the view is republished, except
+    // kernels already in flight and a caller that took its snapshot a moment ago: wait for both, then let go of it.
+    auto drop_abandoned = [&](TableSel sel) {
+        const TableView cur = table_view(sel);
+        if (!cur.next || cur.next->state.load() != 2) return;
+        publish(sel, cur.main, nullptr);
+        (void)hipDeviceSynchronize();
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        (void)hipDeviceSynchronize();
+        std::lock_guard<std::mutex> lk(tab_mu_);
+        retired_.erase(std::remove_if(retired_.begin(), retired_.end(), [](const std::shared_ptr<SharedTable>& r) { return r->state.load() == 2; }), retired_.end());
+    };
     auto widen = [&](TableSel sel, int kind, int w, const void* bases, int n_groups) -> std::shared_ptr<SharedTable> {
         if (cancel_build_.load()) throw BuildCancelled{};
+        drop_abandoned(sel);
         bool created = false;
         auto t = find_or_create_table(dev_, kind, w, n_groups, &created);
         const TableView cur = table_view(sel);
@@ -1100,7 +1114,29 @@ void Engine::build_final_tables() {
         const double p0 = trace_clock_ms();
         launch::preload_code_objects();  // before the first piece is allocated: no caller's first launch of a kernel waits behind a hipMalloc
         if (getenv("ETH_KZG_AMD_TRACE")) fprintf(stderr, "[context] @%.0f ms: code objects preloaded in %.0f ms\n", trace_clock_ms(), trace_clock_ms() - p0);
-        std::lock_guard<std::mutex> lk(g_build_mu);  // one builder of wide tables at a time per process
+        // Another context of the process may be filling the wide tables right now (its helper thread holds g_build_mu until it is
+        // done): this context uses their ready groups meanwhile instead of sitting on its start tables for the other's build.
+        auto attach_growing = [&] {
+            for (TableSel sel : {TAB_SRS, TAB_FK}) {
+                const TableView cur = table_view(sel);
+                if (!cur.main || (cur.next && cur.next->state.load() == 0)) continue;
+                std::shared_ptr<SharedTable> growing;
+                if (sel == TAB_SRS) {
+                    for (int w : {13, 12, 10})
+                        if (!growing && w > cur.c) { auto t = find_table(dev_, 0, w); if (t && t->state.load() == 0) growing = t; }
+                } else if (!want_plain_c_) {
+                    for (int w : launch::GLV_WIDTHS)
+                        if (!growing && (!cur.glv || w > cur.c)) { auto t = find_table(dev_, 2, w); if (t && t->state.load() == 0) growing = t; }
+                }
+                if (growing && growing->glv == cur.main->glv && growing->n_groups == cur.main->n_groups) publish(sel, cur.main, growing);
+            }
+        };
+        std::unique_lock<std::mutex> lk(g_build_mu, std::defer_lock);  // one builder of wide tables at a time per process
+        while (!lk.try_lock()) {
+            attach_growing();
+            if (cancel_build_.load()) throw BuildCancelled{};
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
         if (cancel_build_.load()) throw BuildCancelled{};
         const double budget = table_budget_gb_ > 0 ? table_budget_gb_ * 1e9 : 1e18;
         const TableView srs_now = table_view(TAB_SRS), fk_now = table_view(TAB_FK);

@@ -180,6 +180,52 @@ def test_progressive_start_serves_at_once_and_switches_tables(oracle, monkeypatc
         c.close()
 
 
+def test_contexts_created_and_freed_while_the_tables_are_built(oracle, monkeypatch):
+    """The window tables are shared by the contexts of a process and built by whichever comes first.  (a) A second context created
+    while the first one's helper thread is still filling the wide tables uses their ready groups too, and ends on the same tables
+    without a second 206 GB.  (b) A context freed in the middle of its build abandons it within one piece; what it had built is
+    given back, and the next context builds the tables from scratch.  Bytes always equal to the oracle's."""
+    import torch
+    full._torch_first()
+    monkeypatch.delenv("ETH_KZG_AMD_PROGRESSIVE", raising=False)
+    blobs = full._random_blobs(24, 5151)
+    blobs[3] = 0
+    # (b) first: freed mid-build
+    a = kzg.DASContext(use_precomp=True, wait_tables=False)
+    st, cells0, proofs0 = full._compute_on_device(a, blobs)
+    assert st == [0] * 24
+    full._check_sample_against_oracle(oracle, blobs, cells0, proofs0, [0, 3, 23])
+    for _ in range(200):  # let the build get somewhere (some groups ready), then free the context under it
+        if a.table_groups_ready() >= 8 or a.tables_ready(0) != 0:
+            break
+        time.sleep(0.01)
+    a.close()
+    free_after_close = torch.cuda.mem_get_info()[0]
+    assert free_after_close > 200e9, f"only {free_after_close / 1e9:.0f} GB free after the context was freed mid-build"
+    # (a) two contexts, the second created while the first one builds
+    a = kzg.DASContext(use_precomp=True, wait_tables=False)
+    b = kzg.DASContext(use_precomp=True, wait_tables=False)
+    try:
+        seen_b = set()
+        while a.tables_ready(0) == 0 or b.tables_ready(0) == 0:
+            for c in (a, b):
+                st, cells, proofs = full._compute_on_device(c, blobs)
+                assert st == [0] * 24 and np.array_equal(cells, cells0) and np.array_equal(proofs, proofs0)
+            seen_b.add(b.table_groups_ready())
+            time.sleep(0.005)
+        assert a.tables_ready(-1) == 1 and b.tables_ready(-1) == 1
+        assert a.window_bits() == 16 and b.window_bits() == 16 and a.table_bytes() == b.table_bytes()
+        assert torch.cuda.mem_get_info()[0] > 20e9, "the second context allocated tables of its own"
+        for c in (a, b):
+            st, cells, proofs = full._compute_on_device(c, blobs)
+            assert np.array_equal(cells, cells0) and np.array_equal(proofs, proofs0)
+        assert any(0 < g < 128 for g in seen_b), "the second context never used the first one's growing table"
+        print(f"second context during the build: groups of the shared table it saw in use: {sorted(seen_b)[:5]} ... {sorted(seen_b)[-3:]}")
+    finally:
+        b.close()
+        a.close()
+
+
 def test_non_progressive_start_returns_on_the_final_tables(monkeypatch):
     full._torch_first()
     monkeypatch.setenv("ETH_KZG_AMD_PROGRESSIVE", "0")
