@@ -358,7 +358,7 @@ Engine::Engine(bool use_precomp, int device, const Engine* primary) : dev_(devic
         wave_slots_ = cus * 4 * 2;  // point kernels hold ~240 VGPRs: two waves per SIMD
         if (const char* s = getenv("ETH_KZG_AMD_MSM_CHUNKS")) {
             int v = atoi(s);
-            if (v == 0 || v == 1 || v == 2 || v == 4) msm_chunks_ = v;
+            if (v == 0 || v == 1 || v == 2 || v == 4 || v == 8) msm_chunks_ = v;
         }
     }
     HIPCK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
@@ -424,7 +424,7 @@ Engine::~Engine() {
         if (P.d_naf && P.owns_naf) hipFree(P.d_naf);
     }
     for (Work& w : work_) {
-        void* dev[] = {w.coeffs, w.canon, w.scalars, w.X, w.status, w.dft_tmp, w.dft_prod, w.circ_table, w.slp_arena, w.slp_sync, w.d_in, w.d_cells, w.d_proofs};
+        void* dev[] = {w.coeffs, w.canon, w.scalars, w.X, w.status, w.dft_tmp, w.dft_prod, w.circ_table, w.slp_arena, w.slp_sync, w.d_in, w.d_cells, w.d_proofs, w.msm_partial};
         for (void* p : dev)
             if (p) hipFree(p);
         void* pin[] = {w.h_in, w.h_cells, w.h_proofs, w.h_status};
@@ -1289,25 +1289,25 @@ void Engine::launch_msm(const void* scalars, TableSel which, void* out, int n_gr
 // has stored the scalars as balanced GLV halves already (only meaningful for a GLV table).  While a wider table is under
 // construction its leading ready groups run on it and the rest on the complete table: two launches, one MSM stage.
 void Engine::launch_msm(const void* scalars, const TableView& tv, bool scalars_split, void* out, int n_groups, int n_slices,
-                        int out_stride, int brp_bits, hipStream_t st) {
+                        int out_stride, int brp_bits, hipStream_t st, void* partial) {
     const SharedTable* main = tv.main.get();
     const SharedTable* next = tv.next.get();
     int ready = 0;
     if (next && next->glv == main->glv) ready = std::min(n_groups, next->ready_groups.load(std::memory_order_acquire));
     if (main->glv && !scalars_split) launch::glv_split(const_cast<void*>(scalars), (size_t)n_groups * n_slices * 64, st);  // in place: they feed nothing else
-    if (ready > 0) launch_msm_range(scalars, *next, 0, ready, out, n_groups, n_slices, out_stride, brp_bits, st);
-    if (ready < n_groups) launch_msm_range(scalars, *main, ready, n_groups - ready, out, n_groups, n_slices, out_stride, brp_bits, st);
+    if (ready > 0) launch_msm_range(scalars, *next, 0, ready, out, n_groups, n_slices, out_stride, brp_bits, st, partial);
+    if (ready < n_groups) launch_msm_range(scalars, *main, ready, n_groups - ready, out, n_groups, n_slices, out_stride, brp_bits, st, partial);
 }
 // groups [g0, g0 + gcnt) of every slice on table t
 void Engine::launch_msm_range(const void* scalars, const SharedTable& t, int g0, int gcnt, void* out, int n_groups, int n_slices,
-                              int out_stride, int brp_bits, hipStream_t st) {
+                              int out_stride, int brp_bits, hipStream_t st, void* partial) {
     const launch::TabBlocks tb{(const void* const*)t.d_blocks, g0, gcnt};
     const int c = t.c;
     const long msms = (long)gcnt * n_slices;
     if (t.glv) {
         int mode = 1;
         if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) mode = 0;
-        else if (msm_chunks_ >= 0) mode = msm_chunks_ == 0 ? 1 : msm_chunks_ == 1 ? 3 : msm_chunks_ == 2 ? 4 : 2;  // tuning knob / tests
+        else if (msm_chunks_ >= 0) mode = msm_chunks_ == 0 ? 1 : msm_chunks_ == 1 ? 3 : msm_chunks_ == 2 ? 4 : msm_chunks_ == 8 ? 5 : 2;  // tuning knob / tests
         else if ((msms * 4 + 63) / 64 >= (long)wave_slots_) {
             // The chip is full: four chunks per MSM.  Measured on one box, alternating runs (MSM stage, ms; S = lanes per MSM of
             // the lane kernels):        blobs   256   512   768   1024  1536  2048         3072
@@ -1318,7 +1318,7 @@ void Engine::launch_msm_range(const void* scalars, const SharedTable& t, int g0,
             // still lose 1-2 %: 16384 short waves dealt out as slots free up balance the SIMDs better than 4096 long ones.
             mode = 2;
         }
-        launch::msm_glv(c, mode, scalars, tb, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st);
+        launch::msm_glv(c, mode, scalars, tb, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st, partial);
         return;
     }
     if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) {
@@ -1393,7 +1393,17 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
     launch::g1_set_inf(X, (size_t)128 * bp, st);
     const bool latency_mode = bp <= LATENCY_MODE_MAX_LANES;  // few 64-blob groups: direct 8 x 16 transforms, 4 rounds instead of 14
     const int mk2 = mark_begin(ST_MSM_FIXED, st);
-    launch_msm(w.scalars, tv, tv.glv, X, 128, segs * n, bp, (latency_mode || linmap_mode) ? 0 : 7, st);
+    void* partial = nullptr;
+    if (tv.glv && msm_chunks_ == 8 && segs == 1) {  // the row-sharing schedule's chunk sums
+        const size_t need = (size_t)4 * 128 * bp * launch::SIZEOF_JACQ;
+        if (need > w.msm_partial_bytes) {
+            if (w.msm_partial) { HIPCK(hipStreamSynchronize(st)); HIPCK(hipFree(w.msm_partial)); w.msm_partial = nullptr; }
+            HIPCK(hipMalloc(&w.msm_partial, need));
+            w.msm_partial_bytes = need;
+        }
+        partial = w.msm_partial;
+    }
+    launch_msm(w.scalars, tv, tv.glv, X, 128, segs * n, bp, (latency_mode || linmap_mode) ? 0 : 7, st, partial);
     mark_end(mk2, 1, st);
     if (linmap_mode) {
         const int mk3 = mark_begin(ST_G1_LINMAP, st);

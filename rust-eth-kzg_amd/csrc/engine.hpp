@@ -74,6 +74,8 @@ struct Work {
     void *coeffs = nullptr, *canon = nullptr, *scalars = nullptr, *X = nullptr;
     int* status = nullptr;
     void *dft_tmp = nullptr, *dft_prod = nullptr, *circ_table = nullptr, *slp_arena = nullptr;
+    void* msm_partial = nullptr;  // chunk sums of the row-sharing MSM schedule: 4 x 128 x lanes JacQ
+    size_t msm_partial_bytes = 0;
     size_t slp_arena_bytes = 0;
     int* slp_sync = nullptr;  // tickets and completion counters of the linear map's ticket walker (two blocks of slp_sync_ints)
     size_t slp_sync_ints = 0;
@@ -285,9 +287,9 @@ private:
     void launch_msm(const void* scalars, TableSel table, void* out, int n_groups, int n_slices, int out_stride,
                     int brp_bits, hipStream_t st);
     void launch_msm(const void* scalars, const TableView& tv, bool scalars_split, void* out, int n_groups, int n_slices, int out_stride,
-                    int brp_bits, hipStream_t st);
+                    int brp_bits, hipStream_t st, void* partial = nullptr);
     void launch_msm_range(const void* scalars, const SharedTable& t, int g0, int gcnt, void* out, int n_groups, int n_slices, int out_stride,
-                          int brp_bits, hipStream_t st);
+                          int brp_bits, hipStream_t st, void* partial = nullptr);
     void build_final_tables();  // the wide tables: on the helper thread (progressive start) or inline
     void publish(TableSel which, const std::shared_ptr<SharedTable>& main, const std::shared_ptr<SharedTable>& next);
     void g1_ifft128_take64(void* X, int stride, hipStream_t st);

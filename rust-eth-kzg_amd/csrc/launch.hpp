@@ -56,8 +56,9 @@ constexpr int glv_lower_windows(int c) { return (glv_windows(c) + 1) / 2; }  // 
 constexpr int GLV_WIDTHS[] = {16, 15, 14, 12, 8};  // widest first: the order the engine tries them in
 bool glv_width_supported(int c);
 void glv_split(void* scalars, size_t n, hipStream_t st);
+// mode 5 (width 16): four chunks per MSM with row-sharing blocks; partial = scratch of 4 x n_groups x out_stride JacQ (null: mode 2 instead)
 void msm_glv(int c, int mode, const void* scalars, const TabBlocks& table, void* out /*JacQ*/, int n_groups, int n_slices, int nb, int out_stride,
-             int brp_bits, const Fp12w& beta, hipStream_t st);
+             int brp_bits, const Fp12w& beta, hipStream_t st, void* partial = nullptr);
 void msm_fixed_flat(int c, const void* scalars, const TabBlocks& table, void* out /*G1Jac*/, int n_groups, int n_slices, int nb,
                int out_stride, int brp_bits, hipStream_t st);
 // k_table.hip

@@ -269,6 +269,25 @@ def test_fixed_base_msm_stage_matches_oracle(oracle, monkeypatch, chunks, table)
         c2.close()
 
 
+def test_row_sharing_msm_schedule_matches_oracle(oracle, monkeypatch):
+    """ETH_KZG_AMD_MSM_CHUNKS=8: the four-chunk MSM with blocks made of four 64-blob slices of ONE (group, chunk) and the chunk sums
+    folded by a second kernel (k_msm_glv_chunk_rows + k_msm_glv_fold4) -- a measured negative of round 4 (no faster than four
+    chunks per block at 256 ... 2048 blobs: a CU's translation cache is not what the smaller batches lose), kept as a schedule: same
+    bytes at a ragged count above one quad of slices, at one lane group, and with an all-zero blob."""
+    monkeypatch.setenv("ETH_KZG_AMD_MSM_CHUNKS", "8")
+    _torch_first()
+    c2 = kzg.DASContext(use_precomp=True)
+    try:
+        for n in (70, 300):
+            blobs = _random_blobs(n, 600 + n)
+            blobs[2] = 0
+            st, cells, proofs = _compute_on_device(c2, blobs)
+            assert st == [0] * n
+            _check_sample_against_oracle(oracle, blobs, cells, proofs, [0, 2, 63, 64, n - 1])
+    finally:
+        c2.close()
+
+
 def test_ticket_walking_executor_matches_oracle(oracle, monkeypatch):
     """ETH_KZG_AMD_SLP_WALK=1: the cheap operations of the compiled linear map as one ticket-walking launch per phase (k_slp_walk:
     per-(lane group, level) completion counters, agent-scope release / acquire) instead of one launch per dependency level.
