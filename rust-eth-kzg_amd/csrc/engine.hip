@@ -442,6 +442,8 @@ Engine::~Engine() {
     for (VmSlot& v : vm_slot_) {
         if (v.dev) hipFree(v.dev);
         if (v.pin) hipHostFree(v.pin);
+        if (v.vs.dev) hipFree(v.vs.dev);
+        if (v.vs.pin) hipHostFree(v.vs.pin);
     }
     if (vd_pin_) hipHostFree(vd_pin_);
     for (hipEvent_t e : vd_events_)

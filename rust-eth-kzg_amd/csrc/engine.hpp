@@ -258,6 +258,15 @@ private:
     // dsrc (device-resident form): the cells and proofs already sit in HBM -- they are copied device to device into the arena
     // instead of being gathered on the host and uploaded; the pointer arrays then address their pinned host mirror, which the
     // transcript hash reads, and whose cells arrive in chunks (an event per chunk)
+    // where a single verification stages and computes: the engine's own stream / arena / pinned slab (under mu_), or those of a pass
+    // slot (the caller holds the slot): so that up to four single verifications run side by side, each on its own hardware queue
+    struct VerifyScratch {
+        hipStream_t stream = nullptr;
+        void* dev = nullptr;
+        size_t dev_cap = 0;
+        uint8_t* pin = nullptr;
+        size_t pin_cap = 0;
+    };
     struct VerifyDeviceSource {
         const uint8_t *d_cells, *d_proofs;  // flat [n][2048] / [n][48] in this GPU's memory
         hipEvent_t* chunk_events;           // chunk j = cells [j * chunk_cells, (j + 1) * chunk_cells) of the mirror
@@ -266,7 +275,7 @@ private:
     int verify_cells_partial(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,
                              const uint64_t* cell_indices, uint64_t n_cells, const uint8_t* const* cells, uint64_t n_proofs,
                              const uint8_t* const* proofs, uint64_t lo, uint64_t hi, G1Affine* out2, bool* empty,
-                             const VerifyDeviceSource* dsrc = nullptr);
+                             const VerifyDeviceSource* dsrc = nullptr, VerifyScratch* vs = nullptr);
     bool verify_cells_pairing(const G1Affine* pts2) const;
     int rs_decode(int R, const uint8_t* d_cells, bool flat_source, const std::vector<int>& slot, const std::vector<int>& stof,
                   const std::vector<uint32_t>& present, int* st_out);
@@ -382,6 +391,7 @@ private:
     static constexpr int VM_SLOTS = 3;
     struct VmSlot {
         std::mutex mu;
+        VerifyScratch vs;   // for a "pass" of ONE problem: the single path's arena on this slot's stream
         void* dev = nullptr;
         size_t dev_cap = 0;
         uint8_t* pin = nullptr;

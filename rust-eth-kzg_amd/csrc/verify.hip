@@ -101,7 +101,7 @@ static Fr reduce_be32(const uint8_t* b) {
 int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* commitments, uint64_t n_indices,
                                  const uint64_t* cell_indices, uint64_t n_cells, const uint8_t* const* cells,
                                  uint64_t n_proofs, const uint8_t* const* proofs, uint64_t lo, uint64_t hi,
-                                 G1Affine* out, bool* empty, const VerifyDeviceSource* dsrc) {
+                                 G1Affine* out, bool* empty, const VerifyDeviceSource* dsrc, VerifyScratch* vs) {
     *empty = false;
     out[0] = out[1] = aff_inf();
     // deduplicate_with_indices (verifier.rs:49-65): byte equality, first-occurrence order
@@ -127,7 +127,14 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
     if (lo == hi) return OK;                       // an empty shard contributes the identity twice
     const int n = (int)(hi - lo), k0 = (int)lo;    // this shard: cells k0 .. k0+n, global exponents r^(k0+k)
 
-    std::lock_guard<std::recursive_mutex> lk(mu_);
+    // the engine's own scratch under its lock, or a pass slot's (its holder called)
+    std::unique_lock<std::recursive_mutex> lk(mu_, std::defer_lock);
+    if (!vs) lk.lock();
+    void*& a_dev = vs ? vs->dev : v_dev_;
+    size_t& a_dev_cap = vs ? vs->dev_cap : v_dev_cap_;
+    uint8_t*& a_pin = vs ? vs->pin : v_pin_;
+    size_t& a_pin_cap = vs ? vs->pin_cap : v_pin_cap_;
+    const bool two_streams = v_two_streams_ && !vs;
     const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
@@ -138,7 +145,7 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
     };
     try {
         HIPCK(hipSetDevice(dev_));
-        hipStream_t st = stream_;
+        hipStream_t st = vs ? vs->stream : stream_;
         // ---- stage inputs: gather the caller's scattered buffers into ONE pinned host slab, one async copy to a
         // persistent device arena (no per-call hipMalloc)
         const size_t sz_c = (size_t)m * 48, sz_p = (size_t)n * 48, sz_cells = (size_t)n * BYTES_PER_CELL, sz_i = (size_t)n * sizeof(int);
@@ -165,20 +172,22 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
         const size_t off_ws = o; o += up(shifted ? launch::pip_shift_workspace_bytes((int)npts) : launch::pip_workspace_bytes((int)npts));
         const size_t off_coef = o; o += shifted ? up((size_t)n * CELL_LEN * sizeof(Fr)) : 0;
         const size_t off_out = o; o += 512;  // two affine points, or two Jacobian sums (shifted form)
-        if (o > v_dev_cap_) {
-            if (v_dev_) HIPCK(hipFree(v_dev_));
-            v_dev_ = nullptr;
-            HIPCK(hipMalloc(&v_dev_, o + (o >> 2)));
-            v_dev_cap_ = o + (o >> 2);
+        if (o > a_dev_cap) {
+            if (a_dev) { HIPCK(hipStreamSynchronize(st)); HIPCK(hipFree(a_dev)); }
+            a_dev = nullptr;
+            a_dev_cap = 0;
+            HIPCK(hipMalloc(&a_dev, o + (o >> 2)));
+            a_dev_cap = o + (o >> 2);
         }
-        if (pin_bytes > v_pin_cap_) {
-            if (v_pin_) HIPCK(hipHostFree(v_pin_));
-            v_pin_ = nullptr;
-            HIPCK(hipHostMalloc((void**)&v_pin_, pin_bytes + (pin_bytes >> 2), hipHostMallocDefault));
-            v_pin_cap_ = pin_bytes + (pin_bytes >> 2);
+        if (pin_bytes > a_pin_cap) {
+            if (a_pin) HIPCK(hipHostFree(a_pin));
+            a_pin = nullptr;
+            a_pin_cap = 0;
+            HIPCK(hipHostMalloc((void**)&a_pin, pin_bytes + (pin_bytes >> 2), hipHostMallocDefault));
+            a_pin_cap = pin_bytes + (pin_bytes >> 2);
         }
-        uint8_t* hb = v_pin_;
-        uint8_t* db = (uint8_t*)v_dev_;
+        uint8_t* hb = a_pin;
+        uint8_t* db = (uint8_t*)a_dev;
         uint8_t *hc = hb + off_c, *hp = hb + off_p, *hcells = hb + off_cells;
         int* hidx = (int*)(hb + off_idx);
         int* hrow = (int*)(hb + off_row);
@@ -229,7 +238,7 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
                     launch::g1_decode2((const uint8_t*)d_pb.p, d_prf_p, (int*)d_stp.p, n, (const uint8_t*)d_cb.p, d_comm_p, (int*)d_stc.p, m, beta_, st);
                     launch::copy_affine(d_srs_, d_comm_p + m, 64, st);  // vk.g1s: the first 64 SRS points (verification_key.rs:66-70)
                     launch::cells_to_fr((const uint8_t*)d_cellb.p, d_evals.p, nullptr, (int*)d_ste.p, nullptr, nullptr, n, st);
-                    if (v_two_streams_) {  // round 3's form: the subgroup tests on a second stream (ETH_KZG_AMD_VERIFY_SIDE_STREAM=1)
+                    if (two_streams) {  // round 3's form: the subgroup tests on a second stream (ETH_KZG_AMD_VERIFY_SIDE_STREAM=1)
                         HIPCK(hipEventRecord(v_decoded_, st));
                         HIPCK(hipStreamWaitEvent(v_side_, v_decoded_, 0));
                         launch::g1_subgroup2(d_prf_p, (int*)d_stp.p, n, d_comm_p, (int*)d_stc.p, m, beta_, v_side_);
@@ -240,7 +249,7 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
                                                                (int*)d_stc.p, m, beta_, st);
                     }
                     launch::interp_cells(d_evals.p, (const int*)d_idx.p, d_w8192_, inv64_, db + off_coef, n, st);
-                    if (v_two_streams_) HIPCK(hipStreamWaitEvent(st, v_checked_, 0));
+                    if (two_streams) HIPCK(hipStreamWaitEvent(st, v_checked_, 0));
                 } else {
                     launch::g1_decompress2((const uint8_t*)d_pb.p, d_prf_p, (int*)d_stp.p, n, (const uint8_t*)d_cb.p, d_comm_p, (int*)d_stc.p, m, beta_, st);
                     launch::copy_affine(d_srs_, d_comm_p + m, 64, st);  // vk.g1s: the first 64 SRS points (verification_key.rs:66-70)

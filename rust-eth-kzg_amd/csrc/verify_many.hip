@@ -540,6 +540,34 @@ int Engine::verify_cell_kzg_proof_batch_combined(uint64_t n_commitments, const u
         std::string why;
         std::vector<int> ver, st;
         try {
+          if (B == 1) {
+            // a "pass" of one problem is the single path itself -- 3.3 ms against the 3.65 of a one-problem pass (its points are
+            // shifted before the challenge; a pass multiplies by per-lane scalars after it) -- on a pass slot's stream and arena:
+            // the latency lane and three slots make four single verifications side by side, one hardware queue each
+            VmSlot* slot = nullptr;
+            std::unique_lock<std::mutex> sl;
+            for (int k = 0; k < VM_SLOTS && !slot; k++) {
+                std::unique_lock<std::mutex> t(vm_slot_[k].mu, std::try_to_lock);
+                if (t.owns_lock()) { sl = std::move(t); slot = &vm_slot_[k]; }
+            }
+            if (!slot) {
+                slot = &vm_slot_[vm_rr_.fetch_add(1) % VM_SLOTS];
+                sl = std::unique_lock<std::mutex>(slot->mu);
+            }
+            const int slot_index = (int)(slot - vm_slot_);
+            slot->vs.stream = work_[1 + slot_index % (NW - 1)].stream ? work_[1 + slot_index % (NW - 1)].stream : stream_;
+            VerifyRequest* r = batch[0];
+            G1Affine pts[2];
+            bool empty = false;
+            ver.assign(1, 0);
+            st.assign(1, (int)ERR_DEVICE);
+            HIPCK(hipSetDevice(dev_));
+            st[0] = verify_cells_partial(r->n[0], r->commitments, r->n[1], r->cell_indices, r->n[2], r->cells, r->n[3], r->proofs, 0, r->n[2], pts, &empty, nullptr, &slot->vs);
+            sl.unlock();  // the pairing needs no slot
+            rc = st[0] == ERR_DEVICE ? (int)ERR_DEVICE : (int)OK;
+            if (rc == ERR_DEVICE) why = last_error();
+            if (st[0] == OK) ver[0] = (empty || verify_cells_pairing(pts)) ? 1 : 0;
+          } else {
             std::vector<uint64_t> l0(B), l1(B), l2(B), l3(B);
             std::vector<const uint8_t* const*> pc(B), pl(B), pp(B);
             std::vector<const uint64_t*> pi(B);
@@ -552,6 +580,7 @@ int Engine::verify_cell_kzg_proof_batch_combined(uint64_t n_commitments, const u
             rc = verify_cell_kzg_proof_batch_many_host(B, l0.data(), pc.data(), l1.data(), pi.data(), l2.data(), pl.data(), l3.data(),
                                                        pp.data(), ver.data(), st.data());
             if (rc == ERR_DEVICE) why = last_error();
+          }
         } catch (const std::exception& e) {
             rc = ERR_DEVICE;
             why = std::string("combined verification pass: ") + e.what();
