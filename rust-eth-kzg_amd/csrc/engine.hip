@@ -779,6 +779,7 @@ struct Engine::SharedTable {
         bytes = 0;
         for (int b = 0; b < halves; b++) bytes += block_bytes(b) * (size_t)n_groups;
         h_blocks.assign((size_t)n_groups * halves, nullptr);
+        pieces.reserve((size_t)n_groups * halves);  // never reallocated: table_build_info reads its size from other threads while the builder appends
     }
     double alloc_ms = 0, alloc_ms_max = 0;  // time spent in hipMalloc for the pieces: total and the longest single call (trace)
     // allocate pieces until blocks [0, block_end) exist; false: out of memory (why is set) or cancelled
