@@ -1388,6 +1388,39 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         X = w.slp_arena;
     }
     const TableView tv = tv_pre ? *tv_pre : table_view(TAB_FK);  // one snapshot for the scalars' form AND the MSM that reads them
+    // EXPERIMENT (ETH_KZG_AMD_OVERLAP_HALVES=1): the lane groups in two halves, half A's linear map on the work
+    // set's second (high-priority) stream next to half B's MSM.  Measured, not adopted: see DESIGN.md section 5.
+    static const bool overlap_halves = [] { const char* e = getenv("ETH_KZG_AMD_OVERLAP_HALVES"); return e && atoi(e) != 0; }();
+    if (overlap_halves && linmap_mode && !slp_walk_ && bp >= 128 && w.copy && !profiling_ && segs == 1 && st != w.copy) {
+        const int G = bp / 64, lanesA = ((G + 1) / 2) * 64, lanesB = bp - lanesA, nA = std::min(n, lanesA), nB = n - nA;
+        const SlpProgram* pA = &slp_program(pick_slp_program(lanesA));
+        const SlpProgram* pB = nB > 0 ? &slp_program(pick_slp_program(lanesB)) : nullptr;
+        const size_t need = (size_t)std::max(pA->n_slots, pB ? pB->n_slots : 0) * bp * launch::SIZEOF_JACQ;
+        if (need > w.slp_arena_bytes) {
+            if (w.slp_arena) { HIPCK(hipStreamSynchronize(st)); HIPCK(hipStreamSynchronize(w.copy)); HIPCK(hipFree(w.slp_arena)); w.slp_arena = nullptr; }
+            HIPCK(hipMalloc(&w.slp_arena, need));
+            w.slp_arena_bytes = need;
+        }
+        char* A = (char*)w.slp_arena;
+        if (!tv_pre) launch::fk20_scalars(n, w.coeffs, w.scalars, d_w29_, half_, 1, seg_shift_, tv.glv, st);
+        launch::g1_set_inf(A, (size_t)128 * bp, st);
+        launch_msm(w.scalars, tv, tv.glv, A, 128, nA, bp, 0, st);
+        HIPCK(hipEventRecord(w.ev_coeffs, st));
+        if (nB > 0) launch_msm((char*)w.scalars + (size_t)nA * 128 * 64 * sizeof(Fr), tv, tv.glv, A + (size_t)lanesA * launch::SIZEOF_JACQ, 128, nB, bp, 0, st);
+        HIPCK(hipStreamWaitEvent(w.copy, w.ev_coeffs, 0));
+        for (auto& L : pA->launches)
+            launch::g1_slp_launch(L.kind, A, bp, (const uint32_t*)pA->d_words + (size_t)L.first * 4, L.count, pA->d_naf, beta_, w.copy, lanesA);
+        launch::g1_compress(A + (size_t)128 * bp * launch::SIZEOF_JACQ, d_proofs, 128, bp, nA, w.copy);
+        HIPCK(hipEventRecord(w.ev_side, w.copy));
+        if (nB > 0) {
+            char* AB = A + (size_t)lanesA * launch::SIZEOF_JACQ;
+            for (auto& L : pB->launches)
+                launch::g1_slp_launch(L.kind, AB, bp, (const uint32_t*)pB->d_words + (size_t)L.first * 4, L.count, pB->d_naf, beta_, st, lanesB);
+            launch::g1_compress(AB + (size_t)128 * bp * launch::SIZEOF_JACQ, d_proofs + (size_t)nA * 128 * 48, 128, bp, nB, st);
+        }
+        HIPCK(hipStreamWaitEvent(st, w.ev_side, 0));
+        return;
+    }
     if (!tv_pre) {
         const int mk1 = mark_begin(ST_FK20_SCALARS, st);
         launch::fk20_scalars(n, w.coeffs, w.scalars, d_w29_, linmap_mode ? half_ : inv128_, segs, segs == 2 ? two_segments : seg_shift_, tv.glv, st);

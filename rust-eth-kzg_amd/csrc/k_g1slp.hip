@@ -170,14 +170,15 @@ void preload_k_g1slp() {
 }
 // kind: 3 multiplication by a constant, anything else the mixed addition / subtraction / doubling launch (linmap::OpKind)
 void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int count, const void* naf, const Fp12w& beta,
-                   hipStream_t st) {
-    const dim3 grid((unsigned)count, (unsigned)(stride / 64));
+                   hipStream_t st, int lanes) {
+    if (lanes <= 0) lanes = stride;  // (a sub-range of the lanes: arena already points at its first lane, stride stays the arena's)
+    const dim3 grid((unsigned)count, (unsigned)(lanes / 64));
     if (kind == 3) {
         Fp b384;
         for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
         k_slp_mulc<<<grid, 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fq_from_fp(b384));
     } else {
-        k_slp_add<<<dim3((unsigned)(stride / 64), (unsigned)count), 64, 0, st>>>((JacQ*)arena, stride, words);
+        k_slp_add<<<dim3((unsigned)(lanes / 64), (unsigned)count), 64, 0, st>>>((JacQ*)arena, stride, words);
     }
 }
 size_t g1_slp_walk_sync_ints(int n_groups, int n_levels) { return 32 * 8 + 16 * (size_t)n_groups * n_levels + 32; }
