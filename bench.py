@@ -735,6 +735,45 @@ def _launcher_selftest(args):
         dist.destroy_process_group()
     if os.environ.get("KZG_BENCH_SELFTEST_FAIL_RANK") == str(rank):  # the test of the failure path
         sys.exit(7)
+    watchdog = None
+    if world > 1 and "KZG_BENCH_SELFTEST_HANG_RANK" in os.environ:
+        # the test of the communicator-init watchdog, through the code bench.py itself runs (sharding.attach_library_comm): a
+        # stand-in context whose comm_init never comes back on one rank -- every rank must be told so, none may wait for it
+        sharding = importlib.import_module("rust-eth-kzg_amd.sharding")
+        hang = int(os.environ["KZG_BENCH_SELFTEST_HANG_RANK"])
+
+        class _StuckComm:
+            destroyed = False
+
+            def comm_probe(self):
+                return "librccl (stand-in)"
+
+            def comm_unique_id(self):
+                return bytes(128)
+
+            def comm_init(self, uid, r, w):
+                if r == hang:
+                    time.sleep(3600)
+
+            def comm_info(self):
+                return rank, world
+
+            def comm_destroy(self):
+                self.destroyed = True
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        fake = _StuckComm()
+        t0 = time.perf_counter()
+        ok = sharding.attach_library_comm(fake, dist)
+        mine = {"rank": rank, "attached": ok, "stuck": bool(sharding.attach_library_comm.stuck), "waited_s": round(time.perf_counter() - t0, 2),
+                "error": sharding.attach_library_comm.last_error, "destroyed": fake.destroyed}
+        watchdog = [None] * world
+        dist.all_gather_object(watchdog, mine)
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launcher_selftest": True, "n_gpus": world, "gpus_arg": args.gpus, "ranks": ranks, "watchdog": watchdog}), flush=True)
+        sys.stdout.flush()
+        os._exit(0)  # (the rank with the sleeping thread could not leave otherwise: what bench.py does after a real watchdog event)
     if rank == 0:
         print(json.dumps({"launcher_selftest": True, "n_gpus": world, "gpus_arg": args.gpus, "ranks": ranks}), flush=True)
 

@@ -45,6 +45,23 @@ def test_a_failing_rank_fails_the_launcher():
 
 
 @pytest.mark.timeout(300)
+def test_a_rank_stuck_in_the_communicator_init_is_timed_out_on_every_rank():
+    """ncclCommInitRank is a collective and has never run at world > 1 here.  If one rank never returns from it,
+    the watchdog of sharding.attach_library_comm (the code bench.py runs) gives every rank the same verdict after the timeout -- the
+    library communicator is unusable, go on over torch's -- with the reason; nobody waits for the sleeper, nothing is re-executed,
+    and the launcher still relays exactly one record and exits 0."""
+    r = _run(["--gpus", "2", "--launcher-selftest"], env={"KZG_BENCH_SELFTEST_HANG_RANK": "1", "KZG_COMM_INIT_TIMEOUT_S": "2"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    wd = sorted(json.loads(lines[0])["watchdog"], key=lambda x: x["rank"])
+    assert [w["attached"] for w in wd] == [False, False]
+    assert [w["stuck"] for w in wd] == [False, True] and all("did not return within 2 s" in w["error"] for w in wd)
+    assert all(w["waited_s"] < 30 for w in wd)  # (bounded by the timeout, not by the sleeper's hour)
+    assert wd[0]["destroyed"] and not wd[1]["destroyed"]  # a communicator another thread is still building is left alone
+
+
+@pytest.mark.timeout(300)
 def test_external_launcher_environment_is_respected_and_checked():
     # under torchrun the environment is already there: no second level of children
     r = _run(["--gpus", "1", "--launcher-selftest"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
