@@ -192,6 +192,9 @@ CResult eth_kzg_amd_verify_cell_kzg_proof_batch_many(const DASContext *ctx, uint
  *   status         n ints in HOST memory, or NULL: then nothing is copied back and, if
  *                  `hip_stream` is non-NULL, the call returns without synchronising (work is
  *                  enqueued on that hipStream_t; NULL = the context's own stream, synchronised).
+ * Inputs produced by work the caller has queued on `hip_stream` are waited for on the device; with NULL that is the
+ * work queued so far on the DEFAULT stream (the library's own streams are non-blocking streams: without this a kernel
+ * of the caller's default stream that writes d_blobs could still be running when the call reads them).
  * Calls on one stream are ordered.  The context owns a few sets of intermediate buffers; a call takes a free one and
  * makes its stream wait for the previous user of that set, so asynchronous calls on different streams are safe too
  * (they overlap while sets are free, otherwise they queue). */
@@ -202,9 +205,9 @@ CResult eth_kzg_amd_blob_to_kzg_commitment_device(const DASContext *ctx, uint64_
                                                   uint8_t *d_out, int32_t *status, void *hip_stream);
 
 /* verify_cell_kzg_proof_batch on flat arrays in this GPU's HBM: n * 48 commitment bytes (one per cell, NOT deduplicated, as in
- * the host form), n indices, n * 2048 cell bytes, n * 48 proof bytes.  The transcript hash runs on a host core, so the call
- * copies the bytes down once and is synchronous; work already queued on `hip_stream` (NULL: the context's stream) that
- * produces the inputs is waited for.  Result and error behaviour as eth_kzg_verify_cell_kzg_proof_batch. */
+ * the host form), n indices, n * 2048 cell bytes, n * 48 proof bytes.  The GPU's part reads cells and proofs where they are;
+ * the transcript hash runs on a host core, so its bytes come down (in chunks, under the hash) and the call is synchronous;
+ * work already queued on `hip_stream` (NULL: the default stream) that produces the inputs is waited for.  Result and error behaviour as eth_kzg_verify_cell_kzg_proof_batch. */
 CResult eth_kzg_amd_verify_cell_kzg_proof_batch_device(const DASContext *ctx, uint64_t n, const uint8_t *d_commitments,
                                                        const uint64_t *d_cell_indices, const uint8_t *d_cells,
                                                        const uint8_t *d_proofs, bool *verified, void *hip_stream);

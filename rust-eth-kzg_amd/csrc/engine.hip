@@ -416,6 +416,7 @@ Engine::~Engine() {
     if (build_stream_) hipStreamDestroy(build_stream_);
     host_pool_.reset();  // joins the helper threads before anything they might touch goes away
     vm_pool_.reset();
+    stage_pool_.reset();
     void* ptrs[] = {d_w8192_, d_w29_, d_naf_, d_srs_, d_fk_bases_, d_in_, d_cells_, d_proofs_, d_coset_, d_coset_inv_, d_circ_terms_, d_slp_levels_};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -1560,7 +1561,11 @@ int Engine::compute_cells_and_kzg_proofs_device(int n, const uint8_t* d_blobs, u
         HIPCK(hipSetDevice(dev_));
         Work& w = lease_work(1, NW - 1);
         held = &w;
-        if (!st) st = w.stream;
+        if (!st) {  // NULL: the library's stream, ordered behind whatever the caller has queued on the default stream so far
+            st = w.stream;
+            HIPCK(hipEventRecord(w.ev_in, nullptr));
+            HIPCK(hipStreamWaitEvent(st, w.ev_in, 0));
+        }
         enqueue_compute(w, n, d_blobs, d_cells, d_proofs, st, nullptr);
         if (h_status) HIPCK(hipMemcpyAsync(h_status, w.status, n * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCK(hipEventRecord(w.done, st));
@@ -1582,7 +1587,11 @@ int Engine::blob_to_kzg_commitment_device(int n, const uint8_t* d_blobs, uint8_t
     std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         HIPCK(hipSetDevice(dev_));
-        if (!st) st = stream_;
+        if (!st) {  // NULL: the library's stream, ordered behind whatever the caller has queued on the default stream so far
+            st = stream_;
+            HIPCK(hipEventRecord(work_[0].ev_in, nullptr));
+            HIPCK(hipStreamWaitEvent(st, work_[0].ev_in, 0));
+        }
         ensure_workspace(n);
         HIPCK(hipStreamWaitEvent(st, work_[0].done, 0));  // an earlier asynchronous call on another stream may still use the workspace
         const int bp = ((n + 63) / 64) * 64;

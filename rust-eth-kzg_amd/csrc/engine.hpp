@@ -398,6 +398,8 @@ private:
         size_t pin_cap = 0;
     };
     VmSlot vm_slot_[VM_SLOTS];
+    std::unique_ptr<HostPool> stage_pool_;  // staging of single verifications (a few threads: the lane + the pass slots run side by side)
+    std::once_flag stage_pool_once_;
     std::unique_ptr<HostPool> vm_pool_;  // the host threads of the many-verification passes (hashes, staging, pairing checks)
     std::once_flag vm_pool_once_;
     std::atomic<unsigned> vm_rr_{0};

@@ -7,6 +7,8 @@
 // Work split: all G1 / Fr batch arithmetic on the GPU; the sequential SHA-256 transcript and the
 // constant-size 2-pairing check on the host.
 #include "engine.hpp"
+#include <condition_variable>
+#include <mutex>
 #include "curve29.hpp"
 #include "host_pairing.hpp"
 #include "launch.hpp"
@@ -203,7 +205,16 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
         // ---- staging, upload and deserialisation run on a helper thread while this one hashes the transcript straight from
         // the caller's buffers (the hash is the longest sequential piece of a verification)
         std::exception_ptr stage_error;
-        std::thread stager([&]() {
+        // (a worker of the engine's small persistent pool: starting and joining a fresh thread per call was 50-100 us of a 3.3 ms call)
+        std::call_once(stage_pool_once_, [this] { stage_pool_.reset(new HostPool(primary_ ? 1 : 4, dev_)); });
+        struct StageDone {
+            std::mutex mu;
+            std::condition_variable cv;
+            bool done = false;
+            void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return done; }); }
+        } staged;
+        stage_pool_->submit([&]() {
+            struct Signal { StageDone& s; ~Signal() { std::lock_guard<std::mutex> lk(s.mu); s.done = true; s.cv.notify_all(); } } signal{staged};
             try {
                 HIPCK(hipSetDevice(dev_));
                 for (int i = 0; i < m; i++) memcpy(hc + (size_t)i * 48, uniq[i], 48);
@@ -263,7 +274,7 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
                 stage_error = std::current_exception();
             }
         });
-        struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{stager};
+        struct Joiner { StageDone& s; ~Joiner() { s.wait(); } } joiner{staged};  // whatever happens below, the task has left this frame first
         // ---- Fiat-Shamir challenge on the host while the GPU decompresses (verifier.rs:269-328).
         // Valid inputs are canonical encodings, so the transcript is the input bytes themselves.
         Sha256 sh;
@@ -286,7 +297,7 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
         sh.finish(dig);
         Fr r = reduce_be32(dig);
         lap("sha256 transcript (host)");
-        stager.join();
+        staged.wait();
         if (stage_error) std::rethrow_exception(stage_error);
         SYNC_CHECKED(st);
         lap("wait decompress/deserialise");
@@ -371,7 +382,7 @@ int Engine::verify_cell_kzg_proof_batch_device(uint64_t n, const uint8_t* d_comm
         uint8_t* pin = vd_pin_;
         uint8_t *pin_c = pin, *pin_i = pin + sz_c, *pin_p = pin + sz_c + sz_i, *pin_l = pin + sz_c + sz_i + sz_p;
         hipStream_t st = stream_;
-        if (user_stream && user_stream != st) {  // what the caller has queued on its stream produces the inputs
+        if (user_stream != st) {  // what the caller has queued on its stream (NULL: the default stream) produces the inputs
             HIPCK(hipEventRecord(v_decoded_, user_stream));
             HIPCK(hipStreamWaitEvent(st, v_decoded_, 0));
         }
@@ -541,7 +552,7 @@ int Engine::recover_cells_and_kzg_proofs_device(int R, const uint8_t* d_cells, c
     try {
         HIPCK(hipSetDevice(dev_));
         ensure_workspace(R);  // also orders stream_ behind the previous asynchronous call that used the workspace
-        if (user_stream) {    // the decode runs on the library's stream: it must see what the caller's stream wrote into d_cells
+        {   // the decode runs on the library's stream: it must see what the caller's stream (NULL: the default stream) wrote into d_cells
             HIPCK(hipEventRecord(work_[0].ev_in, user_stream));
             HIPCK(hipStreamWaitEvent(stream_, work_[0].ev_in, 0));
         }
