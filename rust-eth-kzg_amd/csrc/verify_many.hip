@@ -126,6 +126,43 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
     const int B = (int)n_batches;
     for (int b = 0; b < B; b++) { verified[b] = 0; status[b] = OK; }
     if (B == 0) return OK;
+    // A LARGE call is cut into parts that run as passes of their own on different pass slots at the same time: while one part's
+    // products are on the GPU the next one's 100+ MB are still being staged and hashed by the host threads (in one pass the
+    // staging of all 275 MB of a 1024-problem call came first, ~10 ms, and the GPU waited for it).  Each part folds its own
+    // pairing check.  $ETH_KZG_AMD_VM_PARTS (default 3, 1 = one pass as in round 3).
+    static thread_local bool in_part = false;
+    static const int max_parts = [] { const char* e = getenv("ETH_KZG_AMD_VM_PARTS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : v > VM_SLOTS ? (int)VM_SLOTS : v; }();
+    if (!in_part && max_parts > 1 && B >= 192) {
+        uint64_t total_cells = 0;
+        for (int b = 0; b < B; b++) total_cells += n_cells[b];
+        if (total_cells >= 24576) {
+            const int parts = max_parts;
+            std::vector<int> cut{0};
+            uint64_t acc = 0;
+            for (int b = 0; b < B; b++) {  // equal shares of the cells
+                acc += n_cells[b];
+                if ((int)cut.size() < parts && acc * parts >= total_cells * cut.size() && b + 1 < B) cut.push_back(b + 1);
+            }
+            cut.push_back(B);
+            std::vector<int> rcs(cut.size() - 1, OK);
+            std::vector<std::string> errs(cut.size() - 1);
+            auto run_part = [&](int p) {
+                const int lo = cut[p], n = cut[p + 1] - lo;
+                in_part = true;
+                rcs[p] = verify_cell_kzg_proof_batch_many_host((uint64_t)n, n_commitments + lo, commitments + lo, n_indices + lo, cell_indices + lo, n_cells + lo,
+                                                               cells + lo, n_proofs + lo, proofs + lo, verified + lo, status + lo);
+                if (rcs[p] == ERR_DEVICE) errs[p] = last_error();
+                in_part = false;
+            };
+            std::vector<std::thread> th;
+            for (int p = 1; p + 1 < (int)cut.size(); p++) th.emplace_back(run_part, p);
+            run_part(0);
+            for (auto& t : th) t.join();
+            for (size_t p = 0; p < rcs.size(); p++)
+                if (rcs[p] != OK) { set_error(std::runtime_error(errs[p])); return rcs[p]; }
+            return OK;
+        }
+    }
     const int T = host_threads();
     std::call_once(vm_pool_once_, [&] { vm_pool_.reset(new HostPool(T > 1 ? T - 1 : 1, dev_)); });
     HostPool* pool = vm_pool_.get();

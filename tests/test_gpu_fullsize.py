@@ -494,6 +494,34 @@ def test_degenerate_blobs_inside_a_batch_that_fills_the_chip(ctx, oracle):
         assert np.array_equal(proofs[b], inf)
 
 
+def test_a_large_many_verification_call_split_over_the_pass_slots(ctx):
+    """A call of 256 problems x 128 cells is cut into three parts that run as passes of their own on the three pass slots at once
+    (verify_many.hip: staging and hashing of one part under the GPU work of another).  Wrong proofs on both sides of the cuts,
+    a malformed problem and an empty one: verdicts and statuses per problem as if nothing had been cut."""
+    nb = 8
+    blobs = _random_blobs(nb, 8181)
+    st, cells, proofs = _compute_on_device(ctx, blobs)
+    _, comms = ctx.blob_to_kzg_commitment_batch([blobs[b].tobytes() for b in range(nb)])
+    cl = [[cells[b][k * 2048:(k + 1) * 2048].tobytes() for k in range(128)] for b in range(nb)]
+    pl = [[proofs[b][k * 48:(k + 1) * 48].tobytes() for k in range(128)] for b in range(nb)]
+    wrong = {0, 84, 85, 86, 169, 170, 171, 255}
+    probs = []
+    for j in range(256):
+        b = j % nb
+        P = list(pl[b])
+        if j in wrong:
+            P[j % 128] = pl[(b + 1) % nb][j % 128]
+        I = list(range(128))
+        if j == 100:
+            I[5] = 128
+        probs.append(([comms[b]] * 128, I, cl[b], P) if j != 200 else ([], [], [], []))
+    ver, stt = ctx.verify_cell_kzg_proof_batch_many(probs)
+    assert stt == [3 if j == 100 else 0 for j in range(256)]
+    assert ver == [False if j == 100 else j not in wrong for j in range(256)]
+    good = [p for j, p in enumerate(probs) if j not in wrong and j != 100]
+    assert ctx.verify_cell_kzg_proof_batch_many(good) == ([True] * len(good), [0] * len(good))
+
+
 def test_verify_device_resident_matches_the_host_form(ctx, oracle):
     """eth_kzg_amd_verify_cell_kzg_proof_batch_device on the prover's own device buffers (config 3 at full size: cells
     and proofs never leave HBM before the call): true; a flipped proof byte pair, a swapped cell, a wrong commitment:
