@@ -437,7 +437,7 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
                                            "with_one_invalid_proof_ms": round(_median(tb) * 1e3, 2), "with_one_invalid_proof_verifications_per_s": round(1024 / _median(tb)),
                                            "with_eight_invalid_proofs_ms": round(_median(tb8) * 1e3, 2), "with_eight_invalid_proofs_verifications_per_s": round(1024 / _median(tb8)),
                                            "entry": "eth_kzg_amd_verify_cell_kzg_proof_batch_many (host pointers: 275 MB of input per call, staging and 1024 transcript hashes on the "
-                                                    "host threads included; all problems valid: ONE folded pairing check per pass; with invalid proofs in the call: "
+                                                    "host threads included; a call this large runs as three concurrent parts on the pass slots; all problems valid: ONE folded pairing check per part; with invalid proofs in the call: "
                                                     "the wrong problems are searched by folding sub-ranges of the resident weighted sums, one pairing per probe "
                                                     "on the host threads; verdicts checked)"}
     _mark("side configs: single verifications from many threads")
