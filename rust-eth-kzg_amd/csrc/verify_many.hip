@@ -4,14 +4,18 @@
 // its throughput by verifying from many threads on one context (bindings/node/src/lib.rs:92-299,
 // crates/cryptography/bls12_381/src/lib.rs:45-50).  Here the problems of a call share every GPU launch:
 //   host threads : validation + de-duplication per problem, staging into one pinned slab, one SHA-256 transcript per problem
-//                  (in parallel, behind the GPU's decoding), then ONE 2-pairing check per pass: the problems' two G1 sums are
-//                  folded on the GPU with 127-bit weights derived from all the challenges; a pass whose folded check fails
-//                  (some proof is wrong) is re-checked problem by problem, in parallel ($ETH_KZG_AMD_VM_FOLD=0: always so)
+//                  (in parallel, behind the GPU's decoding; a persistent pool), then ONE 2-pairing check per pass: the problems' two
+//                  G1 sums are folded on the GPU with 127-bit weights derived from all the challenges; in a pass whose folded check
+//                  fails (some proof is wrong) the wrong problems are SEARCHED by folding sub-ranges of the resident weighted sums,
+//                  one pairing per probe ($ETH_KZG_AMD_VM_SEARCH=0: re-checked one by one; $ETH_KZG_AMD_VM_FOLD=0: never folded)
 //   GPU          : decode + subgroup-check all points, decode all cells, per-cell interpolation (challenge-free: behind the
 //                  hashes), then per-problem scalars / weights / interpolation sums, ONE LANE PER SCALAR MULTIPLICATION
-//                  (k_verify_many.hip), the 64-term interpolation commitments from the commitment window table, per-problem sums
-// The path owns its stream, device arena and pinned slab (vm_mu_): it does not take the context's big lock, so it runs next
-// to prover, recovery and single verification calls.
+//                  (k_verify_many.hip), the 64-term interpolation commitments from the commitment window table, per-problem sums;
+//                  small passes (concurrent single calls combined) take a short-chain form: everything after the challenge in
+//                  one launch, no fold
+// Three pass slots, each with its own lock, device arena and pinned slab, on the streams of the prover's three work sets (HIP maps
+// a process's streams onto four hardware queues): passes run side by side, a large call is cut into three concurrent parts, and a
+// "pass" of one problem is the single path on the slot.  Nothing here takes the context's big lock.
 #include "engine.hpp"
 #include "curve29.hpp"
 #include "host_pairing.hpp"
