@@ -390,6 +390,7 @@ Engine::Engine(bool use_precomp, int device, const Engine* primary) : dev_(devic
         HIPCK(hipStreamCreateWithPriority(&w.copy, hipStreamNonBlocking, prio_high));
     }
     launch::init_attributes();
+    if (!primary_) settle_streams();
     lap("HIP runtime + stream");
     init_constants();
     lap("twiddles, recodings");
@@ -400,6 +401,56 @@ Engine::Engine(bool use_precomp, int device, const Engine* primary) : dev_(devic
     init_verifier();
     HIPCK(hipStreamSynchronize(stream_));
     lap("verifier (G2 lines, cosets)");
+}
+
+// ROCm maps a process's streams onto four hardware queues per priority level, and which streams end up sharing a queue depends
+// on what the host application created before this context (a PyTorch process holds queues of its own).  Two streams on one
+// queue run in order: the four concurrent single verifications of a multi-threaded caller (the lane on stream_, the pass slots
+// on the work sets' streams) then take turns.  So the mapping is measured, not assumed: a one-wave kernel that stays resident
+// for 0.3 ms is put on two streams at once, and if the pair takes twice that, the second stream is replaced by a fresh one
+// (the rejected ones are kept until the end, so that the runtime's least-used-queue rule moves on).  The test errs to one side
+// only -- a busy GPU can make an overlapping pair look serial, never the reverse -- and the whole probe takes a few ms.
+void Engine::settle_streams() {
+    if (const char* s = getenv("ETH_KZG_AMD_SETTLE_STREAMS"))
+        if (atoi(s) == 0) return;
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev_) != hipSuccess || khz <= 0) khz = 100000;
+    const double spin_us = 300.0;
+    const uint64_t ticks = (uint64_t)(spin_us * 1e-3 * khz);
+    const bool trace = getenv("ETH_KZG_AMD_TRACE_STREAMS") != nullptr;
+    auto overlap = [&](hipStream_t a, hipStream_t b) {
+        for (int t = 0; t < 3; t++) {
+            HIPCK(hipStreamSynchronize(a));
+            HIPCK(hipStreamSynchronize(b));
+            const auto t0 = std::chrono::steady_clock::now();
+            launch::spin(ticks, a);
+            launch::spin(ticks, b);
+            HIPCK(hipStreamSynchronize(a));
+            HIPCK(hipStreamSynchronize(b));
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            if (us < 1.6 * spin_us) return true;
+        }
+        return false;
+    };
+    launch::spin(1, stream_);  // first launch of the kernel (and first use of the stream) outside the measurement
+    std::vector<hipStream_t> chosen{stream_}, rejected;
+    for (int i = 1; i < NW; i++) {
+        Work& w = work_[i];
+        if (!w.stream) continue;
+        for (int attempt = 0;; attempt++) {
+            launch::spin(1, w.stream);
+            bool ok = true;
+            for (hipStream_t c : chosen) ok = ok && overlap(c, w.stream);
+            if (ok || attempt == 5) {
+                if (trace) fprintf(stderr, "[eth_kzg_amd] work set %d: stream %s after %d replacement(s)\n", i, ok ? "runs beside the others" : "still shares a queue", attempt);
+                break;
+            }
+            rejected.push_back(w.stream);
+            HIPCK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+        }
+        chosen.push_back(w.stream);
+    }
+    for (hipStream_t r : rejected) hipStreamDestroy(r);
 }
 
 Engine::~Engine() {

@@ -250,6 +250,7 @@ private:
     void init_constants();
     void init_linmap(const Fr8* w8192_mont);  // host copy of omega_8192^k
     void init_srs();
+    void settle_streams();
     void init_fk20();
     void init_verifier();
     int open_blobs_at(int n, const uint8_t* const* blobs, const Fr8* z_mont, bool want_proofs, uint8_t* h_proofs, Fr8* h_y_canon,

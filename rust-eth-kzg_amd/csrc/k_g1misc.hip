@@ -219,7 +219,14 @@ __global__ void k_test_recompress(const G1Affine* in, uint8_t* out, int n) {
     for (int k = 0; k < 48; k++) out[(size_t)i * 48 + k] = buf[k];
 }
 
+// One wave that stays resident for a fixed wall-clock time: the engine's probe of which streams share a hardware queue.
+__global__ void k_spin(uint64_t ticks) {
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
 namespace launch {
+void spin(uint64_t ticks, hipStream_t st) { k_spin<<<1, 64, 0, st>>>(ticks); }
 // the code object of this translation unit is loaded now (HIP loads a code object on the first launch of one of its kernels, and
 // that load is an allocation: it would wait behind a table piece the builder thread is allocating)
 void preload_k_g1misc() {

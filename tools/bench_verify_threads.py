@@ -21,13 +21,21 @@ def main():
     blobs = rng.randint(0, 256, size=(nb, 4096, 32), dtype=np.uint8)
     blobs[:, :, 0] &= 0x3F
     blobs = [blobs[i].tobytes() for i in range(nb)]
+    if os.environ.get("BVT_TORCH"):  # the same inside a torch process (bench.py is one): torch's streams take hardware queues too
+        import torch
+        torch.cuda.init()
+        keep = (torch.zeros(1 << 20, device="cuda"), torch.cuda.Stream())
     ctx = kzg.DASContext(True)
     st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs)
     _, comms = ctx.blob_to_kzg_commitment_batch(blobs)
     runs = [ctx.prepare_verify_cell_kzg_proof_batch([comms[b]] * 128, list(range(128)), cells[b], proofs[b]) for b in range(nb)]
     for r in runs:
         assert r() is True
-    for n_thr in (1, 2, 4, 8, 16, 32):
+    if os.environ.get("BVT_MANY"):  # a large many-verification call first (bench.py's order): the pass slots get their big arenas
+        many = [([comms[b % nb]] * 128, list(range(128)), cells[b % nb], proofs[b % nb]) for b in range(1024)]
+        ver, stt = ctx.verify_cell_kzg_proof_batch_many(many)
+        assert all(ver)
+    for n_thr in (int(x) for x in os.environ.get("BVT_THREADS", "1,2,4,8,16,32").split(",")):
         def hammer(r):
             for _ in range(reps):
                 assert r()
