@@ -410,28 +410,28 @@ Engine::Engine(bool use_precomp, int device, const Engine* primary) : dev_(devic
 // for 0.3 ms is put on two streams at once, and if the pair takes twice that, the second stream is replaced by a fresh one
 // (the rejected ones are kept until the end, so that the runtime's least-used-queue rule moves on).  The test errs to one side
 // only -- a busy GPU can make an overlapping pair look serial, never the reverse -- and the whole probe takes a few ms.
-void Engine::settle_streams() {
-    if (const char* s = getenv("ETH_KZG_AMD_SETTLE_STREAMS"))
-        if (atoi(s) == 0) return;
+bool Engine::streams_overlap(hipStream_t a, hipStream_t b) {
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev_) != hipSuccess || khz <= 0) khz = 100000;
     const double spin_us = 300.0;
     const uint64_t ticks = (uint64_t)(spin_us * 1e-3 * khz);
+    for (int t = 0; t < 3; t++) {
+        HIPCK(hipStreamSynchronize(a));
+        HIPCK(hipStreamSynchronize(b));
+        const auto t0 = std::chrono::steady_clock::now();
+        launch::spin(ticks, a);
+        launch::spin(ticks, b);
+        HIPCK(hipStreamSynchronize(a));
+        HIPCK(hipStreamSynchronize(b));
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (us < 1.6 * spin_us) return true;
+    }
+    return false;
+}
+void Engine::settle_streams() {
+    if (const char* s = getenv("ETH_KZG_AMD_SETTLE_STREAMS"))
+        if (atoi(s) == 0) return;
     const bool trace = getenv("ETH_KZG_AMD_TRACE_STREAMS") != nullptr;
-    auto overlap = [&](hipStream_t a, hipStream_t b) {
-        for (int t = 0; t < 3; t++) {
-            HIPCK(hipStreamSynchronize(a));
-            HIPCK(hipStreamSynchronize(b));
-            const auto t0 = std::chrono::steady_clock::now();
-            launch::spin(ticks, a);
-            launch::spin(ticks, b);
-            HIPCK(hipStreamSynchronize(a));
-            HIPCK(hipStreamSynchronize(b));
-            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-            if (us < 1.6 * spin_us) return true;
-        }
-        return false;
-    };
     launch::spin(1, stream_);  // first launch of the kernel (and first use of the stream) outside the measurement
     std::vector<hipStream_t> chosen{stream_}, rejected;
     for (int i = 1; i < NW; i++) {
@@ -440,7 +440,7 @@ void Engine::settle_streams() {
         for (int attempt = 0;; attempt++) {
             launch::spin(1, w.stream);
             bool ok = true;
-            for (hipStream_t c : chosen) ok = ok && overlap(c, w.stream);
+            for (hipStream_t c : chosen) ok = ok && streams_overlap(c, w.stream);
             if (ok || attempt == 5) {
                 if (trace) fprintf(stderr, "[eth_kzg_amd] work set %d: stream %s after %d replacement(s)\n", i, ok ? "runs beside the others" : "still shares a queue", attempt);
                 break;
@@ -1418,7 +1418,7 @@ void Engine::g1_fft128_full(void* X, int stride, int inverse, hipStream_t st) {
 // stages C..G of SURVEY 3.2 from coefficients already in w.coeffs
 // tv_pre: the scalars of all n blobs are in w.scalars already, computed in the form of THIS view (the host-pointer path does it
 // sub-batch by sub-batch under the uploads)
-void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream_t st, const TableView* tv_pre) {
+void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream_t st, const TableView* tv_pre, ProofsPhase phase, int msm_cut) {
     const int bp = ((n + 63) / 64) * 64;
     // one or two blobs: the MSM also delivers 2^32 u, 2^64 u, 2^96 u (scaled copies of the scalars, same tables), which
     // cuts the doubling chain of the circulant form into four parallel quarters (needs 32 * 4 >= T - 1 doublings)
@@ -1443,7 +1443,7 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
     // EXPERIMENT (ETH_KZG_AMD_OVERLAP_HALVES=1): the lane groups in two halves, half A's linear map on the work
     // set's second (high-priority) stream next to half B's MSM.  Measured, not adopted: see DESIGN.md section 5.
     static const bool overlap_halves = [] { const char* e = getenv("ETH_KZG_AMD_OVERLAP_HALVES"); return e && atoi(e) != 0; }();
-    if (overlap_halves && linmap_mode && !slp_walk_ && bp >= 128 && w.copy && !profiling_ && segs == 1 && st != w.copy) {
+    if (overlap_halves && phase == PROOFS_ALL && linmap_mode && !slp_walk_ && bp >= 128 && w.copy && !profiling_ && segs == 1 && st != w.copy) {
         const int G = bp / 64, lanesA = ((G + 1) / 2) * 64, lanesB = bp - lanesA, nA = std::min(n, lanesA), nB = n - nA;
         const SlpProgram* pA = &slp_program(pick_slp_program(lanesA));
         const SlpProgram* pB = nB > 0 ? &slp_program(pick_slp_program(lanesB)) : nullptr;
@@ -1478,7 +1478,20 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         launch::fk20_scalars(n, w.coeffs, w.scalars, d_w29_, linmap_mode ? half_ : inv128_, segs, segs == 2 ? two_segments : seg_shift_, tv.glv, st);
         mark_end(mk1, 1, st);
     }
-    launch::g1_set_inf(X, (size_t)128 * bp, st);
+    if (phase != PROOFS_ALL) {
+        // Two MSM launches around a cut (a multiple of 64 blobs): the head is issued while the rest of the batch is still on the
+        // link.  The scalars are blob-major, the outputs lane-major with stride bp: a sub-range is a pointer offset on both.
+        if (!tv_pre || !linmap_mode || segs != 1 || msm_cut <= 0 || msm_cut >= n || msm_cut % 64) throw std::logic_error("run_proofs_from_coeffs: bad MSM cut");
+        // (the head on a stream of its own, next to the later sub-batches' light stages and joined before the linear map, was
+        // measured too: no gain, profiles/r4_early_msm_ab.log)
+        if (phase == PROOFS_HEAD) {
+            launch::g1_set_inf(X, (size_t)128 * bp, st);
+            launch_msm(w.scalars, tv, tv.glv, X, 128, msm_cut, bp, 0, st);
+            return;
+        }
+        launch_msm((char*)w.scalars + (size_t)msm_cut * 128 * 64 * sizeof(Fr), tv, tv.glv, (char*)X + (size_t)msm_cut * launch::SIZEOF_JACQ, 128, n - msm_cut, bp, 0, st);
+    }
+    if (phase == PROOFS_ALL) launch::g1_set_inf(X, (size_t)128 * bp, st);
     const bool latency_mode = bp <= LATENCY_MODE_MAX_LANES;  // few 64-blob groups: direct 8 x 16 transforms, 4 rounds instead of 14
     const int mk2 = mark_begin(ST_MSM_FIXED, st);
     void* partial = nullptr;
@@ -1491,7 +1504,7 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         }
         partial = w.msm_partial;
     }
-    launch_msm(w.scalars, tv, tv.glv, X, 128, segs * n, bp, (latency_mode || linmap_mode) ? 0 : 7, st, partial);
+    if (phase == PROOFS_ALL) launch_msm(w.scalars, tv, tv.glv, X, 128, segs * n, bp, (latency_mode || linmap_mode) ? 0 : 7, st, partial);
     mark_end(mk2, 1, st);
     if (linmap_mode) {
         const int mk3 = mark_begin(ST_G1_LINMAP, st);
@@ -1726,6 +1739,7 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
             // the call instead of 0.6 ms (the gather of 256 blobs)
             std::vector<int> cut{0};
             if (ns > SUB) cut.push_back(SUB / 4);
+            if (ns > SUB) cut.push_back(SUB);
             while (cut.back() < ns) cut.push_back(std::min(ns, cut.back() + SUB));
             const int n_sub = (int)cut.size() - 1;
             ensure_workspace(w, ns);
@@ -1790,6 +1804,15 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
             // (0.77 ms per 2048 blobs that used to sit between the last upload and the MSMs)
             const bool early_scalars = proofs && use_linmap_ && ns > circ_max_;
             const TableView tv_call = table_view(TAB_FK);
+            // A batch of several rounds of the chip: the MSMs of the first 256 blobs are launched as soon as THEIR scalars exist,
+            // 0.7 ms into the call, and run while the other 235 MB are on the link; the MSMs of the rest follow.  (An MSM launch costs
+            // ~1.3 ms beyond its share of the work -- the last waves of a launch -- so the head is as small as will still cover
+            // the uploads: 256 blobs = 6 ms.)  ETH_KZG_AMD_EARLY_MSM=<blobs> moves the cut, 0 = one launch after the last upload.
+            static const int early_msm_blobs = [] { const char* e = getenv("ETH_KZG_AMD_EARLY_MSM"); return e ? atoi(e) : 256; }();
+            int msm_cut = 0;
+            if (early_scalars && early_msm_blobs > 0 && ns >= 4 * early_msm_blobs && msm_chunks_ != 8 && !slp_walk_)
+                for (int c : cut)
+                    if (!msm_cut && c >= early_msm_blobs && c % 64 == 0 && c < ns) msm_cut = c;
             // The uploads run back to back on the copy stream (its own hardware queue), the light per-blob stages follow on the compute
             // stream sub-batch by sub-batch: in one stream the copy engine idled during the kernels and the kernels during the copies
             // (rocprofv3 --memory-copy-trace: 7.6 ms until the MSMs could start, for 5.2 ms of link time)
@@ -1809,6 +1832,7 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
                 if (early_scalars)
                     launch::fk20_scalars(nb, (char*)w.coeffs + (size_t)lo * N_BLOB * sizeof(Fr), (char*)w.scalars + (size_t)lo * 128 * 64 * sizeof(Fr),
                                          d_w29_, half_, 1, seg_shift_, tv_call.glv, w.stream);
+                if (msm_cut && hi == msm_cut) run_proofs_from_coeffs(w, ns, w.d_proofs, w.stream, &tv_call, PROOFS_HEAD, msm_cut);
                 if (trace) fprintf(stderr, "[host-batch] sub-batch %d (%d blobs) enqueued at %.2f ms\n", i, nb, now_ms());
             }
             // The cells go back on the same copy stream, i.e. behind the LAST upload: the fixed-base MSMs run once over the whole batch
@@ -1835,7 +1859,8 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
             }
             step();
             if (proofs) {
-                run_proofs_from_coeffs(w, ns, w.d_proofs, w.stream, early_scalars ? &tv_call : nullptr);
+                if (msm_cut) run_proofs_from_coeffs(w, ns, w.d_proofs, w.stream, &tv_call, PROOFS_TAIL, msm_cut);
+                else run_proofs_from_coeffs(w, ns, w.d_proofs, w.stream, early_scalars ? &tv_call : nullptr);
                 HIPCK(hipMemcpyAsync(w.h_proofs, w.d_proofs, (size_t)ns * N_CELLS * 48, hipMemcpyDeviceToHost, w.stream));
             }
             step();

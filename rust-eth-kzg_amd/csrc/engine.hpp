@@ -251,6 +251,7 @@ private:
     void init_linmap(const Fr8* w8192_mont);  // host copy of omega_8192^k
     void init_srs();
     void settle_streams();
+    bool streams_overlap(hipStream_t a, hipStream_t b);
     void init_fk20();
     void init_verifier();
     int open_blobs_at(int n, const uint8_t* const* blobs, const Fr8* z_mont, bool want_proofs, uint8_t* h_proofs, Fr8* h_y_canon,
@@ -286,7 +287,11 @@ private:
     void ensure_workspace(Work& w, int n);
     void ensure_staging(Work& w, int n);
     void run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st) { run_proofs_from_coeffs(work_[0], n, d_proofs, st); }
-    void run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream_t st, const TableView* tv_pre = nullptr);
+    // msm_cut > 0 (host-pointer path, scalars precomputed): the MSM stage in two launches around the cut -- PROOFS_HEAD issues the
+    // arena set-up and the MSMs of blobs [0, msm_cut) and returns, PROOFS_TAIL the MSMs of [msm_cut, n) and everything after
+    enum ProofsPhase { PROOFS_ALL = 0, PROOFS_HEAD = 1, PROOFS_TAIL = 2 };
+    void run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream_t st, const TableView* tv_pre = nullptr, ProofsPhase phase = PROOFS_ALL,
+                                int msm_cut = 0);
     void enqueue_compute(Work& w, int n, const uint8_t* d_blobs, uint8_t* d_cells, uint8_t* d_proofs, hipStream_t st,
                          hipEvent_t after_cells);
     Work& lease_work(int first, int last);  // locks and returns a free set among work_[first..last] (waits for whichever frees first)

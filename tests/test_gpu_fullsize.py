@@ -130,6 +130,31 @@ def test_compute_512_through_the_host_batch_abi(ctx, oracle):
         assert b"".join(cells[b]) == dcells[b].tobytes() and b"".join(proofs[b]) == dproofs[b].tobytes(), b
 
 
+@pytest.mark.parametrize("n", [1024, 1100, 2048])
+def test_host_batch_with_the_msm_stage_in_two_launches(ctx, oracle, n):
+    """From 1024 blobs the host-pointer path launches the MSMs of the first 256 blobs while the rest is still on the link and
+    the others afterwards (Engine::run_proofs_from_coeffs, PROOFS_HEAD / PROOFS_TAIL): same bytes as the device-resident
+    form (one launch), an invalid blob on either side of the cut reported and the others unaffected, a sample against the oracle."""
+    blobs = _random_blobs(n, 9100 + n)
+    bufs = ctx.host_batch_buffers(n)
+    flat = np.ascontiguousarray(blobs.reshape(n, 131072))
+    st = ctx.compute_cells_and_kzg_proofs_batch_np(flat, bufs)
+    assert st == [0] * n
+    _, dcells, dproofs = _compute_on_device(ctx, blobs)
+    assert np.array_equal(bufs["cells"].reshape(n, -1), dcells.reshape(n, -1))
+    assert np.array_equal(bufs["proofs"].reshape(n, -1), dproofs.reshape(n, -1))
+    _check_sample_against_oracle(oracle, blobs, dcells, dproofs, [0, 255, 256, n - 1])
+    good = bufs["proofs"].copy()
+    bad = flat.copy()
+    bad[100, :32] = 0xFF   # not canonical: before the cut
+    bad[700, 32:64] = 0xFF  # after it
+    st = ctx.compute_cells_and_kzg_proofs_batch_np(bad, bufs)
+    assert [i for i, v in enumerate(st) if v != 0] == [100, 700]
+    keep = np.ones(n, dtype=bool)
+    keep[[100, 700]] = False
+    assert np.array_equal(bufs["proofs"][keep], good[keep])
+
+
 def _config3_inputs(ctx, n_blobs=64):
     blobs = _random_blobs(n_blobs, 3003)
     st, cells, proofs = _compute_on_device(ctx, blobs)
