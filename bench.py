@@ -458,15 +458,25 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
         for t in warm:
             t.join()
         ths = [threading.Thread(target=hammer, args=(r,)) for r in runs_t]
+        # the interpreter's cyclic garbage collector is held off for the timed round: by now this process holds millions of Python
+        # objects (the 1024-problem calls' lists), one full collection takes ~35 ms WITH the GIL -- every caller thread needs the
+        # GIL to return from its call, so all four stood still for it once per round (a fifth of the 4-thread round's 220 ms;
+        # traced: four calls of 39 ms at the same instant, the other 236 at 3.7 ms).  A harness artefact, not library time.
+        import gc
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
         for t in ths:
             t.start()
         for t in ths:
             t.join()
         dtt = time.perf_counter() - t0
+        gc.enable()
         out[key] = {"verifications_per_s": round(n_thr * reps / dtt),
                     "entry": f"eth_kzg_verify_cell_kzg_proof_batch from {n_thr} host threads on one context: one caller at a time takes the latency "
-                             "path, callers that arrive meanwhile are combined into many-verification passes (three pass slots, short-chain form)"}
+                             "path, callers that arrive meanwhile are combined into many-verification passes (three pass slots, short-chain form); "
+                             "the harness's own garbage collector held off during the timed round (one full collection of this process's "
+                             "object graph = 35 ms under the GIL)"}
     _mark("side configs: recover one")
     half_idx, half_cells = list(range(CELLS // 2)), L_[:CELLS // 2]
     ts = []
