@@ -434,15 +434,17 @@ void Engine::settle_streams() {
     const bool trace = getenv("ETH_KZG_AMD_TRACE_STREAMS") != nullptr;
     launch::spin(1, stream_);  // first launch of the kernel (and first use of the stream) outside the measurement
     std::vector<hipStream_t> chosen{stream_}, rejected;
+    bool gave_up = false;
     for (int i = 1; i < NW; i++) {
         Work& w = work_[i];
-        if (!w.stream) continue;
+        if (!w.stream || gave_up) continue;
         for (int attempt = 0;; attempt++) {
             launch::spin(1, w.stream);
             bool ok = true;
             for (hipStream_t c : chosen) ok = ok && streams_overlap(c, w.stream);
             if (ok || attempt == 5) {
                 if (trace) fprintf(stderr, "[eth_kzg_amd] work set %d: stream %s after %d replacement(s)\n", i, ok ? "runs beside the others" : "still shares a queue", attempt);
+                if (!ok) gave_up = true;  // a GPU this busy (another process's kernels) shows every pair as serial: no point in trying the other sets
                 break;
             }
             rejected.push_back(w.stream);
