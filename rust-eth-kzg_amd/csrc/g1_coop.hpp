@@ -1,0 +1,115 @@
+// Point doublings by the four lanes of a quad.  A chain of dependent doublings (the subgroup test's 126, the 120 behind the
+// byte-shifted copies of a verification) is latency, not work, when the batch is a few hundred points: the waves have a SIMD
+// each and the chip is idle.  The seven products of a doubling have a critical path of three,
+//     X^2 | Y^2 | Y Z   ->   X (Y^2) | (3 X^2)^2   ->   E (D - X3) - 8 Y^4,
+// so four lanes that all hold the point compute one level's products side by side (operands picked by lane, one multiplication
+// issued), exchange them with quad-broadcast DPP moves (14 per field element) and repeat the cheap linear steps redundantly:
+// 3.5 multiplication times per doubling instead of 6.5.  Every lane of the quad ends with the whole result, so the additions
+// between doublings (rare in both chains) simply run four times over.  Same formulas and bounds as curve29.hpp: dbl().
+#pragma once
+#include "curve29.hpp"
+
+namespace kzg {
+
+template <class T> struct fq_bound;
+template <int B> struct fq_bound<Fq<B>> { static constexpr int value = B; };
+
+// every lane of a quad (four consecutive lanes) receives lane J's value
+template <int J, int B>
+__device__ __forceinline__ Fq<B> quad_bcast(const Fq<B>& a) {
+    static_assert(J >= 0 && J < 4, "lane of the quad");
+    Fq<B> r;
+#pragma unroll
+    for (int i = 0; i < QL; i++) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v[i], J * 0x55, 0xf, 0xf, true);
+    return r;
+}
+// q = lane & 3; ALL FOUR lanes of the quad must be active and hold the same p
+__device__ __forceinline__ JacQ coop_dbl(const JacQ& p, int q) {
+    const bool l0 = q == 0, l1 = q == 1;
+    // level 1: lane 0 X^2, lane 1 Y^2, lanes 2 and 3 Y Z
+    const Fq<XB> a1 = select(l0, p.x, p.y);
+    const Fq<XB> b1 = select(l0, p.x, select(l1, p.y, relax<XB>(p.z)));
+    const Fq<2> r1 = mul(a1, b1);
+    const Fq<2> A = quad_bcast<0>(r1), B = quad_bcast<1>(r1), YZ = quad_bcast<2>(r1);
+    // level 2: lane 0 X B, the others E^2
+    const Fq<6> E = add(dbl(A), A);
+    const Fq<XB> a2 = select(l0, p.x, relax<XB>(E));
+    const Fq<XB> b2 = select(l0, relax<XB>(B), relax<XB>(E));
+    const Fq<2> r2 = mul(a2, b2);
+    const Fq<2> XY2 = quad_bcast<0>(r2), F = quad_bcast<1>(r2);
+    const Fq<8> D = dbl2(XY2);
+    // level 3, on every lane: one fused product pair
+    JacQ r;
+    auto x3 = sub2(F, D);
+    auto y3 = mul_add(E, sub(D, x3), neg2(B), dbl2(B));
+    r.x = relax<XB>(x3);
+    r.y = relax<XB>(y3);
+    r.z = dbl(YZ);
+    return r;
+}
+
+// Mixed addition (curve29.hpp: add_mixed, madd-2007-bl with Z3 = 2 Z1 H) by the four lanes of a quad: its ten products in five
+// levels --  Z1^2 | y2 Z1  ->  x2 Z1Z1 | (y2 Z1) Z1Z1  ->  H^2 | Z1 H | rr^2  ->  H I | X1 I  ->  the fused pair of Y3  -- instead of
+// 10.5 multiplication times.  Aff: AffQ (canonical; the identity (0,0) is tested up front like add_mixed does) or AffQ2 (table
+// points that are fresh products and never the identity).  Degenerate operands leave by the same exact slow path, on all four lanes.
+__device__ __forceinline__ bool coop_affine_is_inf(const AffQ& q) { return affine_is_inf(q); }
+__device__ __forceinline__ bool coop_affine_is_inf(const AffQ2&) { return false; }
+template <class Aff>
+__device__ __forceinline__ JacQ coop_add_mixed(const JacQ& p, const Aff& q, bool negq, int quad) {
+    if (coop_affine_is_inf(q)) return p;
+    const bool l0 = quad == 0, l1 = quad == 1;
+    const Fq<2> qx = relax<2>(q.x), qy = relax<2>(q.y);
+    // level 1: lane 0 Z1^2, the others y2 Z1
+    const Fq<ZB> a1 = select(l0, p.z, relax<ZB>(qy));
+    const Fq<2> r1 = mul(a1, p.z);
+    const Fq<2> z1z1 = quad_bcast<0>(r1), t = quad_bcast<1>(r1);
+    // level 2: lane 0 U2 = x2 Z1Z1, the others S2 = (y2 Z1) Z1Z1
+    const Fq<2> r2 = mul(select(l0, qx, t), z1z1);
+    const Fq<2> u2 = quad_bcast<0>(r2), s2p = quad_bcast<1>(r2);
+    auto h = sub(u2, p.x);
+    auto rr = dbl(signed_sub(negq, s2p, p.y));
+    // level 3: lane 0 H^2, lane 1 Z1 H, lanes 2 and 3 rr^2
+    constexpr int HB = fq_bound<decltype(h)>::value, RB = fq_bound<decltype(rr)>::value, WB = HB > RB ? HB : RB;
+    const Fq<WB> hw = relax<WB>(h), rw = relax<WB>(rr);
+    const Fq<WB> a3 = select(l0, hw, select(l1, relax<WB>(p.z), rw));
+    const Fq<WB> b3 = select(l0 || l1, hw, rw);
+    const Fq<2> r3 = mul(a3, b3);
+    const Fq<2> hh = quad_bcast<0>(r3), zh = quad_bcast<1>(r3), rr2 = quad_bcast<2>(r3);
+    const Fq<8> i = dbl2(hh);
+    // level 4: lane 0 J = H I, the others V = X1 I
+    constexpr int XH = HB > XB ? HB : XB;
+    const Fq<2> r4 = mul(select(l0, relax<XH>(h), relax<XH>(p.x)), i);
+    const Fq<2> j = quad_bcast<0>(r4), v = quad_bcast<1>(r4);
+    // level 5, on every lane
+    JacQ r;
+    auto x3 = sub_sub2(rr2, j, v);
+    r.x = relax<XB>(x3);
+    r.y = relax<XB>(mul_add(rr, sub(v, x3), neg2(p.y), j));
+    r.z = dbl(zh);
+    if (product_is_zero(zh)) return add_mixed_slow(p, q, negq);
+    return r;
+}
+
+// [|z|] P (g1_subgroup.hpp: mul_by_z_abs_q) with the doublings shared by the quad
+__device__ __forceinline__ JacQ coop_mul_by_z_abs(const JacQ& p, int q) {
+    constexpr uint64_t Z = 0xd201000000010000ULL;
+    JacQ acc = p;
+#pragma unroll 1
+    for (int i = 62; i >= 0; i--) {
+        acc = coop_dbl(acc, q);
+        if ((Z >> i) & 1) acc = add(acc, p);  // five general additions in 63 steps: repeated on every lane
+    }
+    return acc;
+}
+// Scott's test (g1_subgroup.hpp: g1_in_subgroup_q), same verdict on all four lanes
+__device__ __forceinline__ bool g1_in_subgroup_coop(const AffQ& pa, const Fq<1>& beta, int q) {
+    const JacQ p = to_jacq(pa);
+    const JacQ z2p = coop_mul_by_z_abs(coop_mul_by_z_abs(p, q), q);
+    const JacQ r = add_mixed(z2p, pa, true);
+    if (is_inf(r)) return false;
+    const Fq<2> zz = sqr(r.z);
+    if (!is_zero_slow(sub(r.x, mul(mul(pa.x, beta), zz)))) return false;
+    if (!is_zero_slow(sub(r.y, mul(pa.y, mul(zz, r.z))))) return false;
+    return true;
+}
+}  // namespace kzg

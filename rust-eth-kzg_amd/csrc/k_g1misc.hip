@@ -5,6 +5,7 @@
 #include "kcommon.hpp"
 #include "curve29.hpp"
 #include "g1_subgroup.hpp"
+#include "g1_coop.hpp"
 #include "launch.hpp"
 
 namespace kzg {
@@ -100,7 +101,8 @@ __device__ __forceinline__ Fq<2> fq_sqrt_candidate(const Fq<2>& a) {
     return acc;
 }
 // rc 0 ok (out = affine Montgomery-384 point), 1 bad encoding / x >= p / not on the curve, 2 not in the subgroup
-__device__ __forceinline__ int g1_decompress_q(G1Affine& out, const uint8_t* in, bool subgroup_check, const Fq<1>& beta) {
+// quad >= 0: four lanes decode the same point and share the doublings of its subgroup test (g1_coop.hpp)
+__device__ __forceinline__ int g1_decompress_q(G1Affine& out, const uint8_t* in, bool subgroup_check, const Fq<1>& beta, int quad = -1) {
     const uint8_t b0 = in[0];
     const bool compressed = (b0 >> 7) & 1, infinity = (b0 >> 6) & 1, sign = (b0 >> 5) & 1;
     if (!compressed) return 1;
@@ -132,7 +134,7 @@ __device__ __forceinline__ int g1_decompress_q(G1Affine& out, const uint8_t* in,
     AffQ pa;
     pa.x = xq;
     pa.y = fq_from_fp(ym);
-    return g1_in_subgroup_q(pa, beta) ? 0 : 2;
+    return (quad >= 0 ? g1_in_subgroup_coop(pa, beta, quad) : g1_in_subgroup_q(pa, beta)) ? 0 : 2;
 }
 
 // Decompression with validation: thread per point, one wave per block (launch bounds tell the compiler it may use the
@@ -154,6 +156,36 @@ __global__ __launch_bounds__(64) void k_g1_decompress(const uint8_t* __restrict_
     if (rc) a = aff_inf();
     (second ? status1 : status0)[i] = rc;
     (second ? out1 : out0)[i] = a;
+}
+// k_g1_decompress with the endomorphism test for a few points (one, for the EIP-4844 calls): the 126 dependent doublings of the
+// test are the launch's whole duration, so four lanes per point share them; 16 points per block, every lane of a quad
+// writes the same result
+__global__ __launch_bounds__(64) void k_g1_decompress_coop(const uint8_t* __restrict__ in0, G1Affine* __restrict__ out0,
+                                                           int* __restrict__ status0, int n0, const uint8_t* __restrict__ in1,
+                                                           G1Affine* __restrict__ out1, int* __restrict__ status1, int n1, Fq<1> beta_q) {
+    int i = blockIdx.x * 16 + (threadIdx.x >> 2);
+    if (i >= n0 + n1) return;
+    const bool second = i >= n0;
+    if (second) i -= n0;
+    const uint8_t* in = second ? in1 : in0;
+    G1Affine a;
+    const int rc = g1_decompress_q(a, in + (size_t)i * 48, true, beta_q, threadIdx.x & 3);
+    if (rc) a = aff_inf();
+    (second ? status1 : status0)[i] = rc;
+    (second ? out1 : out0)[i] = a;
+}
+__global__ __launch_bounds__(64) void k_g1_subgroup_coop(const G1Affine* __restrict__ pts0, int* __restrict__ status0, int n0,
+                                                         const G1Affine* __restrict__ pts1, int* __restrict__ status1, int n1, Fq<1> beta_q) {
+    int i = blockIdx.x * 16 + (threadIdx.x >> 2);
+    if (i >= n0 + n1) return;
+    const bool second = i >= n0;
+    if (second) i -= n0;
+    int* st = second ? status1 : status0;
+    const int before = st[i];
+    if (before != 0) return;
+    const G1Affine a = (second ? pts1 : pts0)[i];
+    if (is_inf(a)) return;
+    if (!g1_in_subgroup_coop(affq_from_affine(a), beta_q, threadIdx.x & 3)) st[i] = 2;
 }
 // The subgroup test on its own, for points k_g1_decompress has decoded with subgroup_check = 0: a verification runs it on a
 // second stream next to the work that only needs the coordinates (k_verify.hip: k_pip_shift), because each of the two is
@@ -226,6 +258,13 @@ __global__ void k_spin(uint64_t ticks) {
 }
 
 namespace launch {
+// Up to this many points a launch of the four-lanes-per-point kernels (g1_coop.hpp) still gives every wave a SIMD of its own
+// (16 points per wave, 1,024 SIMDs); beyond it the chip fills and one lane per point is less work.  ETH_KZG_AMD_COOP_POINTS=<n>
+// moves the limit, 0 switches the quad form off.
+int coop_points_max() {
+    static const int v = [] { const char* e = getenv("ETH_KZG_AMD_COOP_POINTS"); return e ? atoi(e) : 8192; }();
+    return v;
+}
 void spin(uint64_t ticks, hipStream_t st) { k_spin<<<1, 64, 0, st>>>(ticks); }
 // the code object of this translation unit is loaded now (HIP loads a code object on the first launch of one of its kernels, and
 // that load is an allocation: it would wait behind a table piece the builder thread is allocating)
@@ -247,13 +286,17 @@ void g1_decompress(const uint8_t* in, void* out, int* status, int n, int subgrou
     Fp b;
     for (int i = 0; i < 12; i++) b.v[i] = beta.v[i];
     if (subgroup_check >= 2) k_g1_decompress_reference<<<(n + 63) / 64, 64, 0, st>>>(in, (G1Affine*)out, status, n, subgroup_check, b);
+    else if (subgroup_check == 1 && n <= coop_points_max())
+        k_g1_decompress_coop<<<(n + 15) / 16, 64, 0, st>>>(in, (G1Affine*)out, status, n, nullptr, nullptr, nullptr, 0, fq_from_fp(b));
     else k_g1_decompress<<<(n + 63) / 64, 64, 0, st>>>(in, (G1Affine*)out, status, n, nullptr, nullptr, nullptr, 0, subgroup_check, fq_from_fp(b));
 }
 void g1_decompress2(const uint8_t* in0, void* out0, int* status0, int n0, const uint8_t* in1, void* out1, int* status1, int n1,
                     const Fp12w& beta, hipStream_t st) {
     Fp b;
     for (int i = 0; i < 12; i++) b.v[i] = beta.v[i];
-    k_g1_decompress<<<(n0 + n1 + 63) / 64, 64, 0, st>>>(in0, (G1Affine*)out0, status0, n0, in1, (G1Affine*)out1, status1, n1, 1, fq_from_fp(b));
+    if (n0 + n1 <= coop_points_max())
+        k_g1_decompress_coop<<<(n0 + n1 + 15) / 16, 64, 0, st>>>(in0, (G1Affine*)out0, status0, n0, in1, (G1Affine*)out1, status1, n1, fq_from_fp(b));
+    else k_g1_decompress<<<(n0 + n1 + 63) / 64, 64, 0, st>>>(in0, (G1Affine*)out0, status0, n0, in1, (G1Affine*)out1, status1, n1, 1, fq_from_fp(b));
 }
 // the two halves of g1_decompress2 as separate launches (decode + on-curve; subgroup)
 void g1_decode2(const uint8_t* in0, void* out0, int* status0, int n0, const uint8_t* in1, void* out1, int* status1, int n1,
@@ -265,7 +308,9 @@ void g1_decode2(const uint8_t* in0, void* out0, int* status0, int n0, const uint
 void g1_subgroup2(const void* pts0, int* status0, int n0, const void* pts1, int* status1, int n1, const Fp12w& beta, hipStream_t st) {
     Fp b;
     for (int i = 0; i < 12; i++) b.v[i] = beta.v[i];
-    k_g1_subgroup<<<(n0 + n1 + 63) / 64, 64, 0, st>>>((const G1Affine*)pts0, status0, n0, (const G1Affine*)pts1, status1, n1, fq_from_fp(b));
+    if (n0 + n1 <= coop_points_max())
+        k_g1_subgroup_coop<<<(n0 + n1 + 15) / 16, 64, 0, st>>>((const G1Affine*)pts0, status0, n0, (const G1Affine*)pts1, status1, n1, fq_from_fp(b));
+    else k_g1_subgroup<<<(n0 + n1 + 63) / 64, 64, 0, st>>>((const G1Affine*)pts0, status0, n0, (const G1Affine*)pts1, status1, n1, fq_from_fp(b));
 }
 void fk20_srs_vectors(const void* srs, void* X, hipStream_t st) { k_fk20_srs_vectors<<<128 * 64 / 256, 256, 0, st>>>((const G1Affine*)srs, (JacQ*)X); }
 void fk20_gather_bases(const void* X, void* bases, hipStream_t st) { k_fk20_gather_bases<<<128 * 64 / 256, 256, 0, st>>>((const JacQ*)X, (G1Affine*)bases); }

@@ -7,6 +7,7 @@
 #include "kcommon.hpp"
 #include "curve29.hpp"
 #include "g1_subgroup.hpp"
+#include "g1_coop.hpp"
 #include "launch.hpp"
 #include "glv.hpp"
 
@@ -340,8 +341,10 @@ __global__ __launch_bounds__(64) void k_pip_final(const JacQ* __restrict__ wsum,
 // k_pip_window; the host normalises the two sums.  No doubling at all: 3.4 -> 0.8 ms of GPU time behind the hash.
 //   pts32[(phi * 16 + p) * n_max + i] = phi^phi(2^(8p) P_i)
 constexpr int PS_P = 16, PS_SLICES = 64;
+// quad >= 0: the four lanes of a quad work on point i together (g1_coop.hpp) -- they share each doubling and repeat the rest, every
+// lane writing the same values; quad < 0: one lane per point
 __device__ __forceinline__ void pip_shift_point(int i, const G1Affine* __restrict__ in, AffQ* __restrict__ pts32, JacQ* __restrict__ jac,
-                                                Fq<2>* __restrict__ pre, int n_max, const Fq<1>& beta) {
+                                                Fq<2>* __restrict__ pre, int n_max, const Fq<1>& beta, int quad = -1) {
     auto put = [&](int p, const AffQ& a) {
         pts32[(size_t)p * n_max + i] = a;
         AffQ b = a;
@@ -357,7 +360,8 @@ __device__ __forceinline__ void pip_shift_point(int i, const G1Affine* __restric
     JacQ cur = to_jacq(P);
     Fq<2> prod = relax<2>(fq_one());
     for (int p = 1; p < PS_P; p++) {
-        for (int k = 0; k < 8; k++) cur = dbl(cur);
+        if (quad >= 0) { for (int k = 0; k < 8; k++) cur = coop_dbl(cur, quad); }
+        else { for (int k = 0; k < 8; k++) cur = dbl(cur); }
         jac[(size_t)(p - 1) * n_max + i] = cur;
         pre[(size_t)(p - 1) * n_max + i] = prod;
         prod = mul(prod, cur.z);
@@ -406,6 +410,29 @@ __global__ __launch_bounds__(64) void k_pip_shift_subgroup(const G1Affine* __res
     const G1Affine a = (second ? pts1 : pts0)[i];
     if (is_inf(a)) return;
     if (!g1_in_subgroup_q(affq_from_affine(a), beta)) st[i] = 2;
+}
+// The same launch for a verification of a few hundred points, where both chains are pure latency (every wave has a SIMD to
+// itself): FOUR lanes per point share the doublings (g1_coop.hpp).  16 points per block.
+__global__ __launch_bounds__(64) void k_pip_shift_subgroup_coop(const G1Affine* __restrict__ in, AffQ* __restrict__ pts32, JacQ* __restrict__ jac,
+                                                                Fq<2>* __restrict__ pre, int n, int n_max, int shift_blocks,
+                                                                const G1Affine* __restrict__ pts0, int* __restrict__ status0, int n0,
+                                                                const G1Affine* __restrict__ pts1, int* __restrict__ status1, int n1, Fq<1> beta) {
+    const int quad = threadIdx.x & 3;
+    if ((int)blockIdx.x < shift_blocks) {
+        const int i = blockIdx.x * 16 + (threadIdx.x >> 2);
+        if (i < n) pip_shift_point(i, in, pts32, jac, pre, n_max, beta, quad);
+        return;
+    }
+    int i = ((int)blockIdx.x - shift_blocks) * 16 + (threadIdx.x >> 2);
+    if (i >= n0 + n1) return;
+    const bool second = i >= n0;
+    if (second) i -= n0;
+    int* st = second ? status1 : status0;
+    if (st[i] != 0) return;
+    const G1Affine a = (second ? pts1 : pts0)[i];
+    if (is_inf(a)) return;
+    const bool ok = g1_in_subgroup_coop(affq_from_affine(a), beta, quad);
+    if (!ok && quad == 0) st[i] = 2;
 }
 // counting sort of the 32 n items of a job by their byte.  Half-scalar entry e < 2n (k1 of scalar e, or k2 of scalar e - n)
 // carries 16 items; slice s of PS_SLICES owns a contiguous range of entries.
@@ -717,6 +744,14 @@ void pip_shift_prepare_and_subgroup(const void* points, int n_pts, int n_max, vo
     Fp b384;
     for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
     const PsLayout L = ps_layout(workspace, n_max);
+    // up to a few thousand points every wave of the quad form still has a SIMD to itself (4 lanes per point: 16 points per wave,
+    // 1,024 SIMDs); beyond that the chip fills and one lane per point is less work (launch::coop_points_max)
+    if (n_pts + n0 + n1 <= coop_points_max()) {
+        const int sb = (n_pts + 15) / 16, tb = (n0 + n1 + 15) / 16;
+        k_pip_shift_subgroup_coop<<<sb + tb, 64, 0, st>>>((const G1Affine*)points, L.pts32, L.jac, L.pre, n_pts, n_max, sb, (const G1Affine*)pts0,
+                                                          status0, n0, (const G1Affine*)pts1, status1, n1, fq_from_fp(b384));
+        return;
+    }
     const int shift_blocks = (n_pts + 63) / 64, sub_blocks = (n0 + n1 + 63) / 64;
     k_pip_shift_subgroup<<<shift_blocks + sub_blocks, 64, 0, st>>>((const G1Affine*)points, L.pts32, L.jac, L.pre, n_pts, n_max, shift_blocks,
                                                                    (const G1Affine*)pts0, status0, n0, (const G1Affine*)pts1, status1, n1, fq_from_fp(b384));

@@ -95,6 +95,7 @@ void g1_slp_walk(void* arena, int stride, const uint32_t* words, const int* leve
 
 // k_g1misc.hip
 void g1_set_inf(void* X, size_t n, hipStream_t st);
+int coop_points_max();  // largest launch (points) that takes the four-lanes-per-point kernels (k_g1misc.hip)
 void spin(uint64_t wall_clock_ticks, hipStream_t st);  // one wave, resident for that many ticks of the constant-rate device clock
 void g1_compress(const void* X, uint8_t* out, int n_pos, int stride, int n_slices, hipStream_t st);
 void g1_sum_positions(void* X, int n_pos, int stride, int n_slices, hipStream_t st);

@@ -124,6 +124,16 @@ def test_g1_decompress_matches_oracle(ctx):
             assert (st[i] != 0) == (exp != 0), (i, p.hex(), st[i], exp)
             if exp == 0:
                 assert out.raw[48 * i:48 * i + 48] == p  # decompress -> compress round trip is the identity
+    # Up to 8192 points the production test runs with FOUR lanes per point that share its doublings (g1_coop.hpp), above with
+    # one lane per point: the list above took the first form, the same points repeated past the limit take the second
+    reps = 8192 // n + 2
+    st_one = (C.c_int32 * n)()
+    out_one = C.create_string_buffer(n * 48)
+    assert lib.eth_kzg_amd_test_g1_decompress(ctx.handle, b"".join(allp), n, 1, st_one, out_one) == 0
+    st_big = (C.c_int32 * (n * reps))()
+    out_big = C.create_string_buffer(n * reps * 48)
+    assert lib.eth_kzg_amd_test_g1_decompress(ctx.handle, b"".join(allp) * reps, n * reps, 1, st_big, out_big) == 0
+    assert list(st_big) == list(st_one) * reps and out_big.raw == out_one.raw * reps
 
 
 @pytest.mark.parametrize("inverse", [0, 1])
@@ -852,3 +862,17 @@ def test_concurrent_single_verifications_are_combined(ctx):
     dt = time.perf_counter() - t0
     assert not errors, errors[:3]
     print(f"{n_threads} threads x {reps} single verifications (mixed shapes): {n_threads * reps / dt:.0f} calls/s")
+
+
+@pytest.mark.gpu
+def test_one_lane_per_point_forms_with_the_quad_kernels_switched_off():
+    """Verifications of a few hundred points run with four lanes per point (g1_coop.hpp); the one-lane forms they replaced stay in
+    the library for large inputs and behind ETH_KZG_AMD_COOP_POINTS=0, which is read once per process: tests/coop_off_check.py
+    runs the single path, a small many-verification pass and the EIP-4844 verifier on them, valid, tampered and with a
+    proof outside the subgroup."""
+    import subprocess
+    import sys
+    env = dict(os.environ, ETH_KZG_AMD_COOP_POINTS="0", ETH_KZG_AMD_TABLE_GB="8")  # small tables: the parent test process holds the wide ones
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "coop_off_check.py")], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "coop-off ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
