@@ -312,13 +312,17 @@ __global__ __launch_bounds__(256) void k_pip_window(const JacQ* __restrict__ buc
     }
     if (t == 0) wsum[job * W + w] = T[0];
 }
+// (the 16 windows take the wave's 16 quads: four lanes share each of the up to 120 dependent doublings, g1_coop.hpp)
 __global__ __launch_bounds__(64) void k_pip_final(const JacQ* __restrict__ wsum, G1Affine* __restrict__ out_affine) {
     __shared__ JacQ T[PIP_W];
     const int job = blockIdx.x, t = threadIdx.x;
-    if (t < PIP_W) {
-        JacQ acc = wsum[job * PIP_W + t];
-        for (int k = 0; k < PIP_C * t; k++) acc = dbl(acc);
-        T[t] = acc;
+    static_assert(PIP_W * 4 == 64, "one quad per window");
+    {
+        const int w = t >> 2, quad = t & 3;
+        JacQ acc = wsum[job * PIP_W + w];
+#pragma unroll 1
+        for (int k = 0; k < PIP_C * w; k++) acc = coop_dbl(acc, quad);
+        if (quad == 0) T[w] = acc;
     }
     __syncthreads();
     for (int span = PIP_W / 2; span >= 1; span >>= 1) {
