@@ -90,6 +90,62 @@ __device__ __forceinline__ JacQ coop_add_mixed(const JacQ& p, const Aff& q, bool
     return r;
 }
 
+template <int B>
+__device__ __forceinline__ Fq<B> select4(int quad, const Fq<B>& a, const Fq<B>& b, const Fq<B>& c, const Fq<B>& d) {
+    return select(quad == 0, a, select(quad == 1, b, select(quad == 2, c, d)));
+}
+// General addition (curve29.hpp: add, add-2007-bl with Z3 = 2 Z1 Z2 H) by the four lanes of a quad.  Its fifteen products have
+// more width than the doubling's: four levels of up to four independent ones and the fused pair of Y3,
+//     Z1^2 | Z2^2 | Y1 Z2 | Y2 Z1  ->  U1 | U2 | S1 | S2  ->  (2H)^2 | rr^2 | Z1 Z2  ->  H I | U1 I | Z1 Z2 H  ->  Y3,
+// 5.5 multiplication times instead of 16.5.  p + q, or p - q when negq; degenerate operands leave by add_slow on all four lanes.
+__device__ __forceinline__ JacQ coop_add(const JacQ& p, const JacQ& q, bool negq, int quad) {
+    const Fq<XB> pz = relax<XB>(p.z), qz = relax<XB>(q.z);
+    const Fq<2> r1 = mul(select4(quad, pz, qz, p.y, q.y), select4(quad, pz, qz, qz, pz));
+    const Fq<2> z1z1 = quad_bcast<0>(r1), z2z2 = quad_bcast<1>(r1), y1z2 = quad_bcast<2>(r1), y2z1 = quad_bcast<3>(r1);
+    const Fq<2> r2 = mul(select4(quad, p.x, q.x, relax<XB>(y1z2), relax<XB>(y2z1)), select4(quad, z2z2, z1z1, z2z2, z1z1));
+    const Fq<2> u1 = quad_bcast<0>(r2), u2 = quad_bcast<1>(r2), s1 = quad_bcast<2>(r2), s2p = quad_bcast<3>(r2);
+    auto h = sub(u2, u1);
+    auto rr = dbl(signed_sub(negq, s2p, s1));
+    auto h2 = dbl(h);
+    constexpr int HB = fq_bound<decltype(h2)>::value, RB = fq_bound<decltype(rr)>::value, WB = HB > RB ? HB : RB;
+    const Fq<WB> h2w = relax<WB>(h2), rrw = relax<WB>(rr), pzw = relax<WB>(p.z), qzw = relax<WB>(q.z);
+    const Fq<2> r3 = mul(select4(quad, h2w, rrw, pzw, pzw), select4(quad, h2w, rrw, qzw, qzw));
+    const Fq<2> i = quad_bcast<0>(r3), rr2 = quad_bcast<1>(r3), z1z2 = quad_bcast<2>(r3);
+    constexpr int H1 = fq_bound<decltype(h)>::value;
+    const Fq<H1> hw = h, u1w = relax<H1>(u1), zzw = relax<H1>(z1z2), iw = relax<H1>(i);
+    const Fq<2> r4 = mul(select4(quad, hw, u1w, zzw, zzw), select4(quad, iw, iw, hw, hw));
+    const Fq<2> j = quad_bcast<0>(r4), v = quad_bcast<1>(r4), zh = quad_bcast<2>(r4);
+    JacQ r;
+    auto x3 = sub_sub2(rr2, j, v);
+    r.x = relax<XB>(x3);
+    r.y = relax<XB>(mul_add(rr, sub(v, x3), neg2(s1), j));
+    r.z = dbl(zh);
+    if (product_is_zero(zh)) return add_slow(p, q, negq);
+    return r;
+}
+
+// The tree that ends every block-wide sum: red[0 .. 2 * first_span) hold the lanes' partial sums, red[0] their total on return.
+// A plain tree leaves more lanes idle with every level and still pays a full addition (16.5 multiplication times) per level;
+// here the idle lanes join in: four lanes per addition, NT / 4 additions per round (the first level of a full block takes two
+// rounds).  Called by all NT threads of the block; no extra waves, so it pays whatever the occupancy.
+template <int NT>
+__device__ __forceinline__ void coop_tree_fold(JacQ* red, int first_span, int tid) {
+    const int quad = tid & 3, slot = tid >> 2;
+    __syncthreads();
+#pragma unroll 1
+    for (int span = first_span; span >= 1; span >>= 1) {
+#pragma unroll 1
+        for (int base = 0; base < span; base += NT / 4) {  // a round reads red[a] and red[a + span] and writes red[a]: its own slots only
+            const int a = base + slot;
+            if (a < span) {
+                const JacQ r = coop_add(red[a], red[a + span], false, quad);
+                if (quad == 0) red[a] = r;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // [|z|] P (g1_subgroup.hpp: mul_by_z_abs_q) with the doublings shared by the quad
 __device__ __forceinline__ JacQ coop_mul_by_z_abs(const JacQ& p, int q) {
     constexpr uint64_t Z = 0xd201000000010000ULL;
@@ -97,7 +153,7 @@ __device__ __forceinline__ JacQ coop_mul_by_z_abs(const JacQ& p, int q) {
 #pragma unroll 1
     for (int i = 62; i >= 0; i--) {
         acc = coop_dbl(acc, q);
-        if ((Z >> i) & 1) acc = add(acc, p);  // five general additions in 63 steps: repeated on every lane
+        if ((Z >> i) & 1) acc = coop_add(acc, p, false, q);
     }
     return acc;
 }

@@ -14,6 +14,7 @@
 #include "engine.hpp"
 #include "kcommon.hpp"
 #include "curve29.hpp"
+#include "g1_coop.hpp"
 #include "launch.hpp"
 
 namespace kzg {
@@ -57,27 +58,104 @@ __global__ __launch_bounds__(CIRC_LANES) void k_g1_circ_sum(const JacQ* __restri
     JacQ acc = *entry(terms[l]);
     constexpr int LEVELS = 8;  // log2(CIRC_LANES)
     static_assert(CIRC_LANES == 1 << LEVELS, "tree depth");
-    const int steps = per_lane - 1 + LEVELS;
 #pragma unroll 1
-    for (int s = 0; s < steps; s++) {  // one inlined addition serves the accumulation and the tree
+    for (int s = 0; s < per_lane - 1; s++) {
+        const uint32_t w = terms[(size_t)(s + 1) * CIRC_LANES + l];
+        if ((w >> 17) & 1) acc = add(acc, *entry(w), (w >> 16) & 1);
+    }
+    part[l] = acc;
+    coop_tree_fold<CIRC_LANES>(part, CIRC_LANES / 2, l);  // the tree's idle lanes share its additions (g1_coop.hpp)
+    if (l == 0) X[(size_t)(__brev((unsigned)k) >> 25) * stride + b] = part[0];  // proofs leave in bit-reversed order
+}
+
+// The same two kernels with FOUR lanes per chain (g1_coop.hpp): a handful of blobs leaves the chip idle, and both kernels are
+// dependent chains -- T / segs doublings, then ~30 general additions per lane of the sum.  The quad shares each doubling (the
+// beta X of the phi image rides in a lane the doubling leaves idle) and each addition (5.5 multiplication times instead of 16.5).
+__global__ __launch_bounds__(64) void k_g1_dbl_table_coop(const JacQ* __restrict__ X, int stride, int n, int segs, JacQ* __restrict__ D,
+                                                          int T, Fq<1> beta) {
+    const int tid = blockIdx.x * 16 + (threadIdx.x >> 2), quad = threadIdx.x & 3;
+    if (tid >= segs * n * N_CELLS) return;
+    const int seg = tid / (n * N_CELLS), bj = tid - seg * n * N_CELLS;
+    const int b = bj >> 7, j = bj & 127;
+    const int seg_len = 128 / segs;
+    const int t0 = seg_len * seg;
+    const int t1 = seg + 1 < segs ? t0 + seg_len : T;
+    JacQ p = X[(size_t)j * stride + seg * n + b];
+    JacQ* d0 = D + (size_t)bj * 2 * T;
+    JacQ* d1 = d0 + T;
+    const Fq<XB> bw = relax<XB>(beta);
+#pragma unroll 1
+    for (int t = t0; t < t1; t++) {
+        // coop_dbl with the product beta X in lane 3 of its first level
+        const bool l0 = quad == 0, l1 = quad == 1, l3 = quad == 3;
+        const Fq<XB> a1 = select(l0 || l3, p.x, p.y);
+        const Fq<XB> b1 = select(l0, p.x, select(l1, p.y, select(l3, bw, relax<XB>(p.z))));
+        const Fq<2> r1 = mul(a1, b1);
+        const Fq<2> A = quad_bcast<0>(r1), B = quad_bcast<1>(r1), YZ = quad_bcast<2>(r1), bX = quad_bcast<3>(r1);
+        if (quad == 0) d0[t] = p;
+        if (quad == 1) {
+            JacQ q = p;
+            q.x = relax<XB>(bX);
+            d1[t] = q;
+        }
+        const Fq<6> E = add(dbl(A), A);
+        const Fq<2> r2 = mul(select(l0, p.x, relax<XB>(E)), select(l0, relax<XB>(B), relax<XB>(E)));
+        const Fq<2> XY2 = quad_bcast<0>(r2), F = quad_bcast<1>(r2);
+        const Fq<8> Dd = dbl2(XY2);
+        auto x3 = sub2(F, Dd);
+        auto y3 = mul_add(E, sub(Dd, x3), neg2(B), dbl2(B));
+        p.x = relax<XB>(x3);
+        p.y = relax<XB>(y3);
+        p.z = dbl(YZ);
+    }
+}
+// Two blocks per output (blockIdx.z), each 64 logical lanes of four threads = four waves, one per SIMD of a CU: a block of 128
+// logical lanes would put two waves on every SIMD of its CU and run at half speed next to 128 idle CUs (measured: no gain).
+// Logical lane L of half h takes the columns 128 h + L and 128 h + L + 64 of the term table's rows; the halves' sums meet in
+// k_g1_circ_join.  part2: [blob][k][2].
+__global__ __launch_bounds__(256) void k_g1_circ_sum_coop(const JacQ* __restrict__ D, int T, const uint32_t* __restrict__ terms,
+                                                          int per_lane, JacQ* __restrict__ part2) {
+    constexpr int LL = CIRC_LANES / 4, LEVELS = 6;
+    static_assert(LL == 1 << LEVELS, "tree depth");
+    __shared__ JacQ part[LL];
+    const int k = blockIdx.x, b = blockIdx.y, half = blockIdx.z, l = threadIdx.x >> 2, quad = threadIdx.x & 3;
+    const JacQ* Db = D + (size_t)b * N_CELLS * 2 * T;
+    auto entry = [&](uint32_t w) -> const JacQ* {
+        const int j = (k - (int)(w & 127)) & 127;
+        return Db + ((size_t)(j * 2 + ((w >> 15) & 1))) * T + ((w >> 7) & 255);
+    };
+    const int col0 = 2 * LL * half + l;
+    JacQ acc = *entry(terms[col0]);
+    const int n_terms = 2 * per_lane;  // per logical lane
+    const int steps = n_terms - 1 + LEVELS;
+#pragma unroll 1
+    for (int s = 0; s < steps; s++) {
         JacQ other;
         bool act, minus = false;
-        if (s < per_lane - 1) {
-            const uint32_t w = terms[(size_t)(s + 1) * CIRC_LANES + l];
+        if (s < n_terms - 1) {
+            const int i = s + 1;
+            const uint32_t w = terms[(size_t)(i >> 1) * CIRC_LANES + col0 + LL * (i & 1)];
             act = (w >> 17) & 1;
             minus = (w >> 16) & 1;
             if (act) other = *entry(w);
         } else {
-            const int span = (CIRC_LANES / 2) >> (s - (per_lane - 1));
-            part[l] = acc;
+            const int span = (LL / 2) >> (s - (n_terms - 1));
+            if (quad == 0) part[l] = acc;
             __syncthreads();
             act = l < span;
             if (act) other = part[l + span];
             __syncthreads();
         }
-        if (act) acc = add(acc, other, minus);
+        if (act) acc = coop_add(acc, other, minus, quad);
     }
-    if (l == 0) X[(size_t)(__brev((unsigned)k) >> 25) * stride + b] = acc;  // proofs leave in bit-reversed order
+    if (threadIdx.x == 0) part2[((size_t)b * N_CELLS + k) * 2 + half] = acc;
+}
+__global__ __launch_bounds__(64) void k_g1_circ_join(const JacQ* __restrict__ part2, JacQ* __restrict__ X, int stride, int n) {
+    const int o = blockIdx.x * 16 + (threadIdx.x >> 2), quad = threadIdx.x & 3;
+    if (o >= n * N_CELLS) return;
+    const int b = o >> 7, k = o & 127;
+    const JacQ r = coop_add(part2[(size_t)o * 2], part2[(size_t)o * 2 + 1], false, quad);
+    if (quad == 0) X[(size_t)(__brev((unsigned)k) >> 25) * stride + b] = r;  // proofs leave in bit-reversed order
 }
 
 namespace launch {
@@ -87,12 +165,22 @@ void preload_k_g1circ() {
     hipFuncAttributes a;
     (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_g1_dbl_table));
 }
-size_t g1_circ_table_bytes(int n, int T) { return (size_t)n * N_CELLS * 2 * T * sizeof(JacQ); }
+size_t g1_circ_table_bytes(int n, int T) { return (size_t)n * N_CELLS * 2 * (T + 1) * sizeof(JacQ); }  // + two partial sums per output
 // X: [128][stride] MSM outputs (natural order) -> X: proofs (bit-reversed), for blobs 0 .. n-1
 void g1_circ128(void* X, int stride, int n, int segs, void* D, int T, const void* terms, int per_lane, const Fp12w& beta, hipStream_t st) {
     Fp b384;
     for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
     const Fq<1> bt = fq_from_fp(b384);
+    // one blob: 1.47 -> 1.27 ms per call; from two blobs on the chip is busy enough for the quads' extra instructions to cost more than
+    // the shorter chains save (2 blobs 1.74 -> 1.79 ms, 4 blobs 2.29 -> 2.49): the one-lane forms stay (and ETH_KZG_AMD_COOP_POINTS=0 forces them)
+    if (n == 1 && coop_points_max() > 0) {
+        k_g1_dbl_table_coop<<<(segs * n * N_CELLS + 15) / 16, 64, 0, st>>>((const JacQ*)X, stride, n, segs, (JacQ*)D, T, bt);
+        // the halves' sums go behind the table (g1_circ_table_bytes reserves the room)
+        JacQ* part2 = (JacQ*)D + (size_t)n * N_CELLS * 2 * T;
+        k_g1_circ_sum_coop<<<dim3(N_CELLS, n, 2), CIRC_LANES, 0, st>>>((const JacQ*)D, T, (const uint32_t*)terms, per_lane, part2);
+        k_g1_circ_join<<<(n * N_CELLS + 15) / 16, 64, 0, st>>>(part2, (JacQ*)X, stride, n);
+        return;
+    }
     k_g1_dbl_table<<<(segs * n * N_CELLS + 63) / 64, 64, 0, st>>>((const JacQ*)X, stride, n, segs, (JacQ*)D, T, bt);
     k_g1_circ_sum<<<dim3(N_CELLS, n), CIRC_LANES, 0, st>>>((const JacQ*)D, T, (const uint32_t*)terms, per_lane, (JacQ*)X, stride);
 }

@@ -305,11 +305,7 @@ __global__ __launch_bounds__(256) void k_pip_window(const JacQ* __restrict__ buc
         __syncthreads();
     }
     if (t == 0) T[0] = jacq_inf();  // T[0] counted bucket 0's suffix; the weighted sum starts at b = 1
-    __syncthreads();
-    for (int span = PIP_B / 2; span >= 1; span >>= 1) {
-        if (t < span) T[t] = add(T[t], T[t + span]);
-        __syncthreads();
-    }
+    coop_tree_fold<PIP_B>(T, PIP_B / 2, t);
     if (t == 0) wsum[job * W + w] = T[0];
 }
 // (the 16 windows take the wave's 16 quads: four lanes share each of the up to 120 dependent doublings, g1_coop.hpp)
@@ -519,14 +515,9 @@ __global__ __launch_bounds__(PS_LANES) void k_ps_buckets(const AffQ* __restrict_
             cur = nxt;
         }
     }
-    JacQ sum = to_jacq(acc);
-    for (int span = PS_LANES / 2; span >= 1; span >>= 1) {
-        red[l] = sum;
-        __syncthreads();
-        if (l < span) sum = add(sum, red[l + span]);
-        __syncthreads();
-    }
-    if (l == 0) buckets[(size_t)job * PIP_B + b] = sum;
+    red[l] = to_jacq(acc);
+    coop_tree_fold<PS_LANES>(red, PS_LANES / 2, l);  // the idle lanes of each level join its additions (g1_coop.hpp)
+    if (l == 0) buckets[(size_t)job * PIP_B + b] = red[0];
 }
 // points[dst_off + i] = src[i] (device gather of the 64 SRS points behind the proofs/commitments)
 __global__ void k_copy_affine(const G1Affine* __restrict__ src, G1Affine* __restrict__ dst, int n) {

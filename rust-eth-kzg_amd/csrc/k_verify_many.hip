@@ -313,14 +313,26 @@ __global__ __launch_bounds__(256) void k_vm_reduce_small(const JacQ* __restrict_
         for (int r = rlo + l; r < rhi; r += 128) acc = add(acc, prod[2 * (size_t)n + r]);
         if (l < 64) acc = add(acc, prod[2 * (size_t)n + m + 64 * (size_t)b + l]);
     }
+    // two trees of 128 partial sums side by side (job 0 in red[0..128), job 1 in red[128..256)): each half of the block folds its own
+    red[t] = acc;
+    __syncthreads();
+    {
+        JacQ* mine = red + 128 * job;
+        const int quad = l & 3, slot = l >> 2;  // 32 additions per round and half
 #pragma unroll 1
-    for (int span = 64; span >= 1; span >>= 1) {
-        red[t] = acc;
-        __syncthreads();
-        if (l < span) acc = add(acc, red[t + span]);
-        __syncthreads();
+        for (int span = 64; span >= 1; span >>= 1) {
+#pragma unroll 1
+            for (int base = 0; base < span; base += 32) {
+                const int a = base + slot;
+                if (a < span) {
+                    const JacQ r = coop_add(mine[a], mine[a + span], false, quad);
+                    if (quad == 0) mine[a] = r;
+                }
+            }
+            __syncthreads();
+        }
     }
-    if (l == 0) out[2 * (size_t)b + job] = acc;
+    if (l == 0) out[2 * (size_t)b + job] = red[128 * job];
 }
 // per problem b: out[2b] = sum of prod[cells of b], out[2b + 1] = sum of prod[n + cells of b] + sum of prod[2n + rows of b]
 // + icommit[b]; threads 0-127 take the first sum, 128-255 the second, 7-level trees in LDS
