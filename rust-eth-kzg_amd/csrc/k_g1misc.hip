@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void k_g1_compress(const JacQ* __restrict__ X, 
 }
 
 // sum over positions: out[slice] = sum_pos X[pos*stride + slice]   (final fold of the commitment MSM)
-// A block per slice, a lane per position, a six-level tree through LDS: the lane-per-slice loop this replaces was a chain of 63
+// A block per slice, a lane per position, a six-level tree through LDS (its idle lanes sharing the additions): the lane-per-slice loop this replaces was a chain of 63
 // dependent additions -- 1.0 ms whatever the batch, two thirds of a single blob's commitment (round 4: 1.59 -> 0.7 ms), and
 // still the longer way at 2048 blobs (32 waves for 1.0 ms against 2048 short ones).  X[slice] (position 0) is read by its own
 // block only, so the sum may land there.
@@ -73,14 +73,9 @@ __global__ __launch_bounds__(64) void k_g1_sum_positions(JacQ* __restrict__ X, i
     const int slice = blockIdx.x, t = threadIdx.x;
     JacQ acc = t < n_pos ? X[(size_t)t * stride + slice] : jacq_inf();
     for (int p = t + 64; p < n_pos; p += 64) acc = add(acc, X[(size_t)p * stride + slice]);
-#pragma unroll 1
-    for (int span = 32; span >= 1; span >>= 1) {
-        T[t] = acc;
-        __syncthreads();
-        if (t < span) acc = add(acc, T[t + span]);
-        __syncthreads();
-    }
-    if (t == 0) X[slice] = acc;
+    T[t] = acc;
+    coop_tree_fold<64>(T, 32, t);  // four lanes per addition (g1_coop.hpp)
+    if (t == 0) X[slice] = T[0];
 }
 
 // ------------------------------------------------------------------------------------------------

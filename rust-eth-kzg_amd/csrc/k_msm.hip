@@ -2,6 +2,7 @@
 #include "engine.hpp"
 #include "kcommon.hpp"
 #include "curve29.hpp"
+#include "g1_coop.hpp"
 #include "launch.hpp"
 #include "glv.hpp"
 
@@ -228,17 +229,11 @@ __global__ __launch_bounds__(256) void k_msm_fixed_flat(const Fr* __restrict__ s
             xacc = add_mixed(xacc, p, d < 0);
         }
     }
-    JacQ acc = msm_acc_to_jacq(xacc);
-#pragma unroll 1
-    for (int span = 128; span >= 1; span >>= 1) {
-        red[tid] = acc;
-        __syncthreads();
-        if (tid < span) acc = add(acc, red[tid + span]);
-        __syncthreads();
-    }
+    red[tid] = msm_acc_to_jacq(xacc);
+    coop_tree_fold<256>(red, 128, tid);  // the tree's idle lanes share its additions (g1_coop.hpp)
     if (tid == 0) {
         const int pos = brp_bits ? (int)(__brev((unsigned)group) >> (32 - brp_bits)) : group;
-        out[(size_t)pos * out_stride + slice] = acc;
+        out[(size_t)pos * out_stride + slice] = red[0];
     }
 }
 
