@@ -9,6 +9,7 @@
 // words: 4 per operation: dst slot, a slot, b (slot | number of doublings | constant id), flags (1 = subtract, 2 = doubling run, 4 = a + b to dst AND a - b to slot flags >> 16; bits 3-7 of an addition: doublings of operand a first).
 #include "engine.hpp"
 #include "g1_mulc.hpp"
+#include "g1_coop.hpp"
 
 namespace kzg {
 
@@ -62,6 +63,33 @@ __global__ __launch_bounds__(64, 2) void k_slp_add(JacQ* __restrict__ A, int str
     const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
                    b = __builtin_amdgcn_readfirstlane(w[2]), fl = __builtin_amdgcn_readfirstlane(w[3]);
     slp_cheap_op(A, stride, blockIdx.x * 64 + threadIdx.x, dst, a, b, fl);
+}
+
+// The cheap operations of ONE lane group (<= 64 blobs: BASELINE config 4's and 5's per-GPU shares) with four lanes per blob
+// (g1_coop.hpp): a level is then a few hundred waves on an idle chip, each a single addition -- 16.5 multiplication times for one
+// lane, 5.5 for a quad; a doubling run likewise 3.5 per doubling instead of 6.5.  The sum-and-difference pair is two
+// quad additions (11 against the shared form's 20).  16 blobs per wave; every lane of a quad stores the same result.
+__global__ __launch_bounds__(64, 2) void k_slp_add_coop(JacQ* __restrict__ A, int stride, const uint32_t* __restrict__ words, int lanes) {
+    const uint32_t* w = words + (size_t)blockIdx.y * 4;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
+                   b = __builtin_amdgcn_readfirstlane(w[2]), fl = __builtin_amdgcn_readfirstlane(w[3]);
+    const int lane = blockIdx.x * 16 + (threadIdx.x >> 2), quad = threadIdx.x & 3;
+    if (lane >= lanes) return;
+    JacQ r = A[(size_t)a * stride + lane];
+    const uint32_t runs = (fl & 2u) ? b : (fl >> 3) & 31u;
+#pragma unroll 1
+    for (uint32_t k = 0; k < runs; k++) r = coop_dbl(r, quad);
+    if (!(fl & 2u)) {
+        const JacQ q = A[(size_t)b * stride + lane];
+        if (fl & 4u) {
+            const JacQ d = coop_add(r, q, true, quad);
+            A[(size_t)(fl >> 16) * stride + lane] = d;
+            r = coop_add(r, q, false, quad);
+        } else {
+            r = coop_add(r, q, (fl & 1u) != 0, quad);
+        }
+    }
+    A[(size_t)dst * stride + lane] = r;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -178,7 +206,10 @@ void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int
         for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
         k_slp_mulc<<<grid, 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fq_from_fp(b384));
     } else {
-        k_slp_add<<<dim3((unsigned)(lanes / 64), (unsigned)count), 64, 0, st>>>((JacQ*)arena, stride, words);
+        // one lane group and few enough operations for every quad wave to have a SIMD of its own: four lanes per blob
+        if (lanes == 64 && count * 4 <= 1024 && coop_points_max() > 0)
+            k_slp_add_coop<<<dim3(4u, (unsigned)count), 64, 0, st>>>((JacQ*)arena, stride, words, lanes);
+        else k_slp_add<<<dim3((unsigned)(lanes / 64), (unsigned)count), 64, 0, st>>>((JacQ*)arena, stride, words);
     }
 }
 size_t g1_slp_walk_sync_ints(int n_groups, int n_levels) { return 32 * 8 + 16 * (size_t)n_groups * n_levels + 32; }
