@@ -22,6 +22,18 @@ __global__ __launch_bounds__(64, 2) void k_slp_mulc(JacQ* __restrict__ A, int st
     const JacQ src = A[(size_t)a * stride + lane];
     A[(size_t)dst * stride + lane] = mul_by_recoded(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta);
 }
+// the constant multiplications of a batch of <= 16 blobs: four lanes per blob (a wave = 16 blobs x one operation), the quad sharing
+// the digit loop's doublings and mixed additions
+__global__ __launch_bounds__(64, 2) void k_slp_mulc_coop(JacQ* __restrict__ A, int stride, const uint32_t* __restrict__ words,
+                                                         const uint32_t* __restrict__ naf, Fq<1> beta, int lanes) {
+    const uint32_t* w = words + (size_t)blockIdx.x * 4;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
+                   cid = __builtin_amdgcn_readfirstlane(w[2]);
+    const int lane = blockIdx.y * 16 + (threadIdx.x >> 2), quad = threadIdx.x & 3;
+    if (lane >= lanes) return;
+    const JacQ src = A[(size_t)a * stride + lane];
+    A[(size_t)dst * stride + lane] = mul_by_recoded<true>(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta, quad);
+}
 // one cheap operation of the program on one lane: flags & 2: a run of b doublings; otherwise an addition (flags & 1: subtraction;
 // flags & 4: a + b to dst AND a - b to slot flags >> 16) whose FIRST operand is doubled (flags >> 3) & 31 times in registers
 // before the second one is read -- the schedule folds a doubling run into its only consumer (g1_linmap.hpp: make_schedule)
@@ -198,13 +210,17 @@ void preload_k_g1slp() {
 }
 // kind: 3 multiplication by a constant, anything else the mixed addition / subtraction / doubling launch (linmap::OpKind)
 void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int count, const void* naf, const Fp12w& beta,
-                   hipStream_t st, int lanes) {
+                   hipStream_t st, int lanes, int coop_lanes) {
     if (lanes <= 0) lanes = stride;  // (a sub-range of the lanes: arena already points at its first lane, stride stays the arena's)
     const dim3 grid((unsigned)count, (unsigned)(lanes / 64));
     if (kind == 3) {
         Fp b384;
         for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
-        k_slp_mulc<<<grid, 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fq_from_fp(b384));
+        // coop_lanes: the blobs that are really there when they are few enough for four lanes each (<= 16: one quad wave per operation)
+        if (coop_lanes > 0 && coop_points_max() > 0)
+            k_slp_mulc_coop<<<dim3((unsigned)count, (unsigned)((coop_lanes + 15) / 16)), 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf,
+                                                                                                     fq_from_fp(b384), coop_lanes);
+        else k_slp_mulc<<<grid, 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fq_from_fp(b384));
     } else {
         // one lane group and few enough operations for every quad wave to have a SIMD of its own: four lanes per blob
         if (lanes == 64 && count * 4 <= 1024 && coop_points_max() > 0)
