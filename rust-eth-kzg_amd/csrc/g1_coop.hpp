@@ -146,6 +146,76 @@ __device__ __forceinline__ void coop_tree_fold(JacQ* red, int first_span, int ti
     }
 }
 
+// ---- two lanes per point operation (a batch of 17 .. 32 blobs in a 64-lane wave: lanes 2b and 2b + 1 hold blob b) ----
+// every lane of a pair receives the value of the pair's lane J
+template <int J, int B>
+__device__ __forceinline__ Fq<B> pair_bcast(const Fq<B>& a) {
+    static_assert(J == 0 || J == 1, "lane of the pair");
+    constexpr int CTRL = J == 0 ? 0xA0 : 0xF5;  // quad_perm [0,0,2,2] / [1,1,3,3]
+    Fq<B> r;
+#pragma unroll
+    for (int i = 0; i < QL; i++) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v[i], CTRL, 0xf, 0xf, true);
+    return r;
+}
+// doubling by a pair: X^2 | Y^2  ->  X Y^2 | Y Z  ->  (3 X^2)^2 | (2 Y^2)^2  ->  E (D - X3) on both: 4 multiplication times (6.5 alone)
+__device__ __forceinline__ JacQ coop2_dbl(const JacQ& p, int h) {
+    const bool l0 = h == 0;
+    const Fq<XB> a1 = select(l0, p.x, p.y);
+    const Fq<2> r1 = mul(a1, a1);
+    const Fq<2> A = pair_bcast<0>(r1), B = pair_bcast<1>(r1);
+    const Fq<2> r2 = mul(select(l0, p.x, p.y), select(l0, relax<XB>(B), relax<XB>(p.z)));
+    const Fq<2> XY2 = pair_bcast<0>(r2), YZ = pair_bcast<1>(r2);
+    const Fq<6> E = add(dbl(A), A);
+    const Fq<6> a3 = select(l0, E, relax<6>(dbl(B)));
+    const Fq<2> r3 = mul(a3, a3);
+    const Fq<2> F = pair_bcast<0>(r3), B4 = pair_bcast<1>(r3);  // E^2, 4 B^2
+    const Fq<8> D = dbl2(XY2);
+    JacQ r;
+    auto x3 = sub2(F, D);
+    r.x = relax<XB>(x3);
+    r.y = relax<XB>(sub(mul(E, sub(D, x3)), dbl(B4)));  // E (D - X3) - 8 B^2
+    r.z = dbl(YZ);
+    return r;
+}
+// mixed addition by a pair: Z1^2 | y2 Z1 -> x2 Z1Z1 | (y2 Z1) Z1Z1 -> H^2 | rr^2 -> H I | X1 I -> fused Y3 | Z1 H: 5.5 (10.5 alone)
+template <class Aff>
+__device__ __forceinline__ JacQ coop2_add_mixed(const JacQ& p, const Aff& q, bool negq, int h2) {
+    if (coop_affine_is_inf(q)) return p;
+    const bool l0 = h2 == 0;
+    const Fq<2> qx = relax<2>(q.x), qy = relax<2>(q.y);
+    const Fq<2> r1 = mul(select(l0, p.z, relax<ZB>(qy)), p.z);
+    const Fq<2> z1z1 = pair_bcast<0>(r1), t = pair_bcast<1>(r1);
+    const Fq<2> r2 = mul(select(l0, qx, t), z1z1);
+    const Fq<2> u2 = pair_bcast<0>(r2), s2p = pair_bcast<1>(r2);
+    auto h = sub(u2, p.x);
+    auto rr = dbl(signed_sub(negq, s2p, p.y));
+    constexpr int HB = fq_bound<decltype(h)>::value, RB = fq_bound<decltype(rr)>::value, WB = HB > RB ? HB : RB;
+    const Fq<WB> a3 = select(l0, relax<WB>(h), relax<WB>(rr));
+    const Fq<2> r3 = mul(a3, a3);
+    const Fq<2> hh = pair_bcast<0>(r3), rr2 = pair_bcast<1>(r3);
+    const Fq<8> i = dbl2(hh);
+    constexpr int XH = HB > XB ? HB : XB;
+    const Fq<2> r4 = mul(select(l0, relax<XH>(h), relax<XH>(p.x)), i);
+    const Fq<2> j = pair_bcast<0>(r4), v = pair_bcast<1>(r4);
+    auto x3 = sub_sub2(rr2, j, v);
+    // lane 0: the fused pair of Y3, rr (V - X3) - 2 Y1 J; lane 1: Z1 H as the same instruction stream with a zero second product
+    auto vx = sub(v, x3);
+    auto ny = neg2(p.y);
+    constexpr int VB = fq_bound<decltype(vx)>::value, NB = fq_bound<decltype(ny)>::value;
+    constexpr int AB5 = RB > ZB ? RB : ZB, BB5 = VB > HB ? VB : HB;
+    const Fq<AB5> a5 = select(l0, relax<AB5>(rr), relax<AB5>(p.z));
+    const Fq<BB5> b5 = select(l0, relax<BB5>(vx), relax<BB5>(h));
+    const Fq<NB> c5 = select(l0, ny, relax<NB>(fq_zero()));
+    const Fq<2> r5 = mul_add(a5, b5, c5, j);
+    const Fq<2> y3 = pair_bcast<0>(r5), zh = pair_bcast<1>(r5);
+    JacQ r;
+    r.x = relax<XB>(x3);
+    r.y = relax<XB>(y3);
+    r.z = dbl(zh);
+    if (product_is_zero(zh)) return add_mixed_slow(p, q, negq);
+    return r;
+}
+
 // [|z|] P (g1_subgroup.hpp: mul_by_z_abs_q) with the doublings shared by the quad
 __device__ __forceinline__ JacQ coop_mul_by_z_abs(const JacQ& p, int q) {
     constexpr uint64_t Z = 0xd201000000010000ULL;

@@ -23,9 +23,10 @@ namespace kzg {
 // Every digit test is a scalar branch on wave-uniform data: no lane divergence.
 // tab[k][2][33] words = 2 x 132 signed bytes: digit t of half h is byte t of tab[k][h].
 // row: the 2 x TWIDDLE_WORDS digit words of the constant (wave-uniform address)
-// quad >= 0 (COOP): the four lanes of a quad hold the same p and share the doublings and mixed additions of the digit loop
-// (g1_coop.hpp: 3.5 and 5.5 multiplication times instead of 6.5 and 10.5); the table is built on every lane
-template <bool COOP = false>
+// COOP = 4: the four lanes of a quad hold the same p and share the doublings and mixed additions of the digit loop (g1_coop.hpp:
+// 3.5 and 5.5 multiplication times instead of 6.5 and 10.5); COOP = 2: the two lanes of a pair (4 and 5.5); `quad` is the lane's
+// index in its quad / pair.  The table is built on every lane.
+template <int COOP = 0>
 __device__ __forceinline__ JacQ mul_by_recoded(const JacQ& p, const uint32_t* __restrict__ row, const Fq<1>& beta, int quad = -1) {
     constexpr int NT = 1 << (launch::TWIDDLE_WNAF_W - 2);  // odd multiples P, 3P, .., (2 NT - 1) P
     // The table is brought to ONE common Z = prod z_j without an inversion: (X_j l_j^2, Y_j l_j^3) with l_j = Z / z_j are
@@ -113,7 +114,8 @@ __device__ __forceinline__ JacQ mul_by_recoded(const JacQ& p, const uint32_t* __
 #pragma unroll 1
         for (int q = 3; q >= 0; q--) {
             if (started) {
-                if constexpr (COOP) acc = coop_dbl(acc, quad);
+                if constexpr (COOP == 4) acc = coop_dbl(acc, quad);
+                else if constexpr (COOP == 2) acc = coop2_dbl(acc, quad);
                 else acc = dbl(acc);
             }
 #pragma unroll 1
@@ -128,7 +130,8 @@ __device__ __forceinline__ JacQ mul_by_recoded(const JacQ& p, const uint32_t* __
                     acc.y = d < 0 ? relax<XB>(neg(op.y)) : relax<XB>(op.y);
                     acc.z = relax<ZB>(fq_one());
                     started = true;
-                } else if constexpr (COOP) acc = coop_add_mixed(acc, op, d < 0, quad);
+                } else if constexpr (COOP == 4) acc = coop_add_mixed(acc, op, d < 0, quad);
+                else if constexpr (COOP == 2) acc = coop2_add_mixed(acc, op, d < 0, quad);
                 else acc = add_mixed(acc, op, d < 0);
             }
         }

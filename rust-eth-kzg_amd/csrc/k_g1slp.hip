@@ -32,7 +32,18 @@ __global__ __launch_bounds__(64, 2) void k_slp_mulc_coop(JacQ* __restrict__ A, i
     const int lane = blockIdx.y * 16 + (threadIdx.x >> 2), quad = threadIdx.x & 3;
     if (lane >= lanes) return;
     const JacQ src = A[(size_t)a * stride + lane];
-    A[(size_t)dst * stride + lane] = mul_by_recoded<true>(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta, quad);
+    A[(size_t)dst * stride + lane] = mul_by_recoded<4>(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta, quad);
+}
+// ... and of 17 .. 32 blobs (BASELINE config 5's per-GPU share): two lanes per blob, a wave = 32 blobs x one operation
+__global__ __launch_bounds__(64, 2) void k_slp_mulc_coop2(JacQ* __restrict__ A, int stride, const uint32_t* __restrict__ words,
+                                                          const uint32_t* __restrict__ naf, Fq<1> beta, int lanes) {
+    const uint32_t* w = words + (size_t)blockIdx.x * 4;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
+                   cid = __builtin_amdgcn_readfirstlane(w[2]);
+    const int lane = threadIdx.x >> 1, half = threadIdx.x & 1;
+    if (lane >= lanes) return;
+    const JacQ src = A[(size_t)a * stride + lane];
+    A[(size_t)dst * stride + lane] = mul_by_recoded<2>(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta, half);
 }
 // one cheap operation of the program on one lane: flags & 2: a run of b doublings; otherwise an addition (flags & 1: subtraction;
 // flags & 4: a + b to dst AND a - b to slot flags >> 16) whose FIRST operand is doubled (flags >> 3) & 31 times in registers
@@ -217,7 +228,10 @@ void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int
         Fp b384;
         for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
         // coop_lanes: the blobs that are really there when they are few enough for four lanes each (<= 16: one quad wave per operation)
-        if (coop_lanes > 0 && coop_points_max() > 0)
+        // or two (<= 32: still one wave per operation)
+        if (coop_lanes > 16 && coop_points_max() > 0)
+            k_slp_mulc_coop2<<<(unsigned)count, 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fq_from_fp(b384), coop_lanes);
+        else if (coop_lanes > 0 && coop_points_max() > 0)
             k_slp_mulc_coop<<<dim3((unsigned)count, (unsigned)((coop_lanes + 15) / 16)), 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf,
                                                                                                      fq_from_fp(b384), coop_lanes);
         else k_slp_mulc<<<grid, 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fq_from_fp(b384));

@@ -86,7 +86,7 @@ void g1_dft128_direct(void* X, void* tmpA, void* prod, int stride, int n_in, int
 // k_g1slp.hip: one launch of the straight-line program of the FK20 proofs map (g1_linmap.hpp); kind = linmap::OpKind
 void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int count, const void* naf, const Fp12w& beta,
                    hipStream_t st, int lanes = 0 /* lanes to run (a multiple of 64, from the arena pointer on); 0: all `stride` of them */,
-                   int coop_lanes = 0 /* > 0: the batch has this many blobs (<= 16): the constant multiplications take four lanes per blob */);
+                   int coop_lanes = 0 /* > 0: the batch has this many blobs (<= 32): the constant multiplications take four (<= 16) or two lanes per blob */);
 
 // the cheap operations of one phase (before / after the constant multiplications) in ONE launch: a ticket walker with
 // per-(lane group, level) completion counters; returns the error word's position in `sync` (checked by the caller later)
