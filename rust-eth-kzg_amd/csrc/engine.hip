@@ -1431,8 +1431,15 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
     const bool linmap_mode = use_linmap_ && n > circ_max_;
     void* X = w.X;
     const SlpProgram* prog = nullptr;
+    int mulc_coop_lanes = 0;  // > 0: so few blobs that the constant multiplications take several lanes per blob (launch::g1_slp_launch)
     if (linmap_mode) {
-        prog = &slp_program(slp_walk_ ? (int)SLP_TUNED_FUSED : pick_slp_program(bp));
+        int which = slp_walk_ ? (int)SLP_TUNED_FUSED : pick_slp_program(bp);
+        // 33 .. 64 blobs: the constant multiplications run with two lanes per blob = two waves per operation (k_g1slp.hip), so the
+        // compilation with 456 of them (912 waves, one per SIMD) replaces the one with 712 that a lane per blob takes
+        static const int pair64 = [] { const char* e = getenv("ETH_KZG_AMD_SLP_PAIR64"); return e ? atoi(e) : 1; }();
+        if (pair64 && !slp_walk_ && slp_force_ < 0 && bp == 64 && n > 32 && launch::coop_points_max() > 0) which = SLP_DEPTH_456;
+        mulc_coop_lanes = n <= 32 ? n : (bp == 64 && which == SLP_DEPTH_456) ? n : 0;
+        prog = &slp_program(which);
         const size_t need = (size_t)prog->n_slots * bp * launch::SIZEOF_JACQ;
         if (need > w.slp_arena_bytes) {
             if (w.slp_arena) { HIPCK(hipStreamSynchronize(st)); HIPCK(hipFree(w.slp_arena)); w.slp_arena = nullptr; }
@@ -1551,7 +1558,7 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         } else {
             for (auto& L : prog->launches)
                 launch::g1_slp_launch(L.kind, w.slp_arena, bp, (const uint32_t*)prog->d_words + (size_t)L.first * 4, L.count, prog->d_naf, beta_, st, 0,
-                                      n <= 32 ? n : 0);
+                                      mulc_coop_lanes);
             n_launches = (int)prog->launches.size();
         }
         mark_end(mk3, n_launches, st);

@@ -34,13 +34,14 @@ __global__ __launch_bounds__(64, 2) void k_slp_mulc_coop(JacQ* __restrict__ A, i
     const JacQ src = A[(size_t)a * stride + lane];
     A[(size_t)dst * stride + lane] = mul_by_recoded<4>(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta, quad);
 }
-// ... and of 17 .. 32 blobs (BASELINE config 5's per-GPU share): two lanes per blob, a wave = 32 blobs x one operation
+// ... and of 17 .. 64 blobs (BASELINE config 5's and 4's per-GPU shares): two lanes per blob, a wave = 32 blobs x one operation
+// (from 33 blobs on two waves per operation: the engine then picks a compilation of the map with <= 512 multiplications)
 __global__ __launch_bounds__(64, 2) void k_slp_mulc_coop2(JacQ* __restrict__ A, int stride, const uint32_t* __restrict__ words,
                                                           const uint32_t* __restrict__ naf, Fq<1> beta, int lanes) {
     const uint32_t* w = words + (size_t)blockIdx.x * 4;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
                    cid = __builtin_amdgcn_readfirstlane(w[2]);
-    const int lane = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const int lane = blockIdx.y * 32 + (threadIdx.x >> 1), half = threadIdx.x & 1;
     if (lane >= lanes) return;
     const JacQ src = A[(size_t)a * stride + lane];
     A[(size_t)dst * stride + lane] = mul_by_recoded<2>(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta, half);
@@ -230,7 +231,7 @@ void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int
         // coop_lanes: the blobs that are really there when they are few enough for four lanes each (<= 16: one quad wave per operation)
         // or two (<= 32: still one wave per operation)
         if (coop_lanes > 16 && coop_points_max() > 0)
-            k_slp_mulc_coop2<<<(unsigned)count, 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fq_from_fp(b384), coop_lanes);
+            k_slp_mulc_coop2<<<dim3((unsigned)count, (unsigned)((coop_lanes + 31) / 32)), 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fq_from_fp(b384), coop_lanes);
         else if (coop_lanes > 0 && coop_points_max() > 0)
             k_slp_mulc_coop<<<dim3((unsigned)count, (unsigned)((coop_lanes + 15) / 16)), 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf,
                                                                                                      fq_from_fp(b384), coop_lanes);
