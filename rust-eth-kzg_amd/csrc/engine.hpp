@@ -279,6 +279,8 @@ private:
                              const uint8_t* const* proofs, uint64_t lo, uint64_t hi, G1Affine* out2, bool* empty,
                              const VerifyDeviceSource* dsrc = nullptr, VerifyScratch* vs = nullptr);
     bool verify_cells_pairing(const G1Affine* pts2) const;
+    // the same check with the second pair's Miller loop on a thread of the staging pool (the latency path of a single verification)
+    bool verify_cells_pairing_split(const G1Affine* pts2);
     int rs_decode(int R, const uint8_t* d_cells, bool flat_source, const std::vector<int>& slot, const std::vector<int>& stof,
                   const std::vector<uint32_t>& present, int* st_out);
     int recover_batch_to_coeffs(int R, const uint64_t* n_cells, const uint8_t* const* const* cells,

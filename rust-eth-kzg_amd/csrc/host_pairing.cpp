@@ -243,7 +243,7 @@ static Fp12 pow_x(const Fp12& f) {  // f^x with x negative: conj(f^|x|) inside t
     return conj12(acc);
 }
 
-bool product_is_one(const G1Affine* P, const G2Prepared* const* Q, int n) {
+static Fp12 miller_loop_n(const G1Affine* P, const G2Prepared* const* Q, int n) {
     init();
     Fp12 f = one12();
     size_t idx = 0;
@@ -260,7 +260,16 @@ bool product_is_one(const G1Affine* P, const G2Prepared* const* Q, int n) {
         lines();
         if ((X_ABS >> i) & 1) lines();
     }
-    f = conj12(f);  // x < 0
+    return conj12(f);  // x < 0
+}
+Fp12 miller_loop(const G1Affine& P, const G2Prepared& Q) {
+    const G2Prepared* q = &Q;
+    return miller_loop_n(&P, &q, 1);
+}
+Fp12 fp12_mul(const Fp12& a, const Fp12& b) { return a * b; }
+bool product_is_one(const G1Affine* P, const G2Prepared* const* Q, int n) { return final_exponentiation_is_one(miller_loop_n(P, Q, n)); }
+bool final_exponentiation_is_one(const Fp12& f) {
+    init();
     // easy part: f^((p^6-1)(p^2+1))
     Fp12 t = conj12(f) * inv12(f);
     t = frob12(frob12(t)) * t;

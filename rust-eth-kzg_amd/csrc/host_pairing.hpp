@@ -25,6 +25,11 @@ G2Affine g2_neg(const G2Affine& q);
 G2Prepared prepare(const G2Affine& q);
 // prod_i e(P_i, Q_i) == 1 ?   P_i affine (Montgomery coordinates, identity = (0,0)).
 bool product_is_one(const G1Affine* P, const G2Prepared* const* Q, int n);
+// The same check in pieces, for a caller that runs the Miller loops of different pairs on different threads: the loops are
+// independent (each 63 squarings + 68 line products of its own), their values multiply, one final exponentiation decides.
+Fp12 miller_loop(const G1Affine& P, const G2Prepared& Q);    // conjugated already (the BLS parameter is negative)
+Fp12 fp12_mul(const Fp12& a, const Fp12& b);
+bool final_exponentiation_is_one(const Fp12& f);             // f = product of miller_loop values
 
 }  // namespace pairing
 }  // namespace kzg

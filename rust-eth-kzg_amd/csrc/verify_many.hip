@@ -607,7 +607,7 @@ int Engine::verify_cell_kzg_proof_batch_combined(uint64_t n_commitments, const u
             sl.unlock();  // the pairing needs no slot
             rc = st[0] == ERR_DEVICE ? (int)ERR_DEVICE : (int)OK;
             if (rc == ERR_DEVICE) why = last_error();
-            if (st[0] == OK) ver[0] = (empty || verify_cells_pairing(pts)) ? 1 : 0;
+            if (st[0] == OK) ver[0] = (empty || verify_cells_pairing_split(pts)) ? 1 : 0;
           } else {
             std::vector<uint64_t> l0(B), l1(B), l2(B), l3(B);
             std::vector<const uint8_t* const*> pc(B), pl(B), pp(B);

@@ -73,6 +73,9 @@ int main(int argc, char** argv) {
         const G1Affine ok[2] = {a_tau, neg(a_one)}, no[2] = {a_one, neg(a_one)};
         if (!product_is_one(ok, q, 2)) pbad++;
         if (product_is_one(no, q, 2)) pbad++;
+        // the check in pieces (one Miller loop per pair, as the engine runs them on two threads) decides the same
+        if (!final_exponentiation_is_one(fp12_mul(miller_loop(ok[0], q_one), miller_loop(ok[1], q_tau)))) pbad++;
+        if (final_exponentiation_is_one(fp12_mul(miller_loop(no[0], q_one), miller_loop(no[1], q_tau)))) pbad++;
     }
     // identities: e(O, Q) = 1
     const G1Affine id[2] = {aff_inf(), aff_inf()};
