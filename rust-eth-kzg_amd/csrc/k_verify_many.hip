@@ -176,7 +176,10 @@ __device__ JacQ vm_mul_by_scalar(const Base& P, const uint32_t split[8], const F
 // and the mixed additions of the main loop and of the table are shared (3.5 and 5.5 multiplication times instead of 6.5 and
 // 10.5), the table's common-Z step is repeated on every lane.  All four lanes hold the same P and the same scalar, so the
 // digit tests are uniform in the quad.
-__device__ JacQ vm_mul_by_scalar_coop(const AffQ& P, const uint32_t split[8], const Fq<1>& beta, int quad) {
+__device__ __forceinline__ JacQ vm_step_coop(const JacQ& t, const AffQ& p, int quad) { return coop_add_mixed(t, p, false, quad); }
+__device__ __forceinline__ JacQ vm_step_coop(const JacQ& t, const JacQ& p, int quad) { return coop_add(t, p, false, quad); }
+template <class Base>
+__device__ JacQ vm_mul_by_scalar_coop(const Base& P, const uint32_t split[8], const Fq<1>& beta, int quad) {
     constexpr int NT = 8;
     AffQ2 A[NT];
     Fq<2> bx[NT];
@@ -184,11 +187,11 @@ __device__ JacQ vm_mul_by_scalar_coop(const AffQ& P, const uint32_t split[8], co
     {
         JacQ T[NT];
         Fq<ZB> pre[NT];
-        T[0] = to_jacq(P);
+        T[0] = vm_lift(P);
         pre[0] = T[0].z;
 #pragma unroll 1
         for (int j = 1; j < NT; j++) {
-            T[j] = j == 1 ? coop_dbl(T[0], quad) : coop_add_mixed(T[j - 1], P, false, quad);
+            T[j] = j == 1 ? coop_dbl(T[0], quad) : vm_step_coop(T[j - 1], P, quad);
             pre[j] = relax<ZB>(mul(pre[j - 1], T[j].z));
         }
         zc = pre[NT - 1];
@@ -300,6 +303,25 @@ __global__ __launch_bounds__(64, 2) void k_vm_mul_small_coop(const G1Affine* __r
     glv_split_balanced(k, split);
     prod[e] = vm_mul_by_scalar_coop(affq_from_affine(P), split, beta, quad);
 }
+// two trees of 128 partial sums side by side (job 0 in red[0..128), job 1 in red[128..256)), each folded by its half of the
+// block with four lanes per addition (g1_coop.hpp: the idle lanes of a tree level share its additions); red[128 * job] = the sums
+__device__ __forceinline__ void vm_two_trees(JacQ* red, int t, int first_span = 64) {
+    const int job = t >> 7, l = t & 127, quad = l & 3, slot = l >> 2;  // 32 additions per round and half
+    JacQ* mine = red + 128 * job;
+    __syncthreads();
+#pragma unroll 1
+    for (int span = first_span; span >= 1; span >>= 1) {
+#pragma unroll 1
+        for (int base = 0; base < span; base += 32) {
+            const int a = base + slot;
+            if (a < span) {
+                const JacQ r = coop_add(mine[a], mine[a + span], false, quad);
+                if (quad == 0) mine[a] = r;
+            }
+        }
+        __syncthreads();
+    }
+}
 // the sums of a small pass: as k_vm_reduce, with the 64 interpolation terms of the problem in place of icommit[b]
 __global__ __launch_bounds__(256) void k_vm_reduce_small(const JacQ* __restrict__ prod, const int* __restrict__ cell_start,
                                                          const int* __restrict__ row_start, JacQ* __restrict__ out, int n, int m) {
@@ -313,25 +335,8 @@ __global__ __launch_bounds__(256) void k_vm_reduce_small(const JacQ* __restrict_
         for (int r = rlo + l; r < rhi; r += 128) acc = add(acc, prod[2 * (size_t)n + r]);
         if (l < 64) acc = add(acc, prod[2 * (size_t)n + m + 64 * (size_t)b + l]);
     }
-    // two trees of 128 partial sums side by side (job 0 in red[0..128), job 1 in red[128..256)): each half of the block folds its own
     red[t] = acc;
-    __syncthreads();
-    {
-        JacQ* mine = red + 128 * job;
-        const int quad = l & 3, slot = l >> 2;  // 32 additions per round and half
-#pragma unroll 1
-        for (int span = 64; span >= 1; span >>= 1) {
-#pragma unroll 1
-            for (int base = 0; base < span; base += 32) {
-                const int a = base + slot;
-                if (a < span) {
-                    const JacQ r = coop_add(mine[a], mine[a + span], false, quad);
-                    if (quad == 0) mine[a] = r;
-                }
-            }
-            __syncthreads();
-        }
-    }
+    vm_two_trees(red, t);
     if (l == 0) out[2 * (size_t)b + job] = red[128 * job];
 }
 // per problem b: out[2b] = sum of prod[cells of b], out[2b + 1] = sum of prod[n + cells of b] + sum of prod[2n + rows of b]
@@ -349,14 +354,9 @@ __global__ __launch_bounds__(256) void k_vm_reduce(const JacQ* __restrict__ prod
         for (int r = rlo + l; r < rhi; r += 128) acc = add(acc, prod[2 * (size_t)n + r]);
         if (l == 0) acc = add(acc, icommit[b]);
     }
-#pragma unroll 1
-    for (int span = 64; span >= 1; span >>= 1) {
-        red[t] = acc;
-        __syncthreads();
-        if (l < span) acc = add(acc, red[t + span]);
-        __syncthreads();
-    }
-    if (l == 0) out[2 * (size_t)b + job] = acc;
+    red[t] = acc;
+    vm_two_trees(red, t);
+    if (l == 0) out[2 * (size_t)b + job] = red[128 * job];
 }
 
 // Folding the problems' pairing checks into ONE: with weights rho_b (128 bits, derived by the host from ALL the problems'
@@ -372,19 +372,24 @@ __global__ __launch_bounds__(64, 2) void k_vm_fold_mul(const JacQ* __restrict__ 
     uint32_t split[8] = {rho[4 * b], rho[4 * b + 1], rho[4 * b + 2], rho[4 * b + 3] & 0x7fffffffu, 0, 0, 0, 0};
     prod[e] = vm_mul_by_scalar(sums[e], split, beta);
 }
+// the same with four lanes per product (g1_coop.hpp): the 2 B products of a pass are a few waves on an idle chip, and each is a
+// 127-bit multiplication's chain of 124 doublings and ~32 additions
+__global__ __launch_bounds__(64, 2) void k_vm_fold_mul_coop(const JacQ* __restrict__ sums, const uint32_t* __restrict__ rho /*[B][4]*/,
+                                                            JacQ* __restrict__ prod, int n_batches, Fq<1> beta) {
+    const int e = blockIdx.x * 16 + (threadIdx.x >> 2), quad = threadIdx.x & 3;
+    if (e >= 2 * n_batches) return;
+    const int b = e >> 1;
+    uint32_t split[8] = {rho[4 * b], rho[4 * b + 1], rho[4 * b + 2], rho[4 * b + 3] & 0x7fffffffu, 0, 0, 0, 0};
+    prod[e] = vm_mul_by_scalar_coop(sums[e], split, beta, quad);
+}
 __global__ __launch_bounds__(256) void k_vm_fold_sum(const JacQ* __restrict__ prod, JacQ* __restrict__ out2, int n_batches) {
     __shared__ JacQ red[256];
     const int t = threadIdx.x, job = t >> 7, l = t & 127;
     JacQ acc = jacq_inf();
     for (int b = l; b < n_batches; b += 128) acc = add(acc, prod[2 * (size_t)b + job]);
-#pragma unroll 1
-    for (int span = 64; span >= 1; span >>= 1) {
-        red[t] = acc;
-        __syncthreads();
-        if (l < span) acc = add(acc, red[t + span]);
-        __syncthreads();
-    }
-    if (l == 0) out2[job] = acc;
+    red[t] = acc;
+    vm_two_trees(red, t);
+    if (l == 0) out2[job] = red[128 * job];
 }
 
 // sums of the weighted per-problem pairs over RANGES of problems: out[r][j] = sum of prod[b][j], ranges[r][0] <= b < ranges[r][1]
@@ -455,7 +460,9 @@ void vm_fold(const void* sums, const uint32_t* rho, void* prod, void* out2, int 
     if (n_batches <= 0) return;
     Fp b384;
     for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
-    k_vm_fold_mul<<<(2 * n_batches + 63) / 64, 64, 0, st>>>((const JacQ*)sums, rho, (JacQ*)prod, n_batches, fq_from_fp(b384));
+    if (2 * n_batches <= 2 * coop_points_max())
+        k_vm_fold_mul_coop<<<(2 * n_batches + 15) / 16, 64, 0, st>>>((const JacQ*)sums, rho, (JacQ*)prod, n_batches, fq_from_fp(b384));
+    else k_vm_fold_mul<<<(2 * n_batches + 63) / 64, 64, 0, st>>>((const JacQ*)sums, rho, (JacQ*)prod, n_batches, fq_from_fp(b384));
     k_vm_fold_sum<<<1, 256, 0, st>>>((const JacQ*)prod, (JacQ*)out2, n_batches);
 }
 void vm_fold_ranges(const void* prod, const int* ranges, void* out, int n_ranges, hipStream_t st) {
