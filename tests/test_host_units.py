@@ -79,3 +79,29 @@ def test_host_pairing_building_blocks_and_bilinearity(tmp_path):
     [1]_2, [tau]_2: e(a [tau]_1, [1]_2) e(-a [1]_1, [tau]_2) = 1, the unbalanced pair is not, identities are."""
     out = _build_and_run(tmp_path, "test_pairing", os.path.join(ROOT, "rust-eth-kzg_amd", "data", "trusted_setup_4096.bin"))
     assert "fp12 building blocks: 0 mismatches" in out and "pairing checks: 0 mismatches" in out
+
+
+@pytest.mark.timeout(900)
+def test_signed_13_digit_field_matches_saturated_field_and_python_integers(tmp_path):
+    """csrc/fp30.hpp (13 signed 30-bit digits, R = 2^390: the field of the GLV MSM and the constant multiplications) against
+    csrc/field.hpp at every operand class (centred, floor digits, lazy differences), the fused product-minus-value forms, the
+    one- and two-accumulator product pairs, worst-case digit patterns; then raw digit vectors of 200 rounds against Python's
+    integers: out * 2^390 == a * b (mod p), |out| < p, canonical(w) == w mod p."""
+    dump = str(tmp_path / "fp30_dump.txt")
+    out = _build_and_run(tmp_path, "test_fp30", dump)
+    assert "0 mismatches" in out
+    p = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+    R = 1 << 390
+
+    def val(d):
+        return sum(x << (30 * i) for i, x in enumerate(d))
+
+    rows = [line.split() for line in open(dump)]
+    assert len(rows) == 200 * 11
+    for i in range(0, len(rows), 11):
+        g = {r[0]: val([int(x) for x in r[1:]]) for r in rows[i:i + 11]}
+        a, bu, w, cu, du = g["a"], g["bu"], g["w"], g["cu"], g["du"]
+        for name, want, bound in (("mulCU", a * bu, 1), ("mulWC_U", w * a, 1), ("sqr", a * a, 1),
+                                  ("sqr_inj2", a * a - (cu + 2 * du) * R, 4), ("mul_add_split", a * w + cu * a, 1)):
+            assert (g[name] * R - want) % p == 0 and abs(g[name]) < bound * p, name
+        assert g["canon_w"] == w % p

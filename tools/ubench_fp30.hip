@@ -1,0 +1,112 @@
+// tools/ubench_fp30.hip -- multiplication / squaring / fused-pair rates of the signed 13 x 30-bit field (csrc/fp30.hpp)
+// next to the unsigned 14 x 29-bit field (csrc/fp29.hpp, verbatim chains) in ONE binary on ONE GPU, at 2 and 4 waves per SIMD.
+// VERDICT r4's kill criterion for the 13-digit form: less than +8 % multiplications/s at 2 waves/SIMD -> stop.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DFQ_ASM_MAC -I rust-eth-kzg_amd/csrc tools/ubench_fp30.hip -o tools/ubench_fp30
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include "fp29.hpp"
+#include "fp30.hpp"
+using namespace kzg;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+constexpr int ITER = 512;
+
+template <int OP>
+__global__ __launch_bounds__(256, 2) void k29(uint32_t* out, uint32_t seed) {
+    Fq<2> x, y;
+    for (int i = 0; i < QL; i++) { x.v[i] = (threadIdx.x * 2654435761u + seed + i * 977u) & QMASK; y.v[i] = (x.v[i] ^ 0x9e3779bu) & QMASK; }
+    x.v[QL - 1] &= 0xff; y.v[QL - 1] &= 0xff;
+#pragma unroll 1
+    for (int i = 0; i < ITER; i++) {
+        if (OP == 0) { x = mul(x, y); y = mul(y, x); }
+        else if (OP == 1) { x = sqr(x); y = sqr(y); }
+        else { x = mul_add(x, y, y, x); y = mul_add(y, x, x, y); }
+    }
+    uint32_t h = 0;
+    for (int i = 0; i < QL; i++) h ^= x.v[i] ^ y.v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = h;
+}
+// OP: 0 mul C x C -> C, 1 mul C x U -> U, 2 sqr -> C, 3 mul_add four centred, 4 mul_add split (wide operands)
+template <int OP>
+__global__ __launch_bounds__(256, 2) void k30(uint32_t* out, uint32_t seed) {
+    Fs<1, DC> x, y;
+    for (int i = 0; i < SL; i++) { x.v[i] = (int32_t)((threadIdx.x * 2654435761u + seed + i * 977u) & (uint32_t)SMASK) - SHALF; y.v[i] = (x.v[i] ^ 0x1e3779b) % SHALF; }
+    x.v[SL - 1] &= 0xff; y.v[SL - 1] &= 0xff;
+    Fs<1, DU> xu, yu;
+    for (int i = 0; i < SL; i++) { xu.v[i] = x.v[i] & SMASK; yu.v[i] = y.v[i] & SMASK; }
+    xu.v[SL - 1] &= 0xff; yu.v[SL - 1] &= 0xff;
+#pragma unroll 1
+    for (int i = 0; i < ITER; i++) {
+        if (OP == 0) { x = mul(x, y); y = mul(y, x); }
+        else if (OP == 1) { xu = mul<DU>(x, xu); yu = mul<DU>(y, yu); }
+        else if (OP == 2) { x = sqr(x); y = sqr(y); }
+        else if (OP == 3) { x = mul_add(x, y, y, x); y = mul_add(y, x, x, y); }
+        else if (OP == 4) { xu = mul_add<DU>(x, xu, yu, y); yu = mul_add<DU>(y, yu, xu, x); }
+    }
+    uint32_t h = 0;
+    for (int i = 0; i < SL; i++) h ^= x.v[i] ^ y.v[i] ^ xu.v[i] ^ yu.v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = h;
+}
+// the fused forms keep their widened bounds, so they get their own loop bodies (results folded back with a memcpy-like relax)
+template <int OP>
+__global__ __launch_bounds__(256, 2) void k30f(uint32_t* out, uint32_t seed) {
+    Fs<1, DC> x, y;
+    for (int i = 0; i < SL; i++) { x.v[i] = (int32_t)((threadIdx.x * 2654435761u + seed + i * 977u) & (uint32_t)SMASK) - SHALF; y.v[i] = (x.v[i] ^ 0x1e3779b) % SHALF; }
+    x.v[SL - 1] &= 0xff; y.v[SL - 1] &= 0xff;
+    Fs<1, DU> xu, yu;
+    for (int i = 0; i < SL; i++) { xu.v[i] = x.v[i] & SMASK; yu.v[i] = y.v[i] & SMASK; }
+    xu.v[SL - 1] &= 0xff; yu.v[SL - 1] &= 0xff;
+#pragma unroll 1
+    for (int i = 0; i < ITER; i++) {
+        if (OP == 0) {  // product minus stored value, centred out
+            auto t = mul_inj<-1>(x, xu, yu);
+            auto u = mul_inj<-1>(y, yu, xu);
+            for (int k = 0; k < SL; k++) { x.v[k] = t.v[k]; y.v[k] = u.v[k]; }
+        } else if (OP == 1) {  // square minus two stored values, floor digits out
+            auto t = sqr_inj2<-1, -2, DU>(x, xu, yu);
+            auto u = sqr_inj2<-1, -2, DU>(y, yu, xu);
+            for (int k = 0; k < SL; k++) { xu.v[k] = t.v[k]; yu.v[k] = u.v[k]; x.v[k] ^= t.v[k] & 1; y.v[k] ^= u.v[k] & 1; }
+        } else {  // normalise of a lazy difference
+            auto t = normalise(sub_lazy(xu, yu));
+            auto u = normalise(sub_lazy(yu, xu));
+            for (int k = 0; k < SL; k++) { xu.v[k] = t.v[k] & SMASK; yu.v[k] = (u.v[k] + k) & SMASK; }
+        }
+    }
+    uint32_t h = 0;
+    for (int i = 0; i < SL; i++) h ^= x.v[i] ^ y.v[i] ^ xu.v[i] ^ yu.v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = h;
+}
+template <class K>
+double run(const char* name, int blocks, K kern, uint32_t* out) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    kern<<<blocks, 256>>>(out, 1u); CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int r = 0; r < 5; r++) {
+        CK(hipEventRecord(e0)); kern<<<blocks, 256>>>(out, 1u); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+    }
+    const double g = 2.0 * ITER * blocks * 256 / (best * 1e-3) * 1e-9;
+    printf("%-52s blocks=%5d  %8.3f ms  %8.2f G op/s\n", name, blocks, best, g);
+    return g;
+}
+int main() {
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    uint32_t* out; CK(hipMalloc(&out, 1 << 26));
+    for (int wps : {2, 4}) {
+        int blocks = prop.multiProcessorCount * wps;
+        printf("--- %d waves per SIMD requested ---\n", wps);
+        const double m29 = run("fp29 mul (392+14 MACs)", blocks, k29<0>, out);
+        const double s29 = run("fp29 sqr (301 MACs)", blocks, k29<1>, out);
+        const double p29 = run("fp29 mul_add a*b+c*d (588 MACs)", blocks, k29<2>, out);
+        const double m30 = run("fp30 mul C x C -> centred (338+13 MACs)", blocks, k30<0>, out);
+        const double u30 = run("fp30 mul C x U -> floor digits", blocks, k30<1>, out);
+        const double s30 = run("fp30 sqr -> centred (260 MACs)", blocks, k30<2>, out);
+        const double p30 = run("fp30 mul_add, four centred operands (507 MACs)", blocks, k30<3>, out);
+        const double q30 = run("fp30 mul_add, wide operands: split columns", blocks, k30<4>, out);
+        const double i30 = run("fp30 mul_inj (a b - x), centred out", blocks, k30f<0>, out);
+        const double j30 = run("fp30 sqr_inj2 (a^2 - x - 2 y), floor digits out", blocks, k30f<1>, out);
+        run("fp30 normalise(lazy difference)", blocks, k30f<2>, out);
+        printf("ratio fp30 / fp29 at %d waves/SIMD: mul C %.3f  mul U %.3f  sqr %.3f  mul_add C %.3f  mul_add split %.3f  mul_inj %.3f  sqr_inj2/sqr29 %.3f\n",
+               wps, m30 / m29, u30 / m29, s30 / s29, p30 / p29, q30 / p29, i30 / m29, j30 / s29);
+    }
+    return 0;
+}
