@@ -1375,7 +1375,7 @@ void Engine::launch_msm_range(const void* scalars, const SharedTable& t, int g0,
             // still lose 1-2 %: 16384 short waves dealt out as slots free up balance the SIMDs better than 4096 long ones.
             mode = 2;
         }
-        launch::msm_glv(c, mode, scalars, tb, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st, partial);
+        launch::msm_glv(c, mode, scalars, tb, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st);
         return;
     }
     if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) {

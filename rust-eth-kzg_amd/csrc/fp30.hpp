@@ -247,8 +247,8 @@ HD void mont2w(const ProdMul2& pr, int32_t* r, std::integer_sequence<int, Ks...>
 // ---- products -------------------------------------------------------------------------------------------------
 template <int A, int FA, int B, int FB>
 constexpr bool fs_mul_ok() {
-    // one operand centred; a wide operand's top digit must stay below 2^26: |value| <= 32 p
-    return (FA == DC || FB == DC) && (long)A * B <= 256 && (FA == DC || A <= 32) && (FB == DC || B <= 32);
+    // one operand centred; a wide operand's top digit must stay below 2^27: |value| <= 64 p (column 12: 24 + 0.75 + 6.21 U)
+    return (FA == DC || FB == DC) && (long)A * B <= 256 && (FA == DC || A <= 64) && (FB == DC || B <= 64);
 }
 // a * b / R
 template <int OUTF = DC, int A, int FA, int B, int FB>
@@ -273,7 +273,7 @@ HD Fs<1, OUTF> sqr(const Fs<A, DC>& a) {
 template <int C1, int OUTF = DC, int A, int FA, int B, int FB, int X, int FX>
 HD Fs<1 + (C1 < 0 ? -C1 : C1) * X, OUTF> mul_inj(const Fs<A, FA>& a, const Fs<B, FB>& b, const Fs<X, FX>& x) {
     static_assert(fs_mul_ok<A, FA, B, FB>(), "mul_inj: operand classes / bounds");
-    static_assert(C1 >= -2 && C1 <= 2 && C1 != 0 && X <= 32, "mul_inj: injected value");
+    static_assert(C1 >= -16 && C1 <= 16 && C1 != 0 && X <= 32, "mul_inj: injected value (inline constant)");
     Fs<1 + (C1 < 0 ? -C1 : C1) * X, OUTF> r;
     q30core::mont<OUTF>(q30core::ProdMul{a.v, b.v}, q30core::Inj1<C1>{x.v}, r.v, q30core::Seq{});
     return r;
@@ -281,7 +281,7 @@ HD Fs<1 + (C1 < 0 ? -C1 : C1) * X, OUTF> mul_inj(const Fs<A, FA>& a, const Fs<B,
 // a^2 / R + C1 * x + C2 * y
 template <int C1, int C2, int OUTF = DC, int A, int X, int FX, int Y, int FY>
 HD Fs<1 + (C1 < 0 ? -C1 : C1) * X + (C2 < 0 ? -C2 : C2) * Y, OUTF> sqr_inj2(const Fs<A, DC>& a, const Fs<X, FX>& x, const Fs<Y, FY>& y) {
-    static_assert((long)A * A <= 256 && X <= 32 && Y <= 32, "sqr_inj2: bounds");
+    static_assert((long)A * A <= 256 && X <= 32 && Y <= 32 && C1 >= -16 && C1 <= 16 && C2 >= -16 && C2 <= 16, "sqr_inj2: bounds");
     int32_t a2[SL];
 #pragma unroll
     for (int i = 0; i < SL; i++) a2[i] = a.v[i] * 2;
@@ -291,7 +291,7 @@ HD Fs<1 + (C1 < 0 ? -C1 : C1) * X + (C2 < 0 ? -C2 : C2) * Y, OUTF> sqr_inj2(cons
 }
 template <int C1, int OUTF = DC, int A, int X, int FX>
 HD Fs<1 + (C1 < 0 ? -C1 : C1) * X, OUTF> sqr_inj(const Fs<A, DC>& a, const Fs<X, FX>& x) {
-    static_assert((long)A * A <= 256 && X <= 32, "sqr_inj: bounds");
+    static_assert((long)A * A <= 256 && X <= 32 && C1 >= -16 && C1 <= 16, "sqr_inj: bounds");
     int32_t a2[SL];
 #pragma unroll
     for (int i = 0; i < SL; i++) a2[i] = a.v[i] * 2;
@@ -430,11 +430,8 @@ HD Fs<1, DC> fs_zero() {
     for (int i = 0; i < SL; i++) r.v[i] = 0;
     return r;
 }
-// the representative in [0, p) as floor digits (all 13 digits non-negative)
-template <int B, int F>
-HD Fs<1, DU> canonical(const Fs<B, F>& a) {
-    static_assert(B <= 256 && (F == DC || B <= 32), "canonical: bound");
-    Fs<1, DU> t = mul<DU>(fs_one(), a);  // a * R / R: same value mod p, |t| < p
+// a fresh product as floor digits (|value| < p) -> its representative in [0, p), all 13 digits non-negative
+HD Fs<1, DU> canonical_of_product(Fs<1, DU> t) {
     const bool negative = t.v[SL - 1] < 0;  // the lower digits are >= 0 and below 2^360 in total
     uint32_t c = 0;
 #pragma unroll
@@ -445,6 +442,11 @@ HD Fs<1, DU> canonical(const Fs<B, F>& a) {
     }
     t.v[SL - 1] = t.v[SL - 1] + (negative ? q30::PU[SL - 1] : 0) + (int32_t)c;
     return t;
+}
+// the representative in [0, p) of any value
+template <int B, int F>
+HD Fs<1, DU> canonical(const Fs<B, F>& a) {
+    return canonical_of_product(mul<DU>(fs_one(), a));  // a * R / R: same value mod p, |t| < p
 }
 template <int B, int F>
 HD bool is_zero_slow(const Fs<B, F>& a) {

@@ -1,6 +1,6 @@
 // One-time construction of the fixed-base window tables (context set-up).
 #include "kcommon.hpp"
-#include "curve29.hpp"
+#include "curve30.hpp"
 #include "launch.hpp"
 
 namespace kzg {
@@ -181,10 +181,12 @@ __global__ __launch_bounds__(64) void k_table_fill(const AffQ* __restrict__ qw, 
     }
 }
 
-// GLV table (curve29.hpp: TabP): the scalars are split k = k1 + k2 lambda with |k1|, |k2| < 2^127 and phi is applied to the
+// GLV table (curve30.hpp: TabS): the scalars are split k = k1 + k2 lambda with |k1|, |k2| < 2^127 and phi is applied to the
 // SUM of the k2 terms (phi is a homomorphism), so one table over W = 8 windows of c = 16 bits serves both halves: 16
 // gathered additions per base instead of 19 at width 14 -- and half the memory per window, which is what lets the
 // window be 16 bits wide at all.  Entries are packed canonical coordinates (2 x 48 B): at 128 B they would not fit in HBM.
+// The walk runs in the 14 x 29-bit field; an entry is stored in the form the MSM kernels compute in -- the signed 13 x 30-bit
+// field's Montgomery-390 value as exact centred digits (one product by 2^-16 and the digit recentring per coordinate).
 // Same wave-per-(base, window) walk as k_table_fill; the un-normalised X, Y wait in a scratch (the 96-B entry cannot hold them).
 template <int C, int W>
 __global__ __launch_bounds__(64) void k_table_fill_packed(const AffQ* __restrict__ qw, void* const* __restrict__ blocks,
@@ -200,11 +202,11 @@ __global__ __launch_bounds__(64) void k_table_fill_packed(const AffQ* __restrict
     // a group's lower WL = ceil(W / 2) windows and its upper W - WL windows are two blocks (k_msm_glv.inc: tab_window)
     constexpr int WL = (W + 1) / 2;
     const int upper = w >= WL ? 1 : 0;
-    TabP* dst = reinterpret_cast<TabP*>(blocks[2 * group + upper]) + (((size_t)(w - (upper ? WL : 0)) * nb + i) << (C - 1));
+    TabS* dst = reinterpret_cast<TabS*>(blocks[2 * group + upper]) + (((size_t)(w - (upper ? WL : 0)) * nb + i) << (C - 1));
     Fq<260>* scr = scratch_f + ((size_t)blk << (C - 1));
     Fq<XB>* raw = scratch_xy + ((size_t)blk << C);  // 2 per entry
     if (is_inf(Q)) {  // identity base (wave-uniform): an all-identity block
-        TabP z;
+        TabS z;
         for (int t = 0; t < 24; t++) z.w[t] = 0;
         for (int k = 0; k < K; k++) dst[k * 64 + lane] = z;
         return;
@@ -237,9 +239,9 @@ __global__ __launch_bounds__(64) void k_table_fill_packed(const AffQ* __restrict
         const Fq<XB> X = raw[2 * (size_t)(k * 64 + lane)], Y = raw[2 * (size_t)(k * 64 + lane) + 1];
         const Fq<2> zi2 = sqr(zinv);
         const Fq<1> ax = reduce_once(mul(X, zi2)), ay = reduce_once(mul(Y, mul(zi2, zinv)));
-        TabP e;
-        regroup_29_to_32(e.w, ax.v);
-        regroup_29_to_32(e.w + 12, ay.v);
+        TabS e;
+        tabs_pack_from_fq(e.w, ax);
+        tabs_pack_from_fq(e.w + 12, ay);
         dst[k * 64 + lane] = e;
         if (k > 0) zinv = mul(zinv, scr[(k - 1) * 64 + lane]);
     }

@@ -49,16 +49,15 @@ void msm_fixed(int c, const void* scalars, const TabBlocks& table, void* out /*G
 void msm_fixed_chunked(int c, const void* scalars, const TabBlocks& table, void* out /*JacQ*/, int n_groups, int n_slices, int nb,
                        int out_stride, int brp_bits, int S, hipStream_t st);
 // GLV tables (packed 96-B entries, W = glv_windows(c) windows of c bits over the 128-bit half scalars; k_msm_glv.inc, one
-// translation unit per width): mode 0 flat, 1 windowed, 2 four chunks per MSM (width 16), 3 a lane per MSM, 4 a lane per
-// GLV half.  The scalars must be stored as balanced GLV halves (glv_split, or k_fk20_scalars' fused split).
+// translation unit per width): mode 0 flat, 1 windowed, 2 four chunks per MSM.  The scalars must be stored as balanced GLV
+// halves (glv_split, or k_fk20_scalars' fused split).  Entries and sums are in the signed 13 x 30-bit field (curve30.hpp).
 constexpr int glv_windows(int c) { return (128 + c - 1) / c; }
 constexpr int glv_lower_windows(int c) { return (glv_windows(c) + 1) / 2; }  // windows in the lower block of a group
 constexpr int GLV_WIDTHS[] = {16, 15, 14, 12, 8};  // widest first: the order the engine tries them in
 bool glv_width_supported(int c);
 void glv_split(void* scalars, size_t n, hipStream_t st);
-// mode 5 (width 16): four chunks per MSM with row-sharing blocks; partial = scratch of 4 x n_groups x out_stride JacQ (null: mode 2 instead)
 void msm_glv(int c, int mode, const void* scalars, const TabBlocks& table, void* out /*JacQ*/, int n_groups, int n_slices, int nb, int out_stride,
-             int brp_bits, const Fp12w& beta, hipStream_t st, void* partial = nullptr);
+             int brp_bits, const Fp12w& beta, hipStream_t st);
 void msm_fixed_flat(int c, const void* scalars, const TabBlocks& table, void* out /*G1Jac*/, int n_groups, int n_slices, int nb,
                int out_stride, int brp_bits, hipStream_t st);
 // k_table.hip

@@ -1,0 +1,106 @@
+// CPU check of the signed 13 x 30-bit group law (csrc/curve30.hpp: XYZZ mixed addition with fused subtractions, the general
+// Jacobian addition and doubling of the folds, their exact slow paths, the packed table entry, the conversions to and from
+// the 14 x 29-bit form) against the saturated reference formulas of csrc/curve.hpp, on random curve points and on every
+// exceptional case.  Built and run by tests/test_host_units.py with hipcc's host pass (no kernel is launched).
+#include "curve30.hpp"
+#include <cstdio>
+using namespace kzg;
+
+static uint64_t st = 0x243f6a8885a308d3ull;
+static uint32_t rnd() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)(st >> 11); }
+
+static G1Affine random_point() {  // on the curve y^2 = x^3 + 4 (not necessarily in the r-torsion: irrelevant to the formulas)
+    for (;;) {
+        Fp x;
+        for (int i = 0; i < 12; i++) x.v[i] = rnd();
+        x.v[11] &= 0x0fffffffu;
+        Fp four = zero<FpParams>();
+        four.v[0] = 4;
+        Fp rhs = add(mul(sqr(x), x), to_mont(four)), y;
+        if (fp_sqrt(y, rhs)) { G1Affine a; a.x = x; a.y = (rnd() & 1) ? y : neg(y); return a; }
+    }
+}
+static G1Jac jac_from_jacs(const JacS& p) {
+    if (is_inf(p)) return jac_inf();
+    G1Jac r;
+    r.x = fp_from_fs(p.x);
+    r.y = fp_from_fs(p.y);
+    r.z = fp_from_fs(p.z);
+    return r;
+}
+static int bad = 0, checks = 0;
+static void expect(const JacS& got, const G1Jac& want, const char* what) {
+    checks++;
+    if (!eq(jac_from_jacs(got), want)) { bad++; if (bad < 10) printf("MISMATCH %s\n", what); }
+}
+static void expectq(const JacQ& got, const G1Jac& want, const char* what) {
+    checks++;
+    if (!eq(jac_from_jacq(got), want)) { bad++; if (bad < 10) printf("MISMATCH %s\n", what); }
+}
+int main() {
+    for (int it = 0; it < 300; it++) {
+        G1Affine Pa = random_point(), Qa = random_point();
+        G1Jac P = to_jac(Pa), Q = to_jac(Qa);
+        for (int k = 0; k < (it % 5); k++) { P = dbl(P); Q = add(Q, P); }  // non-trivial Z
+        const JacQ pq = jacq_from_jac(P), qq = jacq_from_jac(Q);
+        const JacS p = jacs_from_jacq(pq), q = jacs_from_jacq(qq);
+        G1Affine Qaff = to_affine(Q), Paff = to_affine(P);
+        const AffQ qa29 = affq_from_affine(Qaff);
+        const AffS qa = affs_from_affq(qa29), pa = affs_from_affq(affq_from_affine(Paff));
+        // conversions and the packed entry
+        expect(p, P, "29 -> 30");
+        expectq(jacq_from_jacs(p), P, "30 -> 29");
+        {
+            TabS e;
+            tabs_pack_from_fq(e.w, qa29.x);
+            tabs_pack_from_fq(e.w + 12, qa29.y);
+            const AffS u = tabs_unpack(e.w);
+            checks++;
+            if (!eq(fp_from_fs(u.x), Qaff.x) || !eq(fp_from_fs(u.y), Qaff.y)) { bad++; printf("MISMATCH packed entry\n"); }
+            for (int i = 0; i < SL - 1; i++)
+                if (u.x.v[i] < -SHALF || u.x.v[i] >= SHALF || u.y.v[i] < -SHALF || u.y.v[i] >= SHALF) { bad++; printf("entry digit not centred\n"); }
+        }
+        expect(dbl(p), dbl(P), "dbl");
+        expect(add(p, q), add(P, Q), "add");
+        expect(add(p, q, true), add(P, neg(Q)), "sub");
+        expect(add(p, p), dbl(P), "P+P");
+        expect(add(p, p, true), jac_inf(), "P-P");
+        expect(add(p, jacs_inf()), P, "P+O");
+        expect(add(jacs_inf(), q, true), neg(Q), "O-Q");
+        expect(add(jacs_inf(), jacs_inf()), jac_inf(), "O+O");
+        expect(dbl(jacs_inf()), jac_inf(), "2O");
+        // XYZZ accumulator (the MSM's): sums of +-q onto p and the exceptional cases
+        {
+            XyzzS xa = xyzz30_inf();
+            xa = add_mixed(xa, pa);                                        // O + P
+            expect(to_jacs(xa), P, "xyzz O+P");
+            expect(to_jacs(add_mixed(xa, qa)), add_mixed(P, Qaff), "xyzz madd");
+            expect(to_jacs(add_mixed(xa, qa, true)), add_mixed(P, neg(Qaff)), "xyzz msub");
+            XyzzS xq = add_mixed(xyzz30_inf(), qa, true);                  // O - Q
+            expect(to_jacs(xq), neg(Q), "xyzz O-Q");
+            expect(to_jacs(add_mixed(xq, qa)), jac_inf(), "xyzz -Q+Q");
+            expect(to_jacs(add_mixed(xq, qa, true)), dbl(neg(Q)), "xyzz -Q-Q");
+            AffS inf_a = affs_from_affq(affq_from_affine(aff_inf()));
+            checks++;
+            if (!affine_is_inf(inf_a)) { bad++; printf("affine identity\n"); }
+            expect(to_jacs(add_mixed(xa, inf_a)), P, "xyzz P+O");
+            XyzzS run = xa;
+            G1Jac RUN = P;
+            for (int k = 0; k < 40; k++) { run = add_mixed(run, k % 2 ? pa : qa, k % 3 == 0); RUN = add_mixed(RUN, (k % 3 == 0) ? neg(k % 2 ? Paff : Qaff) : (k % 2 ? Paff : Qaff)); }
+            expect(to_jacs(run), RUN, "xyzz chain");
+            // the fold of the chunked kernel: (c0 + c1) + phi(c2 + c3) shape, through the 14 x 29-bit form at the end
+            const JacS s01 = add(to_jacs(run), to_jacs(xa));
+            expectq(jacq_from_jacs(s01), add(RUN, P), "fold + convert");
+        }
+        // chains keep the stored bounds
+        JacS acc = p;
+        G1Jac ACC = P;
+        for (int k = 0; k < 40; k++) {
+            if (k % 3 == 0) { acc = dbl(acc); ACC = dbl(ACC); }
+            else { acc = add(acc, q, k & 8); ACC = add(ACC, (k & 8) ? neg(Q) : Q); }
+        }
+        expect(acc, ACC, "chain");
+    }
+    printf("curve30: %d checks, %d mismatches\n", checks, bad);
+    return bad ? 1 : 0;
+}

@@ -105,3 +105,11 @@ def test_signed_13_digit_field_matches_saturated_field_and_python_integers(tmp_p
                                   ("sqr_inj2", a * a - (cu + 2 * du) * R, 4), ("mul_add_split", a * w + cu * a, 1)):
             assert (g[name] * R - want) % p == 0 and abs(g[name]) < bound * p, name
         assert g["canon_w"] == w % p
+
+
+@pytest.mark.timeout(900)
+def test_signed_13_digit_group_law_matches_saturated_formulas(tmp_path):
+    """csrc/curve30.hpp (XYZZ mixed addition with fused subtractions and floor-digit products, the general addition and doubling of
+    the folds, exact slow paths, the packed table entry, conversions to and from the 14 x 29-bit form) against csrc/curve.hpp."""
+    out = _build_and_run(tmp_path, "test_curve30")
+    assert "0 mismatches" in out
