@@ -318,4 +318,76 @@ HD XyzzS add_mixed_slow(const XyzzS& p, const AffS& q, bool negq) {
 #endif
 }
 
+// ---- the constant multiplication's chain (g1_mulc30.hpp): halved doubling and mixed addition on centred digits ------------------
+// Doubling with the projective scaling lambda = 1/2 -- (X3 / 4, Y3 / 8, Z3 / 2) is the same point -- which removes every
+// power of two from dbl-2009-l: with A = X^2, B = Y^2, M = X B and the slope H = 3 A / 2 (one halving mod p),
+//     X3 = H^2 - 2 M,   Y3 = H (M - X3) - B^2,   Z3 = Y Z.
+// Six reductions (2M + 3S + one product pair), M - X3 used un-normalised, -2 M injected: 2,054 multiply-adds against 2,317 of
+// the 14 x 29-bit form's doubling.  The identity (Z = 0) stays the identity.
+HD JacS dbl_half(const JacS& p) {
+    const Fs<1, DC> A = sqr(p.x), B = sqr(p.y);
+    const Fs<1, DC> M = mul(B, p.x);
+    const Fs<2, DC> H = half_of_triple(A);
+    JacS r;
+    r.x = relax<4, DC>(sqr_inj<-2, DC>(H, M));                 // <= 3
+    r.y = mul_add<DC>(H, sub_lazy(M, r.x), neg(B), B);         // H (M - X3) - B^2, one reduction
+    r.z = mul(p.y, p.z);
+    return r;
+}
+// an affine point whose coordinates are fresh products (the multiplication's table on the isomorphic curve, never the identity)
+struct AffT {
+    Fs<1, DC> x, y;
+};
+// add-1998-cmo-2 with Z2 = 1 (7M + 3S + one product pair, no doublings of intermediates): p + q, or p - q when negq
+HD JacS add_mixed_slow(const JacS& p, const AffT& q, bool negq);
+HD JacS add_mixed(const JacS& p, const AffT& q, bool negq) {
+    const Fs<1, DU> z1z1 = sqr<DU>(p.z);
+    const auto h = mul_inj<-1, DC>(q.x, z1z1, p.x);                                  // U2 - X1: <= 5
+    const auto rr = mul_inj<-1, DC>(mul(cneg(negq, q.y), p.z), z1z1, p.y);           // +-S2 - Y1: <= 2
+    const Fs<1, DC> hh = sqr(h), hhh = mul(h, hh);
+    const Fs<1, DC> v = mul(hh, p.x);
+    JacS r;
+    r.x = sqr_inj2<-1, -2, DC>(rr, hhh, v);                                          // <= 4
+    r.y = mul_add<DC>(rr, sub_lazy(v, r.x), neg(p.y), hhh);                          // rr (V - X3) - Y1 HHH
+    r.z = mul(h, p.z);
+    if (__builtin_expect(product_is_zero(r.z), 0)) r = add_mixed_slow(p, q, negq);   // identity accumulator, P + P, P - P
+    return r;
+}
+HD JacS add_mixed_slow_impl(const JacS& p, const AffT& q, bool negq) {
+    JacS qj;
+    qj.x = relax<4, DC>(q.x);
+    qj.y = q.y;
+    qj.z = fs_one();
+    return add_slow(p, qj, negq);
+}
+SLOW_PATH_FN void add_mixed_slow_call_jacs(int32_t* buf, bool negq) {
+    JacS p;
+    AffT q;
+#pragma unroll
+    for (int i = 0; i < SL; i++) {
+        p.x.v[i] = buf[i]; p.y.v[i] = buf[SL + i]; p.z.v[i] = buf[2 * SL + i];
+        q.x.v[i] = buf[3 * SL + i]; q.y.v[i] = buf[4 * SL + i];
+    }
+    const JacS r = add_mixed_slow_impl(p, q, negq);
+#pragma unroll
+    for (int i = 0; i < SL; i++) { buf[i] = r.x.v[i]; buf[SL + i] = r.y.v[i]; buf[2 * SL + i] = r.z.v[i]; }
+}
+HD JacS add_mixed_slow(const JacS& p, const AffT& q, bool negq) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t buf[5 * SL];  // copies made inside the cold branch (see the XYZZ slow path above)
+#pragma unroll
+    for (int i = 0; i < SL; i++) {
+        buf[i] = p.x.v[i]; buf[SL + i] = p.y.v[i]; buf[2 * SL + i] = p.z.v[i];
+        buf[3 * SL + i] = q.x.v[i]; buf[4 * SL + i] = q.y.v[i];
+    }
+    add_mixed_slow_call_jacs(buf, negq);
+    JacS r;
+#pragma unroll
+    for (int i = 0; i < SL; i++) { r.x.v[i] = buf[i]; r.y.v[i] = buf[SL + i]; r.z.v[i] = buf[2 * SL + i]; }
+    return r;
+#else
+    return add_mixed_slow_impl(p, q, negq);
+#endif
+}
+
 }  // namespace kzg

@@ -409,6 +409,21 @@ HD Fs<K * A, DC> mul_small(const Fs<A, DC>& a) {  // K a for K = 2, 3 (3 * (2^29
     return normalise(t);
 }
 
+// 3 a / 2 mod p for a FRESH centred product a (exact digits in [-2^29, 2^29)): t = 3 a, plus p if t is odd (p is odd), then one
+// bit to the right across the digits -- floor halves, the dropped bit of digit i + 1 enters digit i as 2^29 -- and the carry
+// step.  |3 a_i + p_i| < 3.97 * 2^29 fits i32 (max |P_i| = 0.964 * 2^29).  The slope of the halved doubling (curve30.hpp).
+HD Fs<2, DC> half_of_triple(const Fs<1, DC>& a) {
+    int32_t t[SL];
+    const int32_t odd = -(a.v[0] & 1);  // 3 a_0 is odd iff a_0 is
+#pragma unroll
+    for (int i = 0; i < SL; i++) t[i] = a.v[i] * 3 + (odd & q30::P[i]);
+    Fs<2, DW> h;
+#pragma unroll
+    for (int i = 0; i < SL - 1; i++) h.v[i] = (t[i] >> 1) + ((t[i + 1] & 1) << 29);
+    h.v[SL - 1] = t[SL - 1] >> 1;
+    return normalise(h);
+}
+
 // ---- zero tests, canonical form ---------------------------------------------------------------------------------------
 // a FRESH product (|value| < p, exact digits): zero mod p <=> every digit is zero
 template <int F>

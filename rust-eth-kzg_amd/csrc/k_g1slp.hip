@@ -9,18 +9,21 @@
 // words: 4 per operation: dst slot, a slot, b (slot | number of doublings | constant id), flags (1 = subtract, 2 = doubling run, 4 = a + b to dst AND a - b to slot flags >> 16; bits 3-7 of an addition: doublings of operand a first).
 #include "engine.hpp"
 #include "g1_mulc.hpp"
+#include "g1_mulc30.hpp"
 #include "g1_coop.hpp"
 
 namespace kzg {
 
+// (batches that fill the chip: the multiplication runs in the signed 13 x 30-bit field, g1_mulc30.hpp; the point is read from and
+// written to the arena's 14 x 29-bit form)
 __global__ __launch_bounds__(64, 2) void k_slp_mulc(JacQ* __restrict__ A, int stride, const uint32_t* __restrict__ words,
-                                                    const uint32_t* __restrict__ naf, Fq<1> beta) {
+                                                    const uint32_t* __restrict__ naf, Fs<1, DC> beta) {
     const uint32_t* w = words + (size_t)blockIdx.x * 4;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
                    cid = __builtin_amdgcn_readfirstlane(w[2]);
     const int lane = blockIdx.y * 64 + threadIdx.x;
     const JacQ src = A[(size_t)a * stride + lane];
-    A[(size_t)dst * stride + lane] = mul_by_recoded(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta);
+    A[(size_t)dst * stride + lane] = mul_by_recoded30(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta);
 }
 // the constant multiplications of a batch of <= 16 blobs: four lanes per blob (a wave = 16 blobs x one operation), the quad sharing
 // the digit loop's doublings and mixed additions
@@ -235,7 +238,7 @@ void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int
         else if (coop_lanes > 0 && coop_points_max() > 0)
             k_slp_mulc_coop<<<dim3((unsigned)count, (unsigned)((coop_lanes + 15) / 16)), 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf,
                                                                                                      fq_from_fp(b384), coop_lanes);
-        else k_slp_mulc<<<grid, 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fq_from_fp(b384));
+        else k_slp_mulc<<<grid, 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fs_from_fp(b384));
     } else {
         // one lane group and few enough operations for every quad wave to have a SIMD of its own: four lanes per blob
         if (lanes == 64 && count * 4 <= 1024 && coop_points_max() > 0)

@@ -92,6 +92,29 @@ int main() {
             const JacS s01 = add(to_jacs(run), to_jacs(xa));
             expectq(jacq_from_jacs(s01), add(RUN, P), "fold + convert");
         }
+        // the constant multiplication's chain: halved doublings (lambda = 1/2 scaling: same projective point) and mixed additions
+        // with a table entry whose coordinates are fresh products
+        {
+            AffT qt;
+            qt.x = mul(qa.x, fs_one());
+            qt.y = mul(qa.y, fs_one());
+            expect(dbl_half(p), dbl(P), "dbl_half");
+            expect(dbl_half(jacs_inf()), jac_inf(), "dbl_half O");
+            expect(add_mixed(p, qt, false), add_mixed(P, Qaff), "madd T");
+            expect(add_mixed(p, qt, true), add_mixed(P, neg(Qaff)), "msub T");
+            const JacS qj = jacs_from_jacq(jacq_from_jac(to_jac(Qaff)));
+            expect(add_mixed(qj, qt, false), dbl(Q), "Q+Q T");
+            expect(add_mixed(qj, qt, true), jac_inf(), "Q-Q T");
+            expect(add_mixed(jacs_inf(), qt, true), neg(Q), "O-Q T");
+            JacS c = p;
+            G1Jac C = P;
+            for (int k = 0; k < 60; k++) {
+                if (k % 4 != 3) { c = dbl_half(c); C = dbl(C); }
+                else { c = add_mixed(c, qt, k & 8); C = add_mixed(C, (k & 8) ? neg(Qaff) : Qaff); }
+            }
+            expect(c, C, "mulc chain");
+            expectq(jacq_from_jacs(c), C, "mulc chain -> 29");
+        }
         // chains keep the stored bounds
         JacS acc = p;
         G1Jac ACC = P;
