@@ -465,18 +465,30 @@ def side_configs(ctx, kzg, torch, dev, blobs_h, ctx_times):
         import gc
         gc.collect()
         gc.disable()
+        try:  # (a failed assert in a hammer thread must not leave the collector off for the rest of the record: ADVICE r4)
+            t0 = time.perf_counter()
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            dtt = time.perf_counter() - t0
+        finally:
+            gc.enable()
+        # the same round with the collector ON: what a Python host that does not hold it off sees; the library's share of any
+        # round-to-round change is the figure above, the difference between the two is the harness
+        ths = [threading.Thread(target=hammer, args=(r,)) for r in runs_t]
         t0 = time.perf_counter()
         for t in ths:
             t.start()
         for t in ths:
             t.join()
-        dtt = time.perf_counter() - t0
-        gc.enable()
+        dtt_gc = time.perf_counter() - t0
         out[key] = {"verifications_per_s": round(n_thr * reps / dtt),
+                    "verifications_per_s_with_python_gc_enabled": round(n_thr * reps / dtt_gc),
                     "entry": f"eth_kzg_verify_cell_kzg_proof_batch from {n_thr} host threads on one context: one caller at a time takes the latency "
                              "path, callers that arrive meanwhile are combined into many-verification passes (three pass slots, short-chain form); "
                              "the harness's own garbage collector held off during the timed round (one full collection of this process's "
-                             "object graph = 35 ms under the GIL)"}
+                             "object graph = 35 ms under the GIL); the second figure is the same round with the collector on"}
     _mark("side configs: recover one")
     half_idx, half_cells = list(range(CELLS // 2)), L_[:CELLS // 2]
     ts = []
@@ -841,6 +853,9 @@ def main():
     if rehearsal:  # N ranks on GPU 0 (see _Harness): small tables so that N contexts fit, torch's gloo for the harness collectives
         local_rank = 0
         os.environ.setdefault("ETH_KZG_AMD_TABLE_GB", "24")
+    # The library's default table budget is a stated 160 GB (GLV width 15); the bench measures the path at the widest tables the GPU
+    # holds and says so in config.table_budget (blobs_per_s_vs_table_memory carries the default's and every other size's rate)
+    os.environ.setdefault("ETH_KZG_AMD_TABLE_GB", "max")
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} are visible "
                          f"(--gpus {args.gpus})")
@@ -1111,6 +1126,8 @@ def main():
                        "fk20_table": f"GLV: {msm_adds // 2} windows of {wbits} bits per 128-bit half scalar, packed 96-B entries, {msm_adds} gathered additions per base" if ctx.glv_table()
                                      else f"plain: width {wbits}, {msm_adds} gathered additions per base",
                        "table_GB": round(ctx.table_bytes() / 1e9, 2),
+                       "table_budget": "ETH_KZG_AMD_TABLE_GB=" + os.environ.get("ETH_KZG_AMD_TABLE_GB", "") + " (set by bench.py: the widest tables the HBM holds; "
+                                       "the library's default budget is 160 GB = GLV width 15, see configs.blobs_per_s_vs_table_memory)",
                        "g1_transforms": f"compiled linear map: {li[0]} constant multiplications, {li[1]} additions, {li[2]} doublings per blob, {li[3]} launches" if li[0] else "radix-2 network",
                        "exchange": ("ncclAllGather of the proof vectors per step inside libc_eth_kzg.so (eth_kzg_amd_all_gather)" if lib_comm
                                     else "RCCL all-gather of proofs per step (torch.distributed)" + (" -- the library communicator FAILED: " + comm_error if comm_error else "")) if world > 1 else "none",
@@ -1155,7 +1172,7 @@ def main():
             ctx.close()
             ctx = None
             _mark("table curve")
-            for label, env, precomp in (("GLV width 15", {"ETH_KZG_AMD_GLV_WINDOW": "15"}, True), ("GLV width 14", {"ETH_KZG_AMD_GLV_WINDOW": "14"}, True),
+            for label, env, precomp in (("GLV width 15 (the default budget of 160 GB)", {"ETH_KZG_AMD_GLV_WINDOW": "15"}, True), ("GLV width 14", {"ETH_KZG_AMD_GLV_WINDOW": "14"}, True),
                                         ("GLV width 12", {"ETH_KZG_AMD_GLV_WINDOW": "12"}, True), ("GLV width 8 (the start table)", {"ETH_KZG_AMD_GLV_WINDOW": "8"}, True),
                                         ("plain width 4 (use_precomp = false)", {}, False)):
                 try:

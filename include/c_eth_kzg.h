@@ -99,7 +99,7 @@ uint64_t eth_kzg_constant_cells_per_ext_blob(void);
 CResult eth_kzg_compute_kzg_proof(const DASContext *ctx, const uint8_t *blob, const uint8_t *z, uint8_t *out_proof,
                                   uint8_t *out_y);
 CResult eth_kzg_compute_blob_kzg_proof(const DASContext *ctx, const uint8_t *blob, const uint8_t *commitment,
-                                       uint8_t *out);
+                                       uint8_t *out_proof);
 CResult eth_kzg_verify_kzg_proof(const DASContext *ctx, const uint8_t *commitment, const uint8_t *z, const uint8_t *y,
                                  const uint8_t *proof, bool *verified);
 CResult eth_kzg_verify_blob_kzg_proof(const DASContext *ctx, const uint8_t *blob, const uint8_t *commitment,
@@ -116,6 +116,15 @@ CResult eth_kzg_verify_blob_kzg_proof_batch(const DASContext *ctx, uint64_t blob
 
 /* Context on an explicit GPU ordinal (one process per GPU under torch.distributed/RCCL). */
 DASContext *eth_kzg_amd_das_context_new_on_device(bool use_precomp, int device_ordinal);
+
+/* The constructor that never kills the host process.  eth_kzg_das_context_new keeps the reference's behaviour -- the Rust
+ * constructor panics across the FFI when it cannot build a context (bindings/c/src/lib.rs:79-92), this library aborts when there
+ * is no usable GPU or not even the 3.7 GB start tables fit -- which is hostile inside a consensus client.  This form returns NULL
+ * and fills *result (status Err, error_msg to be freed with eth_kzg_free_error_message; may be NULL) instead; on success *result
+ * is Ok.  table_budget_gb bounds the HBM the two window tables take together: > 0 = that many GB (the widest GLV table that
+ * fits is chosen: 160 GB -> width 15, 107 -> 14, 61 -> 12, 45 -> 8), 0 = $ETH_KZG_AMD_TABLE_GB or else the default of 160 GB
+ * (-3 ... -7 % against the widest tables at 64 % of their memory), < 0 = whatever the HBM still holds (249 GB on an idle GPU). */
+DASContext *eth_kzg_amd_das_context_try_new(bool use_precomp, int device_ordinal, double table_budget_gb, CResult *result);
 
 /* Host-pointer batches: n blobs; out_cells[b] / out_proofs[b] are arrays of 128 pointers as in the
  * single-blob calls (either may be NULL to skip that output). */
@@ -232,7 +241,7 @@ int eth_kzg_amd_table_groups_ready(const DASContext *ctx);
  * queues stand still for as long (tools/alloc_test/probe_stall.cpp): the one start-up stall the library cannot remove. */
 void eth_kzg_amd_table_build_info(const DASContext *ctx, double *out4);
 /* The compiled linear map that replaces the two G1 transforms of the prover: out4 = constant multiplications, point
- * additions, point doublings per blob, kernel launches per call (all 0 when ETH_KZG_AMD_G1FFT=radix2 keeps the butterfly network). */
+ * additions, point doublings per blob, kernel launches per call. */
 void eth_kzg_amd_linmap_info(const DASContext *ctx, int32_t *out4);
 
 /* Per-stage HIP-event timing for bench.py's roofline leg.  Stages, in order: blob_to_coeffs,

@@ -48,6 +48,7 @@ EXPORTED_SYMBOLS = [
     "eth_kzg_compute_kzg_proof", "eth_kzg_compute_blob_kzg_proof", "eth_kzg_verify_kzg_proof",
     "eth_kzg_verify_blob_kzg_proof", "eth_kzg_verify_blob_kzg_proof_batch",
     "eth_kzg_amd_das_context_new_on_device",
+    "eth_kzg_amd_das_context_try_new",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_batch", "eth_kzg_amd_blob_to_kzg_commitment_batch",
     "eth_kzg_amd_recover_cells_and_proofs_batch", "eth_kzg_amd_recover_cells_and_proofs_device",
     "eth_kzg_amd_verify_cell_kzg_proof_batch_partial", "eth_kzg_amd_verify_cell_kzg_proof_batch_combine",
@@ -84,6 +85,8 @@ def load_library():
     lib.eth_kzg_das_context_new.argtypes = [C.c_bool]
     lib.eth_kzg_amd_das_context_new_on_device.restype = P
     lib.eth_kzg_amd_das_context_new_on_device.argtypes = [C.c_bool, C.c_int]
+    lib.eth_kzg_amd_das_context_try_new.restype = P
+    lib.eth_kzg_amd_das_context_try_new.argtypes = [C.c_bool, C.c_int, C.c_double, C.POINTER(CResult)]
     lib.eth_kzg_das_context_free.argtypes = [P]
     lib.eth_kzg_free_error_message.argtypes = [P]
     for name, args in {
@@ -216,13 +219,23 @@ class DASContext:
 
     device_index = 0
 
-    def __init__(self, use_precomp=True, device=None, wait_tables=True):
-        """wait_tables: the C entry point returns as soon as the start tables are up (progressive start); by default this
+    def __init__(self, use_precomp=True, device=None, wait_tables=True, table_budget_gb=None):
+        """table_budget_gb: HBM for the two window tables together (None: $ETH_KZG_AMD_TABLE_GB or the library's default of 160 GB;
+        a negative number: whatever the HBM holds) -- given, the context is made by eth_kzg_amd_das_context_try_new, which reports a
+        failure as KzgError instead of aborting the process.
+        wait_tables: the C entry point returns as soon as the start tables are up (progressive start); by default this
         wrapper then waits for the wide tables, so that timing and table introspection see the final state.  Pass False to
         use the context at once (results are identical on every table)."""
         self.device_index = int(device) if device is not None else int(os.environ.get("ETH_KZG_AMD_DEVICE", "0"))
         self._lib = load_library()
-        if device is None:
+        if table_budget_gb is not None:
+            res = CResult()
+            self._ctx = C.c_void_p(self._lib.eth_kzg_amd_das_context_try_new(bool(use_precomp), self.device_index, float(table_budget_gb), C.byref(res)))
+            if not self._ctx.value:
+                msg = C.cast(res.error_msg, C.c_char_p).value.decode() if res.error_msg else "unknown"
+                self._lib.eth_kzg_free_error_message(res.error_msg)
+                raise KzgError(msg)
+        elif device is None:
             self._ctx = C.c_void_p(self._lib.eth_kzg_das_context_new(bool(use_precomp)))
         else:
             self._ctx = C.c_void_p(self._lib.eth_kzg_amd_das_context_new_on_device(bool(use_precomp), int(device)))

@@ -44,16 +44,29 @@ kzg::Engine* eng(const DASContext* ctx) {
 }
 CResult device_err(kzg::Engine* e) { return err("DeviceError(" + e->last_error() + ")"); }
 
-DASContext* make_ctx(bool use_precomp, int device) {
+// the one constructor: NULL + message when the context cannot be built (no usable GPU, not even the 3.7 GB start tables fit)
+DASContext* try_make_ctx(bool use_precomp, int device, double table_budget_gb, std::string* why) {
+    DASContext* c = nullptr;
     try {
-        auto* c = new DASContext{nullptr};
-        c->engine = new kzg::Engine(use_precomp, device);
+        c = new DASContext{nullptr};
+        c->engine = new kzg::Engine(use_precomp, device, nullptr, table_budget_gb);
         return c;
     } catch (const std::exception& e) {
-        // The reference panics when the context cannot be built (bad SRS); here: no usable GPU.  No CPU fallback.
-        fprintf(stderr, "c_eth_kzg: cannot create the MI355X context: %s\n", e.what());
+        delete c;
+        if (why) *why = e.what();
+        return nullptr;
+    }
+}
+DASContext* make_ctx(bool use_precomp, int device) {
+    std::string why;
+    DASContext* c = try_make_ctx(use_precomp, device, 0, &why);
+    if (!c) {
+        // The reference panics when the context cannot be built (bad SRS); here: no usable GPU.  No CPU fallback.  A host that must
+        // not die calls eth_kzg_amd_das_context_try_new instead.
+        fprintf(stderr, "c_eth_kzg: cannot create the MI355X context: %s\n", why.c_str());
         abort();
     }
+    return c;
 }
 
 }  // namespace
@@ -61,12 +74,16 @@ DASContext* make_ctx(bool use_precomp, int device) {
 extern "C" {
 
 DASContext* eth_kzg_das_context_new(bool use_precomp) {
-    int dev = 0;
-    if (const char* s = getenv("ETH_KZG_AMD_DEVICE")) dev = atoi(s);
-    return make_ctx(use_precomp, dev);
+    return make_ctx(use_precomp, kzg::Knobs::from_env().device);  // ETH_KZG_AMD_DEVICE (knobs.hpp), read here, once per context
 }
 DASContext* eth_kzg_amd_das_context_new_on_device(bool use_precomp, int device_ordinal) {
     return make_ctx(use_precomp, device_ordinal);
+}
+DASContext* eth_kzg_amd_das_context_try_new(bool use_precomp, int device_ordinal, double table_budget_gb, CResult* result) {
+    std::string why;
+    DASContext* c = try_make_ctx(use_precomp, device_ordinal, table_budget_gb, &why);
+    if (result) *result = c ? ok() : err("ContextCreation(" + why + ")");
+    return c;
 }
 void eth_kzg_das_context_free(DASContext* ctx) {
     if (!ctx) return;

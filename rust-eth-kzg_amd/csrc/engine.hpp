@@ -2,6 +2,7 @@
 // (reference: crates/eip7594/src/lib.rs:41-87 DASContext, prover.rs:62-171 ProverContext,
 //  verifier.rs:72-112).  One Engine = one context on one GPU.
 #pragma once
+#include "knobs.hpp"
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <cstdint>
@@ -73,12 +74,8 @@ struct Work {
     int cap = 0;    // blobs the arrays below hold
     void *coeffs = nullptr, *canon = nullptr, *scalars = nullptr, *X = nullptr;
     int* status = nullptr;
-    void *dft_tmp = nullptr, *dft_prod = nullptr, *circ_table = nullptr, *slp_arena = nullptr;
-    void* msm_partial = nullptr;  // chunk sums of the row-sharing MSM schedule: 4 x 128 x lanes JacQ
-    size_t msm_partial_bytes = 0;
+    void *circ_table = nullptr, *slp_arena = nullptr;
     size_t slp_arena_bytes = 0;
-    int* slp_sync = nullptr;  // tickets and completion counters of the linear map's ticket walker (two blocks of slp_sync_ints)
-    size_t slp_sync_ints = 0;
     hipEvent_t done = nullptr;  // recorded after the last kernel that touches the set; the next user's stream waits on it
     // host-pointer path: device and pinned-host staging for one chunk, a compute stream, a copy stream, events
     int stage_cap = 0;
@@ -115,7 +112,14 @@ public:
     //              ~3.4x the additions).  Results identical.  Tables are shared by the contexts of a device.
     // primary: the context's engine when this one is an auxiliary lane of it (lease_serial): the lane shares the primary's
     // window tables by reading through to its view -- no registry look-up, no builder thread, no lock shared with a build
-    Engine(bool use_precomp, int device, const Engine* primary = nullptr);
+    // table_budget_gb: > 0: upper bound for both window tables together; 0: $ETH_KZG_AMD_TABLE_GB, else DEFAULT_TABLE_BUDGET_GB;
+    // < 0: whatever the HBM still holds
+    Engine(bool use_precomp, int device, const Engine* primary = nullptr, double table_budget_gb = 0);
+    // The default memory budget of the window tables: GLV width 15 for FK20 (116 GB) + the width-13 commitment table (43 GB).
+    // Measured on one box, same resident 2048-blob batch: -3 ... -7 % against the widest tables (GLV 16: 249 GB in all), at
+    // 64 % of the memory; throughput per GB falls 12x between the narrowest and the widest table, so taking "whatever HBM holds"
+    // is a decision for the host application (ETH_KZG_AMD_TABLE_GB=max, or the budget argument of eth_kzg_amd_das_context_try_new).
+    static constexpr double DEFAULT_TABLE_BUDGET_GB = 160.0;
     ~Engine();
     Engine(const Engine&) = delete;
 
@@ -304,13 +308,11 @@ private:
     void launch_msm(const void* scalars, TableSel table, void* out, int n_groups, int n_slices, int out_stride,
                     int brp_bits, hipStream_t st);
     void launch_msm(const void* scalars, const TableView& tv, bool scalars_split, void* out, int n_groups, int n_slices, int out_stride,
-                    int brp_bits, hipStream_t st, void* partial = nullptr);
+                    int brp_bits, hipStream_t st);
     void launch_msm_range(const void* scalars, const SharedTable& t, int g0, int gcnt, void* out, int n_groups, int n_slices, int out_stride,
-                          int brp_bits, hipStream_t st, void* partial = nullptr);
+                          int brp_bits, hipStream_t st);
     void build_final_tables();  // the wide tables: on the helper thread (progressive start) or inline
     void publish(TableSel which, const std::shared_ptr<SharedTable>& main, const std::shared_ptr<SharedTable>& next);
-    void g1_ifft128_take64(void* X, int stride, hipStream_t st);
-    void g1_fft128_from64(void* X, int stride, hipStream_t st);
     void g1_fft128_full(void* X, int stride, int inverse, hipStream_t st);
 
     struct StageMark { int stage; int launches; hipEvent_t a, b; };
@@ -324,9 +326,10 @@ private:
     int dev_ = 0;
     Comm* comm_ = nullptr;
     bool use_precomp_ = true;
+    Knobs knobs_;            // every environment knob, read once when the context is created (knobs.hpp)
     int want_plain_c_ = 0;   // ETH_KZG_AMD_WINDOW: a plain FK20 table of this width instead of the GLV ladder (0: none)
     int want_glv_c_ = 0;     // ETH_KZG_AMD_GLV_WINDOW: this GLV width exactly (0: the widest that fits memory and budget)
-    double table_budget_gb_ = 0;  // ETH_KZG_AMD_TABLE_GB: upper bound for both tables together (0: what the HBM holds)
+    double table_budget_gb_ = DEFAULT_TABLE_BUDGET_GB;  // upper bound for both tables together (constructor argument, ETH_KZG_AMD_TABLE_GB, or the default); <= 0: what the HBM holds
     mutable std::mutex tab_mu_;
     std::condition_variable tab_cv_;
     TableView views_[2];
@@ -369,7 +372,7 @@ private:
     uint8_t* v_pin_ = nullptr;
     size_t v_pin_cap_ = 0;
     hipStream_t v_side_ = nullptr;  // verification, round 3's form: the subgroup tests run here next to the point shifts on stream_
-    bool v_two_streams_ = false;    // ETH_KZG_AMD_VERIFY_SIDE_STREAM=1 (default: both chains in ONE launch on stream_, k_pip_shift_subgroup)
+    bool v_two_streams_ = false;    // (both chains run in ONE launch on stream_, k_pip_shift_subgroup; the two-stream form of round 3 shared hardware queues)
     hipEvent_t v_decoded_ = nullptr, v_checked_ = nullptr;
 
     // serial-path lanes (lease_serial)
@@ -389,7 +392,7 @@ private:
     std::vector<VerifyRequest*> comb_queue_;
     int comb_running_ = 0;                 // leaders running a pass right now (at most VM_SLOTS)
     std::atomic<int> verify_inflight_{0};  // single verifications on the latency path right now
-    int verify_lanes_ = 1;                 // concurrent single verifications on the latency path (ETH_KZG_AMD_VERIFY_LANES); the others are combined
+    int verify_lanes_ = 1;                 // concurrent single verifications on the latency path ; the others are combined
     int comb_max_cells_ = 1024;            // larger problems always take the single path (their transcript hash is the bound)
 
     // many-verification path (verify_many.hip): its own lock, stream, device arena and pinned slab
@@ -412,7 +415,7 @@ private:
     std::once_flag vm_pool_once_;
     std::atomic<unsigned> vm_rr_{0};
     bool vm_search_ = true;  // ETH_KZG_AMD_VM_SEARCH=0: a pass whose folded check fails is re-checked problem by problem (round 3's form)
-    int vm_small_max_ = -1;  // passes of at most this many problems take the short-chain form (verify_many.hip); -1: 2 x host threads; ETH_KZG_AMD_VM_SMALL
+    int vm_small_max_ = -1;  // passes of at most this many problems take the short-chain form (verify_many.hip); -1: 2 x host threads
     uint8_t* vd_pin_ = nullptr;  // device-resident verification: the host mirror the transcript hash reads (grow-only, guarded by mu_)
     size_t vd_pin_cap_ = 0;
     static constexpr int VD_CHUNKS = 8;
@@ -450,14 +453,8 @@ private:
     int pick_slp_program(int lanes) const;        // lanes = blobs rounded up to 64
     int slp_force_ = -1;                          // ETH_KZG_AMD_SLP_PROGRAM: this program at every batch size (tests, A/B runs)
     // a phase = one multiplication launch (level0 < 0) or a run of cheap dependency levels executed by ONE ticket-walking launch
-    struct SlpPhase { int launch0, level0, n_levels, max_count, total_ops; };
-    std::vector<SlpPhase> slp_phases_;
-    void* d_slp_levels_ = nullptr;  // int[2][slp_level_total_]: first operation / operation count of every cheap level
-    int slp_level_total_ = 0, slp_max_levels_ = 0;
-    bool slp_walk_ = true;
     int slp_fuse_min_ = 1024;  // measured: 512 blobs 5.47 (plain) against 5.55 ms (fused), 2048 blobs 16.13 against 15.93 ms
     int slp_info_[4] = {0, 0, 0, 0};  // constant multiplications, additions, doublings, launches of the tuned program
-    bool use_linmap_ = false;
     Fr8 half_;  // 1/2 in Montgomery form: the scaling folded into the MSM scalars in linear-map mode
 
     // work_[0] under its historical names (grown on demand, guarded by mu_)

@@ -119,103 +119,6 @@ __global__ __launch_bounds__(64, 2) void k_slp_add_coop(JacQ* __restrict__ A, in
     A[(size_t)dst * stride + lane] = r;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// One launch for a whole PHASE of the program's cheap operations (the dependency levels in front of the constant
-// multiplications -- 11 since the doubling runs are folded into their consumers, 21 before -- and the 14 behind them) instead
-// of one launch per level.  A level-by-level sequence of launches leaves the
-// chip part empty at every level boundary (2,800 waves on 2,048 wave slots: a second round 37 % full, 41 times over) and,
-// for a single 64-blob lane group, pays a launch and a tail per level.  Lanes are blobs, so the dependency structure is
-// PER LANE GROUP: level l + 1 of a group needs level l of THAT group only.  The walker hands out operations by ticket:
-//   * the lane groups are dealt to S <= 8 shards (shard = blockIdx % S: blocks b and b + 8 were observed to share an XCD, so
-//     a shard's counters and points mostly stay in one L2 -- speed only, nothing depends on it);
-//   * a shard's operations are numbered level-major across its groups; a wave draws the next number with one atomic add,
-//     waits until the previous level OF THAT GROUP is complete (a counter per (group, level)), runs the operation, makes
-//     its result visible (agent-scope release) and bumps the counter of its own (group, level).
-// Tickets are drawn in dependency order by waves that are already running, so every wait is for a wave that holds an
-// earlier ticket and never waits on a later one: no deadlock, whatever the residency.  Every spin is bounded all the same
-// (a stuck counter sets the error word and the wave leaves; the host turns that into a device error).
-// Visibility follows MI355X_MICROARCH.md ("inter-workgroup visibility"): per-XCD L2s are not coherent and a CU's L1 is never
-// refreshed by another CU's stores, so producer = plain stores, agent-scope release fence, s_waitcnt vmcnt(0) (kept in asm:
-// the compiler may drop the wait it thinks redundant), relaxed agent-scope add; consumer = relaxed agent-scope poll, ONE
-// agent-scope acquire, then plain loads.  A wave is its own workgroup here, so no barrier is involved.
-struct SlpWalk {
-    const uint32_t* words;      // 4 per operation, level-major (the schedule's own order)
-    const int* level_first;     // [n_levels] first operation of the level (index into words / 4)
-    const int* level_count;     // [n_levels]
-    int n_levels, n_groups, n_shards;
-    int spin_limit;             // polls before a waiting wave gives up (about a second)
-    int debug;
-    // counters (zeroed before the launch): ticket[shard] at stride 32 ints, then done[group][level] at stride 16 ints, then error
-    int* sync;
-};
-__device__ __forceinline__ int* slp_ticket(const SlpWalk& w, int shard) { return w.sync + 32 * shard; }
-__device__ __forceinline__ int* slp_done(const SlpWalk& w, int group, int level) {
-    return w.sync + 32 * 8 + 16 * ((size_t)group * w.n_levels + level);
-}
-__device__ __forceinline__ int* slp_error(const SlpWalk& w) { return w.sync + 32 * 8 + 16 * (size_t)w.n_groups * w.n_levels; }
-
-__global__ __launch_bounds__(64) void k_slp_walk(JacQ* __restrict__ A, int stride, SlpWalk w) {
-    const int shard = blockIdx.x % w.n_shards;
-    const int groups_here = (w.n_groups - shard + w.n_shards - 1) / w.n_shards;  // groups shard, shard + S, shard + 2 S, ...
-    if (groups_here <= 0) return;
-    int total = 0;
-    for (int l = 0; l < w.n_levels; l++) total += w.level_count[l];
-    const int tickets = total * groups_here;
-    if (w.debug && blockIdx.x == 0 && threadIdx.x == 0) {
-        int* dbg = slp_error(w) + 4;
-        dbg[8] = total; dbg[9] = tickets; dbg[10] = w.n_levels; dbg[11] = w.level_count[0];
-    }
-    for (int guard = 0;; guard++) {
-        if (guard > 200000) {  // no wave can have this many operations: the tables are corrupt
-            if (threadIdx.x == 0) __hip_atomic_store(slp_error(w), 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        int t = 0;
-        if (threadIdx.x == 0) t = __hip_atomic_fetch_add(slp_ticket(w, shard), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if (t >= tickets) return;
-        // ticket -> (level, group of this shard, operation): level-major across the shard's groups
-        int level = 0, base = 0;
-        for (;; level++) {
-            const int span = w.level_count[level] * groups_here;
-            if (t < base + span) break;
-            base += span;
-        }
-        const int cnt = w.level_count[level];
-        const int gl = (t - base) / cnt, i = (t - base) - gl * cnt;
-        const int group = shard + gl * w.n_shards;
-        if (level > 0) {  // the previous level of this group must be complete
-            const int need = w.level_count[level - 1];
-            const int* flag = slp_done(w, group, level - 1);
-            int spins = 0;
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                __builtin_amdgcn_s_sleep(16);
-                // a stuck counter (or another wave's verdict that one is stuck) ends the walk: fail loudly, never hang the GPU
-                if ((++spins & 1023) == 0 && (spins > w.spin_limit || __hip_atomic_load(slp_error(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                    if (threadIdx.x == 0) {
-                        __hip_atomic_store(slp_error(w), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        int* dbg = slp_error(w) + 4;  // first reporter: ticket, level, group, operation, counter seen, needed
-                        if (__hip_atomic_fetch_add(slp_error(w) + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                            dbg[0] = t; dbg[1] = level; dbg[2] = group; dbg[3] = i;
-                            dbg[4] = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dbg[5] = need; dbg[6] = tickets; dbg[7] = groups_here;
-                        }
-                    }
-                    return;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        const uint32_t* op = w.words + ((size_t)w.level_first[level] + i) * 4;
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(op[0]), a = __builtin_amdgcn_readfirstlane(op[1]),
-                       b = __builtin_amdgcn_readfirstlane(op[2]), fl = __builtin_amdgcn_readfirstlane(op[3]);
-        const int lane = group * 64 + threadIdx.x;
-        slp_cheap_op(A, stride, lane, dst, a, b, fl);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(slp_done(w, group, level), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 namespace launch {
 // the code object of this translation unit is loaded now (HIP loads a code object on the first launch of one of its kernels, and
 // that load is an allocation: it would wait behind a table piece the builder thread is allocating)
@@ -245,30 +148,6 @@ void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int
             k_slp_add_coop<<<dim3(4u, (unsigned)count), 64, 0, st>>>((JacQ*)arena, stride, words, lanes);
         else k_slp_add<<<dim3((unsigned)(lanes / 64), (unsigned)count), 64, 0, st>>>((JacQ*)arena, stride, words);
     }
-}
-size_t g1_slp_walk_sync_ints(int n_groups, int n_levels) { return 32 * 8 + 16 * (size_t)n_groups * n_levels + 32; }
-// one phase of cheap operations in one launch; sync = g1_slp_walk_sync_ints ints (zeroed here); wave_slots = what the chip holds
-void g1_slp_walk(void* arena, int stride, const uint32_t* words, const int* level_first, const int* level_count, int n_levels,
-                 int max_level_count, int total_ops, int* sync, int wave_slots, hipStream_t st) {
-    const int n_groups = stride / 64;
-    SlpWalk w;
-    w.words = words;
-    w.level_first = level_first;
-    w.level_count = level_count;
-    w.n_levels = n_levels;
-    w.n_groups = n_groups;
-    w.n_shards = n_groups < 8 ? n_groups : 8;
-    w.sync = sync;
-    w.spin_limit = 1 << 20;
-    w.debug = getenv("ETH_KZG_AMD_SLP_DEBUG") != nullptr;
-    if (const char* e = getenv("ETH_KZG_AMD_SLP_SPIN_LIMIT")) w.spin_limit = atoi(e);
-    (void)hipMemsetAsync(sync, 0, g1_slp_walk_sync_ints(n_groups, n_levels) * sizeof(int), st);
-    // enough waves to keep every level's operations of every group in flight, at most what the chip holds at once
-    long want = (long)max_level_count * n_groups;
-    if (want > wave_slots) want = wave_slots;
-    if (want > (long)total_ops * n_groups) want = (long)total_ops * n_groups;
-    want = (want + w.n_shards - 1) / w.n_shards * w.n_shards;
-    k_slp_walk<<<(unsigned)want, 64, 0, st>>>((JacQ*)arena, stride, w);
 }
 }  // namespace launch
 }  // namespace kzg

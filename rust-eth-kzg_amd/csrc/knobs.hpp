@@ -1,0 +1,72 @@
+// EVERY environment variable the library reads, in one place.  They are read ONCE per context (Knobs::from_env in the
+// constructor of the context's engine; the auxiliary engines a context creates copy its values): no getenv on any call path.
+// The reference gets by with one runtime knob (UsePrecomp::Yes{width}, crates/cryptography/bls12_381/src/fixed_base_msm.rs:41-49);
+// here eight are for the host application and the rest are hooks the parity tests use to force a schedule.
+//
+//   for the host application
+//   ETH_KZG_AMD_DEVICE=<n>          GPU ordinal of eth_kzg_das_context_new (default 0)
+//   ETH_KZG_AMD_TABLE_GB=<gb>|max   HBM for the two window tables together (default 160 = GLV width 15 + the width-13
+//                                   commitment table; max = whatever the HBM holds: GLV 16, 249 GB)
+//   ETH_KZG_AMD_GLV_WINDOW=<w>      exactly this GLV table width for FK20 (16, 15, 14, 12, 8)
+//   ETH_KZG_AMD_WINDOW=<w>          a PLAIN FK20 table of this width instead (14, 13, 12, 10, 8)
+//   ETH_KZG_AMD_PROGRESSIVE=0       build the wide tables inside the constructor instead of behind it
+//   ETH_KZG_AMD_HOST_THREADS=<n>    helper threads of the host-pointer paths (gather / scatter, hashing, pairings)
+//   ETH_KZG_AMD_SERIAL_LANES=<n>    engine lanes for concurrent recovery / commitment / EIP-4844 calls (default 4)
+//   ETH_KZG_AMD_TRACE=1             timings of context creation and of the verification steps on stderr
+//
+//   test hooks (tests/test_gpu_*.py force every schedule against the oracle)
+//   ETH_KZG_AMD_MSM_CHUNKS=0|4      0: the windowed MSM kernel at every batch size, 4: four chunks per MSM
+//   ETH_KZG_AMD_SLP_PROGRAM=<0..5>  one compilation of the G1 linear map at every batch size
+//   ETH_KZG_AMD_PIP_SHIFT_MIN=<n>   smallest verification that uses byte-shifted point copies
+//   ETH_KZG_AMD_VM_SEARCH=0         many-verification: re-check every problem of a failed pass instead of searching
+//   ETH_KZG_AMD_VM_FOLD=0           many-verification: one pairing per problem instead of one folded check per pass
+//   ETH_KZG_AMD_VERIFY_COMBINE=0    concurrent single verifications are not combined into passes
+//   ETH_KZG_AMD_COOP_POINTS=<n>     largest launch that takes the several-lanes-per-point kernels (0: never; process-wide, read
+//                                   once by launch::coop_points_max: launch geometry is decided outside any context)
+#pragma once
+#include <cstdlib>
+#include <cstring>
+
+namespace kzg {
+
+struct Knobs {
+    int device = 0;
+    double table_budget_gb = 0;  // 0: the engine's default; < 0: what the HBM holds
+    int glv_window = 0, plain_window = 0;
+    bool progressive = true;
+    int host_threads = 0;  // 0: chosen from the core count
+    int serial_lanes = 0;  // 0: the engine's default
+    bool trace = false;
+    int msm_chunks = -1, slp_program = -1, pip_shift_min = 0;
+    bool vm_search = true, vm_fold = true, verify_combine = true;
+
+    static Knobs from_env() {
+        Knobs k;
+        auto num = [](const char* name, int lo, int hi, int& out) {
+            if (const char* s = getenv(name)) { const int v = atoi(s); if (v >= lo && v <= hi) out = v; }
+        };
+        auto flag = [](const char* name, bool& out) {
+            if (const char* s = getenv(name)) out = atoi(s) != 0;
+        };
+        num("ETH_KZG_AMD_DEVICE", 0, 4095, k.device);
+        if (const char* s = getenv("ETH_KZG_AMD_TABLE_GB")) {
+            if (!strcmp(s, "max") || !strcmp(s, "MAX")) k.table_budget_gb = -1;
+            else if (atof(s) > 0) k.table_budget_gb = atof(s);
+        }
+        num("ETH_KZG_AMD_GLV_WINDOW", 8, 16, k.glv_window);
+        num("ETH_KZG_AMD_WINDOW", 8, 14, k.plain_window);
+        flag("ETH_KZG_AMD_PROGRESSIVE", k.progressive);
+        num("ETH_KZG_AMD_HOST_THREADS", 1, 64, k.host_threads);
+        num("ETH_KZG_AMD_SERIAL_LANES", 1, 16, k.serial_lanes);
+        k.trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
+        num("ETH_KZG_AMD_MSM_CHUNKS", 0, 4, k.msm_chunks);
+        num("ETH_KZG_AMD_SLP_PROGRAM", 0, 15, k.slp_program);
+        num("ETH_KZG_AMD_PIP_SHIFT_MIN", 1, 1 << 24, k.pip_shift_min);
+        flag("ETH_KZG_AMD_VM_SEARCH", k.vm_search);
+        flag("ETH_KZG_AMD_VM_FOLD", k.vm_fold);
+        flag("ETH_KZG_AMD_VERIFY_COMBINE", k.verify_combine);
+        return k;
+    }
+};
+
+}  // namespace kzg

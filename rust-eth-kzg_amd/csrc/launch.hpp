@@ -79,19 +79,10 @@ void build_table(int c, const void* bases /*G1Affine*/, void* const* blocks, voi
 void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int mode, const void* tw, const Fp12w& beta,
                   hipStream_t st);
 
-void g1_dft128_direct(void* X, void* tmpA, void* prod, int stride, int n_in, int n_out, int inverse, int brp_out,
-                      const void* tw, const Fp12w& beta, hipStream_t st);
-
 // k_g1slp.hip: one launch of the straight-line program of the FK20 proofs map (g1_linmap.hpp); kind = linmap::OpKind
 void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int count, const void* naf, const Fp12w& beta,
                    hipStream_t st, int lanes = 0 /* lanes to run (a multiple of 64, from the arena pointer on); 0: all `stride` of them */,
                    int coop_lanes = 0 /* > 0: the batch has this many blobs (<= 32): the constant multiplications take four (<= 16) or two lanes per blob */);
-
-// the cheap operations of one phase (before / after the constant multiplications) in ONE launch: a ticket walker with
-// per-(lane group, level) completion counters; returns the error word's position in `sync` (checked by the caller later)
-size_t g1_slp_walk_sync_ints(int n_groups, int n_levels);
-void g1_slp_walk(void* arena, int stride, const uint32_t* words, const int* level_first, const int* level_count, int n_levels,
-                 int max_level_count, int total_ops, int* sync, int wave_slots, hipStream_t st);
 
 // k_g1misc.hip
 void g1_set_inf(void* X, size_t n, hipStream_t st);

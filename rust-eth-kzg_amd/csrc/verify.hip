@@ -137,7 +137,7 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
     uint8_t*& a_pin = vs ? vs->pin : v_pin_;
     size_t& a_pin_cap = vs ? vs->pin_cap : v_pin_cap_;
     const bool two_streams = v_two_streams_ && !vs;
-    const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
+    const bool trace = knobs_.trace;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!trace) return;
@@ -356,8 +356,7 @@ bool Engine::verify_cells_pairing(const G1Affine* pts) const {
 // challenge) and the values meet in front of the one final exponentiation: 63 squarings + 68 line products per thread instead
 // of 63 + 136 on one.  Whoever gets to the second loop first computes it -- a busy pool costs nothing.
 bool Engine::verify_cells_pairing_split(const G1Affine* pts) {
-    static const bool off = [] { const char* e = getenv("ETH_KZG_AMD_PAIRING_SPLIT"); return e && atoi(e) == 0; }();
-    if (off || !stage_pool_) return verify_cells_pairing(pts);
+    if (!stage_pool_) return verify_cells_pairing(pts);
     struct Shared {
         pairing::Fp12 f;
         G1Affine p;
@@ -454,7 +453,7 @@ int Engine::verify_cell_kzg_proof_batch_host(uint64_t n_commitments, const uint8
     if (st) return st;
     const auto t0 = std::chrono::steady_clock::now();
     *verified = (empty || verify_cells_pairing_split(pts)) ? 1 : 0;
-    if (getenv("ETH_KZG_AMD_TRACE"))
+    if (knobs_.trace)
         fprintf(stderr, "[verify] %-28s %8.3f ms\n", "pairing check (host)",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return OK;
@@ -637,7 +636,7 @@ int Engine::recover_cells_and_kzg_proofs_batch_host(int R, const uint64_t* n_cel
     std::lock_guard<std::recursive_mutex> lk(mu_);
     try {
         HIPCK(hipSetDevice(dev_));
-        const bool trace = getenv("ETH_KZG_AMD_TRACE") != nullptr;
+        const bool trace = knobs_.trace;
         auto t0 = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) {
             if (!trace) return;

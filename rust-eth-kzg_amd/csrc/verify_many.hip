@@ -96,11 +96,11 @@ void parallel_for(int n, int threads, HostPool* pool, F fn) {
     }
     if (sh->err) std::rethrow_exception(sh->err);
 }
-int host_threads() {
+int host_threads(const Knobs& k) {
     int t = 16;
     const unsigned hw = std::thread::hardware_concurrency();
     if (hw && (int)hw < t) t = (int)hw;
-    if (const char* e = getenv("ETH_KZG_AMD_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) t = v; }
+    if (k.host_threads) t = k.host_threads;
     return t;
 }
 // reduce_bytes_to_scalar_bias (crates/cryptography/bls12_381/src/lib.rs:128-140): 256-bit big-endian integer mod r
@@ -133,9 +133,9 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
     // A LARGE call is cut into parts that run as passes of their own on different pass slots at the same time: while one part's
     // products are on the GPU the next one's 100+ MB are still being staged and hashed by the host threads (in one pass the
     // staging of all 275 MB of a 1024-problem call came first, ~10 ms, and the GPU waited for it).  Each part folds its own
-    // pairing check.  $ETH_KZG_AMD_VM_PARTS (default 3, 1 = one pass as in round 3).
+    // pairing check (one pass, round 3's form: 28.4-28.9 ms against 24.6-26.2 for 1024 problems).
     static thread_local bool in_part = false;
-    static const int max_parts = [] { const char* e = getenv("ETH_KZG_AMD_VM_PARTS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : v > VM_SLOTS ? (int)VM_SLOTS : v; }();
+    constexpr int max_parts = VM_SLOTS < 3 ? (int)VM_SLOTS : 3;
     if (!in_part && max_parts > 1 && B >= 192) {
         uint64_t total_cells = 0;
         for (int b = 0; b < B; b++) total_cells += n_cells[b];
@@ -167,16 +167,25 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
             return OK;
         }
     }
-    const int T = host_threads();
+    const int T = host_threads(knobs_);
     std::call_once(vm_pool_once_, [&] { vm_pool_.reset(new HostPool(T > 1 ? T - 1 : 1, dev_)); });
     HostPool* pool = vm_pool_.get();
     // a free pass slot (lock, stream, arena, pinned slab); when both are taken, queue on one of them in turn
     VmSlot* slot = nullptr;
     std::unique_lock<std::mutex> lk;
-    for (int k = 0; k < VM_SLOTS && !slot; k++) {
-        std::unique_lock<std::mutex> t(vm_slot_[k].mu, std::try_to_lock);
-        if (t.owns_lock()) { lk = std::move(t); slot = &vm_slot_[k]; }
-    }
+    // first choice: a free slot whose work set (whose in-order stream the pass runs on, below) is not held by a prover call right now
+    // -- otherwise the pass and that call wait on each other's work and a fault of either surfaces in both; a peek, not a
+    // lease: a prover call that takes the set a moment later shares the stream with the pass, which is correct, only serial
+    for (int pass = 0; pass < 2 && !slot; pass++)
+        for (int k = 0; k < VM_SLOTS && !slot; k++) {
+            if (pass == 0) {
+                std::mutex& wm = work_[1 + k % (NW - 1)].mu;
+                if (!wm.try_lock()) continue;
+                wm.unlock();
+            }
+            std::unique_lock<std::mutex> t(vm_slot_[k].mu, std::try_to_lock);
+            if (t.owns_lock()) { lk = std::move(t); slot = &vm_slot_[k]; }
+        }
     if (!slot) {
         slot = &vm_slot_[vm_rr_.fetch_add(1) % VM_SLOTS];
         lk = std::unique_lock<std::mutex>(slot->mu);
@@ -212,7 +221,7 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
         // ---- chunks of problems: at most CHUNK_CELLS cells per pass (the pinned slab and the arena stay bounded)
         constexpr int CHUNK_CELLS = 131072;  // 1024 verifications of 128 cells: 275 MB of pinned staging, ~1 GB of device arena
         bool fold = true;  // one folded pairing check per pass instead of one per problem (falls back to per-problem checks when it fails)
-        if (const char* e = getenv("ETH_KZG_AMD_VM_FOLD")) fold = atoi(e) != 0;
+        if (!knobs_.vm_fold) fold = false;  // (test hook: one pairing per problem)
         for (int b0 = 0; b0 < B;) {
             int b1 = b0, nn = 0, mm = 0;
             while (b1 < B && (b1 == b0 || nn + pr[b1].n <= CHUNK_CELLS)) { nn += pr[b1].n; mm += pr[b1].m; b1++; }
@@ -482,23 +491,28 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
                         const int len = sr.second - sr.first, parts = std::min(K, len);
                         for (int q = 0; q < parts; q++) probes.emplace_back(sr.first + (int)((long)len * q / parts), sr.first + (int)((long)len * (q + 1) / parts));
                     }
-                    if ((int)probes.size() > max_ranges) throw std::runtime_error("many-verification search: too many probes");
-                    for (size_t q = 0; q < probes.size(); q++) { h_rng[2 * q] = probes[q].first; h_rng[2 * q + 1] = probes[q].second; }
-                    memset(hb + poff_rsum, 0xff, probes.size() * 2 * launch::SIZEOF_JACQ);
-                    HIPCK(hipMemcpyAsync(db + off_rng, h_rng, probes.size() * 8, hipMemcpyHostToDevice, st));
-                    launch::vm_fold_ranges(db + off_fprod, (const int*)(db + off_rng), db + off_rsum, (int)probes.size(), st);
-                    HIPCK(hipMemcpyAsync(hb + poff_rsum, db + off_rsum, probes.size() * 2 * launch::SIZEOF_JACQ, hipMemcpyDeviceToHost, st));
-                    SYNC_CHECKED(st);
+                    // a level may need more probes than the range buffers hold (max_ranges = min(Bc, 2048): e.g. > 4096 small problems
+                    // with > 1024 scattered wrong proofs): it then runs in batches over the same buffers -- never an error, the
+                    // valid problems of the pass keep their verdicts
                     std::vector<char> fails(probes.size(), 0);
-                    parallel_for((int)probes.size(), T, pool, [&](int q) {
-                        G1Affine pts[2];
-                        for (int j = 0; j < 2; j++) {
-                            const JacQ& sj = h_rsum[2 * (size_t)q + j];
-                            if (poisoned(sj)) { device_fault.store(1); return; }
-                            pts[j] = to_affine(jac_from_jacq(sj));
-                        }
-                        fails[q] = verify_cells_pairing(pts) ? 0 : 1;
-                    });
+                    for (size_t q0 = 0; q0 < probes.size() && !device_fault.load(); q0 += (size_t)max_ranges) {
+                        const size_t cnt = std::min(probes.size() - q0, (size_t)max_ranges);
+                        for (size_t q = 0; q < cnt; q++) { h_rng[2 * q] = probes[q0 + q].first; h_rng[2 * q + 1] = probes[q0 + q].second; }
+                        memset(hb + poff_rsum, 0xff, cnt * 2 * launch::SIZEOF_JACQ);
+                        HIPCK(hipMemcpyAsync(db + off_rng, h_rng, cnt * 8, hipMemcpyHostToDevice, st));
+                        launch::vm_fold_ranges(db + off_fprod, (const int*)(db + off_rng), db + off_rsum, (int)cnt, st);
+                        HIPCK(hipMemcpyAsync(hb + poff_rsum, db + off_rsum, cnt * 2 * launch::SIZEOF_JACQ, hipMemcpyDeviceToHost, st));
+                        SYNC_CHECKED(st);
+                        parallel_for((int)cnt, T, pool, [&](int q) {
+                            G1Affine pts[2];
+                            for (int j = 0; j < 2; j++) {
+                                const JacQ& sj = h_rsum[2 * (size_t)q + j];
+                                if (poisoned(sj)) { device_fault.store(1); return; }
+                                pts[j] = to_affine(jac_from_jacq(sj));
+                            }
+                            fails[q0 + q] = verify_cells_pairing(pts) ? 0 : 1;
+                        });
+                    }
                     if (device_fault.load()) break;
                     suspects.clear();
                     for (size_t q = 0; q < probes.size(); q++) {
@@ -544,7 +558,7 @@ int Engine::verify_cell_kzg_proof_batch_combined(uint64_t n_commitments, const u
                                                  const uint64_t* cell_indices, uint64_t n_cells, const uint8_t* const* cells,
                                                  uint64_t n_proofs, const uint8_t* const* proofs, int* verified) {
     *verified = 0;
-    static const bool enabled = [] { const char* e = getenv("ETH_KZG_AMD_VERIFY_COMBINE"); return !e || atoi(e) != 0; }();
+    const bool enabled = knobs_.verify_combine;
     // ONE caller at a time (verify_lanes_), a large batch, or the feature switched off: the latency-optimised single path (3.3 ms);
     // callers that arrive while it is taken are combined into passes on the three pass slots (a pass of 1-8 problems: 3.7-4.1 ms
     // in the short-chain form).  Round 3 sent the first four callers to four engine lanes; their streams shared hardware queues
@@ -573,8 +587,6 @@ int Engine::verify_cell_kzg_proof_batch_combined(uint64_t n_commitments, const u
         for (VerifyRequest* r : batch) r->taken = true;
         lk.unlock();
         const size_t B = batch.size();
-        static const bool trace = getenv("ETH_KZG_AMD_TRACE_COMBINE") != nullptr;
-        if (trace) fprintf(stderr, "[combine] leader %p runs %zu problems\n", (void*)&me, B);
         // whatever happens in here (an allocation failure included) the followers must be released with a verdict: a leader that
         // left with comb_running_ set would leave every queued and every later caller waiting for ever
         int rc = ERR_DEVICE;
@@ -629,7 +641,6 @@ int Engine::verify_cell_kzg_proof_batch_combined(uint64_t n_commitments, const u
             rc = ERR_DEVICE;
             why = "combined verification pass: unknown failure";
         }
-        if (trace) fprintf(stderr, "[combine] leader %p done rc=%d\n", (void*)&me, rc);
         lk.lock();
         for (size_t i = 0; i < B; i++) {
             batch[i]->status = (rc == ERR_DEVICE || i >= st.size()) ? (int)ERR_DEVICE : st[i];

@@ -776,6 +776,27 @@ def test_verify_many_finds_wrong_proofs_by_searching_folded_ranges(ctx, monkeypa
         plain_ctx.close()
 
 
+def test_verify_many_search_level_larger_than_its_range_buffers(ctx):
+    """8,200 one-cell problems with 1,150 scattered wrong proofs in ONE pass: the per-problem fallback has not triggered yet
+    (suspects * 4 < live problems), K is clamped to 2 and a level needs more probes than the range buffers hold (2,048).  The
+    level must run in batches -- round 4 threw "too many probes", the whole call returned ERR_DEVICE and every VALID problem
+    lost its verdict (reachable by a caller fed adversarial proofs)."""
+    blobs = [synth.seeded_blob(170 + i) for i in range(2)]
+    st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs)
+    _, comms = ctx.blob_to_kzg_commitment_batch(blobs)
+    n_prob = 8200
+    wrong = set(range(3, n_prob, 7)) - set(range(0, n_prob, 64))
+    wrong = set(sorted(wrong)[:1150])
+    probs = []
+    for j in range(n_prob):
+        b, k = j & 1, (j * 37) % 128
+        p = proofs[1 - b][k] if j in wrong else proofs[b][k]
+        probs.append(([comms[b]], [k], [cells[b][k]], [p]))
+    ver, status = ctx.verify_cell_kzg_proof_batch_many(probs)
+    assert status == [0] * n_prob
+    assert ver == [j not in wrong for j in range(n_prob)], [j for j in range(n_prob) if ver[j] != (j not in wrong)][:10]
+
+
 def test_serial_paths_overlap_across_threads(ctx):
     """The verification / recovery / commitment entry points run on engine lanes created on demand (c_eth_kzg.h, "Threading"):
     four threads calling at once all get correct answers (the overlap itself is measured by bench.py, not asserted here)."""

@@ -1,5 +1,5 @@
 """A caller on the start tables while the helper thread allocates and builds the wide ones: one single-blob call every 5 ms,
-calls slower than 50 ms reported with the builder's trace lines on the same clock (ETH_KZG_AMD_TRACE=1 ETH_KZG_AMD_TRACE_SLOW=50)."""
+calls slower than 50 ms reported with the builder's trace lines on the same clock (ETH_KZG_AMD_TRACE=1 ETH_KZG_AMD_TRACE=50)."""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
