@@ -108,6 +108,15 @@ def _median(xs):
     return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
 
 
+def _oracle_uses_adx():
+    try:
+        import ctypes
+        import oracle_lib
+        return bool(ctypes.CDLL(oracle_lib._SO).oracle_fp_mul_uses_adx())
+    except Exception:
+        return False
+
+
 def cpu_baseline(blobs, gpu_first=None, extra=None):
     """Time the CPU oracle (C restatement of the reference algorithm: FK20, width-8 window tables, batched affine
     additions; portable unsigned __int128 field arithmetic, NOT blst's assembly) on this box's host cores with the
@@ -125,7 +134,9 @@ def cpu_baseline(blobs, gpu_first=None, extra=None):
         # a native build of the same sources for this host (the prebuilt liboracle.so is generic x86-64)
         native = os.path.join("/tmp", "liboracle_native_%d.so" % os.getuid())
         src = [os.path.join(ROOT, "oracle", f) for f in ("field.c", "g1.c", "pairing.c", "sha256.c", "kzg.c")]
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-std=gnu11", "-shared", "-o", native] + src,
+        # -DORACLE_ADX: Fp multiplications on mulx + two carry chains (oracle/field.c: mont_mul6_adx; the portable form stays the
+        # checker: tests/test_oracle_units.py compares them on 10^6 pairs) where the host CPU has BMI2 / ADX
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-DORACLE_ADX", "-fopenmp", "-fPIC", "-std=gnu11", "-shared", "-o", native] + src,
                               stderr=subprocess.DEVNULL)
         oracle_lib._SO = native
     except Exception:
@@ -218,7 +229,9 @@ def cpu_baseline(blobs, gpu_first=None, extra=None):
     best_value, best_cores = (par, cores) if par >= rayon["value"] else (rayon["value"], cores)
     return {"value": best_value, "unit": "blobs/s", "cores": best_cores, "kind": "port", "cpu_model": _cpu_model(),
             "protocol": "criterion-like (BASELINE.md section 3): 3 s warm-up, 30 timed samples, median; context built once outside",
-            "sample": f"C oracle (width-8 tables, portable __int128 field arithmetic -- not blst assembly) on {cores} usable host "
+            "fp_mul": ("ADX/BMI2 (mulx, two carry chains; oracle/field.c: mont_mul6_adx)" if _oracle_uses_adx() else "portable unsigned __int128"),
+            "sample": f"C oracle (width-8 tables; Fp multiplication: {'ADX/BMI2 mulx form, native build' if _oracle_uses_adx() else 'portable __int128'} -- measured +6 % "
+                      f"over gcc's own -march=native code for the __int128 form, which already uses mulx; not blst's hand-scheduled assembly) on {cores} usable host "
                       f"cores: (a) blob-parallel, one single-threaded prover per core, {len(tsp)} rounds of {cores} distinct "
                       f"synthetic blobs, median {_median(tsp):.3f} s per round = {par:.1f} blobs/s (best {par_best:.1f}); (b) one blob "
                       f"at a time with OpenMP over the maybe_rayon axes, {rayon['samples']} samples = {rayon['value']:.1f} blobs/s; "

@@ -185,8 +185,75 @@ void fr_batch_inverse(fr_t *v, size_t n) {
 void fp_add(fp_t *o, const fp_t *a, const fp_t *b) { mod_add(o->l, a->l, b->l, P_MOD, 6); }
 void fp_sub(fp_t *o, const fp_t *a, const fp_t *b) { mod_sub(o->l, a->l, b->l, P_MOD, 6); }
 void fp_neg(fp_t *o, const fp_t *a) { mod_sub(o->l, FP_ZERO.l, a->l, P_MOD, 6); }
+/* The portable product-scanning form above is the CHECKER.  The timed native build of bench.py's cpu_baseline leg (and only it:
+ * -DORACLE_ADX -march=native) multiplies in Fp with the BMI2 / ADX instructions a production CPU library uses -- mulx for the
+ * 64 x 64 -> 128 products, two independent carry chains per row (the compiler schedules them as adcx / adox or adc) -- so that the one
+ * CPU number beside the GPU's is not softer than it needs to be (blst-class assembly is 1.3-2x the __int128 form).
+ * oracle_fp_mul_selftest compares the two forms on random pairs (tests/test_oracle_units.py: 10^6 of them). */
+void fp_mul_portable(fp_t *o, const fp_t *a, const fp_t *b) { mont_mul(o->l, a->l, b->l, P_MOD, P_N0, 6); }
+#if defined(ORACLE_ADX) && defined(__ADX__) && defined(__BMI2__)
+#include <immintrin.h>
+#define ORACLE_ADX_ACTIVE 1
+static inline void mont_mul6_adx(uint64_t *o, const uint64_t *a, const uint64_t *b) {
+    typedef unsigned long long ull;
+    ull t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7;
+    const ull p0 = P_MOD[0], p1 = P_MOD[1], p2 = P_MOD[2], p3 = P_MOD[3], p4 = P_MOD[4], p5 = P_MOD[5], n0 = P_N0;
+    for (int i = 0; i < 6; i++) {
+        ull l0, l1, l2, l3, l4, l5, h0, h1, h2, h3, h4, h5;
+        unsigned char c, d;
+        const ull bi = b[i];
+        /* t += a * b[i]: the low halves on one carry chain, the high halves on another */
+        l0 = _mulx_u64(a[0], bi, &h0); l1 = _mulx_u64(a[1], bi, &h1); l2 = _mulx_u64(a[2], bi, &h2);
+        l3 = _mulx_u64(a[3], bi, &h3); l4 = _mulx_u64(a[4], bi, &h4); l5 = _mulx_u64(a[5], bi, &h5);
+        c = _addcarryx_u64(0, t0, l0, &t0); c = _addcarryx_u64(c, t1, l1, &t1); c = _addcarryx_u64(c, t2, l2, &t2);
+        c = _addcarryx_u64(c, t3, l3, &t3); c = _addcarryx_u64(c, t4, l4, &t4); c = _addcarryx_u64(c, t5, l5, &t5);
+        c = _addcarryx_u64(c, t6, 0, &t6);
+        t7 = c;
+        d = _addcarryx_u64(0, t1, h0, &t1); d = _addcarryx_u64(d, t2, h1, &t2); d = _addcarryx_u64(d, t3, h2, &t3);
+        d = _addcarryx_u64(d, t4, h3, &t4); d = _addcarryx_u64(d, t5, h4, &t5); d = _addcarryx_u64(d, t6, h5, &t6);
+        t7 += d;
+        /* t += q * p with q = t0 * n0: t0 becomes 0; shift one limb down */
+        const ull q = t0 * n0;
+        l0 = _mulx_u64(q, p0, &h0); l1 = _mulx_u64(q, p1, &h1); l2 = _mulx_u64(q, p2, &h2);
+        l3 = _mulx_u64(q, p3, &h3); l4 = _mulx_u64(q, p4, &h4); l5 = _mulx_u64(q, p5, &h5);
+        c = _addcarryx_u64(0, t0, l0, &t0); c = _addcarryx_u64(c, t1, l1, &t1); c = _addcarryx_u64(c, t2, l2, &t2);
+        c = _addcarryx_u64(c, t3, l3, &t3); c = _addcarryx_u64(c, t4, l4, &t4); c = _addcarryx_u64(c, t5, l5, &t5);
+        c = _addcarryx_u64(c, t6, 0, &t6);
+        t7 += c;
+        d = _addcarryx_u64(0, t1, h0, &t0); d = _addcarryx_u64(d, t2, h1, &t1); d = _addcarryx_u64(d, t3, h2, &t2);
+        d = _addcarryx_u64(d, t4, h3, &t3); d = _addcarryx_u64(d, t5, h4, &t4); d = _addcarryx_u64(d, t6, h5, &t5);
+        t6 = t7 + d;
+    }
+    uint64_t t[6] = {t0, t1, t2, t3, t4, t5};
+    if (t6 || ge_n(t, P_MOD, 6)) sub_n(t, t, P_MOD, 6);
+    memcpy(o, t, 48);
+}
+void fp_mul(fp_t *o, const fp_t *a, const fp_t *b) { mont_mul6_adx(o->l, a->l, b->l); }
+#else
+#define ORACLE_ADX_ACTIVE 0
 void fp_mul(fp_t *o, const fp_t *a, const fp_t *b) { mont_mul(o->l, a->l, b->l, P_MOD, P_N0, 6); }
-void fp_sqr(fp_t *o, const fp_t *a) { mont_mul(o->l, a->l, a->l, P_MOD, P_N0, 6); }
+#endif
+int oracle_fp_mul_uses_adx(void) { return ORACLE_ADX_ACTIVE; }
+/* fp_mul (whichever form this build uses) against the portable form on n pseudo-random pairs of values below p, chained so that
+ * every product feeds the next pair; returns the number of mismatches */
+long oracle_fp_mul_selftest(long n, uint64_t seed) {
+    bls_init();
+    fp_t x, y, r1, r2;
+    uint64_t st = seed | 1;
+    for (int i = 0; i < 6; i++) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; x.l[i] = st; st ^= st << 13; st ^= st >> 7; st ^= st << 17; y.l[i] = st; }
+    x.l[5] &= 0x0fffffffffffffffULL; y.l[5] &= 0x0fffffffffffffffULL;
+    long bad = 0;
+    for (long k = 0; k < n; k++) {
+        fp_mul(&r1, &x, &y);
+        fp_mul_portable(&r2, &x, &y);
+        if (memcmp(&r1, &r2, sizeof r1)) bad++;
+        x = y;
+        y = r2;
+        if ((k & 1023) == 1023) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; y.l[0] ^= st; y.l[5] &= 0x0fffffffffffffffULL; }
+    }
+    return bad;
+}
+void fp_sqr(fp_t *o, const fp_t *a) { fp_mul(o, a, a); }
 int fp_is_zero(const fp_t *a) {
     return (a->l[0] | a->l[1] | a->l[2] | a->l[3] | a->l[4] | a->l[5]) == 0;
 }

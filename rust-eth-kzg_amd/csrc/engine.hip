@@ -125,39 +125,6 @@ static thread_local std::string t_last_error;
 const std::string& Engine::last_error() const { return t_last_error; }
 void Engine::set_error(const std::exception& e) { t_last_error = e.what(); }
 
-HostPool::HostPool(int threads, int device) {
-    for (int i = 0; i < threads; i++) th_.emplace_back([this, device] { run(device); });
-}
-HostPool::~HostPool() {
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        stop_ = true;
-    }
-    cv_.notify_all();
-    for (auto& t : th_) t.join();
-}
-void HostPool::submit(std::function<void()> fn) {
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        q_.push_back(std::move(fn));
-    }
-    cv_.notify_one();
-}
-void HostPool::run(int device) {
-    (void)hipSetDevice(device);
-    for (;;) {
-        std::function<void()> fn;
-        {
-            std::unique_lock<std::mutex> lk(mu_);
-            cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
-            if (q_.empty()) return;
-            fn = std::move(q_.front());
-            q_.pop_front();
-        }
-        fn();
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 BufferPool::~BufferPool() {
     for (auto& f : free_) {
@@ -228,52 +195,18 @@ void stop_all_builders_at_exit() {
     for (Engine* e : live) e->stop_builder();
 }
 
+// the primary when it is idle, an idle auxiliary lane, a new lane built OUTSIDE the pool's lock (0.1 s of set-up kernels: callers that
+// find the existing lanes busy meanwhile queue on one of those instead of behind this constructor; the lane shares this engine's
+// window tables -- no registry look-up, no lock a table build could hold), else wait on a lane, round-robin: host_sync.hpp (LanePool)
 Engine::SerialLease Engine::lease_serial() {
-    SerialLease L;
-    L.busy = std::unique_lock<std::mutex>(lane_busy_, std::try_to_lock);
-    if (L.busy.owns_lock() || auxiliary_ || max_lanes_ <= 1) {
-        if (!L.busy.owns_lock()) L.busy.lock();
-        L.e = this;
-        return L;
-    }
-    bool create = false;
-    {
-        std::lock_guard<std::mutex> lk(lanes_mu_);
-        for (auto& a : aux_) {
-            L.busy = std::unique_lock<std::mutex>(a->lane_busy_, std::try_to_lock);
-            if (L.busy.owns_lock()) { L.e = a.get(); return L; }
-        }
-        if ((int)aux_.size() + lanes_pending_ + 1 < max_lanes_) { lanes_pending_++; create = true; }
-    }
-    if (create) {
-        // a new lane is built OUTSIDE lanes_mu_ (0.1 s of set-up kernels): callers that find the existing lanes busy meanwhile
-        // queue on one of those instead of behind this constructor; the lane shares this engine's window tables (no registry
-        // look-up, no lock a table build could hold)
-        std::unique_ptr<Engine> fresh;
+    return lanes_.lease(this, max_lanes_, auxiliary_, [this] {
         try {
-            fresh.reset(new Engine(use_precomp_, dev_, /*primary=*/this));
-        } catch (const std::exception&) {
-            (void)hipGetLastError();  // no room for another lane: queue on an existing one
+            return std::unique_ptr<Engine>(new Engine(use_precomp_, dev_, /*primary=*/this));
+        } catch (...) {
+            (void)hipGetLastError();  // no room for another lane: the caller queues on an existing one
+            throw;
         }
-        std::lock_guard<std::mutex> lk(lanes_mu_);
-        lanes_pending_--;
-        if (fresh) {
-            L.busy = std::unique_lock<std::mutex>(fresh->lane_busy_);
-            L.e = fresh.get();
-            aux_.push_back(std::move(fresh));
-            return L;
-        }
-    }
-    // all lanes busy: wait on one of them, round-robin
-    Engine* pick = this;
-    {
-        std::lock_guard<std::mutex> lk(lanes_mu_);
-        const unsigned k = lane_rr_.fetch_add(1) % (unsigned)(aux_.size() + 1);
-        if (k > 0) pick = aux_[k - 1].get();
-    }
-    L.busy = std::unique_lock<std::mutex>(pick->lane_busy_);
-    L.e = pick;
-    return L;
+    });
 }
 
 Engine::Engine(bool use_precomp, int device, const Engine* primary, double table_budget_gb) : dev_(device), use_precomp_(use_precomp), primary_(primary), auxiliary_(primary != nullptr) {
@@ -403,10 +336,7 @@ void Engine::settle_streams() {
 
 Engine::~Engine() {
     hipSetDevice(dev_);
-    {
-        std::lock_guard<std::mutex> lk(lanes_mu_);
-        aux_.clear();
-    }
+    lanes_.clear();
     stop_builder();  // an unfinished build of the wide tables is abandoned (within one 2 GB piece)
     {
         std::lock_guard<std::mutex> lk(g_engines_mu);

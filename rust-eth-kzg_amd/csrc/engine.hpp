@@ -3,6 +3,7 @@
 //  verifier.rs:72-112).  One Engine = one context on one GPU.
 #pragma once
 #include "knobs.hpp"
+#include "host_sync.hpp"
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <cstdint>
@@ -87,22 +88,7 @@ struct Work {
     hipEvent_t ev_coeffs = nullptr, ev_side = nullptr;  // small batches: coefficients ready / cells written on the second stream
     std::vector<hipEvent_t> sub_events;  // per sub-batch of a host-pointer call: [2i] cells computed, [2i+1] cells on the host
 };
-// A few helper threads for the host-side memcpy work of the host-pointer entry points (gathering blobs into pinned
-// memory, scattering cells / proofs to the caller's 256 buffers per blob), so that it overlaps the GPU.
-class HostPool {
-public:
-    explicit HostPool(int threads, int device);
-    ~HostPool();
-    void submit(std::function<void()> fn);
-private:
-    void run(int device);
-    std::vector<std::thread> th_;
-    std::deque<std::function<void()>> q_;
-    std::mutex mu_;
-    std::condition_variable cv_;
-    bool stop_ = false;
-};
-
+// (HostPool, the combiner, pass-slot and lane leases: host_sync.hpp -- HIP-free, driven under ThreadSanitizer on the CPU)
 class Engine {
 public:
     friend struct PoolBuf;
@@ -128,11 +114,9 @@ public:
     // (bindings/node/src/lib.rs:92-299), the context keeps up to ETH_KZG_AMD_SERIAL_LANES (default 4) engines: the primary one
     // and auxiliaries created on demand (0.1 s each; the window tables are shared, so no memory to speak of).  lease_serial()
     // hands out a free one -- the primary when it is idle -- and blocks only when all are busy.
-    struct SerialLease {
-        Engine* e = nullptr;
-        std::unique_lock<std::mutex> busy;
-        Engine* operator->() const { return e; }
-    };
+    using SerialLease = LanePool<Engine>::Lease;  // {Engine* e; std::unique_lock<std::mutex> busy;}
+    friend class LanePool<Engine>;
+
     SerialLease lease_serial();
 
     int device() const { return dev_; }
@@ -332,8 +316,7 @@ private:
     double table_budget_gb_ = DEFAULT_TABLE_BUDGET_GB;  // upper bound for both tables together (constructor argument, ETH_KZG_AMD_TABLE_GB, or the default); <= 0: what the HBM holds
     mutable std::mutex tab_mu_;
     std::condition_variable tab_cv_;
-    TableView views_[2];
-    std::vector<std::shared_ptr<SharedTable>> retired_;  // start tables stay alive for kernels already in flight
+    Published<SharedTable> pub_[2];  // per table kind: main / next / retired (host_sync.hpp); start tables stay alive for kernels already in flight
     int tables_state_ = 0;  // 0 building, 1 final, 2 wide build failed (guarded by tab_mu_)
     std::string tables_error_;
     std::thread builder_;
@@ -378,19 +361,13 @@ private:
     // serial-path lanes (lease_serial)
     const Engine* primary_ = nullptr;   // set in an auxiliary lane
     bool auxiliary_ = false;
-    int lanes_pending_ = 0;             // lanes under construction (outside lanes_mu_)
     std::mutex lane_busy_;              // held while a leased call runs on THIS engine
-    std::mutex lanes_mu_;               // guards aux_
-    std::vector<std::unique_ptr<Engine>> aux_;
+    LanePool<Engine> lanes_;            // the auxiliary lanes of a context (host_sync.hpp)
     int max_lanes_ = 4;
-    std::atomic<unsigned> lane_rr_{0};
 
     // combiner of concurrent single verifications (verify_many.hip: verify_cell_kzg_proof_batch_combined)
     struct VerifyRequest;
-    std::mutex comb_mu_;
-    std::condition_variable comb_cv_;
-    std::vector<VerifyRequest*> comb_queue_;
-    int comb_running_ = 0;                 // leaders running a pass right now (at most VM_SLOTS)
+    Combiner<VerifyRequest> combiner_{VM_SLOTS};  // at most VM_SLOTS leaders run a pass at a time (host_sync.hpp)
     std::atomic<int> verify_inflight_{0};  // single verifications on the latency path right now
     int verify_lanes_ = 1;                 // concurrent single verifications on the latency path ; the others are combined
     int comb_max_cells_ = 1024;            // larger problems always take the single path (their transcript hash is the bound)
@@ -400,8 +377,7 @@ private:
     // staging, transcript hashes and pairing checks run on the host threads (concurrent single calls are combined into passes:
     // verify_cell_kzg_proof_batch_combined lets two leaders run at a time)
     static constexpr int VM_SLOTS = 3;
-    struct VmSlot {
-        std::mutex mu;
+    struct VmSlot {  // (its lock: vm_slots_)
         VerifyScratch vs;   // for a "pass" of ONE problem: the single path's arena on this slot's stream
         void* dev = nullptr;
         size_t dev_cap = 0;
@@ -409,11 +385,11 @@ private:
         size_t pin_cap = 0;
     };
     VmSlot vm_slot_[VM_SLOTS];
+    SlotSet<VM_SLOTS> vm_slots_;  // leases of the pass slots (host_sync.hpp)
     std::unique_ptr<HostPool> stage_pool_;  // staging of single verifications (a few threads: the lane + the pass slots run side by side)
     std::once_flag stage_pool_once_;
     std::unique_ptr<HostPool> vm_pool_;  // the host threads of the many-verification passes (hashes, staging, pairing checks)
     std::once_flag vm_pool_once_;
-    std::atomic<unsigned> vm_rr_{0};
     bool vm_search_ = true;  // ETH_KZG_AMD_VM_SEARCH=0: a pass whose folded check fails is re-checked problem by problem (round 3's form)
     int vm_small_max_ = -1;  // passes of at most this many problems take the short-chain form (verify_many.hip); -1: 2 x host threads
     uint8_t* vd_pin_ = nullptr;  // device-resident verification: the host mirror the transcript hash reads (grow-only, guarded by mu_)

@@ -377,7 +377,7 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
                 const unsigned hw = std::thread::hardware_concurrency();
                 if (hw && (int)hw < 2 * t) t = (int)hw / 2 > 1 ? (int)hw / 2 : 1;
                 if (knobs_.host_threads) t = knobs_.host_threads;
-                host_pool_.reset(new HostPool(t, dev_));
+                host_pool_.reset(new HostPool(t, [d = dev_] { (void)hipSetDevice(d); }));
             });
         Work& w = lease_work(1, NW - 1);
         held = &w;

@@ -143,22 +143,22 @@ static std::shared_ptr<Engine::SharedTable> obtain_table(int dev, int kind, int 
     return t->state.load() == 1 ? t : nullptr;
 }
 
+// One snapshot per MSM launch; publish / retire / reap: host_sync.hpp (Published), driven under ThreadSanitizer on the CPU
 Engine::TableView Engine::table_view(TableSel which) const {
     if (primary_) return primary_->table_view(which);  // an engine lane reads through to the context's engine
-    std::lock_guard<std::mutex> lk(tab_mu_);
-    return views_[which];
+    const auto s = pub_[which].snapshot();
+    TableView v;
+    v.main = s.main;
+    v.next = s.next;
+    v.c = s.main ? s.main->c : 0;
+    v.glv = s.main ? s.main->glv : false;
+    v.bytes = s.main ? s.main->bytes : 0;
+    return v;
 }
-// main: the complete table calls run on; next: a wider one under construction whose ready groups are used already
+// main: the complete table calls run on; next: a wider one under construction whose ready groups are used already; what falls out
+// of the view is retired (kernels in flight may still read it) until nobody refers to it
 void Engine::publish(TableSel which, const std::shared_ptr<SharedTable>& main, const std::shared_ptr<SharedTable>& next) {
-    std::lock_guard<std::mutex> lk(tab_mu_);
-    TableView& v = views_[which];
-    if (v.main && v.main != main) retired_.push_back(v.main);  // kernels in flight may still read it
-    if (v.next && v.next != next && v.next != main) retired_.push_back(v.next);
-    v.main = main;
-    v.next = next;
-    v.c = main ? main->c : 0;
-    v.glv = main ? main->glv : false;
-    v.bytes = main ? main->bytes : 0;
+    pub_[which].publish(main, next);
 }
 int Engine::tables_ready(int wait_ms) {
     if (primary_) return const_cast<Engine*>(primary_)->tables_ready(wait_ms);
@@ -269,21 +269,9 @@ void Engine::build_final_tables() {
             const TableView cur = table_view(sel);  // (this snapshot is itself a reference: it ends with the block)
             if (cur.next && cur.next->state.load() == 2) publish(sel, cur.main, nullptr);
         }
-        for (int spin = 0; spin < 2000; spin++) {
-            std::vector<std::shared_ptr<SharedTable>> dead;
-            bool waiting = false;
-            {
-                std::lock_guard<std::mutex> lk(tab_mu_);
-                for (auto it = retired_.begin(); it != retired_.end();) {
-                    if ((*it)->state.load() != 2) { ++it; continue; }
-                    if (it->use_count() == 1) { dead.push_back(std::move(*it)); it = retired_.erase(it); }
-                    else { waiting = true; ++it; }
-                }
-            }
-            dead.clear();  // ~SharedTable: hipFree of every piece, outside the lock, on this thread
-            if (!waiting) break;
+        // ~SharedTable (hipFree of every piece) runs inside reap(): outside the lock, on this thread
+        for (int spin = 0; spin < 2000 && pub_[sel].reap([](const SharedTable& r) { return r.state.load() == 2; }) > 0; spin++)
             std::this_thread::sleep_for(std::chrono::milliseconds(1));
-        }
     };
     auto widen = [&](TableSel sel, int kind, int w, const void* bases, int n_groups) -> std::shared_ptr<SharedTable> {
         if (cancel_build_.load()) throw BuildCancelled{};

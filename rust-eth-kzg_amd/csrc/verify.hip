@@ -206,7 +206,7 @@ int Engine::verify_cells_partial(uint64_t n_commitments, const uint8_t* const* c
         // the caller's buffers (the hash is the longest sequential piece of a verification)
         std::exception_ptr stage_error;
         // (a worker of the engine's small persistent pool: starting and joining a fresh thread per call was 50-100 us of a 3.3 ms call)
-        std::call_once(stage_pool_once_, [this] { stage_pool_.reset(new HostPool(primary_ ? 1 : 4, dev_)); });
+        std::call_once(stage_pool_once_, [this] { stage_pool_.reset(new HostPool(primary_ ? 1 : 4, [d = dev_] { (void)hipSetDevice(d); })); });
         struct StageDone {
             std::mutex mu;
             std::condition_variable cv;

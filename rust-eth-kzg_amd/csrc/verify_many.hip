@@ -54,48 +54,6 @@ namespace kzg {
 static constexpr int N_BLOB = 4096, N_CELLS = 128, CELL_LEN = 64, BYTES_PER_CELL = 2048;
 
 namespace {
-// fork-join over [0, n) on the calling thread and up to `threads` - 1 workers of a persistent pool (work stealing by an atomic
-// counter; the first exception is rethrown).  Round 3 started fresh std::threads here, five times per pass: ~0.5 ms of thread
-// churn on a pass that should last 4.
-template <class F>
-void parallel_for(int n, int threads, HostPool* pool, F fn) {
-    if (n <= 0) return;
-    if (threads > n) threads = n;
-    if (threads <= 1 || !pool) { for (int i = 0; i < n; i++) fn(i); return; }
-    struct Shared {
-        std::atomic<int> next{0};
-        std::atomic<unsigned> state{0};  // helpers inside body | CLOSED: the caller has left its own share and admits no more
-        std::exception_ptr err;
-        std::mutex mu;
-        std::condition_variable cv;
-    };
-    constexpr unsigned CLOSED = 0x80000000u;
-    auto sh = std::make_shared<Shared>();  // outlives this frame: a helper the pool gets to late finds the door closed and leaves
-    auto body = [sh, n, &fn] {
-        try {
-            for (int i; (i = sh->next.fetch_add(1)) < n;) fn(i);
-        } catch (...) {
-            std::lock_guard<std::mutex> lk(sh->mu);
-            if (!sh->err) sh->err = std::current_exception();
-            sh->next.store(n);
-        }
-    };
-    for (int t = 0; t < threads - 1; t++)
-        pool->submit([sh, body, CLOSED] {
-            unsigned s = sh->state.load();
-            do {
-                if (s & CLOSED) return;  // too late: nothing of the caller's frame may be touched any more
-            } while (!sh->state.compare_exchange_weak(s, s + 1));
-            body();
-            if (sh->state.fetch_sub(1) == (CLOSED | 1u)) { std::lock_guard<std::mutex> lk(sh->mu); sh->cv.notify_all(); }
-        });
-    body();
-    {   // no new helper may enter; those inside are waited for (fn and the caller's captures die with this frame)
-        std::unique_lock<std::mutex> lk(sh->mu);
-        if (sh->state.fetch_or(CLOSED) != 0) sh->cv.wait(lk, [&] { return sh->state.load() == CLOSED; });
-    }
-    if (sh->err) std::rethrow_exception(sh->err);
-}
 int host_threads(const Knobs& k) {
     int t = 16;
     const unsigned hw = std::thread::hardware_concurrency();
@@ -168,28 +126,14 @@ int Engine::verify_cell_kzg_proof_batch_many_host(uint64_t n_batches, const uint
         }
     }
     const int T = host_threads(knobs_);
-    std::call_once(vm_pool_once_, [&] { vm_pool_.reset(new HostPool(T > 1 ? T - 1 : 1, dev_)); });
+    std::call_once(vm_pool_once_, [&] { vm_pool_.reset(new HostPool(T > 1 ? T - 1 : 1, [d = dev_] { (void)hipSetDevice(d); })); });
     HostPool* pool = vm_pool_.get();
-    // a free pass slot (lock, stream, arena, pinned slab); when both are taken, queue on one of them in turn
-    VmSlot* slot = nullptr;
-    std::unique_lock<std::mutex> lk;
-    // first choice: a free slot whose work set (whose in-order stream the pass runs on, below) is not held by a prover call right now
-    // -- otherwise the pass and that call wait on each other's work and a fault of either surfaces in both; a peek, not a
-    // lease: a prover call that takes the set a moment later shares the stream with the pass, which is correct, only serial
-    for (int pass = 0; pass < 2 && !slot; pass++)
-        for (int k = 0; k < VM_SLOTS && !slot; k++) {
-            if (pass == 0) {
-                std::mutex& wm = work_[1 + k % (NW - 1)].mu;
-                if (!wm.try_lock()) continue;
-                wm.unlock();
-            }
-            std::unique_lock<std::mutex> t(vm_slot_[k].mu, std::try_to_lock);
-            if (t.owns_lock()) { lk = std::move(t); slot = &vm_slot_[k]; }
-        }
-    if (!slot) {
-        slot = &vm_slot_[vm_rr_.fetch_add(1) % VM_SLOTS];
-        lk = std::unique_lock<std::mutex>(slot->mu);
-    }
+    // a free pass slot (lock, stream, arena, pinned slab); when all are taken, queue on one of them in turn (host_sync.hpp: SlotSet).
+    // First choice: a free slot whose work set (whose in-order stream the pass runs on, below) is not held by a prover call right
+    // now -- otherwise the pass and that call wait on each other's work and a fault of either surfaces in both; a peek,
+    // not a lease: a prover call that takes the set a moment later shares the stream with the pass, which is correct, only serial
+    auto slot_lease = vm_slots_.acquire([&](int k) { return mutex_is_free(work_[1 + k % (NW - 1)].mu); });
+    VmSlot* slot = &vm_slot_[slot_lease.index];
     try {
         HIPCK(hipSetDevice(dev_));
         // A slot runs on the stream of one of the prover's three work sets instead of a stream of its own: HIP maps a process's
@@ -576,82 +520,64 @@ int Engine::verify_cell_kzg_proof_batch_combined(uint64_t n_commitments, const u
     VerifyRequest me;
     me.n[0] = n_commitments; me.n[1] = n_indices; me.n[2] = n_cells; me.n[3] = n_proofs;
     me.commitments = commitments; me.cell_indices = cell_indices; me.cells = cells; me.proofs = proofs;
-    std::unique_lock<std::mutex> lk(comb_mu_);
-    comb_queue_.push_back(&me);
-    while (!me.done) {
-        if (me.taken || comb_running_ >= VM_SLOTS) { comb_cv_.wait(lk); continue; }
-        // become a leader (one per pass slot): run everything queued so far (this request included) as ONE many-verification pass
-        comb_running_++;
-        std::vector<VerifyRequest*> batch;
-        batch.swap(comb_queue_);
-        for (VerifyRequest* r : batch) r->taken = true;
-        lk.unlock();
-        const size_t B = batch.size();
-        // whatever happens in here (an allocation failure included) the followers must be released with a verdict: a leader that
-        // left with comb_running_ set would leave every queued and every later caller waiting for ever
-        int rc = ERR_DEVICE;
-        std::string why;
-        std::vector<int> ver, st;
-        try {
-          if (B == 1) {
-            // a "pass" of one problem is the single path itself -- 3.3 ms against the 3.65 of a one-problem pass (its points are
-            // shifted before the challenge; a pass multiplies by per-lane scalars after it) -- on a pass slot's stream and arena:
-            // the latency lane and three slots make four single verifications side by side, one hardware queue each
-            VmSlot* slot = nullptr;
-            std::unique_lock<std::mutex> sl;
-            for (int k = 0; k < VM_SLOTS && !slot; k++) {
-                std::unique_lock<std::mutex> t(vm_slot_[k].mu, std::try_to_lock);
-                if (t.owns_lock()) { sl = std::move(t); slot = &vm_slot_[k]; }
-            }
-            if (!slot) {
-                slot = &vm_slot_[vm_rr_.fetch_add(1) % VM_SLOTS];
-                sl = std::unique_lock<std::mutex>(slot->mu);
-            }
-            const int slot_index = (int)(slot - vm_slot_);
-            slot->vs.stream = work_[1 + slot_index % (NW - 1)].stream ? work_[1 + slot_index % (NW - 1)].stream : stream_;
-            VerifyRequest* r = batch[0];
-            G1Affine pts[2];
-            bool empty = false;
-            ver.assign(1, 0);
-            st.assign(1, (int)ERR_DEVICE);
-            HIPCK(hipSetDevice(dev_));
-            st[0] = verify_cells_partial(r->n[0], r->commitments, r->n[1], r->cell_indices, r->n[2], r->cells, r->n[3], r->proofs, 0, r->n[2], pts, &empty, nullptr, &slot->vs);
-            sl.unlock();  // the pairing needs no slot
-            rc = st[0] == ERR_DEVICE ? (int)ERR_DEVICE : (int)OK;
-            if (rc == ERR_DEVICE) why = last_error();
-            if (st[0] == OK) ver[0] = (empty || verify_cells_pairing_split(pts)) ? 1 : 0;
-          } else {
-            std::vector<uint64_t> l0(B), l1(B), l2(B), l3(B);
-            std::vector<const uint8_t* const*> pc(B), pl(B), pp(B);
-            std::vector<const uint64_t*> pi(B);
-            ver.assign(B, 0);
-            st.assign(B, (int)ERR_DEVICE);
-            for (size_t i = 0; i < B; i++) {
-                l0[i] = batch[i]->n[0]; l1[i] = batch[i]->n[1]; l2[i] = batch[i]->n[2]; l3[i] = batch[i]->n[3];
-                pc[i] = batch[i]->commitments; pi[i] = batch[i]->cell_indices; pl[i] = batch[i]->cells; pp[i] = batch[i]->proofs;
-            }
-            rc = verify_cell_kzg_proof_batch_many_host(B, l0.data(), pc.data(), l1.data(), pi.data(), l2.data(), pl.data(), l3.data(),
-                                                       pp.data(), ver.data(), st.data());
-            if (rc == ERR_DEVICE) why = last_error();
-          }
-        } catch (const std::exception& e) {
-            rc = ERR_DEVICE;
-            why = std::string("combined verification pass: ") + e.what();
-        } catch (...) {
-            rc = ERR_DEVICE;
-            why = "combined verification pass: unknown failure";
+    // leader election, follower wake-up and the release of the followers whatever happens in a pass: host_sync.hpp (Combiner), which
+    // tests/c/test_host_sync.cpp drives under ThreadSanitizer with fake passes
+    combiner_.submit(me, [&](std::vector<VerifyRequest*>& batch) {
+    const size_t B = batch.size();
+    // whatever happens in here (an allocation failure included) the followers must be released with a verdict: a leader that
+    // left with comb_running_ set would leave every queued and every later caller waiting for ever
+    int rc = ERR_DEVICE;
+    std::string why;
+    std::vector<int> ver, st;
+    try {
+      if (B == 1) {
+        // a "pass" of one problem is the single path itself -- 3.3 ms against the 3.65 of a one-problem pass (its points are
+        // shifted before the challenge; a pass multiplies by per-lane scalars after it) -- on a pass slot's stream and arena:
+        // the latency lane and three slots make four single verifications side by side, one hardware queue each
+        auto sl = vm_slots_.acquire();
+        VmSlot* slot = &vm_slot_[sl.index];
+        const int slot_index = (int)(slot - vm_slot_);
+        slot->vs.stream = work_[1 + slot_index % (NW - 1)].stream ? work_[1 + slot_index % (NW - 1)].stream : stream_;
+        VerifyRequest* r = batch[0];
+        G1Affine pts[2];
+        bool empty = false;
+        ver.assign(1, 0);
+        st.assign(1, (int)ERR_DEVICE);
+        HIPCK(hipSetDevice(dev_));
+        st[0] = verify_cells_partial(r->n[0], r->commitments, r->n[1], r->cell_indices, r->n[2], r->cells, r->n[3], r->proofs, 0, r->n[2], pts, &empty, nullptr, &slot->vs);
+        sl.lock.unlock();  // the pairing needs no slot
+        rc = st[0] == ERR_DEVICE ? (int)ERR_DEVICE : (int)OK;
+        if (rc == ERR_DEVICE) why = last_error();
+        if (st[0] == OK) ver[0] = (empty || verify_cells_pairing_split(pts)) ? 1 : 0;
+      } else {
+        std::vector<uint64_t> l0(B), l1(B), l2(B), l3(B);
+        std::vector<const uint8_t* const*> pc(B), pl(B), pp(B);
+        std::vector<const uint64_t*> pi(B);
+        ver.assign(B, 0);
+        st.assign(B, (int)ERR_DEVICE);
+        for (size_t i = 0; i < B; i++) {
+            l0[i] = batch[i]->n[0]; l1[i] = batch[i]->n[1]; l2[i] = batch[i]->n[2]; l3[i] = batch[i]->n[3];
+            pc[i] = batch[i]->commitments; pi[i] = batch[i]->cell_indices; pl[i] = batch[i]->cells; pp[i] = batch[i]->proofs;
         }
-        lk.lock();
+        rc = verify_cell_kzg_proof_batch_many_host(B, l0.data(), pc.data(), l1.data(), pi.data(), l2.data(), pl.data(), l3.data(),
+                                                   pp.data(), ver.data(), st.data());
+        if (rc == ERR_DEVICE) why = last_error();
+      }
+    } catch (const std::exception& e) {
+        rc = ERR_DEVICE;
+        why = std::string("combined verification pass: ") + e.what();
+    } catch (...) {
+        rc = ERR_DEVICE;
+        why = "combined verification pass: unknown failure";
+    }
         for (size_t i = 0; i < B; i++) {
             batch[i]->status = (rc == ERR_DEVICE || i >= st.size()) ? (int)ERR_DEVICE : st[i];
             batch[i]->verified = i < ver.size() ? ver[i] : 0;
             batch[i]->error = why;
-            batch[i]->done = true;
         }
-        comb_running_--;
-        comb_cv_.notify_all();
-    }
-    lk.unlock();
+    }, [&](std::vector<VerifyRequest*>& batch, const std::string& what) {
+        for (VerifyRequest* r : batch) { r->status = ERR_DEVICE; r->verified = 0; r->error = "combined verification pass: " + what; }
+    });
     if (me.status == ERR_DEVICE) set_error(std::runtime_error(me.error));  // the error text belongs to the calling thread
     *verified = me.status == OK ? me.verified : 0;
     return me.status;

@@ -4,6 +4,10 @@ Booth digits (booth_encoding.rs:10-11,56-99), FFT round trips and the G1 FFT aga
 (polynomial/src/domain.rs:230-308), lincomb against naive sums (lincomb.rs tests)."""
 import ctypes as C
 
+import os
+
+import pytest
+
 import oracle_lib
 import synth
 
@@ -95,3 +99,23 @@ def test_point_codec_edge_cases():
     flipped = bytes([GEN[0] ^ 0x20]) + GEN[1:]                           # the other square root: still a valid point (-G)
     assert oracle_lib.g1_validate(flipped) == 0
     assert oracle_lib.g1_msm(GEN + flipped, (1).to_bytes(32, "big") * 2) == IDENT
+
+
+def test_adx_multiplication_of_the_timed_build_equals_the_portable_checker(tmp_path):
+    """bench.py's cpu_baseline leg times a native build of the oracle with -DORACLE_ADX (Fp products on mulx + two carry chains,
+    oracle/field.c: mont_mul6_adx).  The portable __int128 form stays the checker: here the two are compared on 10^6 chained
+    pseudo-random pairs inside C (oracle_fp_mul_selftest), and the whole prover of the ADX build must reproduce a golden vector.
+    Skipped on a CPU without BMI2 / ADX (the build then falls back to the portable form and says so)."""
+    import ctypes
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "liboracle_adx.so")
+    src = [os.path.join(root, "oracle", f) for f in ("field.c", "g1.c", "pairing.c", "sha256.c", "kzg.c")]
+    subprocess.check_call(["gcc", "-O3", "-march=native", "-DORACLE_ADX", "-fopenmp", "-fPIC", "-std=gnu11", "-shared", "-o", so] + src)
+    lib = ctypes.CDLL(so)
+    lib.oracle_fp_mul_selftest.restype = ctypes.c_long
+    lib.oracle_fp_mul_selftest.argtypes = [ctypes.c_long, ctypes.c_uint64]
+    if not lib.oracle_fp_mul_uses_adx():
+        pytest.skip("this CPU has no BMI2 / ADX: the native build uses the portable form")
+    assert lib.oracle_fp_mul_selftest(1000000, 0x243f6a8885a308d3) == 0
+    assert lib.oracle_fp_mul_selftest(1000, 1) == 0

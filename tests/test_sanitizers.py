@@ -3,6 +3,9 @@ sanitizers, and none is needed for this: the oracle is plain C and the host unit
   * oracle/*.c driven through every entry point by tests/c/oracle_sanitize_main.c
   * the host units tests/c/test_{inverse,host_mul,linmap,glv,pairing}.cpp (csrc headers compiled for the host; test_curve29 is left
     out: the fully unrolled 14-limb field code takes the instrumenting compiler more than 15 minutes)
+  * the host-side concurrency protocols of a context (csrc/host_sync.hpp: the helper pool, the combiner of concurrent verifications,
+    pass-slot and lane leases, publish / snapshot / retire of the window tables) under ThreadSanitizer and under ASan + UBSan,
+    driven by tests/c/test_host_sync.cpp with fake device passes -- the product (engine.hip, verify_many.hip) uses these very classes
 A sanitizer report aborts the program (-fno-sanitize-recover): exit code 0 means a clean run."""
 import os
 import shutil
@@ -39,3 +42,22 @@ def test_host_units_under_asan_and_ubsan(tmp_path, name):
     out = subprocess.run([exe, *args], capture_output=True, text=True, timeout=800, env=ENV)
     assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-4000:]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_host_concurrency_protocols_under_sanitizers(tmp_path, san):
+    """32 threads x mixed operations (combined verifications whose pass sleeps / throws / reports wrong proofs, lane leases, MSM stages
+    reading a table that a builder thread is publishing group by group, abandoned tables reaped on the builder's thread, parallel_for
+    with a failing index) on two shared contexts while a third party creates and frees contexts: no data race, no lost wake-up, no
+    table destroyed on a caller's thread, every verdict right.  The same header builds into libc_eth_kzg.so."""
+    exe = str(tmp_path / "host_sync")
+    flags = ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-g"] + (["-fno-sanitize-recover=all"] if "address" in san else [])
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", *flags, "-I", CSRC, os.path.join(ROOT, "tests", "c", "test_host_sync.cpp"), "-o", exe])
+    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
+    out = subprocess.run([exe, "32", "1500"], capture_output=True, text=True, timeout=800, env=env)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-2000:] + out.stderr[-6000:]
+    assert "ThreadSanitizer" not in out.stderr and "AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-6000:]
+    assert "elsewhere: 0" in out.stdout
+    # the product is built from the same header
+    assert '#include "host_sync.hpp"' in open(os.path.join(CSRC, "engine.hpp")).read()
