@@ -36,14 +36,16 @@ ALG_BYTES_PER_BLOB = BYTES_PER_BLOB + CELLS * BYTES_PER_CELL + CELLS * 48  # 399
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_INT_PEAK_GOPS = 34000.0     # measured on MI355X with tools/ubench.hip: integer VALU ops (v_mad_u64_u32,
                                  # v_addc_co_u32, ...) all issue at ~31-35 T lane-ops/s chip-wide
-FP_MUL_PEAK_G = 78.1             # measured ceiling of the 14x29-bit Montgomery multiplication (392 v_mad_u64_u32 + 68 shifts /
-                                 # masks as verbatim chains, fp29_mac.hpp) at 4 waves/SIMD: tools/ubench_fp29.hip,
-                                 # profiles/r1e_ubench_fp29.log (66.0 G/s at the 2 waves/SIMD the point kernels can hold)
+VALU_MIX_PEAK_TLOPS = 34.4      # measured issue ceiling of the point kernels' 12 : 4 multiply-add mix at 2 waves/SIMD (profiles/r3_ubench_issue.log), T lane-ops/s at 2.4 GHz
+FP_MUL_PEAK_G = 82.2             # measured SUSTAINED rate of the signed 13x30-bit Montgomery multiplication with centred result (338 + 13
+                                 # v_mad_i64_i32 as verbatim chains, fp30_mac.hpp) at the 2 waves/SIMD the point kernels hold:
+                                 # tools/ubench_fp30 --sustained, profiles/r5_ubench_fp30_sustained.log (14x29-bit form: 76.2 G/s)
 
 
 def fp_mul_eq_per_blob(window_bits, linmap, glv=False, batch_lanes=2048):
-    """Fp multiplication equivalents this build spends per blob, counted in multiply-add passes of 392 MACs
-    (M = 1, squaring S = 301/392, fused pair a*b + c*d with one reduction F = 588/392):
+    """Fp multiplication equivalents this build spends per blob, counted in multiply-add passes of the signed 13-digit field's
+    351 MACs (M = 1, squaring S = 273/351, fused pair a*b + c*d with one reduction F = 520/351; the cheap levels of the linear
+    map still run in the 14-digit field and are counted with the same weights):
     stage D: 128 MSMs x 64 bases x W windows XYZZ mixed additions (6M + 2S + F);
     stages E+F as one compiled linear map (g1_linmap.hpp): `mulc` constant multiplications, each = the co-Z table of 8 odd
     multiples (a doubling with update 2M + 4S + F, 7 co-Z additions 4M + 2S, 8 lifts to the common Z with the beta multiple
@@ -52,7 +54,7 @@ def fp_mul_eq_per_blob(window_bits, linmap, glv=False, batch_lanes=2048):
     addition of the same two values (g1_linmap.hpp: 548 pairs of its 3162 additions and subtractions): the second result of a
     pair costs S + F."""
     w = 16 if glv else (255 + window_bits) // window_bits  # gathered additions per (scalar, base)
-    S, F = 301 / 392, 588 / 392
+    S, F = 273 / 351, 520 / 351
     madd, dbl, add, madd_jac = 6 + 2 * S + F, 2 + 3 * S + F, 10 + 4 * S + F, 6 + 3 * S + F
     mulc, adds, dbls = linmap
     table = (dbl + S) + 7 * (4 + 2 * S) + 8 * (5 + S) + 1
@@ -699,7 +701,7 @@ def kernel_sources_hash():
     ties a committed PMC profile to the build it was collected on (tools/pmc_summary.py stores it, bench.py compares it)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("k_msm_glv.inc", "k_msm_glv16.hip", "curve29.hpp", "fp29.hpp", "fp29_mac.hpp", "fp29_consts.hpp", "glv.hpp", "Makefile"):
+    for f in ("k_msm_glv.inc", "k_msm_glv16.hip", "curve30.hpp", "fp30.hpp", "fp30_mac.hpp", "fp30_consts.hpp", "curve29.hpp", "fp29.hpp", "fp29_mac.hpp", "fp29_consts.hpp", "glv.hpp", "Makefile"):
         with open(os.path.join(ROOT, "rust-eth-kzg_amd", "csrc", f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()
@@ -1100,7 +1102,7 @@ def main():
         achieved = alg_bytes / per_launch_s / 1e9
         # HBM traffic of the dominant kernel: NOT measured in this run (PMC passes need rocprofv3) -- taken from the newest
         # committed profile of this round and labelled with its file name; valid only for the configuration it was collected on
-        traffic, traffic_source = None, None
+        traffic, traffic_source, insts_valu, insts_source = None, None, None, None
         try:
             import glob
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_pmc_b2048*.json")))
@@ -1110,15 +1112,22 @@ def main():
             # kernel's sources (tools/pmc_summary.py); a build whose sources differ gets traffic = null instead of stale numbers
             if pmc_doc.get("msm_kernel_sources_sha256") != kernel_sources_hash():
                 raise RuntimeError("committed PMC profile belongs to another build of the kernel")
-            want = {"msm_fixed": ("k_msm_glv_chunked", "k_msm_glv_lane<1>") if ctx.glv_table() else ("k_msm_fixed_chunked<14>",), "g1_linmap": ("k_slp_mulc",)}.get(dom, ())
+            want = {"msm_fixed": ("k_msm_glv_chunked",) if ctx.glv_table() else ("k_msm_fixed_chunked<14>",), "g1_linmap": ("k_slp_mulc",)}.get(dom, ())
             key = next((k for w_ in want for k in pm if w_ in k), None)  # the newest profile names the kernel the default schedule runs
             if key in pm and B == 2048 and ctx.glv_table() and ctx.window_bits() == 16:
                 # gfx950 correction (MI355X_MICROARCH.md, calibrated for this kernel's 16-B-per-lane gathers in
                 # profiles/r1f_calib_fetch.log): FETCH_SIZE tallies every 128-B line request at 64 B -> double it; WRITE_SIZE is exact
                 traffic = (2.0 * pm[key]["FETCH_SIZE_per_launch_max"] + pm[key]["WRITE_SIZE_per_launch_max"]) * 1024.0
                 traffic_source = os.path.relpath(files[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command; not re-measured here)"
+                insts_valu = pm[key].get("SQ_INSTS_VALU_per_launch_max")
+                insts_source = os.path.relpath(files[-1], ROOT) + " (SQ_INSTS_VALU of the same build, rocprofv3 --pmc)"
         except Exception:
             pass
+        if insts_valu is None and dom == "msm_fixed" and ctx.glv_table():
+            # no counter file for this build: the static count of the kernel's hot loop (4,066 VALU instructions per gathered addition in
+            # the disassembly + the folds; 4,090 per addition measured by SQ_INSTS_VALU on round 5's build) x the additions of a launch
+            insts_valu = 4090.0 * B * 128 * 64 * msm_adds / 64.0
+            insts_source = "static count: 4,090 wave-instructions per gathered addition (profiles/r5c_pmc_sq_b2048_glv16.json) x additions per launch / 64 lanes"
         stage_ms_per_step = {s: round(stages[s][0] / args.steps, 3) for s in stages}
         # integer-VALU view (the bound that actually binds)
         mac_rate = value * 1.0e9 / 1e9  # reference-algorithm count: ~1.0e9 32x32 MACs per blob
@@ -1131,7 +1140,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "ms_per_step_without_stage_events": round(dt_plain / args.steps * 1e3, 3),
             "ms_per_step_per_rank": per_rank_ms, "all_gather_ms_per_step": gather_ms,
-            "vs_baseline": None, "dtype": "u32", "dtype_note": "381-bit Fp as 14x29-bit / 12x32-bit limbs, 255-bit Fr as 8x32-bit (stored) and 9x29-bit (inside the transforms) limbs, Montgomery integers; exact arithmetic", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u32", "dtype_note": "381-bit Fp as 13 signed 30-bit digits (MSM, constant multiplications), 14x29-bit / 12x32-bit limbs elsewhere, 255-bit Fr as 8x32-bit (stored) and 9x29-bit (inside the transforms) limbs, Montgomery integers; exact arithmetic", "data": "synthetic",
             "config": {"workload": f"compute_cells_and_kzg_proofs on DEVICE-RESIDENT blobs (inputs and outputs stay in HBM; the "
                                    f"host-pointer ABI rate is configs.abi_host_pointer_batch), batch-saturated: {B} synthetic blobs "
                                    f"per GPU per step (config 2's single blob is reported as single_blob_latency_ms)",
@@ -1149,15 +1158,33 @@ def main():
                        "launcher": os.environ.get("KZG_BENCH_LAUNCHER", "external (torch.distributed.run)") if world > 1 else "none",
                        "rehearsal": "KZG_BENCH_REHEARSAL=1: all ranks share GPU 0, gloo for the harness, small tables -- a check of the N > 1 code paths, NOT a measurement" if rehearsal else None,
                        "gathered_proofs_checked": gather_checked},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg_bytes,
+            # What binds the dominant kernel is integer-VALU issue: achieved = wave-instructions x 64 lanes
+            # / launch time, peak = the measured issue ceiling of this kernel's own 12 : 4 multiply-add mix at the two waves per SIMD its
+            # 212 registers allow (34.4 T lane-ops/s at 2.4 GHz, profiles/r3_ubench_issue.log).  NOTE: under this kernel the chip does
+            # not hold 2.4 GHz -- the SMI reports ~2.0-2.1 GHz at ~1.27 kW (profiles/r5c_bench_clocks_power.log) -- so frac < 1 is mostly
+            # clock, not idle issue slots: GRBM_GUI_ACTIVE / launch time gives the clock, SQ_INSTS_VALU / GRBM cycles the issue rate.
+            "roofline": {"bound": "valu-int", "kernel": dom,
+                         "achieved": (insts_valu * 64.0 / per_launch_s / 1e12) if insts_valu else None, "peak": VALU_MIX_PEAK_TLOPS, "unit": "T lane-ops/s",
+                         "frac": (insts_valu * 64.0 / per_launch_s / 1e12 / VALU_MIX_PEAK_TLOPS) if insts_valu else None,
+                         "wave_instructions_per_launch": insts_valu, "instructions_source": insts_source,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": per_launch_s * 1e3, "launches_per_step": dom_launches // max(1, args.steps),
-                         "note": "the path is integer-VALU bound, not HBM bound (SURVEY.md 8d); see roofline_valu"},
+                         "note": "integer-VALU issue is what binds (MFMA unused: no dense contraction); peak = measured issue ceiling of the kernel's "
+                                 "multiply-add mix at 2 waves/SIMD and 2.4 GHz; the kernel runs at ~2.0-2.1 GHz (power), see roofline_hbm for the byte view"},
+            # the HBM view the contract names, kept as the secondary: both byte counts side by side -- the MANDATORY bytes of SURVEY 8(d)
+            # for this kernel (scalars in + sums out) and the bytes the design chooses to gather from its window table
+            "roofline_hbm": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch_gathered": alg_bytes,
+                             "algorithmic_bytes_per_launch_mandatory": B * (128 * 64 * 32 + 128 * 168) if dom == "msm_fixed" else alg_bytes,
+                             "frac_mandatory": (B * (128 * 64 * 32 + 128 * 168) if dom == "msm_fixed" else alg_bytes) / per_launch_s / 1e9 / HBM_PEAK_GBS,
+                             "whole_path_mandatory_bytes_per_blob": ALG_BYTES_PER_BLOB,
+                             "traffic": traffic, "traffic_source": traffic_source},
             "roofline_valu": {"bound": "valu-int", "achieved": mul_rate, "peak": FP_MUL_PEAK_G, "unit": "G Fp-mul/s",
                               "frac": mul_rate / FP_MUL_PEAK_G, "fp_mul_eq_per_blob": round(mul_eq),
                               "reference_algorithm_mac_rate_G": mac_rate, "mac_issue_peak_G": VALU_INT_PEAK_GOPS,
-                              "note": "blobs/s x Fp-multiplication equivalents this build executes per blob / measured "
-                                      "multiplication ceiling; reference_algorithm_mac_rate = blobs/s x 1.0e9 MACs (SURVEY 8d)"},
+                              "note": "blobs/s x Fp-multiplication equivalents this build executes per blob / measured sustained "
+                                      "multiplication rate of the signed 13 x 30-bit field (tools/ubench_fp30 --sustained, 2 waves/SIMD); "
+                                      "reference_algorithm_mac_rate = blobs/s x 1.0e9 MACs (SURVEY 8d)"},
             "whole_path_hbm_frac": value * ALG_BYTES_PER_BLOB / 1e9 / HBM_PEAK_GBS,
             "stage_ms_per_step": stage_ms_per_step,
             "single_blob_latency_ms": (min(lat) * 1e3) if lat else None,

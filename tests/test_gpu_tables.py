@@ -128,18 +128,22 @@ def test_default_budget_is_a_stated_160_gb(oracle, monkeypatch):
             c.close()
 
 
-def test_context_next_to_200_gb_held_by_someone_else_comes_up_narrower(oracle, monkeypatch):
-    """A host application that shares the GPU: with 200 GB of the 288 taken (here by a torch tensor of this process; the library only
-    sees free memory) a context created with the default budget does not fail or abort -- it comes up on the widest tables that
-    still fit (narrower than width 15) and gives the oracle's bytes."""
+def test_context_next_to_150_gb_held_by_someone_else_comes_up_narrower(oracle, monkeypatch):
+    """A host application that shares the GPU: with 150 GB of the 288 taken (here by a torch tensor of this process; the library only
+    sees free memory) a context created with the default budget (160 GB) does not fail or abort -- it comes up on the widest tables
+    that still fit (narrower than width 15) and gives the oracle's bytes."""
     import torch
     full._torch_first()
     monkeypatch.delenv("ETH_KZG_AMD_TABLE_GB", raising=False)
-    hog = torch.empty(200 * 10**9, dtype=torch.uint8, device="cuda")
+    for _ in range(100):  # the tables of the previous test's contexts are freed by their builder threads: wait until the memory is back
+        if torch.cuda.mem_get_info()[0] > 270 * 10**9:
+            break
+        time.sleep(0.1)
+    hog = torch.empty(150 * 10**9, dtype=torch.uint8, device="cuda")
     try:
         c = kzg.DASContext(use_precomp=True, table_budget_gb=0)  # through eth_kzg_amd_das_context_try_new: an error would be raised, not an abort
         try:
-            assert c.glv_table() and c.window_bits() < 15 and c.table_bytes() < 88e9, (c.window_bits(), c.table_bytes())
+            assert c.glv_table() and c.window_bits() < 15 and c.table_bytes() < 138e9, (c.window_bits(), c.table_bytes())
             blobs = full._random_blobs(70, 7812)
             st, cells, proofs = full._compute_on_device(c, blobs)
             assert st == [0] * 70
