@@ -132,15 +132,30 @@ def cpu_baseline(blobs, gpu_first=None, extra=None):
     import concurrent.futures as cf
     cores = _host_cores()
     import oracle_lib
+    fp_mul_ab = {}
     try:
-        # a native build of the same sources for this host (the prebuilt liboracle.so is generic x86-64)
-        native = os.path.join("/tmp", "liboracle_native_%d.so" % os.getuid())
+        # native builds of the same sources for this host (the prebuilt liboracle.so is generic x86-64), in BOTH forms of the Fp
+        # multiplication: gcc's code for the portable unsigned __int128 product scanning (with -march=native it already uses mulx)
+        # and -DORACLE_ADX (oracle/field.c: mont_mul6_adx, mulx + two explicit carry chains; checked against the portable form on
+        # 10^6 pairs by tests/test_oracle_units.py).  Which is faster depends on the CPU (measured: the explicit form +6 % on the
+        # build container's CPU, -9 % on the GPU boxes' EPYC 9575F), so both are timed on two blobs and the FASTER one is the baseline.
         src = [os.path.join(ROOT, "oracle", f) for f in ("field.c", "g1.c", "pairing.c", "sha256.c", "kzg.c")]
-        # -DORACLE_ADX: Fp multiplications on mulx + two carry chains (oracle/field.c: mont_mul6_adx; the portable form stays the
-        # checker: tests/test_oracle_units.py compares them on 10^6 pairs) where the host CPU has BMI2 / ADX
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-DORACLE_ADX", "-fopenmp", "-fPIC", "-std=gnu11", "-shared", "-o", native] + src,
-                              stderr=subprocess.DEVNULL)
-        oracle_lib._SO = native
+        best = None
+        for tag, flags in (("portable", []), ("adx", ["-DORACLE_ADX"])):
+            so = os.path.join("/tmp", "liboracle_native_%s_%d.so" % (tag, os.getuid()))
+            subprocess.check_call(["gcc", "-O3", "-march=native", *flags, "-fopenmp", "-fPIC", "-std=gnu11", "-shared", "-o", so] + src, stderr=subprocess.DEVNULL)
+            oracle_lib._SO = so
+            o1 = oracle_lib.Oracle(use_precomp=True, threads=1)
+            o1.compute_cells_and_kzg_proofs(blobs[0])
+            t0 = time.perf_counter()
+            o1.compute_cells_and_kzg_proofs(blobs[1 % len(blobs)])
+            o1.compute_cells_and_kzg_proofs(blobs[2 % len(blobs)])
+            fp_mul_ab[tag] = round((time.perf_counter() - t0) / 2 * 1e3, 1)
+            o1.close()
+            if best is None or fp_mul_ab[tag] < fp_mul_ab[best]:
+                best = tag
+        oracle_lib._SO = os.path.join("/tmp", "liboracle_native_%s_%d.so" % (best, os.getuid()))
+        fp_mul_ab["used"] = best
     except Exception:
         pass
     from oracle_lib import Oracle
@@ -231,9 +246,10 @@ def cpu_baseline(blobs, gpu_first=None, extra=None):
     best_value, best_cores = (par, cores) if par >= rayon["value"] else (rayon["value"], cores)
     return {"value": best_value, "unit": "blobs/s", "cores": best_cores, "kind": "port", "cpu_model": _cpu_model(),
             "protocol": "criterion-like (BASELINE.md section 3): 3 s warm-up, 30 timed samples, median; context built once outside",
-            "fp_mul": ("ADX/BMI2 (mulx, two carry chains; oracle/field.c: mont_mul6_adx)" if _oracle_uses_adx() else "portable unsigned __int128"),
-            "sample": f"C oracle (width-8 tables; Fp multiplication: {'ADX/BMI2 mulx form, native build' if _oracle_uses_adx() else 'portable __int128'} -- measured +6 % "
-                      f"over gcc's own -march=native code for the __int128 form, which already uses mulx; not blst's hand-scheduled assembly) on {cores} usable host "
+            "fp_mul": ("ADX/BMI2 (mulx, two carry chains; oracle/field.c: mont_mul6_adx)" if _oracle_uses_adx() else "gcc's -march=native code for the portable unsigned __int128 form (it uses mulx)"),
+            "fp_mul_forms_ms_per_blob_single_thread": fp_mul_ab,
+            "sample": f"C oracle (width-8 tables; native build; Fp multiplication: the faster on this CPU of the explicit ADX/BMI2 form and gcc's own "
+                      f"code for the __int128 form -- {fp_mul_ab}; not blst's hand-scheduled assembly) on {cores} usable host "
                       f"cores: (a) blob-parallel, one single-threaded prover per core, {len(tsp)} rounds of {cores} distinct "
                       f"synthetic blobs, median {_median(tsp):.3f} s per round = {par:.1f} blobs/s (best {par_best:.1f}); (b) one blob "
                       f"at a time with OpenMP over the maybe_rayon axes, {rayon['samples']} samples = {rayon['value']:.1f} blobs/s; "
