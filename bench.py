@@ -884,7 +884,7 @@ def main():
     if rehearsal:  # N ranks on GPU 0 (see _Harness): small tables so that N contexts fit, torch's gloo for the harness collectives
         local_rank = 0
         os.environ.setdefault("ETH_KZG_AMD_TABLE_GB", "24")
-    # The library's default table budget is a stated 160 GB (GLV width 15); the bench measures the path at the widest tables the GPU
+    # The library's default table budget is a stated 116 GB (the nine-window GLV table); the bench measures the path at the widest tables the GPU
     # holds and says so in config.table_budget (blobs_per_s_vs_table_memory carries the default's and every other size's rate)
     os.environ.setdefault("ETH_KZG_AMD_TABLE_GB", "max")
     if torch.cuda.device_count() <= local_rank:
@@ -1165,7 +1165,7 @@ def main():
                                      else f"plain: width {wbits}, {msm_adds} gathered additions per base",
                        "table_GB": round(ctx.table_bytes() / 1e9, 2),
                        "table_budget": "ETH_KZG_AMD_TABLE_GB=" + os.environ.get("ETH_KZG_AMD_TABLE_GB", "") + " (set by bench.py: the widest tables the HBM holds; "
-                                       "the library's default budget is 160 GB = GLV width 15, see configs.blobs_per_s_vs_table_memory)",
+                                       "the library's default budget is 116 GB = the nine-window GLV table, see configs.blobs_per_s_vs_table_memory)",
                        "g1_transforms": f"compiled linear map: {li[0]} constant multiplications, {li[1]} additions, {li[2]} doublings per blob, {li[3]} launches" if li[0] else "radix-2 network",
                        "exchange": ("ncclAllGather of the proof vectors per step inside libc_eth_kzg.so (eth_kzg_amd_all_gather)" if lib_comm
                                     else "RCCL all-gather of proofs per step (torch.distributed)" + (" -- the library communicator FAILED: " + comm_error if comm_error else "")) if world > 1 else "none",
@@ -1228,7 +1228,7 @@ def main():
             ctx.close()
             ctx = None
             _mark("table curve")
-            for label, env, precomp in (("GLV width 15 (the default budget of 160 GB)", {"ETH_KZG_AMD_GLV_WINDOW": "15"}, True), ("GLV width 14", {"ETH_KZG_AMD_GLV_WINDOW": "14"}, True),
+            for label, env, precomp in (("GLV width 15: nine windows (the default budget of 116 GB)", {"ETH_KZG_AMD_GLV_WINDOW": "15"}, True), ("GLV width 14", {"ETH_KZG_AMD_GLV_WINDOW": "14"}, True),
                                         ("GLV width 12", {"ETH_KZG_AMD_GLV_WINDOW": "12"}, True), ("GLV width 8 (the start table)", {"ETH_KZG_AMD_GLV_WINDOW": "8"}, True),
                                         ("plain width 4 (use_precomp = false)", {}, False)):
                 try:

@@ -122,8 +122,9 @@ DASContext *eth_kzg_amd_das_context_new_on_device(bool use_precomp, int device_o
  * is no usable GPU or not even the 3.7 GB start tables fit -- which is hostile inside a consensus client.  This form returns NULL
  * and fills *result (status Err, error_msg to be freed with eth_kzg_free_error_message; may be NULL) instead; on success *result
  * is Ok.  table_budget_gb bounds the HBM the two window tables take together: > 0 = that many GB (the widest GLV table that
- * fits is chosen: 160 GB -> width 15, 107 -> 14, 61 -> 12, 45 -> 8), 0 = $ETH_KZG_AMD_TABLE_GB or else the default of 160 GB
- * (-3 ... -7 % against the widest tables at 64 % of their memory), < 0 = whatever the HBM still holds (249 GB on an idle GPU). */
+ * fits is chosen: 116 GB -> nine windows / nominal width 15, 72 -> ten / 14, 58 -> eleven / 12, 45 -> sixteen / 8), 0 =
+ * $ETH_KZG_AMD_TABLE_GB or else the default of 116 GB (-7 % against the widest tables at 46 % of their memory), < 0 = whatever the
+ * HBM still holds (249 GB on an idle GPU: eight windows of 16 bits). */
 DASContext *eth_kzg_amd_das_context_try_new(bool use_precomp, int device_ordinal, double table_budget_gb, CResult *result);
 
 /* Host-pointer batches: n blobs; out_cells[b] / out_proofs[b] are arrays of 128 pointers as in the

@@ -101,11 +101,12 @@ public:
     // table_budget_gb: > 0: upper bound for both window tables together; 0: $ETH_KZG_AMD_TABLE_GB, else DEFAULT_TABLE_BUDGET_GB;
     // < 0: whatever the HBM still holds
     Engine(bool use_precomp, int device, const Engine* primary = nullptr, double table_budget_gb = 0);
-    // The default memory budget of the window tables: GLV width 15 for FK20 (116 GB) + the width-13 commitment table (43 GB).
-    // Measured on one box, same resident 2048-blob batch: -3 ... -7 % against the widest tables (GLV 16: 249 GB in all), at
-    // 64 % of the memory; throughput per GB falls 12x between the narrowest and the widest table, so taking "whatever HBM holds"
-    // is a decision for the host application (ETH_KZG_AMD_TABLE_GB=max, or the budget argument of eth_kzg_amd_das_context_try_new).
-    static constexpr double DEFAULT_TABLE_BUDGET_GB = 160.0;
+    // The default memory budget of the window tables: the nine-window GLV table for FK20 (nominal width 15: two windows of 15 bits
+    // and seven of 14, 70.9 GB, 18 gathered additions per base) + the width-13 commitment table (43 GB).  Measured on one box, same
+    // resident 2048-blob batch: -7 % against the widest tables (eight windows of 16 bits: 249 GB in all) at 46 % of the memory;
+    // the next step down (ten windows, 29 + 43 GB) costs another 6 %.  Taking "whatever HBM holds" is a decision for the host
+    // application (ETH_KZG_AMD_TABLE_GB=max, or the budget argument of eth_kzg_amd_das_context_try_new).
+    static constexpr double DEFAULT_TABLE_BUDGET_GB = 116.0;
     ~Engine();
     Engine(const Engine&) = delete;
 

@@ -67,9 +67,9 @@ struct Engine::SharedTable {
         dev = device; kind = kind_; c = width; glv = kind_ == 2; n_groups = groups;
         halves = glv ? 2 : 1;
         if (glv) {
-            const size_t per_window = (size_t)nb << (c - 1);
-            block_entries[0] = per_window * launch::glv_lower_windows(c);
-            block_entries[1] = per_window * (launch::glv_windows(c) - launch::glv_lower_windows(c));
+            const int WLc = launch::glv_lower_windows(c), Wc = launch::glv_windows(c);  // windows of mixed widths (launch.hpp)
+            block_entries[0] = launch::glv_entries_per_base(c, 0, WLc) * (size_t)nb;
+            block_entries[1] = launch::glv_entries_per_base(c, WLc, Wc) * (size_t)nb;
         } else {
             block_entries[0] = launch::table_entries(c, 1, nb);
         }

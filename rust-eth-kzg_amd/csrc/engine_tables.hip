@@ -245,11 +245,12 @@ void Engine::init_fk20() {
 
 // The wide tables, widest first, each taken from the process-wide registry if another context of this GPU holds it already:
 //   commitments: plain width 13 (43 GB; 20 windows), 12, 10, 8
-//   FK20: GLV width 16 (206 GB; 16 gathered additions per base), 15 (116 GB; 18), 14 (64 GB; 20), 12 (18 GB; 22), 8 (1.6 GB; 32)
+//   FK20: GLV width 16 (206 GB; 16 gathered additions per base), 15 (71 GB; 18), 14 (29 GB; 20), 12 (14.5 GB; 22), 8 (1.6 GB; 32)
+//         (mixed window widths that cover the 128-bit half exactly, launch.hpp)
 //         -- GLV first at every size: the endomorphism halves the memory per window bit (a plain width-14 table costs
 //         163 GB for 19 additions) -- or the plain width ETH_KZG_AMD_WINDOW names;
 // bounded by what the HBM still holds (another process may own part of it) and by ETH_KZG_AMD_TABLE_GB (both tables
-// together; the commitment table gets at most 27 % of it; default Engine::DEFAULT_TABLE_BUDGET_GB = 160).  A table this thread creates is published as the view's `next`
+// together; the commitment table gets at most 38 % of it; default Engine::DEFAULT_TABLE_BUDGET_GB = 116).  A table this thread creates is published as the view's `next`
 // BEFORE it is filled, so the MSMs use its groups as they become ready.  Never throws: a failure leaves the context on the
 // tables it has.
 void Engine::build_final_tables() {
@@ -330,7 +331,7 @@ void Engine::build_final_tables() {
         for (int w : {13, 12, 10, 8}) {
             if (srs) break;
             if (srs_now.main && w <= srs_now.c) break;  // nothing wider than what is in use fits
-            if ((double)plain_table_bytes(w, 64) > std::max(0.27 * budget, 2.2e9)) continue;  // (0.27 x the default 160 GB = the width-13 table)
+            if ((double)plain_table_bytes(w, 64) > std::max(0.38 * budget, 2.2e9)) continue;  // (0.38 x the default 116 GB = the width-13 table)
             srs = widen(TAB_SRS, 0, w, d_srs_, 64);
         }
         if (srs) publish(TAB_SRS, srs, nullptr);

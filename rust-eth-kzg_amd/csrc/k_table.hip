@@ -88,7 +88,8 @@ __device__ __forceinline__ JacQ add_mixed_f(const JacQ& p, const AffQ& q, Fq<260
     return r;
 }
 
-template <int C, int W = (255 + C) / C>
+// GLV: the windows of a GLV table have mixed widths (launch::glv_window_bits): Q_w = 2^(first bit of window w) P
+template <int C, int W = (255 + C) / C, bool GLV = false>
 __global__ void k_table_windows(const G1Affine* __restrict__ bases, AffQ* __restrict__ qw /*[n][2][W]*/, JacQ* __restrict__ tmp,
                                 Fq<2>* __restrict__ pre, int n_bases) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,7 +105,8 @@ __global__ void k_table_windows(const G1Affine* __restrict__ bases, AffQ* __rest
     JacQ cur = to_jacq(P);
     for (int w = 0; w < W; w++) {
         J[w] = cur;
-        for (int s = 0; s < C; s++) {
+        const int bits = GLV ? launch::glv_window_bits(C, w) : C;
+        for (int s = 0; s < bits; s++) {
             cur = dbl(cur);
             if (s == 5) J[W + w] = cur;  // 64 Q_w
         }
@@ -192,19 +194,22 @@ template <int C, int W>
 __global__ __launch_bounds__(64) void k_table_fill_packed(const AffQ* __restrict__ qw, void* const* __restrict__ blocks,
                                                           Fq<260>* __restrict__ scratch_f, Fq<XB>* __restrict__ scratch_xy,
                                                           int nb, int* __restrict__ err) {
-    constexpr int T = 1 << (C - 1), K = T / 64;
     const int lane = threadIdx.x;
     const long blk = blockIdx.x;  // = (group * W + w) * nb + i : the table's own block order
     const int i = (int)(blk % nb), w = (int)((blk / nb) % W);
     const long group = blk / ((long)nb * W);
+    const int T = 1 << (launch::glv_window_bits(C, w) - 1), K = T / 64;  // entries of this window per base (mixed widths)
     const long base = group * nb + i;
     const AffQ Q = qw[(size_t)base * 2 * W + w], S = qw[(size_t)base * 2 * W + W + w];
     // a group's lower WL = ceil(W / 2) windows and its upper W - WL windows are two blocks (k_msm_glv.inc: tab_window)
     constexpr int WL = (W + 1) / 2;
     const int upper = w >= WL ? 1 : 0;
-    TabS* dst = reinterpret_cast<TabS*>(blocks[2 * group + upper]) + (((size_t)(w - (upper ? WL : 0)) * nb + i) << (C - 1));
-    Fq<260>* scr = scratch_f + ((size_t)blk << (C - 1));
-    Fq<XB>* raw = scratch_xy + ((size_t)blk << C);  // 2 per entry
+    // inside a block: [window][base][digit]; the scratch follows the table's own order: [group][window][base][digit]
+    const size_t in_block = launch::glv_entries_per_base(C, upper ? WL : 0, w) * (size_t)nb + (size_t)i * T;
+    TabS* dst = reinterpret_cast<TabS*>(blocks[2 * group + upper]) + in_block;
+    const size_t in_table = ((size_t)group * launch::glv_entries_per_base(C, 0, W) + launch::glv_entries_per_base(C, 0, w)) * (size_t)nb + (size_t)i * T;
+    Fq<260>* scr = scratch_f + in_table;
+    Fq<XB>* raw = scratch_xy + 2 * in_table;  // 2 per entry
     if (is_inf(Q)) {  // identity base (wave-uniform): an all-identity block
         TabS z;
         for (int t = 0; t < 24; t++) z.w[t] = 0;
@@ -281,9 +286,9 @@ bool build_table_fast(int c, const void* bases, void* const* table, void* scratc
     else return false;
     return true;
 }
-// GLV tables: W = glv_windows(c) windows of c bits, packed 96-B entries; scratch = 168 B per entry of the chunk (56 for the
+// GLV tables: W = glv_windows(c) windows of mixed widths (launch::glv_window_bits), packed 96-B entries; scratch = 168 B per entry of the chunk (56 for the
 // Z factors, 112 for the waiting X, Y); side as for the plain builder with that W
-size_t table_glv_entries(int c, int n_groups, int nb) { return ((size_t)n_groups * nb * glv_windows(c)) << (c - 1); }
+size_t table_glv_entries(int c, int n_groups, int nb) { return (size_t)n_groups * nb * glv_entries_per_base(c, 0, glv_windows(c)); }
 size_t table_glv_side_bytes(int c, int n_groups, int nb) {
     const size_t n = (size_t)n_groups * nb;
     return n * 2 * glv_windows(c) * (SIZEOF_AFFQ + SIZEOF_JACQ + 56) + 256;
@@ -297,7 +302,7 @@ static void table_glv_c(const void* bases, void* const* table, void* scratch, vo
     char* pre = tmp + n * 2 * W * SIZEOF_JACQ;
     char* scr_f = (char*)scratch;
     char* scr_xy = scr_f + entries * 56;
-    k_table_windows<C, W><<<((int)n + 63) / 64, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)qw, (JacQ*)tmp, (Fq<2>*)pre, (int)n);
+    k_table_windows<C, W, true><<<((int)n + 63) / 64, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)qw, (JacQ*)tmp, (Fq<2>*)pre, (int)n);
     k_table_fill_packed<C, W><<<(unsigned)(n * W), 64, 0, st>>>((const AffQ*)qw, table, (Fq<260>*)scr_f, (Fq<XB>*)scr_xy, nb, err);
 }
 bool build_table_glv(int c, const void* bases, void* const* table, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st) {

@@ -51,8 +51,22 @@ void msm_fixed_chunked(int c, const void* scalars, const TabBlocks& table, void*
 // GLV tables (packed 96-B entries, W = glv_windows(c) windows of c bits over the 128-bit half scalars; k_msm_glv.inc, one
 // translation unit per width): mode 0 flat, 1 windowed, 2 four chunks per MSM.  The scalars must be stored as balanced GLV
 // halves (glv_split, or k_fk20_scalars' fused split).  Entries and sums are in the signed 13 x 30-bit field (curve30.hpp).
+// A GLV table is NAMED by its nominal width c and has W = ceil(128 / c) windows -- but W windows of c bits cover W c >= 128 bits, and
+// at widths that do not divide 128 the surplus doubles the table for nothing (nine windows of 15 bits = 135 bits: 116 GB; the same
+// nine windows as two of 15 and seven of 14 bits = 128 bits: 58 GB, the same 18 gathered additions).  So the windows have MIXED
+// widths (round 5): b = floor(128 / W) bits, the lowest 128 - W b of them one bit more.  c = 16 and c = 8 divide 128: unchanged.
 constexpr int glv_windows(int c) { return (128 + c - 1) / c; }
 constexpr int glv_lower_windows(int c) { return (glv_windows(c) + 1) / 2; }  // windows in the lower block of a group
+constexpr int glv_base_bits(int c) { return 128 / glv_windows(c); }
+constexpr int glv_wide_windows(int c) { return 128 - glv_windows(c) * glv_base_bits(c); }  // the lowest windows, one bit wider
+constexpr int glv_window_bits(int c, int w) { return glv_base_bits(c) + (w < glv_wide_windows(c) ? 1 : 0); }
+constexpr int glv_window_lo(int c, int w) { return w * glv_base_bits(c) + (w < glv_wide_windows(c) ? w : glv_wide_windows(c)); }  // its first bit
+// entries per base of the windows [w0, w1): sum of 2^(bits - 1)
+constexpr size_t glv_entries_per_base(int c, int w0, int w1) {
+    size_t n = 0;
+    for (int w = w0; w < w1; w++) n += (size_t)1 << (glv_window_bits(c, w) - 1);
+    return n;
+}
 constexpr int GLV_WIDTHS[] = {16, 15, 14, 12, 8};  // widest first: the order the engine tries them in
 bool glv_width_supported(int c);
 void glv_split(void* scalars, size_t n, hipStream_t st);
