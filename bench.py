@@ -884,7 +884,7 @@ def main():
     if rehearsal:  # N ranks on GPU 0 (see _Harness): small tables so that N contexts fit, torch's gloo for the harness collectives
         local_rank = 0
         os.environ.setdefault("ETH_KZG_AMD_TABLE_GB", "24")
-    # The library's default table budget is a stated 116 GB (the nine-window GLV table); the bench measures the path at the widest tables the GPU
+    # The library's default table budget is a stated 108 GB (nine-window GLV tables for FK20 and for commitments); the bench measures the path at the widest tables the GPU
     # holds and says so in config.table_budget (blobs_per_s_vs_table_memory carries the default's and every other size's rate)
     os.environ.setdefault("ETH_KZG_AMD_TABLE_GB", "max")
     if torch.cuda.device_count() <= local_rank:
@@ -1165,7 +1165,7 @@ def main():
                                      else f"plain: width {wbits}, {msm_adds} gathered additions per base",
                        "table_GB": round(ctx.table_bytes() / 1e9, 2),
                        "table_budget": "ETH_KZG_AMD_TABLE_GB=" + os.environ.get("ETH_KZG_AMD_TABLE_GB", "") + " (set by bench.py: the widest tables the HBM holds; "
-                                       "the library's default budget is 116 GB = the nine-window GLV table, see configs.blobs_per_s_vs_table_memory)",
+                                       "the library's default budget is 108 GB = nine-window GLV tables, see configs.blobs_per_s_vs_table_memory)",
                        "g1_transforms": f"compiled linear map: {li[0]} constant multiplications, {li[1]} additions, {li[2]} doublings per blob, {li[3]} launches" if li[0] else "radix-2 network",
                        "exchange": ("ncclAllGather of the proof vectors per step inside libc_eth_kzg.so (eth_kzg_amd_all_gather)" if lib_comm
                                     else "RCCL all-gather of proofs per step (torch.distributed)" + (" -- the library communicator FAILED: " + comm_error if comm_error else "")) if world > 1 else "none",
@@ -1222,15 +1222,18 @@ def main():
             # blobs/s against window-table memory: the main context goes first (its 249 GB leave no room),
             # then one context per table size on the same resident batch.  UsePrecomp::Yes{width} is the reference's knob
             # (fixed_base_msm.rs:41-49).
-            curve = [{"table": f"GLV width {ctx.window_bits()}" if ctx.glv_table() else f"plain width {ctx.window_bits()}", "table_GB": round(ctx.table_bytes() / 1e9, 1),
+            curve = [{"table": f"GLV width {ctx.window_bits()} for FK20 (eight windows of 16 bits) + nine windows for commitments (ETH_KZG_AMD_TABLE_GB=max)" if ctx.glv_table() else f"plain width {ctx.window_bits()}", "table_GB": round(ctx.table_bytes() / 1e9, 1),
                       "gathered_additions_per_base": 2 * -(-128 // ctx.window_bits()) if ctx.glv_table() else -(-255 // ctx.window_bits()),
                       "blobs_per_s": round(value), "ms_per_step": round(dt / args.steps * 1e3, 2)}]
             ctx.close()
             ctx = None
             _mark("table curve")
-            for label, env, precomp in (("GLV width 15: nine windows (the default budget of 116 GB)", {"ETH_KZG_AMD_GLV_WINDOW": "15"}, True), ("GLV width 14", {"ETH_KZG_AMD_GLV_WINDOW": "14"}, True),
-                                        ("GLV width 12", {"ETH_KZG_AMD_GLV_WINDOW": "12"}, True), ("GLV width 8 (the start table)", {"ETH_KZG_AMD_GLV_WINDOW": "8"}, True),
+            for label, env, precomp in (("nine GLV windows for FK20 and for commitments (ETH_KZG_AMD_TABLE_GB=108: the library's default budget)", {"ETH_KZG_AMD_TABLE_GB": "108"}, True),
+                                        ("ten windows each (ETH_KZG_AMD_TABLE_GB=44)", {"ETH_KZG_AMD_TABLE_GB": "44"}, True),
+                                        ("eleven windows each (ETH_KZG_AMD_TABLE_GB=22)", {"ETH_KZG_AMD_TABLE_GB": "22"}, True),
+                                        ("sixteen windows each: the start tables (ETH_KZG_AMD_TABLE_GB=3)", {"ETH_KZG_AMD_TABLE_GB": "3"}, True),
                                         ("plain width 4 (use_precomp = false)", {}, False)):
+                saved_env = {k: os.environ.get(k) for k in env}
                 try:
                     _mark("table curve: " + label)
                     os.environ.update(env)
@@ -1252,9 +1255,12 @@ def main():
                 except Exception as e:
                     curve.append({"table": label, "error": repr(e)})
                 finally:
-                    for k in env:
-                        os.environ.pop(k, None)
-            out["configs"]["blobs_per_s_vs_table_memory"] = {"batch": B, "note": "table_GB = FK20 table + commitment table (43 GB at its default width 13); same resident batch, median of 3 steps", "points": curve}
+                    for k, v in saved_env.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
+            out["configs"]["blobs_per_s_vs_table_memory"] = {"batch": B, "note": "table_GB = FK20 table + commitment table (both GLV tables; the commitment table has half the groups, and at most nine windows: 35 GB); same resident batch, median of 3 steps", "points": curve}
         os.write(record_fd, (json.dumps(out) + "\n").encode())
     if world > 1 and getattr(sharding.attach_library_comm, "stuck", False):
         # a thread of this rank is still inside ncclCommInitRank (the watchdog gave up on it): the record is out, leave without

@@ -46,8 +46,8 @@ typedef struct DASContext DASContext;
 
 /* bindings/c/src/lib.rs:79-92.  use_precomp = true selects precomputed window tables (the reference: width 8,
  * RECOMMENDED_PRECOMP_WIDTH, on the CPU; here the widest tables that fit in HBM: a GLV table of 16-bit windows for FK20,
- * 206 GB, and a width-13 table for commitments, 43 GB, on an otherwise empty MI355X; narrower automatically when memory
- * is short or $ETH_KZG_AMD_TABLE_GB bounds them), false the 0.8 GB width-4 tables; results are identical.
+ * 206 GB, and one of nine windows for commitments, 35 GB, when $ETH_KZG_AMD_TABLE_GB=max; by default the tables take 108 GB
+ * -- nine windows each --; narrower automatically when memory is short or the budget bounds them), false the 0.8 GB width-4 tables; results are identical.
  * Progressive start: the call returns as soon as small start tables are up (about 0.5 s) and every entry point works from
  * then on; the wide tables are built by a helper thread, in pieces of under a gigabyte so that no other HIP call of the process
  * waits long, and taken into use group by group (eth_kzg_amd_tables_ready, eth_kzg_amd_table_groups_ready;
@@ -119,12 +119,12 @@ DASContext *eth_kzg_amd_das_context_new_on_device(bool use_precomp, int device_o
 
 /* The constructor that never kills the host process.  eth_kzg_das_context_new keeps the reference's behaviour -- the Rust
  * constructor panics across the FFI when it cannot build a context (bindings/c/src/lib.rs:79-92), this library aborts when there
- * is no usable GPU or not even the 3.7 GB start tables fit -- which is hostile inside a consensus client.  This form returns NULL
+ * is no usable GPU or not even the 2.4 GB start tables fit -- which is hostile inside a consensus client.  This form returns NULL
  * and fills *result (status Err, error_msg to be freed with eth_kzg_free_error_message; may be NULL) instead; on success *result
- * is Ok.  table_budget_gb bounds the HBM the two window tables take together: > 0 = that many GB (the widest GLV table that
- * fits is chosen: 116 GB -> nine windows / nominal width 15, 72 -> ten / 14, 58 -> eleven / 12, 45 -> sixteen / 8), 0 =
- * $ETH_KZG_AMD_TABLE_GB or else the default of 116 GB (-7 % against the widest tables at 46 % of their memory), < 0 = whatever the
- * HBM still holds (249 GB on an idle GPU: eight windows of 16 bits). */
+ * is Ok.  table_budget_gb bounds the HBM the two window tables take together: > 0 = that many GB (the commitment table takes the
+ * widest GLV table within a third of it, the FK20 table the widest within the rest: 108 GB -> nine windows each, 44 -> ten, 22 ->
+ * eleven, 3 -> sixteen), 0 = $ETH_KZG_AMD_TABLE_GB or else the default of 108 GB (-7 % against the widest tables at 44 % of their
+ * memory), < 0 = whatever the HBM still holds (242 GB on an idle GPU: eight windows of 16 bits for FK20, nine for commitments). */
 DASContext *eth_kzg_amd_das_context_try_new(bool use_precomp, int device_ordinal, double table_budget_gb, CResult *result);
 
 /* Host-pointer batches: n blobs; out_cells[b] / out_proofs[b] are arrays of 128 pointers as in the

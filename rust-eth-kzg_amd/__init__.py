@@ -220,7 +220,7 @@ class DASContext:
     device_index = 0
 
     def __init__(self, use_precomp=True, device=None, wait_tables=True, table_budget_gb=None):
-        """table_budget_gb: HBM for the two window tables together (None: $ETH_KZG_AMD_TABLE_GB or the library's default of 116 GB;
+        """table_budget_gb: HBM for the two window tables together (None: $ETH_KZG_AMD_TABLE_GB or the library's default of 108 GB;
         a negative number: whatever the HBM holds) -- given, the context is made by eth_kzg_amd_das_context_try_new, which reports a
         failure as KzgError instead of aborting the process.
         wait_tables: the C entry point returns as soon as the start tables are up (progressive start); by default this

@@ -101,12 +101,12 @@ public:
     // table_budget_gb: > 0: upper bound for both window tables together; 0: $ETH_KZG_AMD_TABLE_GB, else DEFAULT_TABLE_BUDGET_GB;
     // < 0: whatever the HBM still holds
     Engine(bool use_precomp, int device, const Engine* primary = nullptr, double table_budget_gb = 0);
-    // The default memory budget of the window tables: the nine-window GLV table for FK20 (nominal width 15: two windows of 15 bits
-    // and seven of 14, 70.9 GB, 18 gathered additions per base) + the width-13 commitment table (43 GB).  Measured on one box, same
-    // resident 2048-blob batch: -7 % against the widest tables (eight windows of 16 bits: 249 GB in all) at 46 % of the memory;
-    // the next step down (ten windows, 29 + 43 GB) costs another 6 %.  Taking "whatever HBM holds" is a decision for the host
-    // application (ETH_KZG_AMD_TABLE_GB=max, or the budget argument of eth_kzg_amd_das_context_try_new).
-    static constexpr double DEFAULT_TABLE_BUDGET_GB = 116.0;
+    // The default memory budget of the window tables: the nine-window GLV tables (nominal width 15: two windows of 15 bits and seven
+    // of 14, 18 gathered additions per base) for FK20 (70.9 GB) and for the commitments (35.4 GB).  Measured on one box, same
+    // resident 2048-blob batch: -8 % against the widest FK20 table (eight windows of 16 bits: 206 GB) at 43 % of the memory; the next
+    // step down (ten windows, 29 GB) costs another 6 %.  Taking "whatever HBM holds" is a decision for the host application
+    // (ETH_KZG_AMD_TABLE_GB=max, or the budget argument of eth_kzg_amd_das_context_try_new).
+    static constexpr double DEFAULT_TABLE_BUDGET_GB = 108.0;
     ~Engine();
     Engine(const Engine&) = delete;
 

@@ -49,7 +49,7 @@ double trace_clock_ms();  // milliseconds since the library first asked (ETH_KZG
 //   * the table is usable GROUP BY GROUP while it is built: ready_groups counts the leading groups whose entries are final,
 //     an MSM stage runs those on the new table and the rest on the table the context started on (Engine::launch_msm).
 struct Engine::SharedTable {
-    int dev = 0, kind = 0, c = 0;  // kind: 0 = commitments (plain, monomial SRS as [64][64]), 1 = FK20 plain, 2 = FK20 GLV
+    int dev = 0, kind = 0, c = 0;  // kind: 0 = commitments plain (monomial SRS as [64][64]; use_precomp = false only), 1 = FK20 plain, 2 = FK20 GLV, 3 = commitments GLV
     bool glv = false;
     int n_groups = 0, nb = 64, halves = 1;
     size_t bytes = 0;                      // of all blocks
@@ -64,7 +64,7 @@ struct Engine::SharedTable {
     size_t entry_bytes() const { return glv ? launch::SIZEOF_TABP : launch::SIZEOF_TABQ; }
     size_t block_bytes(int b) const { return block_entries[b % halves] * entry_bytes(); }
     void shape(int device, int kind_, int width, int groups) {
-        dev = device; kind = kind_; c = width; glv = kind_ == 2; n_groups = groups;
+        dev = device; kind = kind_; c = width; glv = kind_ >= 2; n_groups = groups;
         halves = glv ? 2 : 1;
         if (glv) {
             const int WLc = launch::glv_lower_windows(c), Wc = launch::glv_windows(c);  // windows of mixed widths (launch.hpp)
@@ -84,7 +84,7 @@ struct Engine::SharedTable {
     bool trace_allocs = false;  // (ETH_KZG_AMD_TRACE of the context that builds the table)
     // allocate pieces until blocks [0, block_end) exist; false: out of memory (why is set) or cancelled
     bool alloc_until(int block_end, const std::atomic<bool>* cancel) {
-        constexpr size_t PIECE = (size_t)850 << 20;  // (one piece for the whole table was round 3's single hipMalloc: seconds of stall for every HIP call of the process)
+        constexpr size_t PIECE = (size_t)850 << 20, HEADROOM = (size_t)8 << 30;  // (one piece for the whole table was round 3's single hipMalloc: seconds of stall for every HIP call of the process)
         const int total = n_groups * halves;
         if (block_end > total) block_end = total;
         if (!d_blocks) {
@@ -96,6 +96,14 @@ struct Engine::SharedTable {
             int n = 0;
             size_t sz = 0;
             while (blocks_allocated + n < total && (n == 0 || sz + block_bytes(blocks_allocated + n) <= PIECE)) { sz += block_bytes(blocks_allocated + n); n++; }
+            // fill_table has checked that the whole table fits, but another process (or thread) may have taken memory since: a table
+            // that grows to the GPU's last byte leaves nothing for anybody's kernel scratch or batch buffers, and the runtime
+            // aborts the process whose queue asks next (seen with two ranks racing for one GPU).  Stop a piece early instead.
+            size_t free_now = 0, total_now = 0;
+            if (hipMemGetInfo(&free_now, &total_now) == hipSuccess && free_now < sz + HEADROOM) {
+                why = "not enough free device memory (taken by someone else since the build began)";
+                return false;
+            }
             void* p = nullptr;
             const auto a0 = std::chrono::steady_clock::now();
             const hipError_t e = hipMalloc(&p, sz);  // (physically contiguous pieces, hipDeviceMallocContiguous, measured the same in round 4)
@@ -128,6 +136,6 @@ extern std::vector<Engine*> g_engines;
 void stop_all_builders_at_exit();
 struct BuildCancelled {};  // thrown out of a table build when its context (or the process) is going away
 inline size_t plain_table_bytes(int c, int n_groups) { return launch::table_entries(c, n_groups, 64) * launch::SIZEOF_TABQ; }
-inline size_t glv_table_bytes(int c) { return launch::table_glv_entries(c, 128, 64) * launch::SIZEOF_TABP; }
+inline size_t glv_table_bytes(int c, int n_groups = 128) { return launch::table_glv_entries(c, n_groups, 64) * launch::SIZEOF_TABP; }
 
 }  // namespace kzg

@@ -223,9 +223,9 @@ void Engine::init_fk20() {
             for (int w : launch::GLV_WIDTHS)
                 if (!fk) fk = obtain_table(dev_, 2, w, nullptr, 128, stream_, /*only_if_live=*/true);
         if (!fk) fk = obtain_table(dev_, 2, 8, d_fk_bases_, 128, stream_);
-        for (int w : {13, 12, 10, 8})
-            if (!srs) srs = obtain_table(dev_, 0, w, nullptr, 64, stream_, true);
-        if (!srs) srs = obtain_table(dev_, 0, 8, d_srs_, 64, stream_);
+        for (int w : launch::GLV_WIDTHS)
+            if (!srs) srs = obtain_table(dev_, 3, w, nullptr, 64, stream_, true);
+        if (!srs) srs = obtain_table(dev_, 3, 8, d_srs_, 64, stream_);
         if (!fk || !srs) throw std::runtime_error("not enough device memory for the start window tables");
         publish(TAB_FK, fk, nullptr);
         publish(TAB_SRS, srs, nullptr);
@@ -243,16 +243,17 @@ void Engine::init_fk20() {
     });
 }
 
-// The wide tables, widest first, each taken from the process-wide registry if another context of this GPU holds it already:
-//   commitments: plain width 13 (43 GB; 20 windows), 12, 10, 8
-//   FK20: GLV width 16 (206 GB; 16 gathered additions per base), 15 (71 GB; 18), 14 (29 GB; 20), 12 (14.5 GB; 22), 8 (1.6 GB; 32)
-//         (mixed window widths that cover the 128-bit half exactly, launch.hpp)
-//         -- GLV first at every size: the endomorphism halves the memory per window bit (a plain width-14 table costs
-//         163 GB for 19 additions) -- or the plain width ETH_KZG_AMD_WINDOW names;
-// bounded by what the HBM still holds (another process may own part of it) and by ETH_KZG_AMD_TABLE_GB (both tables
-// together; the commitment table gets at most 38 % of it; default Engine::DEFAULT_TABLE_BUDGET_GB = 116).  A table this thread creates is published as the view's `next`
-// BEFORE it is filled, so the MSMs use its groups as they become ready.  Never throws: a failure leaves the context on the
-// tables it has.
+// The wide tables, widest first, each taken from the process-wide registry if another context of this GPU holds it already. Both are
+// GLV tables (the endomorphism halves the memory per window bit: a plain width-14 FK20 table costs 163 GB for 19 additions, the
+// plain width-13 commitment table of rounds 2-4 cost 43 GB for the 20 additions that ten GLV windows give in 14.5 GB), their W
+// windows of mixed widths that cover the 128-bit half exactly (launch.hpp):
+//   FK20 (128 groups):       8 windows 206 GB (16 gathered additions per base) . 9: 71 GB (18) . 10: 29 GB (20) . 11: 14.5 GB (22) . 16: 1.6 GB (32)
+//   commitments (64 groups): 9 windows 35 GB (18) . 10: 14.5 GB (20) . 11: 7.3 GB (22) . 16: 0.8 GB (32)
+//   -- or, for FK20, the plain width ETH_KZG_AMD_WINDOW names;
+// bounded by what the HBM still holds (another process may own part of it) and by ETH_KZG_AMD_TABLE_GB (both tables together; the
+// commitment table gets at most a third of it; default Engine::DEFAULT_TABLE_BUDGET_GB = 108 = nine windows each).  A table this
+// thread creates is published as the view's `next` BEFORE it is filled, so the MSMs use its groups as they become ready.  Never
+// throws: a failure leaves the context on the tables it has.
 void Engine::build_final_tables() {
     int state = 1;
     std::string why;
@@ -309,8 +310,8 @@ void Engine::build_final_tables() {
                 if (!cur.main || (cur.next && cur.next->state.load() == 0)) continue;
                 std::shared_ptr<SharedTable> growing;
                 if (sel == TAB_SRS) {
-                    for (int w : {13, 12, 10})
-                        if (!growing && w > cur.c) { auto t = find_table(dev_, 0, w); if (t && t->state.load() == 0) growing = t; }
+                    for (int w : launch::GLV_WIDTHS)
+                        if (!growing && (!cur.glv || w > cur.c)) { auto t = find_table(dev_, 3, w); if (t && t->state.load() == 0) growing = t; }
                 } else if (!want_plain_c_) {
                     for (int w : launch::GLV_WIDTHS)
                         if (!growing && (!cur.glv || w > cur.c)) { auto t = find_table(dev_, 2, w); if (t && t->state.load() == 0) growing = t; }
@@ -328,11 +329,12 @@ void Engine::build_final_tables() {
         const double budget = table_budget_gb_ > 0 ? table_budget_gb_ * 1e9 : 1e18;
         const TableView srs_now = table_view(TAB_SRS), fk_now = table_view(TAB_FK);
         std::shared_ptr<SharedTable> srs;
-        for (int w : {13, 12, 10, 8}) {
+        for (int w : launch::GLV_WIDTHS) {
             if (srs) break;
-            if (srs_now.main && w <= srs_now.c) break;  // nothing wider than what is in use fits
-            if ((double)plain_table_bytes(w, 64) > std::max(0.38 * budget, 2.2e9)) continue;  // (0.38 x the default 116 GB = the width-13 table)
-            srs = widen(TAB_SRS, 0, w, d_srs_, 64);
+            if (w == 16) continue;  // (eight windows for the commitments would be 103 GB: the FK20 table has the better use for them)
+            if (srs_now.main && srs_now.glv && w <= srs_now.c) break;  // nothing wider than what is in use fits
+            if ((double)glv_table_bytes(w, 64) > std::max(budget / 3, 0.9e9)) continue;  // (a third of the default 108 GB = the nine-window table)
+            srs = widen(TAB_SRS, 3, w, d_srs_, 64);
         }
         if (srs) publish(TAB_SRS, srs, nullptr);
         const double left = budget - (double)table_view(TAB_SRS).bytes;

@@ -5,8 +5,8 @@
 //
 //   for the host application
 //   ETH_KZG_AMD_DEVICE=<n>          GPU ordinal of eth_kzg_das_context_new (default 0)
-//   ETH_KZG_AMD_TABLE_GB=<gb>|max   HBM for the two window tables together (default 116 = the nine-window GLV table, 71 GB, + the
-//                                   width-13 commitment table, 43 GB; max = whatever the HBM holds: eight windows of 16 bits, 249 GB)
+//   ETH_KZG_AMD_TABLE_GB=<gb>|max   HBM for the two window tables together (default 108 = the nine-window GLV tables: 71 GB for FK20,
+//                                   35 GB for commitments; max = whatever the HBM holds: eight windows of 16 bits for FK20, 242 GB in all)
 //   ETH_KZG_AMD_GLV_WINDOW=<w>      exactly this GLV table width for FK20 (16, 15, 14, 12, 8)
 //   ETH_KZG_AMD_WINDOW=<w>          a PLAIN FK20 table of this width instead (14, 13, 12, 10, 8)
 //   ETH_KZG_AMD_PROGRESSIVE=0       build the wide tables inside the constructor instead of behind it

@@ -7,8 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-# The GPU suite exercises the WIDEST window tables (GLV width 16: 249 GB with the commitment table) unless a test sets its own
-# budget: the library's default since round 5 is a stated 116 GB (tests/test_gpu_tables.py covers that default on its own).
+# The GPU suite exercises the WIDEST window tables (GLV width 16: 242 GB with the commitment table) unless a test sets its own
+# budget: the library's default since round 5 is a stated 108 GB (tests/test_gpu_tables.py covers that default on its own).
 os.environ.setdefault("ETH_KZG_AMD_TABLE_GB", "max")
 
 

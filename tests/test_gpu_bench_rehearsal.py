@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _rehearse(extra):
     env = dict(os.environ, KZG_BENCH_REHEARSAL="1")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "ETH_KZG_AMD_TABLE_GB"):  # (the suite's "max" budget is for ONE context per GPU: the rehearsal sets its own)
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--blobs-per-gpu", "128"] + extra,
                        env=env, capture_output=True, text=True, timeout=400)

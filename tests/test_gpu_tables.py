@@ -4,7 +4,10 @@ and switches to the wide ones when a helper thread has built them; bytes never d
 Reference knob: UsePrecomp::Yes{width} (crates/cryptography/bls12_381/src/fixed_base_msm.rs:41-49); reference bench:
 "Initialize context" (crates/eip7594/benches/benchmark-mt.rs:103-113).
 
-This module holds no module-wide context: a 116 GB table does not fit next to the default 249 GB ones."""
+Since round 5 the commitment table (the monomial SRS as 64 groups of 64 bases) is a GLV table of the same kind (half the groups of
+the FK20 table: half its size at every width), so every width is also checked through blob_to_kzg_commitment at every batch regime.
+
+This module holds no module-wide context: a 71 GB table does not fit next to the 242 GB the other tests' contexts hold."""
 import ctypes as C
 import importlib
 import os
@@ -28,6 +31,22 @@ kzg = importlib.import_module("rust-eth-kzg_amd")
 INF = b"\xc0" + bytes(47)
 GLV_ADDS = {16: 16, 15: 18, 14: 20, 12: 22, 8: 32}  # gathered additions per (scalar, base) = 2 ceil(128 / w)
 GLV_GB = {16: 206.2, 15: 70.9, 14: 29.0, 12: 14.5, 8: 1.6}  # mixed window widths (launch.hpp): W windows cover the 128-bit half exactly
+SRS_GB = {15: 35.4, 14: 14.5, 12: 7.3, 8: 0.8}            # the commitment table: 64 groups instead of 128 (never eight windows: 103 GB)
+
+
+def _commitments_check(ctx, oracle, seed, sizes=(1, 5, 70, 600)):
+    """blob_to_kzg_commitment over the context's commitment table in every MSM regime (one block per MSM, a lane per window,
+    four chunks per MSM) against the oracle on a sample; blob 2 is the zero polynomial (the point at infinity)."""
+    for n in sizes:
+        blobs = full._random_blobs(n, seed + n)
+        if n > 2:
+            blobs[2] = 0
+        st, comms = ctx.blob_to_kzg_commitment_batch([blobs[b].tobytes() for b in range(n)])
+        assert list(st) == [0] * n
+        if n > 2:
+            assert comms[2] == INF
+        for b in sorted({0, n // 2, n - 1}):
+            assert comms[b] == oracle.blob_to_kzg_commitment(blobs[b].tobytes()), (n, b)
 
 
 def _msm_stage_check(ctx, tag):
@@ -74,7 +93,7 @@ def test_every_glv_width_matches_oracle(oracle, monkeypatch, width):
     keep = kzg.DASContext(use_precomp=True)  # holds the table while the schedule variants come and go
     try:
         assert keep.glv_table() and keep.window_bits() == width and keep.tables_ready() == 1
-        assert abs(keep.table_bytes() / 1e9 - GLV_GB[width]) < 0.06 * GLV_GB[width] + 50  # + the commitment table (<= 43 GB)
+        assert abs(keep.table_bytes() / 1e9 - GLV_GB[width] - SRS_GB[15]) < 0.02 * GLV_GB[width] + 0.5  # + the nine-window commitment table (the suite's budget is "max")
         for chunks in ("auto", "0", "4"):
             if chunks == "auto":
                 monkeypatch.delenv("ETH_KZG_AMD_MSM_CHUNKS", raising=False)
@@ -100,15 +119,18 @@ def test_every_glv_width_matches_oracle(oracle, monkeypatch, width):
 
 
 def test_table_budget_picks_the_widest_glv_table_that_fits(oracle, monkeypatch):
-    """ETH_KZG_AMD_TABLE_GB bounds both tables together; the FK20 table stays a GLV table at every budget (a plain one of
-    the same speed needs 2.5x the memory)."""
+    """ETH_KZG_AMD_TABLE_GB bounds both tables together: the commitment table takes the widest GLV table within a third of it, the
+    FK20 table the widest within the rest (a plain table of the same speed needs more than twice the memory).  Every commitment
+    table width gives the oracle's commitments in every batch regime."""
     full._torch_first()
-    for budget, want_w in ((80, 14), (25, 12), (3, 8)):
+    for budget, want_w, want_srs in ((90, 15, 14), (80, 14, 14), (25, 12, 12), (3, 8, 8)):
         monkeypatch.setenv("ETH_KZG_AMD_TABLE_GB", str(budget))
         c = kzg.DASContext(use_precomp=True)
         try:
             assert c.glv_table() and c.window_bits() == want_w, (budget, c.window_bits())
-            assert c.table_bytes() <= budget * 1e9 + 2.2e9
+            assert c.table_bytes() <= budget * 1e9
+            assert abs(c.table_bytes() / 1e9 - GLV_GB[want_w] - SRS_GB[want_srs]) < 0.5, (budget, c.table_bytes())
+            _commitments_check(c, oracle, 7600 + budget)
             blobs = full._random_blobs(20, 7700 + budget)
             st, cells, proofs = full._compute_on_device(c, blobs)
             assert st == [0] * 20
@@ -118,8 +140,8 @@ def test_table_budget_picks_the_widest_glv_table_that_fits(oracle, monkeypatch):
             c.close()
 
 
-def test_default_budget_is_a_stated_116_gb(oracle, monkeypatch):
-    """Without ETH_KZG_AMD_TABLE_GB the window tables take at most 116 GB (the nine-window GLV table + the width-13 commitment table), not
+def test_default_budget_is_a_stated_108_gb(oracle, monkeypatch):
+    """Without ETH_KZG_AMD_TABLE_GB the window tables take at most 108 GB (the nine-window GLV tables: 70.9 GB for FK20, 35.4 GB for commitments), not
     whatever the HBM holds; "max" and a negative budget argument give the widest tables; the budget argument of
     eth_kzg_amd_das_context_try_new wins over the environment.  Same bytes on every table."""
     full._torch_first()
@@ -130,7 +152,8 @@ def test_default_budget_is_a_stated_116_gb(oracle, monkeypatch):
         try:
             assert c.glv_table() and c.window_bits() == want_w, (kwargs, c.window_bits())
             if want_w == 15:
-                assert 110e9 < c.table_bytes() <= 116e9 + 2.2e9, c.table_bytes()
+                assert 105e9 < c.table_bytes() <= 108e9, c.table_bytes()
+                _commitments_check(c, oracle, 7820, sizes=(3, 600))
             st, cells, proofs = full._compute_on_device(c, blobs)
             assert st == [0] * 20
             full._check_sample_against_oracle(oracle, blobs, cells, proofs, [0, 19])
@@ -141,7 +164,7 @@ def test_default_budget_is_a_stated_116_gb(oracle, monkeypatch):
 
 def test_context_next_to_190_gb_held_by_someone_else_comes_up_narrower(oracle, monkeypatch):
     """A host application that shares the GPU: with 190 GB of the 288 taken (here by a torch tensor of this process; the library only
-    sees free memory) a context created with the default budget (116 GB) does not fail or abort -- it comes up on the widest tables
+    sees free memory) a context created with the default budget (108 GB) does not fail or abort -- it comes up on the widest tables
     that still fit (narrower than width 15) and gives the oracle's bytes."""
     import torch
     full._torch_first()
@@ -167,7 +190,7 @@ def test_context_next_to_190_gb_held_by_someone_else_comes_up_narrower(oracle, m
 
 
 def test_progressive_start_serves_at_once_and_switches_tables(oracle, monkeypatch):
-    """eth_kzg_das_context_new returns on the start tables (GLV width 8 / plain width 8).  The wide tables are allocated in pieces
+    """eth_kzg_das_context_new returns on the start tables (GLV width 8 for FK20 and for commitments).  The wide tables are allocated in pieces
     of under a gigabyte and taken into use GROUP BY GROUP while the helper thread builds them (an MSM stage = the ready groups on
     the wide table + the rest on the start table): calls made before, during -- at every mix of the two tables the loop happens
     to meet -- and after the switch give identical bytes (and match the oracle), and a commitment / a verification issued from
