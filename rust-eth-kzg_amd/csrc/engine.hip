@@ -215,7 +215,6 @@ Engine::Engine(bool use_precomp, int device, const Engine* primary, double table
     if (knobs_.serial_lanes) max_lanes_ = knobs_.serial_lanes;
     if (use_precomp) {
         // default: the widest GLV table inside the budget (108 GB: nine windows, 71 GB, 18 gathered additions per base; the commitment table likewise, 35 GB), see build_final_tables
-        { const int c = knobs_.plain_window; if (c == 8 || c == 10 || c == 12 || c == 13 || c == 14) want_plain_c_ = c; }
         if (launch::glv_width_supported(knobs_.glv_window)) want_glv_c_ = knobs_.glv_window;
         // memory budget for the window tables (both together), in GB: the constructor's argument, else ETH_KZG_AMD_TABLE_GB
         // (a number, or "max" = whatever the HBM still holds -- the behaviour up to round 4), else DEFAULT_TABLE_BUDGET_GB

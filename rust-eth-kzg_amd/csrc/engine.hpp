@@ -312,7 +312,6 @@ private:
     Comm* comm_ = nullptr;
     bool use_precomp_ = true;
     Knobs knobs_;            // every environment knob, read once when the context is created (knobs.hpp)
-    int want_plain_c_ = 0;   // ETH_KZG_AMD_WINDOW: a plain FK20 table of this width instead of the GLV ladder (0: none)
     int want_glv_c_ = 0;     // ETH_KZG_AMD_GLV_WINDOW: this GLV width exactly (0: the widest that fits memory and budget)
     double table_budget_gb_ = DEFAULT_TABLE_BUDGET_GB;  // upper bound for both tables together (constructor argument, ETH_KZG_AMD_TABLE_GB, or the default); <= 0: what the HBM holds
     mutable std::mutex tab_mu_;

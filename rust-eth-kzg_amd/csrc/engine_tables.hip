@@ -21,17 +21,16 @@ static bool fill_table(Engine::SharedTable& t, const void* bases, hipStream_t st
     auto t0 = std::chrono::steady_clock::now();
     auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     const int c = t.c, nb = t.nb;
-    const bool fast = t.glv || c >= 10;  // plain width 8 (128 entries per window = two wave steps) is quicker with the simple builder
     const size_t per_group = t.glv ? launch::table_glv_entries(c, 1, nb) : launch::table_entries(c, 1, nb);
-    const size_t scratch_per_entry = t.glv ? 168 : fast ? 56 : sizeof(G1Jac);
-    int chunk = (int)((t.glv || fast ? (9ull << 30) : (24ull << 30)) / (per_group * scratch_per_entry));
+    const size_t scratch_per_entry = t.glv ? 168 : sizeof(G1Jac);
+    int chunk = (int)((t.glv ? (9ull << 30) : (24ull << 30)) / (per_group * scratch_per_entry));
     if (chunk < 1) chunk = 1;
     if (chunk > t.n_groups) chunk = t.n_groups;
     if (gentle) {  // <= ~512 builder waves in flight (a wave per (base, window): 64 x W per group)
         const int W = t.glv ? launch::glv_windows(c) : (255 + c) / c;
         chunk = std::max(1, std::min(chunk, 512 / (nb * W)));
     }
-    const size_t side_bytes = t.glv ? launch::table_glv_side_bytes(c, chunk, nb) : fast ? launch::table_fast_side_bytes(c, chunk, nb) : 0;
+    const size_t side_bytes = t.glv ? launch::table_glv_side_bytes(c, chunk, nb) : 0;
     void *scratch = nullptr, *side = nullptr;
     int* d_err = nullptr;
     auto cleanup = [&] {
@@ -78,8 +77,6 @@ static bool fill_table(Engine::SharedTable& t, const void* bases, hipStream_t st
             void* const* blocks = t.d_blocks + (size_t)g0 * t.halves;
             if (t.glv) {
                 if (!launch::build_table_glv(c, b, blocks, scratch, side, g, nb, d_err, st)) throw std::runtime_error("GLV table width not built in");
-            } else if (fast) {
-                if (!launch::build_table_fast(c, b, blocks, scratch, side, g, nb, d_err, st)) throw std::runtime_error("table width not built in");
             } else {
                 launch::build_table(c, b, blocks, scratch, g, nb, st);
             }
@@ -219,9 +216,8 @@ void Engine::init_fk20() {
     // or from whatever wider table another context of this process already holds -- and build the wide ones on a helper thread.
     {
         std::shared_ptr<SharedTable> fk, srs;
-        if (!want_plain_c_)
-            for (int w : launch::GLV_WIDTHS)
-                if (!fk) fk = obtain_table(dev_, 2, w, nullptr, 128, stream_, /*only_if_live=*/true);
+        for (int w : launch::GLV_WIDTHS)
+            if (!fk) fk = obtain_table(dev_, 2, w, nullptr, 128, stream_, /*only_if_live=*/true);
         if (!fk) fk = obtain_table(dev_, 2, 8, d_fk_bases_, 128, stream_);
         for (int w : launch::GLV_WIDTHS)
             if (!srs) srs = obtain_table(dev_, 3, w, nullptr, 64, stream_, true);
@@ -249,7 +245,6 @@ void Engine::init_fk20() {
 // windows of mixed widths that cover the 128-bit half exactly (launch.hpp):
 //   FK20 (128 groups):       8 windows 206 GB (16 gathered additions per base) . 9: 71 GB (18) . 10: 29 GB (20) . 11: 14.5 GB (22) . 16: 1.6 GB (32)
 //   commitments (64 groups): 9 windows 35 GB (18) . 10: 14.5 GB (20) . 11: 7.3 GB (22) . 16: 0.8 GB (32)
-//   -- or, for FK20, the plain width ETH_KZG_AMD_WINDOW names;
 // bounded by what the HBM still holds (another process may own part of it) and by ETH_KZG_AMD_TABLE_GB (both tables together; the
 // commitment table gets at most a third of it; default Engine::DEFAULT_TABLE_BUDGET_GB = 108 = nine windows each).  A table this
 // thread creates is published as the view's `next` BEFORE it is filled, so the MSMs use its groups as they become ready.  Never
@@ -312,7 +307,7 @@ void Engine::build_final_tables() {
                 if (sel == TAB_SRS) {
                     for (int w : launch::GLV_WIDTHS)
                         if (!growing && (!cur.glv || w > cur.c)) { auto t = find_table(dev_, 3, w); if (t && t->state.load() == 0) growing = t; }
-                } else if (!want_plain_c_) {
+                } else {
                     for (int w : launch::GLV_WIDTHS)
                         if (!growing && (!cur.glv || w > cur.c)) { auto t = find_table(dev_, 2, w); if (t && t->state.load() == 0) growing = t; }
                 }
@@ -339,20 +334,12 @@ void Engine::build_final_tables() {
         if (srs) publish(TAB_SRS, srs, nullptr);
         const double left = budget - (double)table_view(TAB_SRS).bytes;
         std::shared_ptr<SharedTable> fk;
-        if (want_plain_c_) {
-            static const int widths[] = {14, 13, 12, 10, 8};
-            for (int w : widths) {
-                if (fk || w > want_plain_c_) continue;
-                fk = widen(TAB_FK, 1, w, d_fk_bases_, 128);
-            }
-        } else {
-            for (int w : launch::GLV_WIDTHS) {
-                if (fk) break;
-                if (want_glv_c_ && w != want_glv_c_) continue;
-                if (fk_now.main && fk_now.glv && w <= fk_now.c) break;
-                if ((double)glv_table_bytes(w) > std::max(left, 1.7e9)) continue;
-                fk = widen(TAB_FK, 2, w, d_fk_bases_, 128);
-            }
+        for (int w : launch::GLV_WIDTHS) {
+            if (fk) break;
+            if (want_glv_c_ && w != want_glv_c_) continue;
+            if (fk_now.main && fk_now.glv && w <= fk_now.c) break;
+            if ((double)glv_table_bytes(w) > std::max(left, 1.7e9)) continue;
+            fk = widen(TAB_FK, 2, w, d_fk_bases_, 128);
         }
         if (fk) publish(TAB_FK, fk, nullptr);
         if (!table_view(TAB_FK).main) {  // not even the narrowest GLV table fits: the plain width-4 tables (0.8 GB)

@@ -5,6 +5,7 @@
 #include "g1_coop.hpp"
 #include "launch.hpp"
 #include "glv.hpp"
+#include <stdexcept>
 
 namespace kzg {
 
@@ -264,12 +265,8 @@ static void msm_flat_c(const void* scalars, const TabBlocks& table, void* out, i
 }
 void msm_fixed_flat(int c, const void* scalars, const TabBlocks& table, void* out, int n_groups, int n_slices, int nb, int out_stride,
                     int brp_bits, hipStream_t st) {
-    if (c == 8) msm_flat_c<8>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
-    else if (c == 12) msm_flat_c<12>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
-    else if (c == 13) msm_flat_c<13>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
-    else if (c == 14) msm_flat_c<14>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
-    else if (c == 10) msm_flat_c<10>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
-    else msm_flat_c<4>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
+    if (c != PLAIN_WIDTH) throw std::runtime_error("plain window tables exist at width 4 only");
+    msm_flat_c<PLAIN_WIDTH>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
 }
 // k_msm_glv.inc (one translation unit per window width) holds the GLV kernels; the split of the scalars is shared
 void glv_split(void* scalars, size_t n, hipStream_t st) {
@@ -310,12 +307,8 @@ static void msm_chunked_c(const void* scalars, const TabBlocks& table, void* out
 }
 void msm_fixed_chunked(int c, const void* scalars, const TabBlocks& table, void* out, int n_groups, int n_slices, int nb, int out_stride,
                        int brp_bits, int S, hipStream_t st) {
-    if (c == 8) msm_chunked_c<8>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, S, st);
-    else if (c == 12) msm_chunked_c<12>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, S, st);
-    else if (c == 13) msm_chunked_c<13>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, S, st);
-    else if (c == 14) msm_chunked_c<14>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, S, st);
-    else if (c == 10) msm_chunked_c<10>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, S, st);
-    else msm_chunked_c<4>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, S, st);
+    if (c != PLAIN_WIDTH) throw std::runtime_error("plain window tables exist at width 4 only");
+    msm_chunked_c<PLAIN_WIDTH>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, S, st);
 }
 template <int C>
 static void msm_c(const void* scalars, const TabBlocks& table, void* out, int n_groups, int n_slices, int nb, int out_stride,
@@ -328,12 +321,8 @@ static void msm_c(const void* scalars, const TabBlocks& table, void* out, int n_
 }
 void msm_fixed(int c, const void* scalars, const TabBlocks& table, void* out, int n_groups, int n_slices, int nb, int out_stride,
                int brp_bits, hipStream_t st) {
-    if (c == 8) msm_c<8>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
-    else if (c == 12) msm_c<12>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
-    else if (c == 13) msm_c<13>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
-    else if (c == 14) msm_c<14>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
-    else if (c == 10) msm_c<10>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
-    else msm_c<4>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
+    if (c != PLAIN_WIDTH) throw std::runtime_error("plain window tables exist at width 4 only");
+    msm_c<PLAIN_WIDTH>(scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, st);
 }
 }  // namespace launch
 }  // namespace kzg

@@ -2,6 +2,7 @@
 #include "kcommon.hpp"
 #include "curve30.hpp"
 #include "launch.hpp"
+#include <stdexcept>
 
 namespace kzg {
 
@@ -54,15 +55,15 @@ __global__ __launch_bounds__(64) void k_build_table(const G1Affine* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fast builder for widths >= 8 (2^(c-1) entries per (base, window) is a multiple of 64): two kernels in the unsaturated field.
-//  k_table_windows : thread per base: Q_w = 2^(c w) P and 64 Q_w for every window, normalised to affine with one inversion.
-//  k_table_fill    : ONE WAVE per (base, window).  Lane l starts at (l + 1) Q and steps by 64 Q, so at step k the wave
+// The builder of the GLV tables (2^(bits-1) entries per (base, window) is a multiple of 64): two kernels in the unsaturated field.
+//  k_table_windows : thread per base: Q_w = 2^(first bit of window w) P and 64 Q_w for every window, normalised to affine with one inversion.
+//  k_table_fill_packed : ONE WAVE per (base, window).  Lane l starts at (l + 1) Q and steps by 64 Q, so at step k the wave
 //                    holds the 64 consecutive entries d = 64 k + l + 1: every load and store is a contiguous 7 KiB run
 //                    (the thread-per-(base, window) builder above strides each lane through its own 0.9 MB region and is
 //                    bound by address translation, not arithmetic).  Normalisation without a per-entry inversion: along a
 //                    lane Z_(k+1) = Z_k * f_k with f_k = 2 H_k from the mixed addition, so 1 / Z_k = (1 / Z_(k+1)) * f_k:
 //                    one binary-GCD inversion per lane per 2^(c-1) / 64 entries, one multiplication per entry on the way back.
-//                    X, Y wait in the destination slot (2 x 56 B = one table entry), f_k in a 56 B/entry scratch.
+//                    X, Y (2 x 56 B) and f_k (56 B) wait in a scratch of 168 B per entry of the chunk being built.
 // p + q with the factor f = Z3 / Z1 (2 H in general; 2 Y1 when p == q and the sum is a doubling)
 __device__ __forceinline__ JacQ add_mixed_f(const JacQ& p, const AffQ& q, Fq<260>& f) {
     Fq<2> z1z1 = sqr(p.z);
@@ -88,8 +89,8 @@ __device__ __forceinline__ JacQ add_mixed_f(const JacQ& p, const AffQ& q, Fq<260
     return r;
 }
 
-// GLV: the windows of a GLV table have mixed widths (launch::glv_window_bits): Q_w = 2^(first bit of window w) P
-template <int C, int W = (255 + C) / C, bool GLV = false>
+// the windows of a GLV table have mixed widths (launch::glv_window_bits)
+template <int C, int W>
 __global__ void k_table_windows(const G1Affine* __restrict__ bases, AffQ* __restrict__ qw /*[n][2][W]*/, JacQ* __restrict__ tmp,
                                 Fq<2>* __restrict__ pre, int n_bases) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,7 +106,7 @@ __global__ void k_table_windows(const G1Affine* __restrict__ bases, AffQ* __rest
     JacQ cur = to_jacq(P);
     for (int w = 0; w < W; w++) {
         J[w] = cur;
-        const int bits = GLV ? launch::glv_window_bits(C, w) : C;
+        const int bits = launch::glv_window_bits(C, w);
         for (int s = 0; s < bits; s++) {
             cur = dbl(cur);
             if (s == 5) J[W + w] = cur;  // 64 Q_w
@@ -123,63 +124,6 @@ __global__ void k_table_windows(const G1Affine* __restrict__ bases, AffQ* __rest
         a.x = reduce_once(mul(p.x, zi2));
         a.y = reduce_once(mul(p.y, mul(zi2, zi)));
         out[i] = a;
-    }
-}
-
-template <int C>
-__global__ __launch_bounds__(64) void k_table_fill(const AffQ* __restrict__ qw, void* const* __restrict__ blocks, Fq<260>* __restrict__ scratch,
-                                                   int nb, int* __restrict__ err) {
-    constexpr int W = (255 + C) / C;
-    constexpr int T = 1 << (C - 1), K = T / 64;
-    static_assert(T % 64 == 0, "wave-wide fill needs at least 64 entries per window");
-    const int lane = threadIdx.x;
-    const long blk = blockIdx.x;  // = (group * W + w) * nb + i : the table's own block order
-    const int i = (int)(blk % nb), w = (int)((blk / nb) % W);
-    const long group = blk / ((long)nb * W);
-    const long base = group * nb + i;
-    const AffQ Q = qw[(size_t)base * 2 * W + w], S = qw[(size_t)base * 2 * W + W + w];
-    TabQ* dst = reinterpret_cast<TabQ*>(blocks[group]) + (((size_t)w * nb + i) << (C - 1));  // the group's block: [window][base][digit]
-    Fq<260>* scr = scratch + ((size_t)blk << (C - 1));
-    if (is_inf(Q)) {  // identity base (wave-uniform): an all-identity block
-        for (int k = 0; k < K; k++) dst[k * 64 + lane].a = Q;
-        return;
-    }
-    // (lane + 1) Q by double-and-add over 7 bits, branch-free across lanes
-    JacQ cur = jacq_inf();
-    const int n = lane + 1;
-#pragma unroll 1
-    for (int bit = 6; bit >= 0; bit--) {
-        cur = dbl(cur);
-        const JacQ t = add_mixed(cur, Q);
-        const bool take = (n >> bit) & 1;
-        cur.x = select(take, t.x, cur.x);
-        cur.y = select(take, t.y, cur.y);
-        cur.z = select(take, t.z, cur.z);
-    }
-    struct Raw { Fq<XB> x, y; uint32_t pad[4]; };  // X, Y wait in the entry they will become
-    static_assert(sizeof(Raw) == sizeof(TabQ), "in-place normalisation");
-    Raw* raw = reinterpret_cast<Raw*>(dst);
-#pragma unroll 1
-    for (int k = 0; k < K; k++) {
-        raw[k * 64 + lane].x = cur.x;
-        raw[k * 64 + lane].y = cur.y;
-        if (k + 1 < K) {
-            Fq<260> f;
-            cur = add_mixed_f(cur, S, f);
-            scr[k * 64 + lane] = f;
-        }
-    }
-    if (is_inf(cur)) atomicOr(err, 1);  // cannot happen for a base of prime order
-    Fq<2> zinv = relax<2>(fq_inv(cur.z));
-#pragma unroll 1
-    for (int k = K - 1; k >= 0; k--) {
-        const Fq<XB> X = raw[k * 64 + lane].x, Y = raw[k * 64 + lane].y;
-        const Fq<2> zi2 = sqr(zinv);
-        AffQ a;
-        a.x = reduce_once(mul(X, zi2));
-        a.y = reduce_once(mul(Y, mul(zi2, zinv)));
-        dst[k * 64 + lane].a = a;
-        if (k > 0) zinv = mul(zinv, scr[(k - 1) * 64 + lane]);
     }
 }
 
@@ -259,35 +203,8 @@ void preload_k_table() {
     hipFuncAttributes a;
     (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>((&k_build_table<4>)));
 }
-template <int C>
-static void table_fast_c(const void* bases, void* const* table, void* scratch, void* qw, void* tmp, void* pre, int n_groups, int nb, int* err,
-                         hipStream_t st) {
-    const int n_bases = n_groups * nb;
-    constexpr int W = (255 + C) / C;
-    k_table_windows<C><<<(n_bases + 63) / 64, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)qw, (JacQ*)tmp, (Fq<2>*)pre, n_bases);
-    k_table_fill<C><<<(unsigned)((long)n_bases * W), 64, 0, st>>>((const AffQ*)qw, table, (Fq<260>*)scratch, nb, err);
-}
-// side buffers of the fast builder, in bytes, for a chunk of n_groups groups
-size_t table_fast_side_bytes(int c, int n_groups, int nb) {
-    const size_t W = (255 + c) / c, n = (size_t)n_groups * nb;
-    return n * 2 * W * (SIZEOF_AFFQ + SIZEOF_JACQ + 56) + 256;
-}
-bool build_table_fast(int c, const void* bases, void* const* table, void* scratch /*56 B per entry*/, void* side, int n_groups, int nb,
-                      int* err, hipStream_t st) {
-    const size_t W = (255 + c) / c, n = (size_t)n_groups * nb;
-    char* qw = (char*)side;
-    char* tmp = qw + n * 2 * W * SIZEOF_AFFQ;
-    char* pre = tmp + n * 2 * W * SIZEOF_JACQ;
-    if (c == 8) table_fast_c<8>(bases, table, scratch, qw, tmp, pre, n_groups, nb, err, st);
-    else if (c == 10) table_fast_c<10>(bases, table, scratch, qw, tmp, pre, n_groups, nb, err, st);
-    else if (c == 12) table_fast_c<12>(bases, table, scratch, qw, tmp, pre, n_groups, nb, err, st);
-    else if (c == 13) table_fast_c<13>(bases, table, scratch, qw, tmp, pre, n_groups, nb, err, st);
-    else if (c == 14) table_fast_c<14>(bases, table, scratch, qw, tmp, pre, n_groups, nb, err, st);
-    else return false;
-    return true;
-}
 // GLV tables: W = glv_windows(c) windows of mixed widths (launch::glv_window_bits), packed 96-B entries; scratch = 168 B per entry of the chunk (56 for the
-// Z factors, 112 for the waiting X, Y); side as for the plain builder with that W
+// Z factors, 112 for the waiting X, Y); side = the per-base window points (affine, Jacobian, prefix products)
 size_t table_glv_entries(int c, int n_groups, int nb) { return (size_t)n_groups * nb * glv_entries_per_base(c, 0, glv_windows(c)); }
 size_t table_glv_side_bytes(int c, int n_groups, int nb) {
     const size_t n = (size_t)n_groups * nb;
@@ -302,7 +219,7 @@ static void table_glv_c(const void* bases, void* const* table, void* scratch, vo
     char* pre = tmp + n * 2 * W * SIZEOF_JACQ;
     char* scr_f = (char*)scratch;
     char* scr_xy = scr_f + entries * 56;
-    k_table_windows<C, W, true><<<((int)n + 63) / 64, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)qw, (JacQ*)tmp, (Fq<2>*)pre, (int)n);
+    k_table_windows<C, W><<<((int)n + 63) / 64, 64, 0, st>>>((const G1Affine*)bases, (AffQ*)qw, (JacQ*)tmp, (Fq<2>*)pre, (int)n);
     k_table_fill_packed<C, W><<<(unsigned)(n * W), 64, 0, st>>>((const AffQ*)qw, table, (Fq<260>*)scr_f, (Fq<XB>*)scr_xy, nb, err);
 }
 bool build_table_glv(int c, const void* bases, void* const* table, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st) {
@@ -318,16 +235,11 @@ size_t table_entries(int c, int n_groups, int nb) {
     int W = (255 + c) / c;
     return ((size_t)n_groups * nb * W) << (c - 1);
 }
+// the plain width-4 tables of use_precomp = false (0.4 GB each): the only plain width left (rounds 1-4 had 8 ... 14 as well)
 void build_table(int c, const void* bases, void* const* table, void* scratch, int n_groups, int nb, hipStream_t st) {
-    int W = (255 + c) / c;
-    long threads = (long)n_groups * nb * W;
-    unsigned blocks = (unsigned)((threads + 63) / 64);
-    if (c == 8) k_build_table<8><<<blocks, 64, 0, st>>>((const G1Affine*)bases, table, (G1Jac*)scratch, n_groups, nb);
-    else if (c == 12) k_build_table<12><<<blocks, 64, 0, st>>>((const G1Affine*)bases, table, (G1Jac*)scratch, n_groups, nb);
-    else if (c == 13) k_build_table<13><<<blocks, 64, 0, st>>>((const G1Affine*)bases, table, (G1Jac*)scratch, n_groups, nb);
-    else if (c == 14) k_build_table<14><<<blocks, 64, 0, st>>>((const G1Affine*)bases, table, (G1Jac*)scratch, n_groups, nb);
-    else if (c == 10) k_build_table<10><<<blocks, 64, 0, st>>>((const G1Affine*)bases, table, (G1Jac*)scratch, n_groups, nb);
-    else k_build_table<4><<<blocks, 64, 0, st>>>((const G1Affine*)bases, table, (G1Jac*)scratch, n_groups, nb);
+    if (c != PLAIN_WIDTH) throw std::runtime_error("plain window tables exist at width 4 only");
+    const long threads = (long)n_groups * nb * ((255 + PLAIN_WIDTH) / PLAIN_WIDTH);
+    k_build_table<PLAIN_WIDTH><<<(unsigned)((threads + 63) / 64), 64, 0, st>>>((const G1Affine*)bases, table, (G1Jac*)scratch, n_groups, nb);
 }
 }  // namespace launch
 }  // namespace kzg

@@ -8,7 +8,6 @@
 //   ETH_KZG_AMD_TABLE_GB=<gb>|max   HBM for the two window tables together (default 108 = the nine-window GLV tables: 71 GB for FK20,
 //                                   35 GB for commitments; max = whatever the HBM holds: eight windows of 16 bits for FK20, 242 GB in all)
 //   ETH_KZG_AMD_GLV_WINDOW=<w>      exactly this GLV table width for FK20 (16, 15, 14, 12, 8)
-//   ETH_KZG_AMD_WINDOW=<w>          a PLAIN FK20 table of this width instead (14, 13, 12, 10, 8)
 //   ETH_KZG_AMD_PROGRESSIVE=0       build the wide tables inside the constructor instead of behind it
 //   ETH_KZG_AMD_HOST_THREADS=<n>    helper threads of the host-pointer paths (gather / scatter, hashing, pairings)
 //   ETH_KZG_AMD_SERIAL_LANES=<n>    engine lanes for concurrent recovery / commitment / EIP-4844 calls (default 4)
@@ -32,7 +31,7 @@ namespace kzg {
 struct Knobs {
     int device = 0;
     double table_budget_gb = 0;  // 0: the engine's default; < 0: what the HBM holds
-    int glv_window = 0, plain_window = 0;
+    int glv_window = 0;
     bool progressive = true;
     int host_threads = 0;  // 0: chosen from the core count
     int serial_lanes = 0;  // 0: the engine's default
@@ -54,7 +53,6 @@ struct Knobs {
             else if (atof(s) > 0) k.table_budget_gb = atof(s);
         }
         num("ETH_KZG_AMD_GLV_WINDOW", 8, 16, k.glv_window);
-        num("ETH_KZG_AMD_WINDOW", 8, 14, k.plain_window);
         flag("ETH_KZG_AMD_PROGRESSIVE", k.progressive);
         num("ETH_KZG_AMD_HOST_THREADS", 1, 64, k.host_threads);
         num("ETH_KZG_AMD_SERIAL_LANES", 1, 16, k.serial_lanes);

@@ -43,6 +43,7 @@ struct TabBlocks {
     const void* const* blocks;
     int g0, gcnt;
 };
+// plain tables: c must be PLAIN_WIDTH (k_msm.hip)
 void msm_fixed(int c, const void* scalars, const TabBlocks& table, void* out /*G1Jac*/, int n_groups, int n_slices, int nb,
                int out_stride, int brp_bits, hipStream_t st);
 // S = 1, 2 or 4 threads per MSM, each summing a chunk of the windows (large batches: no window-sum fold to speak of)
@@ -81,11 +82,10 @@ size_t table_glv_side_bytes(int c, int n_groups, int nb);
 // scratch: 168 B per entry of the chunk; side: table_glv_side_bytes; false if the width is not built in.
 // blocks: device array of 2 * n_groups block pointers of THIS chunk's groups (lower / upper windows of each)
 bool build_table_glv(int c, const void* bases, void* const* blocks, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st);
+// plain tables (128-B entries over the full 255-bit scalar) exist at ONE width: the 0.4 GB tables of use_precomp = false
+constexpr int PLAIN_WIDTH = 4;
 size_t table_entries(int c, int n_groups, int nb);
-size_t table_fast_side_bytes(int c, int n_groups, int nb);
-// widths >= 8: wave-per-(base, window) builder; scratch = 56 B per entry of the chunk, side = table_fast_side_bytes; false if c unsupported.
 // blocks: device array of n_groups block pointers of THIS chunk's groups
-bool build_table_fast(int c, const void* bases, void* const* blocks, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st);
 void build_table(int c, const void* bases /*G1Affine*/, void* const* blocks, void* scratch /*G1Jac*/, int n_groups,
                  int nb, hipStream_t st);
 

@@ -91,14 +91,15 @@ def _check_sample_against_oracle(oracle, blobs_np, cells, proofs, sample):
         assert proofs[b].tobytes() == b"".join(ep), f"blob {b}: proofs differ from the oracle"
 
 
-@pytest.mark.parametrize("width", [8, 12])
-def test_fallback_window_widths_match_oracle(oracle, monkeypatch, width):
-    """The plain table widths the engine falls back to when HBM is short (GLV -> 14 -> 13 -> 12 -> 10 -> 8): identical
-    bytes.  Runs before the module's default context exists: a width-12 table (47 GB) does not fit next to the GLV one."""
-    monkeypatch.setenv("ETH_KZG_AMD_WINDOW", str(width))
+def test_plain_width_4_tables_match_oracle(oracle):
+    """use_precomp = false: the 0.8 GB plain width-4 tables (64 windows over the full 255-bit scalar, the 14-digit kernels of
+    k_msm.hip -- the only plain width left since the commitment table became a GLV table): identical bytes in the windowed and the
+    chunked MSM schedule, commitments included."""
+    width = 4
     _torch_first()
-    c2 = kzg.DASContext(use_precomp=True)
+    c2 = kzg.DASContext(use_precomp=False)
     try:
+        assert not c2.glv_table()
         assert c2.window_bits() == width
         blobs = _random_blobs(70, 800 + width)
         blobs[1] = 0
@@ -110,6 +111,10 @@ def test_fallback_window_widths_match_oracle(oracle, monkeypatch, width):
         st, cells, proofs = _compute_on_device(c2, blobs)
         assert st == [0] * 1024
         _check_sample_against_oracle(oracle, blobs, cells, proofs, [0, 511, 1023])
+        st, comms = c2.blob_to_kzg_commitment_batch([blobs[b].tobytes() for b in range(300)])
+        assert list(st) == [0] * 300
+        for b in (0, 150, 299):
+            assert comms[b] == oracle.blob_to_kzg_commitment(blobs[b].tobytes())
     finally:
         c2.close()
 
@@ -302,9 +307,7 @@ def test_fixed_base_msm_stage_matches_oracle(oracle, monkeypatch, chunks, table)
     import ctypes as C
     if chunks != "auto":
         monkeypatch.setenv("ETH_KZG_AMD_MSM_CHUNKS", chunks)
-    if table == "plain":
-        monkeypatch.setenv("ETH_KZG_AMD_WINDOW", "12")  # a plain table (whichever width <= 12 still fits next to the default context)
-    c2 = kzg.DASContext(use_precomp=True)
+    c2 = kzg.DASContext(use_precomp=table == "glv")  # "plain": the width-4 tables of use_precomp = false
     try:
         assert c2.glv_table() == (table == "glv")
         lib = kzg.load_library()
