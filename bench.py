@@ -42,7 +42,7 @@ FP_MUL_PEAK_G = 82.2             # measured SUSTAINED rate of the signed 13x30-b
                                  # tools/ubench_fp30 --sustained, profiles/r5_ubench_fp30_sustained.log (14x29-bit form: 76.2 G/s)
 
 
-def fp_mul_eq_per_blob(window_bits, linmap, glv=False, batch_lanes=2048):
+def fp_mul_eq_per_blob(window_bits, linmap, batch_lanes=2048):
     """Fp multiplication equivalents this build spends per blob, counted in multiply-add passes of the signed 13-digit field's
     351 MACs (M = 1, squaring S = 273/351, fused pair a*b + c*d with one reduction F = 520/351; the cheap levels of the linear
     map still run in the 14-digit field and are counted with the same weights):
@@ -53,7 +53,7 @@ def fp_mul_eq_per_blob(window_bits, linmap, glv=False, batch_lanes=2048):
     additions (10M + 4S + F) and doublings.  From 1024 lanes on, every subtraction of the FK20 program shares the work of the
     addition of the same two values (g1_linmap.hpp: 548 pairs of its 3162 additions and subtractions): the second result of a
     pair costs S + F."""
-    w = 16 if glv else (255 + window_bits) // window_bits  # gathered additions per (scalar, base)
+    w = 2 * -(-128 // window_bits)  # gathered additions per (scalar, base): both 128-bit halves over ceil(128 / w) windows
     S, F = 273 / 351, 520 / 351
     madd, dbl, add, madd_jac = 6 + 2 * S + F, 2 + 3 * S + F, 10 + 4 * S + F, 6 + 3 * S + F
     mulc, adds, dbls = linmap
@@ -1098,7 +1098,7 @@ def main():
         # gathered additions per (scalar, base) of the FK20 table IN USE: 2 ceil(128 / w) for a GLV table of width w (both 128-bit
         # halves over the same windows), ceil(255 / w) for a plain one
         wbits = ctx.window_bits()
-        msm_adds = 2 * -(-128 // wbits) if ctx.glv_table() else -(-255 // wbits)
+        msm_adds = 2 * -(-128 // wbits)
         # algorithmic bytes per launch of each kernel family (DESIGN.md "kernels"):
         alg_bytes = {
             "blob_to_coeffs": B * (BYTES_PER_BLOB + 4096 * 32),
@@ -1106,7 +1106,7 @@ def main():
             "fk20_scalars": B * (4096 * 32 + 128 * 64 * 32),
             # scalars in + one 96-B table entry per (scalar, window) + 128 Jacobian sums out
             # (GLV table: 16 packed 96-B entries per scalar; plain table of width c: ceil(256/c) entries of 112 B)
-            "msm_fixed": B * (128 * 64 * 32 + 128 * 64 * msm_adds * (96 if ctx.glv_table() else 112) + 128 * 168),
+            "msm_fixed": B * (128 * 64 * 32 + 128 * 64 * msm_adds * 96 + 128 * 168),
             # one radix-2 layer: 64 butterflies x (2 points in, 2 points out) x 168 B per blob
             "g1_ifft": B * 64 * 4 * 168,
             "g1_fft": B * 64 * 4 * 168,
@@ -1128,9 +1128,9 @@ def main():
             # kernel's sources (tools/pmc_summary.py); a build whose sources differ gets traffic = null instead of stale numbers
             if pmc_doc.get("msm_kernel_sources_sha256") != kernel_sources_hash():
                 raise RuntimeError("committed PMC profile belongs to another build of the kernel")
-            want = {"msm_fixed": ("k_msm_glv_chunked",) if ctx.glv_table() else ("k_msm_fixed_chunked<14>",), "g1_linmap": ("k_slp_mulc",)}.get(dom, ())
+            want = {"msm_fixed": ("k_msm_glv_chunked",), "g1_linmap": ("k_slp_mulc",)}.get(dom, ())
             key = next((k for w_ in want for k in pm if w_ in k), None)  # the newest profile names the kernel the default schedule runs
-            if key in pm and B == 2048 and ctx.glv_table() and ctx.window_bits() == 16:
+            if key in pm and B == 2048 and ctx.window_bits() == 16:
                 # gfx950 correction (MI355X_MICROARCH.md, calibrated for this kernel's 16-B-per-lane gathers in
                 # profiles/r1f_calib_fetch.log): FETCH_SIZE tallies every 128-B line request at 64 B -> double it; WRITE_SIZE is exact
                 traffic = (2.0 * pm[key]["FETCH_SIZE_per_launch_max"] + pm[key]["WRITE_SIZE_per_launch_max"]) * 1024.0
@@ -1139,7 +1139,7 @@ def main():
                 insts_source = os.path.relpath(files[-1], ROOT) + " (SQ_INSTS_VALU of the same build, rocprofv3 --pmc)"
         except Exception:
             pass
-        if insts_valu is None and dom == "msm_fixed" and ctx.glv_table():
+        if insts_valu is None and dom == "msm_fixed":
             # no counter file for this build: the static count of the kernel's hot loop (4,066 VALU instructions per gathered addition in
             # the disassembly + the folds; 4,090 per addition measured by SQ_INSTS_VALU on round 5's build) x the additions of a launch
             insts_valu = 4090.0 * B * 128 * 64 * msm_adds / 64.0
@@ -1148,7 +1148,7 @@ def main():
         # integer-VALU view (the bound that actually binds)
         mac_rate = value * 1.0e9 / 1e9  # reference-algorithm count: ~1.0e9 32x32 MACs per blob
         li = ctx.linmap_info()
-        mul_eq = fp_mul_eq_per_blob(ctx.window_bits(), li[:3] if li[0] else (642, 14 * 64 * 1.5, 0), ctx.glv_table(), args.blobs_per_gpu)
+        mul_eq = fp_mul_eq_per_blob(ctx.window_bits(), li[:3] if li[0] else (642, 14 * 64 * 1.5, 0), args.blobs_per_gpu)
         mul_rate = value * mul_eq / 1e9
         out = {
             "metric": "blobs/sec compute_cells_and_kzg_proofs (4096-pt blob)",
@@ -1161,8 +1161,7 @@ def main():
                                    f"host-pointer ABI rate is configs.abi_host_pointer_batch), batch-saturated: {B} synthetic blobs "
                                    f"per GPU per step (config 2's single blob is reported as single_blob_latency_ms)",
                        "blobs_per_gpu": B, "use_precomp": True, "window_bits": ctx.window_bits(),
-                       "fk20_table": f"GLV: {msm_adds // 2} windows of {wbits} bits per 128-bit half scalar, packed 96-B entries, {msm_adds} gathered additions per base" if ctx.glv_table()
-                                     else f"plain: width {wbits}, {msm_adds} gathered additions per base",
+                       "fk20_table": f"GLV: {msm_adds // 2} windows of {wbits} bits per 128-bit half scalar, packed 96-B entries, {msm_adds} gathered additions per base",
                        "table_GB": round(ctx.table_bytes() / 1e9, 2),
                        "table_budget": "ETH_KZG_AMD_TABLE_GB=" + os.environ.get("ETH_KZG_AMD_TABLE_GB", "") + " (set by bench.py: the widest tables the HBM holds; "
                                        "the library's default budget is 108 GB = nine-window GLV tables, see configs.blobs_per_s_vs_table_memory)",
@@ -1222,8 +1221,8 @@ def main():
             # blobs/s against window-table memory: the main context goes first (its 249 GB leave no room),
             # then one context per table size on the same resident batch.  UsePrecomp::Yes{width} is the reference's knob
             # (fixed_base_msm.rs:41-49).
-            curve = [{"table": f"GLV width {ctx.window_bits()} for FK20 (eight windows of 16 bits) + nine windows for commitments (ETH_KZG_AMD_TABLE_GB=max)" if ctx.glv_table() else f"plain width {ctx.window_bits()}", "table_GB": round(ctx.table_bytes() / 1e9, 1),
-                      "gathered_additions_per_base": 2 * -(-128 // ctx.window_bits()) if ctx.glv_table() else -(-255 // ctx.window_bits()),
+            curve = [{"table": f"GLV width {ctx.window_bits()} for FK20 (eight windows of 16 bits) + nine windows for commitments (ETH_KZG_AMD_TABLE_GB=max)", "table_GB": round(ctx.table_bytes() / 1e9, 1),
+                      "gathered_additions_per_base": 2 * -(-128 // ctx.window_bits()),
                       "blobs_per_s": round(value), "ms_per_step": round(dt / args.steps * 1e3, 2)}]
             ctx.close()
             ctx = None
@@ -1231,8 +1230,7 @@ def main():
             for label, env, precomp in (("nine GLV windows for FK20 and for commitments (ETH_KZG_AMD_TABLE_GB=108: the library's default budget)", {"ETH_KZG_AMD_TABLE_GB": "108"}, True),
                                         ("ten windows each (ETH_KZG_AMD_TABLE_GB=44)", {"ETH_KZG_AMD_TABLE_GB": "44"}, True),
                                         ("eleven windows each (ETH_KZG_AMD_TABLE_GB=22)", {"ETH_KZG_AMD_TABLE_GB": "22"}, True),
-                                        ("sixteen windows each: the start tables (ETH_KZG_AMD_TABLE_GB=3)", {"ETH_KZG_AMD_TABLE_GB": "3"}, True),
-                                        ("plain width 4 (use_precomp = false)", {}, False)):
+                                        ("sixteen windows each (use_precomp = false; also the tables every context starts on)", {}, False)):
                 saved_env = {k: os.environ.get(k) for k in env}
                 try:
                     _mark("table curve: " + label)
@@ -1249,7 +1247,7 @@ def main():
                             ts.append(time.perf_counter() - t0)
                     w = c2.window_bits()
                     curve.append({"table": label, "table_GB": round(c2.table_bytes() / 1e9, 1),
-                                  "gathered_additions_per_base": 2 * -(-128 // w) if c2.glv_table() else -(-255 // w),
+                                  "gathered_additions_per_base": 2 * -(-128 // w),
                                   "blobs_per_s": round(B / _median(ts)), "ms_per_step": round(_median(ts) * 1e3, 2)})
                     c2.close()
                 except Exception as e:

@@ -47,7 +47,8 @@ typedef struct DASContext DASContext;
 /* bindings/c/src/lib.rs:79-92.  use_precomp = true selects precomputed window tables (the reference: width 8,
  * RECOMMENDED_PRECOMP_WIDTH, on the CPU; here the widest tables that fit in HBM: a GLV table of 16-bit windows for FK20,
  * 206 GB, and one of nine windows for commitments, 35 GB, when $ETH_KZG_AMD_TABLE_GB=max; by default the tables take 108 GB
- * -- nine windows each --; narrower automatically when memory is short or the budget bounds them), false the 0.8 GB width-4 tables; results are identical.
+ * -- nine windows each --; narrower automatically when memory is short or the budget bounds them), false the 2.4 GB sixteen-window tables and nothing wider (the
+ * tables a use_precomp = true context starts on); results are identical.
  * Progressive start: the call returns as soon as small start tables are up (about 0.5 s) and every entry point works from
  * then on; the wide tables are built by a helper thread, in pieces of under a gigabyte so that no other HIP call of the process
  * waits long, and taken into use group by group (eth_kzg_amd_tables_ready, eth_kzg_amd_table_groups_ready;
@@ -222,12 +223,11 @@ CResult eth_kzg_amd_verify_cell_kzg_proof_batch_device(const DASContext *ctx, ui
                                                        const uint64_t *d_cell_indices, const uint8_t *d_cells,
                                                        const uint8_t *d_proofs, bool *verified, void *hip_stream);
 
-/* Introspection used by bench.py / DESIGN.md: bytes of window tables resident in HBM, window width. */
+/* Introspection used by bench.py / DESIGN.md: bytes of both window tables resident in HBM; nominal window width w of the FK20
+ * table in use (a GLV table: ceil(128 / w) windows over the two 128-bit halves of each scalar, packed 96-byte entries: 16
+ * gathered additions per base at w = 16, 32 at w = 8 -- the start tables, and all there is with use_precomp = false). */
 uint64_t eth_kzg_amd_table_bytes(const DASContext *ctx);
 int eth_kzg_amd_window_bits(const DASContext *ctx);
-/* 1 if the FK20 window table in use is a GLV table (ceil(128 / w) windows of w = eth_kzg_amd_window_bits bits over the two
- * 128-bit halves of each scalar, packed 96-byte entries: 16 gathered additions per base at w = 16), 0 for a plain table. */
-int eth_kzg_amd_glv_table(const DASContext *ctx);
 /* 1 once the final window tables are in use, 0 while the context still runs on its start tables (waits up to wait_ms
  * milliseconds for the switch; negative: until it happened), 2 if the wide tables could not be built (memory) and the
  * context stays on what it has.  Results never depend on the table in use. */

@@ -54,7 +54,7 @@ EXPORTED_SYMBOLS = [
     "eth_kzg_amd_verify_cell_kzg_proof_batch_partial", "eth_kzg_amd_verify_cell_kzg_proof_batch_combine",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_device", "eth_kzg_amd_blob_to_kzg_commitment_device",
     "eth_kzg_amd_verify_cell_kzg_proof_batch_device", "eth_kzg_amd_verify_cell_kzg_proof_batch_many",
-    "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits", "eth_kzg_amd_glv_table", "eth_kzg_amd_tables_ready", "eth_kzg_amd_table_groups_ready", "eth_kzg_amd_table_build_info", "eth_kzg_amd_linmap_info",
+    "eth_kzg_amd_table_bytes", "eth_kzg_amd_window_bits", "eth_kzg_amd_tables_ready", "eth_kzg_amd_table_groups_ready", "eth_kzg_amd_table_build_info", "eth_kzg_amd_linmap_info",
     "eth_kzg_amd_set_profiling", "eth_kzg_amd_get_stage_times",
     "eth_kzg_amd_comm_probe", "eth_kzg_amd_comm_unique_id", "eth_kzg_amd_comm_init", "eth_kzg_amd_comm_info",
     "eth_kzg_amd_all_gather", "eth_kzg_amd_comm_destroy",
@@ -129,7 +129,6 @@ def load_library():
     lib.eth_kzg_amd_table_bytes.restype = U64
     lib.eth_kzg_amd_table_bytes.argtypes = [P]
     lib.eth_kzg_amd_window_bits.argtypes = [P]
-    lib.eth_kzg_amd_glv_table.argtypes = [P]
     lib.eth_kzg_amd_tables_ready.argtypes = [P, C.c_int]
     lib.eth_kzg_amd_tables_ready.restype = C.c_int
     lib.eth_kzg_amd_table_build_info.argtypes = [P, C.POINTER(C.c_double)]
@@ -619,9 +618,6 @@ class DASContext:
 
     def window_bits(self):
         return int(self._lib.eth_kzg_amd_window_bits(self._ctx))
-
-    def glv_table(self):
-        return bool(self._lib.eth_kzg_amd_glv_table(self._ctx))
 
     def linmap_info(self):
         """(constant multiplications, additions, doublings per blob, launches per call) of the compiled G1 linear map."""

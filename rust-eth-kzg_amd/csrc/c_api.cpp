@@ -335,7 +335,6 @@ int eth_kzg_amd_get_stage_times(const DASContext* ctx, double* ms, uint64_t* lau
 }
 uint64_t eth_kzg_amd_table_bytes(const DASContext* ctx) { return eng(ctx)->table_bytes(); }
 int eth_kzg_amd_window_bits(const DASContext* ctx) { return eng(ctx)->window_bits(); }
-int eth_kzg_amd_glv_table(const DASContext* ctx) { return eng(ctx)->glv_table() ? 1 : 0; }
 int eth_kzg_amd_tables_ready(const DASContext* ctx, int wait_ms) { return eng(ctx)->tables_ready(wait_ms); }
 void eth_kzg_amd_table_build_info(const DASContext* ctx, double* out4) { eng(ctx)->table_build_info(out4); }
 int eth_kzg_amd_table_groups_ready(const DASContext* ctx) { return eng(ctx)->table_groups_ready(kzg::Engine::TAB_FK); }

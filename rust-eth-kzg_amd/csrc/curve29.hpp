@@ -18,13 +18,6 @@ constexpr int ZB = 4;   // bound of stored z
 struct AffQ {  // canonical coordinates; identity = (0, 0)
     Fq<1> x, y;
 };
-// A window-table entry: the affine point padded to one 128-byte line.  At the natural 112-byte stride an entry straddles
-// 1.75 lines on average and the MSM's gathers fetch twice their algorithmic bytes (profiles/r1f_calib_fetch.log).
-struct alignas(16) TabQ {
-    AffQ a;
-    uint32_t pad[4];
-};
-static_assert(sizeof(TabQ) == 128, "table entries are one cache line");
 // A GLV window-table entry: both coordinates canonical (Montgomery-406 values < p), packed 12 x 32 bits each
 // (k_table.hip: k_table_fill_packed).  Identity = all zero.
 struct alignas(16) TabP {

@@ -93,9 +93,9 @@ class Engine {
 public:
     friend struct PoolBuf;
     struct SharedTable;  // engine.hip
-    // use_precomp: true -> the widest FK20 window table that fits in HBM (width 14 = 163 GB on an otherwise empty
-    //              MI355X; the reference's UsePrecomp::Yes uses width 8 on the CPU), false -> width-4 tables (0.8 GB,
-    //              ~3.4x the additions).  Results identical.  Tables are shared by the contexts of a device.
+    // use_precomp: true -> the widest GLV window tables inside the budget (engine_tables.hip: build_final_tables; the reference's
+    //              UsePrecomp::Yes uses width 8 on the CPU), false -> the sixteen-window tables only (2.4 GB, twice the additions of
+    //              eight windows).  Results identical.  Tables are shared by the contexts of a device.
     // primary: the context's engine when this one is an auxiliary lane of it (lease_serial): the lane shares the primary's
     // window tables by reading through to its view -- no registry look-up, no builder thread, no lock shared with a build
     // table_budget_gb: > 0: upper bound for both window tables together; 0: $ETH_KZG_AMD_TABLE_GB, else DEFAULT_TABLE_BUDGET_GB;
@@ -212,10 +212,9 @@ public:
     // are identical for every table (tests), only the speed changes.  ETH_KZG_AMD_PROGRESSIVE=0 builds them before the
     // constructor returns.
     struct TableView {  // a snapshot: main = the complete table calls run on, next = a wider one under construction (its
-                        // leading ready groups are used already; launch_msm); c / glv / bytes describe main
+                        // leading ready groups are used already; launch_msm); c / bytes describe main
         std::shared_ptr<SharedTable> main, next;
         int c = 0;          // window width
-        bool glv = false;   // packed GLV table (k_msm_glv.inc) or plain (k_msm.hip)
         size_t bytes = 0;
     };
     enum TableSel { TAB_FK = 0, TAB_SRS = 1 };
@@ -232,7 +231,6 @@ public:
     void stop_builder();  // abandon an unfinished build of the wide tables and join the helper thread
     size_t table_bytes() const { return table_view(TAB_FK).bytes + table_view(TAB_SRS).bytes; }
     int window_bits() const { return table_view(TAB_FK).c; }  // of the FK20 table in use
-    bool glv_table() const { return table_view(TAB_FK).glv; }
     const int* linmap_info() const { return slp_info_; }
 
 private:

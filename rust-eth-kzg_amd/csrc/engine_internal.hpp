@@ -41,19 +41,20 @@ double trace_clock_ms();  // milliseconds since the library first asked (ETH_KZG
 // A table is NOT one allocation.  Mapping 200+ GB with one hipMalloc takes the driver seconds during which every other HIP
 // call of the process waits (measured in round 3: a 214 GB hipMalloc on the helper thread stalled the caller's launches for
 // 4.3 s; the virtual-memory API that would back one address range piece by piece produced GPU memory faults on ROCm 7.0.2 and
-// is gone).  Instead the kernels reach a table through a device array of BLOCK pointers -- one block per group for a plain
-// table, two for a GLV table (its lower and upper windows; launch::TabBlocks) -- and the blocks live in PIECES of at most
+// is gone).  Instead the kernels reach a table through a device array of BLOCK pointers -- two per group: its lower and
+// upper windows (launch::TabBlocks) -- and the blocks live in PIECES of at most
 // ~0.85 GB (one 0.8 GB block of the widest table; many blocks of a small one), each its own hipMalloc of a few milliseconds:
 //   * other threads' HIP calls slip in between the pieces (tests/test_gpu_tables.py: a caller every 5 ms never waits long),
 //   * a build is abandoned within one piece,
 //   * the table is usable GROUP BY GROUP while it is built: ready_groups counts the leading groups whose entries are final,
 //     an MSM stage runs those on the new table and the rest on the table the context started on (Engine::launch_msm).
 struct Engine::SharedTable {
-    int dev = 0, kind = 0, c = 0;  // kind: 0 = commitments plain (monomial SRS as [64][64]; use_precomp = false only), 1 = FK20 plain, 2 = FK20 GLV, 3 = commitments GLV
-    bool glv = false;
-    int n_groups = 0, nb = 64, halves = 1;
+    int dev = 0, kind = 0, c = 0;  // kind: 2 = FK20 (128 groups of 64 bases), 3 = commitments (the monomial SRS as 64 groups of 64); both GLV tables
+                                   // of nominal width c (launch.hpp: W = glv_windows(c) windows of mixed widths).  (0 and 1 were the plain tables of rounds 1-4.)
+    int n_groups = 0, nb = 64;
+    static constexpr int halves = 2;       // blocks per group: the lower and the upper windows
     size_t bytes = 0;                      // of all blocks
-    size_t block_entries[2] = {0, 0};      // entries of a group's block(s)
+    size_t block_entries[2] = {0, 0};      // entries of a group's two blocks
     std::vector<void*> pieces;
     std::vector<void*> h_blocks;           // host copy of the pointer array (entries of unallocated blocks are null)
     void** d_blocks = nullptr;             // device: [n_groups * halves]
@@ -61,18 +62,13 @@ struct Engine::SharedTable {
     std::atomic<int> ready_groups{0};      // leading groups whose entries are final and whose pointers are on the device
     std::atomic<int> state{0};             // 0 under construction, 1 complete, 2 abandoned (cancelled / out of memory): what is ready stays usable
     std::string why;                       // of state 2
-    size_t entry_bytes() const { return glv ? launch::SIZEOF_TABP : launch::SIZEOF_TABQ; }
+    static size_t entry_bytes() { return launch::SIZEOF_TABP; }
     size_t block_bytes(int b) const { return block_entries[b % halves] * entry_bytes(); }
     void shape(int device, int kind_, int width, int groups) {
-        dev = device; kind = kind_; c = width; glv = kind_ >= 2; n_groups = groups;
-        halves = glv ? 2 : 1;
-        if (glv) {
-            const int WLc = launch::glv_lower_windows(c), Wc = launch::glv_windows(c);  // windows of mixed widths (launch.hpp)
-            block_entries[0] = launch::glv_entries_per_base(c, 0, WLc) * (size_t)nb;
-            block_entries[1] = launch::glv_entries_per_base(c, WLc, Wc) * (size_t)nb;
-        } else {
-            block_entries[0] = launch::table_entries(c, 1, nb);
-        }
+        dev = device; kind = kind_; c = width; n_groups = groups;
+        const int WLc = launch::glv_lower_windows(c), Wc = launch::glv_windows(c);
+        block_entries[0] = launch::glv_entries_per_base(c, 0, WLc) * (size_t)nb;
+        block_entries[1] = launch::glv_entries_per_base(c, WLc, Wc) * (size_t)nb;
         bytes = 0;
         for (int b = 0; b < halves; b++) bytes += block_bytes(b) * (size_t)n_groups;
         h_blocks.assign((size_t)n_groups * halves, nullptr);
@@ -135,7 +131,6 @@ extern std::mutex g_engines_mu;
 extern std::vector<Engine*> g_engines;
 void stop_all_builders_at_exit();
 struct BuildCancelled {};  // thrown out of a table build when its context (or the process) is going away
-inline size_t plain_table_bytes(int c, int n_groups) { return launch::table_entries(c, n_groups, 64) * launch::SIZEOF_TABQ; }
 inline size_t glv_table_bytes(int c, int n_groups = 128) { return launch::table_glv_entries(c, n_groups, 64) * launch::SIZEOF_TABP; }
 
 }  // namespace kzg

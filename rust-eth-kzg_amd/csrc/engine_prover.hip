@@ -109,8 +109,8 @@ void Engine::launch_msm(const void* scalars, const TableView& tv, bool scalars_s
     const SharedTable* main = tv.main.get();
     const SharedTable* next = tv.next.get();
     int ready = 0;
-    if (next && next->glv == main->glv) ready = std::min(n_groups, next->ready_groups.load(std::memory_order_acquire));
-    if (main->glv && !scalars_split) launch::glv_split(const_cast<void*>(scalars), (size_t)n_groups * n_slices * 64, st);  // in place: they feed nothing else
+    if (next) ready = std::min(n_groups, next->ready_groups.load(std::memory_order_acquire));
+    if (!scalars_split) launch::glv_split(const_cast<void*>(scalars), (size_t)n_groups * n_slices * 64, st);  // in place: they feed nothing else
     if (ready > 0) launch_msm_range(scalars, *next, 0, ready, out, n_groups, n_slices, out_stride, brp_bits, st);
     if (ready < n_groups) launch_msm_range(scalars, *main, ready, n_groups - ready, out, n_groups, n_slices, out_stride, brp_bits, st);
 }
@@ -120,31 +120,15 @@ void Engine::launch_msm_range(const void* scalars, const SharedTable& t, int g0,
     const launch::TabBlocks tb{(const void* const*)t.d_blocks, g0, gcnt};
     const int c = t.c;
     const long msms = (long)gcnt * n_slices;
-    if (t.glv) {
-        int mode = 1;
-        if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) mode = 0;
-        else if (msm_chunks_ >= 0) mode = msm_chunks_ == 0 ? 1 : 2;  // tests: 0 = the windowed kernel, anything else = four chunks per MSM
-        else if ((msms * 4 + 63) / 64 >= (long)wave_slots_) {
-            // The chip is full: four chunks per MSM, 16384 short waves dealt out as slots free up.  (A lane per MSM and a lane per GLV
-            // half -- no folds, no barriers, exact rounds of long waves -- were measured 1-2 % SLOWER in rounds 3 and 4 and are gone.)
-            mode = 2;
-        }
-        launch::msm_glv(c, mode, scalars, tb, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st);
-        return;
+    int mode = 1;  // a lane per (MSM, window)
+    if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) mode = 0;  // a handful of blobs: one block per MSM
+    else if (msm_chunks_ >= 0) mode = msm_chunks_ == 0 ? 1 : 2;  // tests: 0 = the windowed kernel, anything else = four chunks per MSM
+    else if ((msms * 4 + 63) / 64 >= (long)wave_slots_) {
+        // The chip is full: four chunks per MSM, 16384 short waves dealt out as slots free up.  (A lane per MSM and a lane per GLV
+        // half -- no folds, no barriers, exact rounds of long waves -- were measured 1-2 % SLOWER in rounds 3 and 4 and are gone.)
+        mode = 2;
     }
-    if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) {
-        launch::msm_fixed_flat(c, scalars, tb, out, n_groups, n_slices, 64, out_stride, brp_bits, st);
-        return;
-    }
-    // Large batches: threads own a chunk of the windows of an MSM (S = 4 chunks: the fold is two additions per ~300, and
-    // the waves are short enough for the tail of a launch not to matter; measured equal or better than S = 1, 2 at every
-    // batch that fills the chip).  Below one round of the chip's 2-per-SIMD wave slots the windowed kernel (one thread
-    // per window) has more parallelism.
-    int S = 0;
-    if (msm_chunks_ >= 0) S = msm_chunks_;  // tuning knob ETH_KZG_AMD_MSM_CHUNKS: 0 = windowed kernel, 1/2/4 = chunked
-    else if ((msms * 4 + 63) / 64 >= (long)wave_slots_) S = 4;
-    if (S) launch::msm_fixed_chunked(c, scalars, tb, out, n_groups, n_slices, 64, out_stride, brp_bits, S, st);
-    else launch::msm_fixed(c, scalars, tb, out, n_groups, n_slices, 64, out_stride, brp_bits, st);
+    launch::msm_glv(c, mode, scalars, tb, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st);
 }
 
 // full FFT_128.  forward: DIF natural -> bit-reversed.  inverse: DIT bit-reversed -> natural (no scaling).
@@ -191,7 +175,7 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
     const TableView tv = tv_pre ? *tv_pre : table_view(TAB_FK);  // one snapshot for the scalars' form AND the MSM that reads them
     if (!tv_pre) {
         const int mk1 = mark_begin(ST_FK20_SCALARS, st);
-        launch::fk20_scalars(n, w.coeffs, w.scalars, d_w29_, linmap_mode ? half_ : inv128_, segs, segs == 2 ? two_segments : seg_shift_, tv.glv, st);
+        launch::fk20_scalars(n, w.coeffs, w.scalars, d_w29_, linmap_mode ? half_ : inv128_, segs, segs == 2 ? two_segments : seg_shift_, st);
         mark_end(mk1, 1, st);
     }
     if (phase != PROOFS_ALL) {
@@ -202,14 +186,14 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         // measured too: no gain, profiles/r4_early_msm_ab.log)
         if (phase == PROOFS_HEAD) {
             launch::g1_set_inf(X, (size_t)128 * bp, st);
-            launch_msm(w.scalars, tv, tv.glv, X, 128, msm_cut, bp, 0, st);
+            launch_msm(w.scalars, tv, true, X, 128, msm_cut, bp, 0, st);
             return;
         }
-        launch_msm((char*)w.scalars + (size_t)msm_cut * 128 * 64 * sizeof(Fr), tv, tv.glv, (char*)X + (size_t)msm_cut * launch::SIZEOF_JACQ, 128, n - msm_cut, bp, 0, st);
+        launch_msm((char*)w.scalars + (size_t)msm_cut * 128 * 64 * sizeof(Fr), tv, true, (char*)X + (size_t)msm_cut * launch::SIZEOF_JACQ, 128, n - msm_cut, bp, 0, st);
     }
     if (phase == PROOFS_ALL) launch::g1_set_inf(X, (size_t)128 * bp, st);
     const int mk2 = mark_begin(ST_MSM_FIXED, st);
-    if (phase == PROOFS_ALL) launch_msm(w.scalars, tv, tv.glv, X, 128, segs * n, bp, 0, st);
+    if (phase == PROOFS_ALL) launch_msm(w.scalars, tv, true, X, 128, segs * n, bp, 0, st);
     mark_end(mk2, 1, st);
     if (linmap_mode) {
         const int mk3 = mark_begin(ST_G1_LINMAP, st);
@@ -480,7 +464,7 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
                 HIPCK(hipEventRecord(w.sub_events[2 * i], w.stream));
                 if (early_scalars)
                     launch::fk20_scalars(nb, (char*)w.coeffs + (size_t)lo * N_BLOB * sizeof(Fr), (char*)w.scalars + (size_t)lo * 128 * 64 * sizeof(Fr),
-                                         d_w29_, half_, 1, seg_shift_, tv_call.glv, w.stream);
+                                         d_w29_, half_, 1, seg_shift_, w.stream);
                 if (msm_cut && hi == msm_cut) run_proofs_from_coeffs(w, ns, w.d_proofs, w.stream, &tv_call, PROOFS_HEAD, msm_cut);
                 if (trace) fprintf(stderr, "[host-batch] sub-batch %d (%d blobs) enqueued at %.2f ms\n", i, nb, now_ms());
             }

@@ -21,16 +21,13 @@ static bool fill_table(Engine::SharedTable& t, const void* bases, hipStream_t st
     auto t0 = std::chrono::steady_clock::now();
     auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     const int c = t.c, nb = t.nb;
-    const size_t per_group = t.glv ? launch::table_glv_entries(c, 1, nb) : launch::table_entries(c, 1, nb);
-    const size_t scratch_per_entry = t.glv ? 168 : sizeof(G1Jac);
-    int chunk = (int)((t.glv ? (9ull << 30) : (24ull << 30)) / (per_group * scratch_per_entry));
+    const size_t per_group = launch::table_glv_entries(c, 1, nb);
+    const size_t scratch_per_entry = 168;
+    int chunk = (int)((9ull << 30) / (per_group * scratch_per_entry));
     if (chunk < 1) chunk = 1;
     if (chunk > t.n_groups) chunk = t.n_groups;
-    if (gentle) {  // <= ~512 builder waves in flight (a wave per (base, window): 64 x W per group)
-        const int W = t.glv ? launch::glv_windows(c) : (255 + c) / c;
-        chunk = std::max(1, std::min(chunk, 512 / (nb * W)));
-    }
-    const size_t side_bytes = t.glv ? launch::table_glv_side_bytes(c, chunk, nb) : 0;
+    if (gentle) chunk = std::max(1, std::min(chunk, 512 / (nb * launch::glv_windows(c))));  // <= ~512 builder waves in flight (a wave per (base, window): 64 x W per group)
+    const size_t side_bytes = launch::table_glv_side_bytes(c, chunk, nb);
     void *scratch = nullptr, *side = nullptr;
     int* d_err = nullptr;
     auto cleanup = [&] {
@@ -75,11 +72,7 @@ static bool fill_table(Engine::SharedTable& t, const void* bases, hipStream_t st
                                  hipMemcpyHostToDevice, st));
             const char* b = (const char*)bases + (size_t)g0 * nb * sizeof(G1Affine);
             void* const* blocks = t.d_blocks + (size_t)g0 * t.halves;
-            if (t.glv) {
-                if (!launch::build_table_glv(c, b, blocks, scratch, side, g, nb, d_err, st)) throw std::runtime_error("GLV table width not built in");
-            } else {
-                launch::build_table(c, b, blocks, scratch, g, nb, st);
-            }
+            if (!launch::build_table_glv(c, b, blocks, scratch, side, g, nb, d_err, st)) throw std::runtime_error("GLV table width not built in");
         }
         HIPCK(hipStreamSynchronize(st));
         int err = 0;
@@ -148,7 +141,6 @@ Engine::TableView Engine::table_view(TableSel which) const {
     v.main = s.main;
     v.next = s.next;
     v.c = s.main ? s.main->c : 0;
-    v.glv = s.main ? s.main->glv : false;
     v.bytes = s.main ? s.main->bytes : 0;
     return v;
 }
@@ -197,8 +189,8 @@ void Engine::init_fk20() {
     HIPCK(hipStreamSynchronize(stream_));
     HIPCK(hipFree(X));
     if (primary_) return;  // an engine lane: the tables are the context's (table_view reads through)
-    if (!use_precomp_) {  // UsePrecomp::No: the 0.8 GB width-4 tables, nothing else to build
-        auto srs = obtain_table(dev_, 0, 4, d_srs_, 64, stream_), fk = obtain_table(dev_, 1, 4, d_fk_bases_, 128, stream_);
+    if (!use_precomp_) {  // UsePrecomp::No: the sixteen-window tables (1.6 + 0.8 GB: what a use_precomp = true context STARTS on), nothing else to build
+        auto srs = obtain_table(dev_, 3, 8, d_srs_, 64, stream_), fk = obtain_table(dev_, 2, 8, d_fk_bases_, 128, stream_);
         if (!srs || !fk) throw std::runtime_error("not enough device memory for the window tables");
         publish(TAB_SRS, srs, nullptr);
         publish(TAB_FK, fk, nullptr);
@@ -276,7 +268,7 @@ void Engine::build_final_tables() {
         bool created = false;
         auto t = find_or_create_table(dev_, kind, w, n_groups, &created);
         const TableView cur = table_view(sel);
-        const bool same_form = cur.main && cur.main->glv == t->glv && cur.main->n_groups == t->n_groups;
+        const bool same_form = cur.main && cur.main->n_groups == t->n_groups;
         if (t->state.load() == 0 && same_form) publish(sel, cur.main, t);  // its ready groups serve at once
         if (created) {
             t->trace_allocs = knobs_.trace;
@@ -306,12 +298,12 @@ void Engine::build_final_tables() {
                 std::shared_ptr<SharedTable> growing;
                 if (sel == TAB_SRS) {
                     for (int w : launch::GLV_WIDTHS)
-                        if (!growing && (!cur.glv || w > cur.c)) { auto t = find_table(dev_, 3, w); if (t && t->state.load() == 0) growing = t; }
+                        if (!growing && w > cur.c) { auto t = find_table(dev_, 3, w); if (t && t->state.load() == 0) growing = t; }
                 } else {
                     for (int w : launch::GLV_WIDTHS)
-                        if (!growing && (!cur.glv || w > cur.c)) { auto t = find_table(dev_, 2, w); if (t && t->state.load() == 0) growing = t; }
+                        if (!growing && w > cur.c) { auto t = find_table(dev_, 2, w); if (t && t->state.load() == 0) growing = t; }
                 }
-                if (growing && growing->glv == cur.main->glv && growing->n_groups == cur.main->n_groups) publish(sel, cur.main, growing);
+                if (growing && growing->n_groups == cur.main->n_groups) publish(sel, cur.main, growing);
             }
         };
         std::unique_lock<std::mutex> lk(g_build_mu, std::defer_lock);  // one builder of wide tables at a time per process
@@ -327,7 +319,7 @@ void Engine::build_final_tables() {
         for (int w : launch::GLV_WIDTHS) {
             if (srs) break;
             if (w == 16) continue;  // (eight windows for the commitments would be 103 GB: the FK20 table has the better use for them)
-            if (srs_now.main && srs_now.glv && w <= srs_now.c) break;  // nothing wider than what is in use fits
+            if (srs_now.main && w <= srs_now.c) break;  // nothing wider than what is in use fits
             if ((double)glv_table_bytes(w, 64) > std::max(budget / 3, 0.9e9)) continue;  // (a third of the default 108 GB = the nine-window table)
             srs = widen(TAB_SRS, 3, w, d_srs_, 64);
         }
@@ -337,19 +329,11 @@ void Engine::build_final_tables() {
         for (int w : launch::GLV_WIDTHS) {
             if (fk) break;
             if (want_glv_c_ && w != want_glv_c_) continue;
-            if (fk_now.main && fk_now.glv && w <= fk_now.c) break;
+            if (fk_now.main && w <= fk_now.c) break;
             if ((double)glv_table_bytes(w) > std::max(left, 1.7e9)) continue;
             fk = widen(TAB_FK, 2, w, d_fk_bases_, 128);
         }
         if (fk) publish(TAB_FK, fk, nullptr);
-        if (!table_view(TAB_FK).main) {  // not even the narrowest GLV table fits: the plain width-4 tables (0.8 GB)
-            auto f4 = obtain_table(dev_, 1, 4, d_fk_bases_, 128, build_stream_);
-            if (f4) publish(TAB_FK, f4, nullptr);
-        }
-        if (!table_view(TAB_SRS).main) {
-            auto s4 = obtain_table(dev_, 0, 4, d_srs_, 64, build_stream_);
-            if (s4) publish(TAB_SRS, s4, nullptr);
-        }
     } catch (const BuildCancelled&) {
         state = 2;
         why = "cancelled: the context is being freed";

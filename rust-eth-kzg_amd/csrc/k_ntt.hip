@@ -136,7 +136,7 @@ __global__ __launch_bounds__(1024) void k_coeffs_to_cells(const Fr* __restrict__
 // batch_toeplitz.rs:94-106).  For blob b and i < 64 the length-128 vector is
 //   v[0] = a[4095-i];  v[1..64] = 0;  v[64+k] = a[64k-1-i], k = 1..63
 // scalars[b][j][i] = NTT_128(v)[j] * 128^-1  (the 128^-1 of the later G1 inverse FFT, domain.rs:189-191,
-// folded in here because everything downstream is linear), stored as plain integers for the MSM's window extraction.
+// folded in here because everything downstream is linear), stored as balanced GLV halves (glv.hpp) for the MSM's window extraction.
 // grid = n_blobs * 16, block = 256 (4 vectors per block, one per wave).
 // segs > 1 (tiny batches only): copies of every scalar multiplied by 2^(128 seg / segs) are written as extra "blobs"
 // seg * n + b, so that the MSM stage also delivers 2^32 u, 2^64 u, 2^96 u (four segments; 2^64 u for two) and the
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(1024) void k_coeffs_to_cells(const Fr* __restrict__
 struct SegShifts { Fr29 p[3]; };  // the segment shifts as plain integers times 2^261 (this form), p[seg - 1]
 __global__ __launch_bounds__(256) void k_fk20_scalars(const Fr* __restrict__ coeffs, Fr* __restrict__ scalars,
                                                       const Fr29* __restrict__ w29, Fr29 scale /* 128^-1 or 1/2, this form */, int n,
-                                                      int segs, SegShifts sh, int glv /* store the balanced GLV halves (k_msm_glv.inc) instead of the integer */) {
+                                                      int segs, SegShifts sh) {
     __shared__ uint32_t s[4][RL][128];
     const int b = blockIdx.x >> 4, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = ((blockIdx.x & 15) << 2) + wv;
@@ -176,17 +176,15 @@ __global__ __launch_bounds__(256) void k_fk20_scalars(const Fr* __restrict__ coe
         for (int l = 0; l < RL; l++) { sv[l][i0] = sum.v[l]; sv[l][i1] = d.v[l]; }
         __builtin_amdgcn_wave_barrier();  // a wave owns its whole vector: its LDS operations execute in program order, no block barrier
     }
-    // position q holds NTT[brp7(q)].  For a GLV window table the scalar leaves already split k = k1 + k2 lambda (what the separate
+    // position q holds NTT[brp7(q)].  The scalar leaves already split k = k1 + k2 lambda for the GLV window tables (what the separate
     // k_glv_split pass of round 2 did in place: 0.19 ms of reading and writing 0.5 GB at 2048 blobs)
     const Fr29 one_plain = fr29_const(r29::ONE_PLAIN);
     auto emit = [&](size_t at, const Fr29& x_form) {
         Fr k = fr_words_of(fr29_reduce_once(fr29_mul(x_form, one_plain)));
-        if (glv) {
-            uint32_t h[8];
-            glv_split_balanced(k, h);
+        uint32_t h[8];
+        glv_split_balanced(k, h);
 #pragma unroll
-            for (int l = 0; l < 8; l++) k.v[l] = h[l];
-        }
+        for (int l = 0; l < 8; l++) k.v[l] = h[l];
         scalars[at] = k;
     };
     for (int q = lane; q < 128; q += 64) {
@@ -278,10 +276,10 @@ void coeffs_to_cells(int n, const void* coeffs, uint8_t* cells, const void* w29,
     k_coeffs_to_cells<<<dim3(n, 2), 1024, LDS_NTT29, st>>>((const Fr*)coeffs, cells, (const Fr29*)w29);
 }
 void fk20_scalars(int n, const void* coeffs, void* scalars, const void* w29, const Fr8& inv128, int segs, const Fr8* seg_shifts,
-                  bool glv_split, hipStream_t st) {
+                  hipStream_t st) {
     SegShifts sh;
     for (int i = 0; i < 3; i++) sh.p[i] = fr29_mont_of(seg_shifts[i]);
-    k_fk20_scalars<<<n * 16, 256, 0, st>>>((const Fr*)coeffs, (Fr*)scalars, (const Fr29*)w29, fr29_mont_of(inv128), n, segs, sh, glv_split ? 1 : 0);
+    k_fk20_scalars<<<n * 16, 256, 0, st>>>((const Fr*)coeffs, (Fr*)scalars, (const Fr29*)w29, fr29_mont_of(inv128), n, segs, sh);
 }
 void test_ntt4096(const uint8_t* in, uint8_t* out, const void* w29, const Fr8& n_inv, int inverse_dit, hipStream_t st) {
     k_test_ntt4096<<<1, 1024, LDS_NTT29, st>>>(in, out, (const Fr29*)w29, ntt_consts(n_inv), inverse_dit);

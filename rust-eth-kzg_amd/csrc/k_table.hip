@@ -2,57 +2,8 @@
 #include "kcommon.hpp"
 #include "curve30.hpp"
 #include "launch.hpp"
-#include <stdexcept>
 
 namespace kzg {
-
-// Build the window table.  One thread per (base, window): Q = 2^(c*w) * P, entries d*Q for d = 1..2^(c-1),
-// normalised to affine with one inversion per thread (Montgomery's trick over the thread's entries).
-// bases: [n_groups][nb] affine.  scratch: one Fp per table entry (prefix products of the Z's).
-template <int C>
-__global__ __launch_bounds__(64) void k_build_table(const G1Affine* __restrict__ bases, void* const* __restrict__ blocks,
-                                                    G1Jac* __restrict__ scratch, int n_groups, int nb) {
-    constexpr int W = (255 + C) / C;
-    constexpr int T = 1 << (C - 1);
-    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long total = (long)n_groups * nb * W;
-    if (t >= total) return;
-    int w = (int)(t % W);
-    long bi = t / W;
-    int i = (int)(bi % nb), group = (int)(bi / nb);
-    G1Affine P = bases[bi];
-    TabQ* dst = reinterpret_cast<TabQ*>(blocks[group]) + ((((size_t)w * nb + i) << (C - 1)));  // the group's block: [window][base][digit]
-    G1Jac* scr = scratch + ((((size_t)group * W + w) * nb + i) << (C - 1));
-    if (is_inf(P)) {
-        for (int d = 0; d < T; d++) dst[d].a = affq_from_affine(aff_inf());
-        return;
-    }
-    G1Jac Q = to_jac(P);
-    for (int k = 0; k < C * w; k++) Q = dbl(Q);
-    G1Affine Qa = to_affine(Q);
-    // pass 1: Jacobian multiples d*Q (never the identity: d < r, Q != O)
-    G1Jac cur = to_jac(Qa);
-    for (int d = 0; d < T; d++) {
-        scr[d] = cur;
-        cur = add_mixed(cur, Qa);
-    }
-    // pass 2: prefix products of the Z's, parked in the x slot of the destination entries
-    Fp prod = one<FpParams>();
-    for (int d = 0; d < T; d++) {
-        *reinterpret_cast<Fp*>(&dst[d]) = prod;  // parked in the (larger) destination slot until the back sweep
-        prod = mul(prod, scr[d].z);
-    }
-    Fp invp = inv_fast(prod);
-    for (int d = T - 1; d >= 0; d--) {
-        Fp zi = mul(invp, *reinterpret_cast<const Fp*>(&dst[d]));
-        invp = mul(invp, scr[d].z);
-        Fp zi2 = sqr(zi);
-        G1Affine a;
-        a.x = mul(scr[d].x, zi2);
-        a.y = mul(scr[d].y, mul(zi2, zi));
-        dst[d].a = affq_from_affine(a);  // canonical, Montgomery-406, 14 x 29-bit limbs
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // The builder of the GLV tables (2^(bits-1) entries per (base, window) is a multiple of 64): two kernels in the unsaturated field.
@@ -201,7 +152,7 @@ namespace launch {
 // that load is an allocation: it would wait behind a table piece the builder thread is allocating)
 void preload_k_table() {
     hipFuncAttributes a;
-    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>((&k_build_table<4>)));
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>((&k_table_windows<8, glv_windows(8)>)));
 }
 // GLV tables: W = glv_windows(c) windows of mixed widths (launch::glv_window_bits), packed 96-B entries; scratch = 168 B per entry of the chunk (56 for the
 // Z factors, 112 for the waiting X, Y); side = the per-base window points (affine, Jacobian, prefix products)
@@ -230,16 +181,6 @@ bool build_table_glv(int c, const void* bases, void* const* table, void* scratch
     else if (c == 8) table_glv_c<8>(bases, table, scratch, side, n_groups, nb, err, st);
     else return false;
     return true;
-}
-size_t table_entries(int c, int n_groups, int nb) {
-    int W = (255 + c) / c;
-    return ((size_t)n_groups * nb * W) << (c - 1);
-}
-// the plain width-4 tables of use_precomp = false (0.4 GB each): the only plain width left (rounds 1-4 had 8 ... 14 as well)
-void build_table(int c, const void* bases, void* const* table, void* scratch, int n_groups, int nb, hipStream_t st) {
-    if (c != PLAIN_WIDTH) throw std::runtime_error("plain window tables exist at width 4 only");
-    const long threads = (long)n_groups * nb * ((255 + PLAIN_WIDTH) / PLAIN_WIDTH);
-    k_build_table<PLAIN_WIDTH><<<(unsigned)((threads + 63) / 64), 64, 0, st>>>((const G1Affine*)bases, table, (G1Jac*)scratch, n_groups, nb);
 }
 }  // namespace launch
 }  // namespace kzg

@@ -26,9 +26,9 @@ void ntt_twiddles29(const void* w8192_mont_host /*Fr[8192]*/, void* out_host /*8
 void blob_to_coeffs(int n, const uint8_t* blobs, void* coeffs /*Fr*/, void* canon /*Fr or null*/, int* status,
                     const void* w29, const Fr8& n_inv, hipStream_t st);
 void coeffs_to_cells(int n, const void* coeffs, uint8_t* cells, const void* w29, hipStream_t st);
-// glv_split: store every scalar as its balanced GLV halves (what msm_glv's own split pass would make of it)
+// every scalar leaves as its balanced GLV halves (what launch::glv_split would make of it)
 void fk20_scalars(int n, const void* coeffs, void* scalars, const void* w29, const Fr8& inv128, int segs, const Fr8* seg_shifts,
-                  bool glv_split, hipStream_t st);
+                  hipStream_t st);
 void test_ntt4096(const uint8_t* in, uint8_t* out, const void* w29, const Fr8& n_inv, int inverse_dit, hipStream_t st);
 void test_scalars_be(const uint8_t* in, void* out, size_t n, hipStream_t st);
 void test_field_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, int n, int is_fp, hipStream_t st);
@@ -43,12 +43,6 @@ struct TabBlocks {
     const void* const* blocks;
     int g0, gcnt;
 };
-// plain tables: c must be PLAIN_WIDTH (k_msm.hip)
-void msm_fixed(int c, const void* scalars, const TabBlocks& table, void* out /*G1Jac*/, int n_groups, int n_slices, int nb,
-               int out_stride, int brp_bits, hipStream_t st);
-// S = 1, 2 or 4 threads per MSM, each summing a chunk of the windows (large batches: no window-sum fold to speak of)
-void msm_fixed_chunked(int c, const void* scalars, const TabBlocks& table, void* out /*JacQ*/, int n_groups, int n_slices, int nb,
-                       int out_stride, int brp_bits, int S, hipStream_t st);
 // GLV tables (packed 96-B entries, W = glv_windows(c) windows of c bits over the 128-bit half scalars; k_msm_glv.inc, one
 // translation unit per width): mode 0 flat, 1 windowed, 2 four chunks per MSM.  The scalars must be stored as balanced GLV
 // halves (glv_split, or k_fk20_scalars' fused split).  Entries and sums are in the signed 13 x 30-bit field (curve30.hpp).
@@ -73,8 +67,6 @@ bool glv_width_supported(int c);
 void glv_split(void* scalars, size_t n, hipStream_t st);
 void msm_glv(int c, int mode, const void* scalars, const TabBlocks& table, void* out /*JacQ*/, int n_groups, int n_slices, int nb, int out_stride,
              int brp_bits, const Fp12w& beta, hipStream_t st);
-void msm_fixed_flat(int c, const void* scalars, const TabBlocks& table, void* out /*G1Jac*/, int n_groups, int n_slices, int nb,
-               int out_stride, int brp_bits, hipStream_t st);
 // k_table.hip
 constexpr size_t SIZEOF_TABP = 96;    // a packed GLV table entry
 size_t table_glv_entries(int c, int n_groups, int nb);
@@ -82,12 +74,6 @@ size_t table_glv_side_bytes(int c, int n_groups, int nb);
 // scratch: 168 B per entry of the chunk; side: table_glv_side_bytes; false if the width is not built in.
 // blocks: device array of 2 * n_groups block pointers of THIS chunk's groups (lower / upper windows of each)
 bool build_table_glv(int c, const void* bases, void* const* blocks, void* scratch, void* side, int n_groups, int nb, int* err, hipStream_t st);
-// plain tables (128-B entries over the full 255-bit scalar) exist at ONE width: the 0.4 GB tables of use_precomp = false
-constexpr int PLAIN_WIDTH = 4;
-size_t table_entries(int c, int n_groups, int nb);
-// blocks: device array of n_groups block pointers of THIS chunk's groups
-void build_table(int c, const void* bases /*G1Affine*/, void* const* blocks, void* scratch /*G1Jac*/, int n_groups,
-                 int nb, hipStream_t st);
 
 // k_g1fft.hip
 void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int mode, const void* tw, const Fp12w& beta,
@@ -182,7 +168,6 @@ void quotient_by_linear(int n, const void* coeffs, const void* z_mont, void* quo
 
 constexpr size_t SIZEOF_FR = 32, SIZEOF_G1AFFINE = 96, SIZEOF_G1JAC = 144;
 constexpr size_t SIZEOF_AFFQ = 112, SIZEOF_JACQ = 168;  // unsaturated 14 x 29-bit forms (curve29.hpp): affine points, FFT arrays
-constexpr size_t SIZEOF_TABQ = 128;                     // a window-table entry: an AffQ padded to one 128-B line
 
 }  // namespace launch
 }  // namespace kzg

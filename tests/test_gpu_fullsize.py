@@ -91,16 +91,15 @@ def _check_sample_against_oracle(oracle, blobs_np, cells, proofs, sample):
         assert proofs[b].tobytes() == b"".join(ep), f"blob {b}: proofs differ from the oracle"
 
 
-def test_plain_width_4_tables_match_oracle(oracle):
-    """use_precomp = false: the 0.8 GB plain width-4 tables (64 windows over the full 255-bit scalar, the 14-digit kernels of
-    k_msm.hip -- the only plain width left since the commitment table became a GLV table): identical bytes in the windowed and the
-    chunked MSM schedule, commitments included."""
-    width = 4
+def test_use_precomp_false_matches_oracle(oracle):
+    """use_precomp = false (UsePrecomp::No, fixed_base_msm.rs:41-49): the 2.4 GB sixteen-window GLV tables and nothing wider -- the
+    tables a use_precomp = true context starts on: identical bytes in the windowed and the chunked MSM schedule, commitments
+    included.  (Rounds 1-4 had plain width-4 tables and their own kernels here.)"""
+    width = 8
     _torch_first()
     c2 = kzg.DASContext(use_precomp=False)
     try:
-        assert not c2.glv_table()
-        assert c2.window_bits() == width
+        assert c2.tables_ready(0) == 1 and c2.window_bits() == width and 2.3e9 < c2.table_bytes() < 2.5e9
         blobs = _random_blobs(70, 800 + width)
         blobs[1] = 0
         st, cells, proofs = _compute_on_device(c2, blobs)
@@ -298,18 +297,17 @@ def _fk20_base_column(i):
     return _FK20_BASES[i]
 
 
-@pytest.mark.parametrize("table", ["glv", "plain"])
+@pytest.mark.parametrize("precomp", [True, False])
 @pytest.mark.parametrize("chunks", ["auto", "0", "4"])
-def test_fixed_base_msm_stage_matches_oracle(oracle, monkeypatch, chunks, table):
+def test_fixed_base_msm_stage_matches_oracle(oracle, monkeypatch, chunks, precomp):
     """Stage D alone (128 fixed-base MSM_64 per scalar set over the FK20 window tables) against oracle_g1_msm, for
     every MSM schedule: the windowed kernel (0) and four chunks of windows per MSM (4).  Scalars include 0,
     1, r-1 and values whose Booth digits hit the table ends (2^(c-1) and its negative)."""
     import ctypes as C
     if chunks != "auto":
         monkeypatch.setenv("ETH_KZG_AMD_MSM_CHUNKS", chunks)
-    c2 = kzg.DASContext(use_precomp=table == "glv")  # "plain": the width-4 tables of use_precomp = false
+    c2 = kzg.DASContext(use_precomp=precomp)  # False: the sixteen-window tables only
     try:
-        assert c2.glv_table() == (table == "glv")
         lib = kzg.load_library()
         n_msm = 9  # > FLAT_MSM_MAX_SLICES so that the batch kernels run, not the one-block-per-MSM form
         sc = [synth.seeded_scalars(128 * 64, b"msm%d" % m) for m in range(n_msm)]

@@ -557,12 +557,12 @@ def test_second_context_shares_the_window_tables(ctx, oracle):
 
 
 def test_narrower_window_table_gives_identical_results(ctx, oracle, monkeypatch):
-    """use_precomp = false next to the default context: the narrowest tables there are (plain width 4, the last fall-back of
-    the ladder when HBM is short) change nothing but speed: same cells, proofs and commitment.  (Every GLV width and every
+    """use_precomp = false next to the default context: the narrowest tables there are (sixteen windows, the last step of the
+    ladder when HBM is short) change nothing but speed: same cells, proofs and commitment.  (Every GLV width and every
     budget: tests/test_gpu_tables.py, in processes that do not hold the widest tables already -- a live table is shared.)"""
     c2 = kzg.DASContext(use_precomp=False)
     try:
-        assert c2.window_bits() == 4 and not c2.glv_table() and c2.table_bytes() < ctx.table_bytes()
+        assert c2.window_bits() == 8 and c2.table_bytes() < ctx.table_bytes()
         blobs = [synth.seeded_blob(92 + i) for i in range(3)]
         assert c2.compute_cells_and_kzg_proofs_batch(blobs) == ctx.compute_cells_and_kzg_proofs_batch(blobs)
         assert c2.compute_cells_and_kzg_proofs(blobs[0]) == tuple(oracle.compute_cells_and_kzg_proofs(blobs[0]))

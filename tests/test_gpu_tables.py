@@ -92,7 +92,7 @@ def test_every_glv_width_matches_oracle(oracle, monkeypatch, width):
     monkeypatch.setenv("ETH_KZG_AMD_GLV_WINDOW", str(width))
     keep = kzg.DASContext(use_precomp=True)  # holds the table while the schedule variants come and go
     try:
-        assert keep.glv_table() and keep.window_bits() == width and keep.tables_ready() == 1
+        assert keep.window_bits() == width and keep.tables_ready() == 1
         assert abs(keep.table_bytes() / 1e9 - GLV_GB[width] - SRS_GB[15]) < 0.02 * GLV_GB[width] + 0.5  # + the nine-window commitment table (the suite's budget is "max")
         for chunks in ("auto", "0", "4"):
             if chunks == "auto":
@@ -127,7 +127,7 @@ def test_table_budget_picks_the_widest_glv_table_that_fits(oracle, monkeypatch):
         monkeypatch.setenv("ETH_KZG_AMD_TABLE_GB", str(budget))
         c = kzg.DASContext(use_precomp=True)
         try:
-            assert c.glv_table() and c.window_bits() == want_w, (budget, c.window_bits())
+            assert c.window_bits() == want_w, (budget, c.window_bits())
             assert c.table_bytes() <= budget * 1e9
             assert abs(c.table_bytes() / 1e9 - GLV_GB[want_w] - SRS_GB[want_srs]) < 0.5, (budget, c.table_bytes())
             _commitments_check(c, oracle, 7600 + budget)
@@ -150,7 +150,7 @@ def test_default_budget_is_a_stated_108_gb(oracle, monkeypatch):
     for kwargs, want_w in (({}, 15), ({"table_budget_gb": 60}, 14), ({"table_budget_gb": -1}, 16)):
         c = kzg.DASContext(use_precomp=True, **kwargs)
         try:
-            assert c.glv_table() and c.window_bits() == want_w, (kwargs, c.window_bits())
+            assert c.window_bits() == want_w, (kwargs, c.window_bits())
             if want_w == 15:
                 assert 105e9 < c.table_bytes() <= 108e9, c.table_bytes()
                 _commitments_check(c, oracle, 7820, sizes=(3, 600))
@@ -177,7 +177,7 @@ def test_context_next_to_190_gb_held_by_someone_else_comes_up_narrower(oracle, m
     try:
         c = kzg.DASContext(use_precomp=True, table_budget_gb=0)  # through eth_kzg_amd_das_context_try_new: an error would be raised, not an abort
         try:
-            assert c.glv_table() and c.window_bits() < 15 and c.table_bytes() < 90e9, (c.window_bits(), c.table_bytes())
+            assert c.window_bits() < 15 and c.table_bytes() < 90e9, (c.window_bits(), c.table_bytes())
             blobs = full._random_blobs(70, 7812)
             st, cells, proofs = full._compute_on_device(c, blobs)
             assert st == [0] * 70
@@ -246,7 +246,7 @@ def test_progressive_start_serves_at_once_and_switches_tables(oracle, monkeypatc
             th.join()
         assert not side_errors, side_errors
         assert c.tables_ready(-1) == 1
-        assert c.glv_table() and c.window_bits() == 16 and c.table_groups_ready() == 128
+        assert c.window_bits() == 16 and c.table_groups_ready() == 128
         st, cells, proofs = full._compute_on_device(c, blobs)
         assert np.array_equal(cells, cells0) and np.array_equal(proofs, proofs0)
         assert c.blob_to_kzg_commitment(blobs[5].tobytes()) == comm0
@@ -313,11 +313,11 @@ def test_non_progressive_start_returns_on_the_final_tables(monkeypatch):
     monkeypatch.setenv("ETH_KZG_AMD_PROGRESSIVE", "0")
     c = kzg.DASContext(use_precomp=True, wait_tables=False)
     try:
-        assert c.tables_ready(0) == 1 and c.glv_table() and c.window_bits() == 16
+        assert c.tables_ready(0) == 1 and c.window_bits() == 16
     finally:
         c.close()
     c = kzg.DASContext(use_precomp=False, wait_tables=False)
     try:
-        assert c.tables_ready(0) == 1 and not c.glv_table() and c.window_bits() == 4
+        assert c.tables_ready(0) == 1 and c.window_bits() == 8 and c.table_bytes() < 2.5e9
     finally:
         c.close()
