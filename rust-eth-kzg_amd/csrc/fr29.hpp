@@ -34,24 +34,33 @@ HD void fr29_normalise(Fr29& a) {
         a.v[i] &= RMASK;
     }
 }
-// a + b (bounds add)
+// a + b (bounds add).  NORM = false leaves the carries where they are: every second layer of a transform does (LAZY LIMBS below).
+template <bool NORM = true>
 HD Fr29 fr29_add(const Fr29& a, const Fr29& b) {
     Fr29 r;
 #pragma unroll
     for (int i = 0; i < RL; i++) r.v[i] = a.v[i] + b.v[i];
-    fr29_normalise(r);
+    if (NORM) fr29_normalise(r);
     return r;
 }
 // a - b + 2r for b < 2r with normalised limbs (every subtrahend in the transforms is a fresh product): bound(a) + 2
+template <bool NORM = true>
 HD Fr29 fr29_sub2r(const Fr29& a, const Fr29& b) {
     Fr29 r;
 #pragma unroll
     for (int i = 0; i < RL; i++) r.v[i] = a.v[i] + r29::SUBK[0][i] - b.v[i];
-    fr29_normalise(r);
+    if (NORM) fr29_normalise(r);
     return r;
 }
+// LAZY LIMBS (round 5): the carry sweep of a sum or difference is 16 of a butterfly's ~310 instructions, twice per butterfly, and
+// only every SECOND layer needs it.  With a, t normalised (limbs < 2^29; SUBK's limbs are in [2^30 - 2, 1.5 * 2^30)): a + t < 2^30
+// and a + 2r - t < 2^31 per limb, stored as they are.  The next layer reads such values as a (then a + t < 2^31 + 2^29 and
+// a + 2r - t < 3.5 * 2^30 < 2^32: no wrap, swept before the store) or as the product's first operand b: a column is
+// 9 * 2^31 * 2^29 + 9 * 2^58 = 45 * 2^58 < 2^64, and fr29_partial_reduce carries in 64 bits whatever the limbs are.  The VALUE
+// bounds (B r) are untouched.  tests/c/test_fr29.cpp runs the 4096-point network both ways and measures the limbs.
+//
 // Montgomery product a * b / 2^261 mod r, product scanning; bound(a) * bound(b) <= 64 -> result < 2r, limbs normalised.
-// One of the operands may carry un-normalised limbs up to 2^30 (9 * 2^59 + 9 * 2^58 < 2^64).
+// ONE of the operands may carry un-normalised limbs up to 2^31 (9 * 2^60 + 9 * 2^58 = 45 * 2^58 < 2^64), the other < 2^29.
 HD Fr29 fr29_mul(const Fr29& a, const Fr29& b) {
     uint32_t m[RL];
     Fr29 r;

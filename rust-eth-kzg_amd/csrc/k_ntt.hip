@@ -26,49 +26,59 @@ __device__ __forceinline__ void lds_store(uint32_t* s, int idx, const Fr29& a) {
 }
 
 // w29[k] = omega_8192^k in the 9 x 29-bit Montgomery form (canonical), k < 8192.  omega_m^j = w29[j * 8192/m].
+// A layer stores its sums and differences with the carries swept (NORM) or as they are (fr29.hpp, LAZY LIMBS): the layers alternate,
+// lazy first, and the last one of every transform is swept.
 // Inverse transform: input in bit-reversed order -> natural order, inverse twiddles, in LDS, 1024 threads.
 // Bound: in < B  ->  out < B + 24.
+template <bool NORM>
+__device__ __forceinline__ void dit_inverse_layer(uint32_t* s, const Fr29* __restrict__ w29, int half) {
+    const int tw_step = N_EXT / (2 * half);  // exponent step in units of omega_8192
+    for (int q = threadIdx.x; q < N_BLOB / 2; q += 1024) {
+        const int j = q & (half - 1);
+        const int i0 = ((q - j) << 1) + j, i1 = i0 + half;
+        const Fr29 a = lds_load(s, i0);
+        const Fr29 b = lds_load(s, i1);
+        const Fr29 t = j ? fr29_mul(b, w29[(N_EXT - j * tw_step) & (N_EXT - 1)]) : fr29_partial_reduce(b);  // omega^-j b; < 2r either way
+        lds_store(s, i0, fr29_add<NORM>(a, t));
+        lds_store(s, i1, fr29_sub2r<NORM>(a, t));
+    }
+    // Butterfly q touches elements 2 (q - j) + j and + half: for half <= 64 a wave (q = 64 w .. 64 w + 63, and the same + 1024)
+    // stays inside its own 128 elements, so the layers half = 1 .. 32 need no block barrier -- a wave's LDS operations execute in
+    // program order -- and the first one stands after half = 64, whose results other waves read: 6 barriers instead of 12.
+    if (half >= 64) __syncthreads();
+    else __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ void ntt4096_dit_inverse(uint32_t* s, const Fr29* __restrict__ w29) {
-    const int tid = threadIdx.x;
-    for (int half = 1; half < N_BLOB; half <<= 1) {
-        const int tw_step = N_EXT / (2 * half);  // exponent step in units of omega_8192
-        for (int q = tid; q < N_BLOB / 2; q += 1024) {
-            const int j = q & (half - 1);
-            const int i0 = ((q - j) << 1) + j, i1 = i0 + half;
-            const Fr29 a = lds_load(s, i0);
-            const Fr29 b = lds_load(s, i1);
-            const Fr29 t = j ? fr29_mul(b, w29[(N_EXT - j * tw_step) & (N_EXT - 1)]) : fr29_partial_reduce(b);  // omega^-j b; < 2r either way
-            lds_store(s, i0, fr29_add(a, t));
-            lds_store(s, i1, fr29_sub2r(a, t));
-        }
-        // Butterfly q touches elements 2 (q - j) + j and + half: for half <= 64 a wave (q = 64 w .. 64 w + 63, and the same + 1024)
-        // stays inside its own 128 elements, so the layers half = 1 .. 32 need no block barrier -- a wave's LDS operations execute in
-        // program order -- and the first one stands after half = 64, whose results other waves read: 6 barriers instead of 12.
-        if (half >= 64) __syncthreads();
-        else __builtin_amdgcn_wave_barrier();
+    for (int half = 1; half < N_BLOB; half <<= 2) {
+        dit_inverse_layer<false>(s, w29, half);
+        dit_inverse_layer<true>(s, w29, 2 * half);
     }
 }
 // Forward transform: natural order -> bit-reversed order (position q holds X[brp(q)]), Cooley-Tukey butterflies with the
 // twiddles taken in bit-reversed order: at stride `half` the block i = q / half uses omega_4096^(brp(i) * half).
 // (Round 2 used Gentleman-Sande butterflies here, whose sum path doubles the bound per layer.)  Bound: in < B -> out < B + 24.
+template <bool NORM>
+__device__ __forceinline__ void ct_forward_layer(uint32_t* s, const Fr29* __restrict__ w29, int half, int log_m /* blocks at this stride = 2^log_m */) {
+    for (int q = threadIdx.x; q < N_BLOB / 2; q += 1024) {
+        const int j = q & (half - 1), blk = q / half;
+        const int i0 = ((q - j) << 1) + j, i1 = i0 + half;
+        const int e = log_m ? (int)(__brev((unsigned)blk) >> (32 - log_m)) * half * (N_EXT / N_BLOB) : 0;  // omega_4096 = omega_8192^2
+        const Fr29 a = lds_load(s, i0);
+        const Fr29 b = lds_load(s, i1);
+        const Fr29 t = e ? fr29_mul(b, w29[e]) : fr29_partial_reduce(b);  // twiddle 1 (block 0 of every layer, 1 butterfly in 6): no product, < 2r all the same
+        lds_store(s, i0, fr29_add<NORM>(a, t));
+        lds_store(s, i1, fr29_sub2r<NORM>(a, t));
+    }
+    // the layers half = 64 .. 1 are wave-local (see dit_inverse_layer): the barrier after half = 128 covers their input, the
+    // one after half = 1 the output that the callers read across waves
+    if (half >= 128 || half == 1) __syncthreads();
+    else __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ void ntt4096_ct_forward(uint32_t* s, const Fr29* __restrict__ w29) {
-    const int tid = threadIdx.x;
-    int log_m = 0;  // blocks at this stride = 2^log_m
-    for (int half = N_BLOB / 2; half >= 1; half >>= 1, log_m++) {
-        for (int q = tid; q < N_BLOB / 2; q += 1024) {
-            const int j = q & (half - 1), blk = q / half;
-            const int i0 = ((q - j) << 1) + j, i1 = i0 + half;
-            const int e = log_m ? (int)(__brev((unsigned)blk) >> (32 - log_m)) * half * (N_EXT / N_BLOB) : 0;  // omega_4096 = omega_8192^2
-            const Fr29 a = lds_load(s, i0);
-            const Fr29 b = lds_load(s, i1);
-            const Fr29 t = e ? fr29_mul(b, w29[e]) : fr29_partial_reduce(b);  // twiddle 1 (block 0 of every layer, 1 butterfly in 6): no product, < 2r all the same
-            lds_store(s, i0, fr29_add(a, t));
-            lds_store(s, i1, fr29_sub2r(a, t));
-        }
-        // the layers half = 64 .. 1 are wave-local (see ntt4096_dit_inverse): the barrier after half = 128 covers their input, the
-        // one after half = 1 the output that the callers read across waves
-        if (half >= 128 || half == 1) __syncthreads();
-        else __builtin_amdgcn_wave_barrier();
+    int log_m = 0;
+    for (int half = N_BLOB / 2; half >= 1; half >>= 2, log_m += 2) {
+        ct_forward_layer<false>(s, w29, half, log_m);
+        ct_forward_layer<true>(s, w29, half >> 1, log_m + 1);
     }
 }
 __device__ __forceinline__ Fr fr_words_of(const Fr29& canonical) {
@@ -83,10 +93,13 @@ __device__ __forceinline__ Fr fr_words_of(const Fr29& canonical) {
 // grid = n_blobs, block = 1024, dynamic LDS = 144 KiB.  status[b] |= 1 if any element >= r.
 // Outputs stay in the engine's stored forms: coeffs = saturated Montgomery (8 x 32 bits, canonical), canon_out = the
 // plain integers (MSM scalars), both through the final multiplication by n^-1 with the right constant.
+// The blob's elements go through the inverse transform as the PLAIN integers they are (round 5): a product of a plain value with a
+// twiddle in Montgomery form is plain again, so the conversion product the input stage had (x * 2^522 / 2^261) is gone, and the
+// final product every element has anyway carries the 2^261 instead.
 struct NttConsts {
-    Fr29 to_mont;       // 2^522 mod r: canonical -> this form
-    Fr29 ninv_to_sat;   // n^-1 * 2^256 (an integer): mul(X, .) = x n^-1 2^256 = the saturated Montgomery form of the coefficient
-    Fr29 ninv_plain;    // n^-1 (an integer): mul(X, .) = x n^-1
+    Fr29 ninv_to_sat;   // n^-1 * 2^256 * 2^261 mod r: mul(x, .) = x n^-1 2^256 = the saturated Montgomery form of the coefficient
+    Fr29 ninv_plain;    // n^-1 * 2^261 mod r: mul(x, .) = x n^-1
+    Fr29 one;           // 2^261 mod r: mul(x, .) = x (the test kernel's forward direction: reduction only)
 };
 __global__ __launch_bounds__(1024) void k_blob_to_coeffs(const uint8_t* __restrict__ blobs, Fr* __restrict__ coeffs,
                                                         Fr* __restrict__ canon_out, int* __restrict__ status,
@@ -98,11 +111,11 @@ __global__ __launch_bounds__(1024) void k_blob_to_coeffs(const uint8_t* __restri
     for (int e = tid; e < N_BLOB; e += 1024) {
         const Fr x = load_fr_be(blob + 32 * e);
         bad |= geq_mod<FrParams>(x.v);
-        lds_store(s, e, fr29_mul(fr29_from_plain(x), K.to_mont));  // x < 2^256 < 3r, constant < r -> < 2r
+        lds_store(s, e, fr29_from_plain(x));  // the integer itself: < 2^256 < 3r, normalised limbs
     }
     if (bad) atomicOr(&status[b], 1);
     __syncthreads();
-    ntt4096_dit_inverse(s, w29);  // < 26 r
+    ntt4096_dit_inverse(s, w29);  // < 27 r
     for (int e = tid; e < N_BLOB; e += 1024) {
         const Fr29 x = lds_load(s, e);
         coeffs[(size_t)b * N_BLOB + e] = fr_words_of(fr29_reduce_once(fr29_mul(x, K.ninv_to_sat)));
@@ -171,7 +184,8 @@ __global__ __launch_bounds__(256) void k_fk20_scalars(const Fr* __restrict__ coe
 #pragma unroll
         for (int l = 0; l < RL; l++) { x.v[l] = sv[l][i0]; y.v[l] = sv[l][i1]; }
         const Fr29 t = e ? fr29_mul(y, w29[e]) : fr29_partial_reduce(y);
-        const Fr29 sum = fr29_add(x, t), d = fr29_sub2r(x, t);
+        Fr29 sum = fr29_add<false>(x, t), d = fr29_sub2r<false>(x, t);
+        if ((log_m & 1) || half == 1) { fr29_normalise(sum); fr29_normalise(d); }  // every second layer and the last one sweep the carries (fr29.hpp, LAZY LIMBS)
 #pragma unroll
         for (int l = 0; l < RL; l++) { sv[l][i0] = sum.v[l]; sv[l][i1] = d.v[l]; }
         __builtin_amdgcn_wave_barrier();  // a wave owns its whole vector: its LDS operations execute in program order, no block barrier
@@ -200,14 +214,13 @@ __global__ __launch_bounds__(256) void k_fk20_scalars(const Fr* __restrict__ coe
 
 __global__ __launch_bounds__(1024) void k_test_ntt4096(const uint8_t* in, uint8_t* out, const Fr29* w29, NttConsts K, int inverse_dit) {
     extern __shared__ uint32_t s[];
-    for (int e = threadIdx.x; e < N_BLOB; e += 1024) lds_store(s, e, fr29_mul(fr29_from_plain(load_fr_be(in + 32 * e)), K.to_mont));
+    for (int e = threadIdx.x; e < N_BLOB; e += 1024) lds_store(s, e, fr29_from_plain(load_fr_be(in + 32 * e)));  // plain values (see NttConsts)
     __syncthreads();
     if (inverse_dit) ntt4096_dit_inverse(s, w29);
     else ntt4096_ct_forward(s, w29);
-    const Fr29 one_plain = fr29_const(r29::ONE_PLAIN);
     for (int e = threadIdx.x; e < N_BLOB; e += 1024) {
         const Fr29 c = lds_load(s, e);
-        store_fr_be(out + 32 * e, fr_words_of(fr29_reduce_once(fr29_mul(c, inverse_dit ? K.ninv_plain : one_plain))));
+        store_fr_be(out + 32 * e, fr_words_of(fr29_reduce_once(fr29_mul(c, inverse_dit ? K.ninv_plain : K.one))));
     }
 }
 __global__ void k_test_scalars_be(const uint8_t* in, Fr* out, size_t n) {
@@ -250,18 +263,18 @@ void init_attributes() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_test_ntt4096), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_NTT29);
 }
 // host-side constants of the 9 x 29-bit form from the engine's saturated Montgomery values (Y = y 2^256 mod r, canonical)
-static Fr29 fr29_of_value(const Fr& plain) { return fr29_from_plain(plain); }            // the integer itself
 // X = y 2^261 mod r = 32 Y mod r: in Fr arithmetic, the Montgomery form of (y * 32) read as a plain integer
-static Fr29 fr29_mont_of(const Fr8& y_mont) {
+static Fr29 fr29_mont_of(const Fr& y_mont) {
     Fr c32 = zero<FrParams>();
     c32.v[0] = 32;
-    return fr29_from_plain(mul(as_fr(y_mont), to_mont(c32)));
+    return fr29_from_plain(mul(y_mont, to_mont(c32)));
 }
+static Fr29 fr29_mont_of(const Fr8& y_mont) { return fr29_mont_of(as_fr(y_mont)); }
 static NttConsts ntt_consts(const Fr8& n_inv_mont) {
     NttConsts K;
-    K.to_mont = fr29_const(r29::R2);
-    K.ninv_to_sat = fr29_of_value(as_fr(n_inv_mont));             // the stored Montgomery words ARE n^-1 2^256 mod r as an integer
-    K.ninv_plain = fr29_of_value(from_mont(as_fr(n_inv_mont)));   // n^-1
+    K.ninv_to_sat = fr29_mont_of(to_mont(as_fr(n_inv_mont)));     // (n^-1 2^256) 2^261: the Montgomery form of the INTEGER n^-1 2^256 mod r, times 32
+    K.ninv_plain = fr29_mont_of(n_inv_mont);                      // n^-1 2^261
+    K.one = fr29_mont_of(one<FrParams>());                        // 2^261 (one<>() is the Montgomery form of 1)
     return K;
 }
 void ntt_twiddles29(const void* w8192_mont_host /*Fr[8192]*/, void* out_host /*8192 x 9 words*/) {

@@ -122,6 +122,48 @@ int main() {
         }
         // the top limb never ran out of room
         for (int i = 0; i < n; i++) if (x[i].v[RL - 1] >> 29) { bad++; if (bad < 8) printf("OVERFLOW top limb\n"); break; }
+        // LAZY LIMBS (fr29.hpp): the same transform as the kernels run it -- the layers alternate, lazy first, the carries swept
+        // only in every second layer -- must give the same residues in every position, and its limbs must stay inside the bounds the
+        // header states (checked in 64 bits: a limb-wise sum that wrapped would still compare equal mod 2^32).  Twice: random
+        // inputs, and inputs with every limb at its maximum.
+        for (int worst = 0; worst < 2; worst++) {
+            std::vector<Fr29> y(n), z(n);
+            for (int i = 0; i < n; i++) {
+                y[i] = fr29_from_fr_mont(in[i]);
+                if (worst) { for (int l = 0; l < RL - 1; l++) y[i].v[l] = RMASK; y[i].v[RL - 1] = (32u << 24) - 1; }  // < 32 r, limbs full
+                z[i] = y[i];
+            }
+            uint64_t max_lazy = 0, max_presweep = 0;
+            log_m = 0;
+            for (int half = n / 2; half >= 1; half >>= 1, log_m++) {
+                const bool norm = log_m & 1;
+                for (int q = 0; q < n / 2; q++) {
+                    const int j = q & (half - 1), blk = q / half, i0 = ((q - j) << 1) + j, i1 = i0 + half;
+                    int br = 0;
+                    for (int b = 0; b < log_m; b++) br |= ((blk >> b) & 1) << (log_m - 1 - b);
+                    const Fr29 tz = br ? fr29_mul(z[i1], w29[(size_t)br * half]) : fr29_partial_reduce(z[i1]);
+                    const Fr29 az = z[i0];
+                    z[i0] = fr29_add(az, tz);
+                    z[i1] = fr29_sub2r(az, tz);
+                    const Fr29 t = br ? fr29_mul(y[i1], w29[(size_t)br * half]) : fr29_partial_reduce(y[i1]);
+                    const Fr29 a = y[i0];
+                    for (int l = 0; l < RL - 1; l++) {
+                        const uint64_t sum = (uint64_t)a.v[l] + t.v[l], dif = (uint64_t)a.v[l] + r29::SUBK[0][l] - t.v[l];
+                        uint64_t& m = norm ? max_presweep : max_lazy;
+                        if (sum > m) m = sum;
+                        if (dif > m) m = dif;
+                    }
+                    if (norm) { y[i0] = fr29_add<true>(a, t); y[i1] = fr29_sub2r<true>(a, t); }
+                    else { y[i0] = fr29_add<false>(a, t); y[i1] = fr29_sub2r<false>(a, t); }
+                }
+            }
+            if (max_lazy >= (4ull << 29) || max_presweep >= (7ull << 29)) { bad++; printf("LAZY LIMBS out of bounds: %llx %llx\n", (unsigned long long)max_lazy, (unsigned long long)max_presweep); }
+            const Fr29 one_p = fr29_const(r29::ONE_PLAIN);
+            for (int i = 0; i < n; i++)
+                if (!same(canon(fr29_mul(y[i], one_p)), canon(fr29_mul(z[i], one_p)))) { bad++; if (bad < 8) printf("MISMATCH lazy transform at %d (worst %d)\n", i, worst); }
+            for (int i = 0; i < n; i++) for (int l = 0; l < RL - 1; l++) if (y[i].v[l] > RMASK) { bad++; if (bad < 8) printf("lazy transform: output limbs not swept\n"); i = n; break; }
+            if (worst == 0) printf("lazy limbs: largest stored %.3f x 2^30, largest before a sweep %.3f x 2^30\n", max_lazy / 1073741824.0, max_presweep / 1073741824.0);
+        }
     }
     printf("%d mismatches\n", bad);
     return bad != 0;
