@@ -1105,7 +1105,7 @@ def main():
             "coeffs_to_cells": B * (4096 * 32 * 2 + 8192 * 32),
             "fk20_scalars": B * (4096 * 32 + 128 * 64 * 32),
             # scalars in + one 96-B table entry per (scalar, window) + 128 Jacobian sums out
-            # (GLV table: 16 packed 96-B entries per scalar; plain table of width c: ceil(256/c) entries of 112 B)
+            # (2 ceil(128 / w) packed 96-B entries per scalar: 16 at the widest table)
             "msm_fixed": B * (128 * 64 * 32 + 128 * 64 * msm_adds * 96 + 128 * 168),
             # one radix-2 layer: 64 butterflies x (2 points in, 2 points out) x 168 B per blob
             "g1_ifft": B * 64 * 4 * 168,

@@ -206,8 +206,8 @@ public:
     // sums since the last call: ms[ST_COUNT], launches[ST_COUNT]; synchronises the device
     void get_stage_times(double* ms, uint64_t* launches);
 
-    // ---- window tables.  A context is usable as soon as its START tables are up (FK20: GLV width 8, 1.6 GB; commitments:
-    // plain width 8, 2.1 GB); the wide ones (GLV 16 / plain 13 by default, or the widest inside ETH_KZG_AMD_TABLE_GB) are
+    // ---- window tables.  A context is usable as soon as its START tables are up (sixteen-window GLV tables: FK20 1.6 GB,
+    // commitments 0.8 GB); the wide ones (the widest GLV tables inside the budget: engine_tables.hip, build_final_tables) are
     // built by a helper thread and published with one pointer swap: every MSM launch takes a snapshot of the view, results
     // are identical for every table (tests), only the speed changes.  ETH_KZG_AMD_PROGRESSIVE=0 builds them before the
     // constructor returns.

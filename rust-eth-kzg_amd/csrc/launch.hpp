@@ -34,9 +34,8 @@ void test_scalars_be(const uint8_t* in, void* out, size_t n, hipStream_t st);
 void test_field_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, int n, int is_fp, hipStream_t st);
 
 // k_msm.hip
-// A window table as the kernels see it: a device array of block pointers -- one block per group for a plain table
-// (blocks[group]: [window][base][digit]), two per group for a GLV table (blocks[2 group + upper]: the lower ceil(W / 2) windows,
-// the upper rest) -- and the range [g0, g0 + gcnt) of groups this launch covers (of the n_groups MSMs per slice the scalars hold).
+// A window table as the kernels see it: a device array of block pointers -- two per group (blocks[2 group + upper]: the lower
+// ceil(W / 2) windows, the upper rest; inside a block [window][base][digit]) -- and the range [g0, g0 + gcnt) of groups this launch covers (of the n_groups MSMs per slice the scalars hold).
 // Tables are allocated in pieces and published group by group while they are built (engine.hip: SharedTable): a launch over
 // the groups already built on the new table and one over the rest on the old table make one MSM stage.
 struct TabBlocks {
