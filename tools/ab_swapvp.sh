@@ -1,6 +1,8 @@
 #!/bin/bash
-# ON THE GPU BOX: the in-tree library against the build with the constant factor of the m * p multiply-adds first (-DFP30_SWAP_VP),
-# alternating processes on one box; prints blobs/s and the MSM / linear-map stage times of each run.
+# ON THE GPU BOX: the in-tree library against a second build of it, alternating processes on one box; prints blobs/s and the MSM /
+# linear-map stage times of each run.  Round 5 used it for the order of the multiply-adds' factors (the second build then had the
+# modulus digit first; today that is the default and -DFP30_VP_M_FIRST gives the old order).  Build the second library HERE first:
+#   make -C rust-eth-kzg_amd/csrc -j8 HIPCC="hipcc -DFP30_VP_M_FIRST" OBJDIR=/tmp/build_ab OUT=$PWD/tools/ab/libc_eth_kzg_swapvp.so STATIC=/tmp/build_ab/lib.a
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 for round in 1 2 3; do
   for lib in "" "$REPO/tools/ab/libc_eth_kzg_swapvp.so"; do

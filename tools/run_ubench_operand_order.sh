@@ -1,6 +1,7 @@
 #!/bin/bash
 # ON THE GPU BOX: the sustained rates of the 13-digit products with the multiply-adds' two factors in either order
-# (tools/gen_fp30_mac.py: FP30_SWAP_VP / FP30_SWAP_VV), each binary twice, alternating, with the shader clock and package power
+# (round 5: tools/gen_fp30_mac.py then had -DFP30_SWAP_VP / -DFP30_SWAP_VV; today the modulus digit is first by default and
+# -DFP30_VP_M_FIRST gives the other order), each binary twice, alternating, with the shader clock and package power
 # sampled beside them.  Build first (here): for v in "" -DFP30_SWAP_VP -DFP30_SWAP_VV "-DFP30_SWAP_VP -DFP30_SWAP_VV"; hipcc ... -o tools/ubench_fp30_v<flags>
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/ubench_operand_order.log
