@@ -4,6 +4,7 @@
 #include "engine.hpp"
 #include "kcommon.hpp"
 #include "fr29.hpp"
+#include "fr29_ntt.hpp"
 #include "glv.hpp"
 #include "launch.hpp"
 
@@ -26,60 +27,66 @@ __device__ __forceinline__ void lds_store(uint32_t* s, int idx, const Fr29& a) {
 }
 
 // w29[k] = omega_8192^k in the 9 x 29-bit Montgomery form (canonical), k < 8192.  omega_m^j = w29[j * 8192/m].
-// A layer stores its sums and differences with the carries swept (NORM) or as they are (fr29.hpp, LAZY LIMBS): the layers alternate,
-// lazy first, and the last one of every transform is swept.
-// Inverse transform: input in bit-reversed order -> natural order, inverse twiddles, in LDS, 1024 threads.
+//
+// RADIX-4 PASSES IN REGISTERS (round 5).  Two layers of the radix-2 network are one pass: a thread loads the four
+// elements i0 + {0, h, 2h, 3h} of a unit, runs the two butterflies of the first layer and the two of the second on them in registers,
+// and stores four results -- the same four products as before (in a prime field the fourth root of unity is a twiddle like any other:
+// radix 4 saves no multiplication), but half the LDS round trips, half the index arithmetic, and the first layer's sums and
+// differences stay un-swept (fr29.hpp, LAZY LIMBS: they are what the second layer reads).  Bit-identical to the radix-2 network.
+// Thread tid owns unit tid (1024 units of four elements).  Which passes need a block barrier follows from who wrote a unit's
+// elements in the pass before (worked out at the two functions): three barriers per transform instead of six.
+struct LdsElems {  // the transform's 4096 elements in LDS, limb-major (lds_load / lds_store above)
+    uint32_t* s;
+    __device__ __forceinline__ Fr29 load(int i) const { return lds_load(s, i); }
+    __device__ __forceinline__ void store(int i, const Fr29& v) const { lds_store(s, i, v); }
+};
+// Inverse transform: input in bit-reversed order -> natural order, inverse twiddles omega^-j, in LDS, 1024 threads.
 // Bound: in < B  ->  out < B + 24.
-template <bool NORM>
-__device__ __forceinline__ void dit_inverse_layer(uint32_t* s, const Fr29* __restrict__ w29, int half) {
-    const int tw_step = N_EXT / (2 * half);  // exponent step in units of omega_8192
-    for (int q = threadIdx.x; q < N_BLOB / 2; q += 1024) {
-        const int j = q & (half - 1);
-        const int i0 = ((q - j) << 1) + j, i1 = i0 + half;
-        const Fr29 a = lds_load(s, i0);
-        const Fr29 b = lds_load(s, i1);
-        const Fr29 t = j ? fr29_mul(b, w29[(N_EXT - j * tw_step) & (N_EXT - 1)]) : fr29_partial_reduce(b);  // omega^-j b; < 2r either way
-        lds_store(s, i0, fr29_add<NORM>(a, t));
-        lds_store(s, i1, fr29_sub2r<NORM>(a, t));
-    }
-    // Butterfly q touches elements 2 (q - j) + j and + half: for half <= 64 a wave (q = 64 w .. 64 w + 63, and the same + 1024)
-    // stays inside its own 128 elements, so the layers half = 1 .. 32 need no block barrier -- a wave's LDS operations execute in
-    // program order -- and the first one stands after half = 64, whose results other waves read: 6 barriers instead of 12.
-    if (half >= 64) __syncthreads();
-    else __builtin_amdgcn_wave_barrier();
+// Pass h (layers half = h, then 2h): unit u = blk * h + j (j < h) holds the elements blk * 4h + j + {0, h, 2h, 3h}; they were written
+// in pass h / 4 by the units (4 blk + k) * (h / 4) + (j mod h / 4), k < 4: the same 4-, 16-, 64-thread group for h = 4, 16, 64 (a wave's
+// LDS operations execute in program order: no barrier), four different waves for h = 256 and h = 1024 (a block barrier before each).
+// The last pass leaves unit j's results at j + 1024 k -- exactly what thread j reads afterwards: no barrier at the end.
+__device__ __forceinline__ void dit_inverse_pass(uint32_t* s, const Fr29* __restrict__ w29, int h) {
+    ntt4096_dit_inverse_unit(LdsElems{s}, w29, h, (int)threadIdx.x);
 }
-__device__ __forceinline__ void ntt4096_dit_inverse(uint32_t* s, const Fr29* __restrict__ w29) {
-    for (int half = 1; half < N_BLOB; half <<= 2) {
-        dit_inverse_layer<false>(s, w29, half);
-        dit_inverse_layer<true>(s, w29, 2 * half);
-    }
+__device__ __forceinline__ void ntt4096_dit_inverse(uint32_t* s, const Fr29* __restrict__ w29) {  // the caller's barrier stands before
+    dit_inverse_pass(s, w29, 1);
+    __builtin_amdgcn_wave_barrier();
+    dit_inverse_pass(s, w29, 4);
+    __builtin_amdgcn_wave_barrier();
+    dit_inverse_pass(s, w29, 16);
+    __builtin_amdgcn_wave_barrier();
+    dit_inverse_pass(s, w29, 64);
+    __syncthreads();
+    dit_inverse_pass(s, w29, 256);
+    __syncthreads();
+    dit_inverse_pass(s, w29, 1024);
+    __builtin_amdgcn_wave_barrier();  // thread j reads j + 1024 k next: its own unit's results
 }
 // Forward transform: natural order -> bit-reversed order (position q holds X[brp(q)]), Cooley-Tukey butterflies with the
 // twiddles taken in bit-reversed order: at stride `half` the block i = q / half uses omega_4096^(brp(i) * half).
 // (Round 2 used Gentleman-Sande butterflies here, whose sum path doubles the bound per layer.)  Bound: in < B -> out < B + 24.
-template <bool NORM>
-__device__ __forceinline__ void ct_forward_layer(uint32_t* s, const Fr29* __restrict__ w29, int half, int log_m /* blocks at this stride = 2^log_m */) {
-    for (int q = threadIdx.x; q < N_BLOB / 2; q += 1024) {
-        const int j = q & (half - 1), blk = q / half;
-        const int i0 = ((q - j) << 1) + j, i1 = i0 + half;
-        const int e = log_m ? (int)(__brev((unsigned)blk) >> (32 - log_m)) * half * (N_EXT / N_BLOB) : 0;  // omega_4096 = omega_8192^2
-        const Fr29 a = lds_load(s, i0);
-        const Fr29 b = lds_load(s, i1);
-        const Fr29 t = e ? fr29_mul(b, w29[e]) : fr29_partial_reduce(b);  // twiddle 1 (block 0 of every layer, 1 butterfly in 6): no product, < 2r all the same
-        lds_store(s, i0, fr29_add<NORM>(a, t));
-        lds_store(s, i1, fr29_sub2r<NORM>(a, t));
-    }
-    // the layers half = 64 .. 1 are wave-local (see dit_inverse_layer): the barrier after half = 128 covers their input, the
-    // one after half = 1 the output that the callers read across waves
-    if (half >= 128 || half == 1) __syncthreads();
-    else __builtin_amdgcn_wave_barrier();
+// Pass h (layers half = 2h, then h; log_m = log2(1024 / h) blocks of 4h elements): unit u = blk * h + j holds blk * 4h + j + {0, h, 2h, 3h}.
+// The first pass (h = 1024) reads j + 1024 k: what thread j itself stored in the input stage (no barrier before it); the passes h = 256
+// and h = 64 read other waves' results (a block barrier before each); h = 16, 4, 1 stay inside the 64-thread group that wrote their
+// elements; the callers read across waves afterwards: a block barrier at the end.
+__device__ __forceinline__ void ct_forward_pass(uint32_t* s, const Fr29* __restrict__ w29, int h, int log_m) {
+    ntt4096_ct_forward_unit(LdsElems{s}, w29, h, log_m, (int)threadIdx.x);
 }
-__device__ __forceinline__ void ntt4096_ct_forward(uint32_t* s, const Fr29* __restrict__ w29) {
-    int log_m = 0;
-    for (int half = N_BLOB / 2; half >= 1; half >>= 2, log_m += 2) {
-        ct_forward_layer<false>(s, w29, half, log_m);
-        ct_forward_layer<true>(s, w29, half >> 1, log_m + 1);
-    }
+__device__ __forceinline__ void ntt4096_ct_forward(uint32_t* s, const Fr29* __restrict__ w29) {  // input stored by thread e mod 1024
+    __builtin_amdgcn_wave_barrier();
+    ct_forward_pass(s, w29, 1024, 0);
+    __syncthreads();
+    ct_forward_pass(s, w29, 256, 2);
+    __syncthreads();
+    ct_forward_pass(s, w29, 64, 4);
+    __builtin_amdgcn_wave_barrier();
+    ct_forward_pass(s, w29, 16, 6);
+    __builtin_amdgcn_wave_barrier();
+    ct_forward_pass(s, w29, 4, 8);
+    __builtin_amdgcn_wave_barrier();
+    ct_forward_pass(s, w29, 1, 10);
+    __syncthreads();
 }
 __device__ __forceinline__ Fr fr_words_of(const Fr29& canonical) {
     Fr r;

@@ -4,6 +4,7 @@
 // ntt4096_ct_forward) against the definition of the DFT -- including the claim that 12 layers need no reduction.
 // Built and run by tests/test_host_units.py with hipcc's host pass (no kernel is launched).
 #include "fr29.hpp"
+#include "fr29_ntt.hpp"
 #include <cstdio>
 #include <vector>
 using namespace kzg;
@@ -163,6 +164,85 @@ int main() {
                 if (!same(canon(fr29_mul(y[i], one_p)), canon(fr29_mul(z[i], one_p)))) { bad++; if (bad < 8) printf("MISMATCH lazy transform at %d (worst %d)\n", i, worst); }
             for (int i = 0; i < n; i++) for (int l = 0; l < RL - 1; l++) if (y[i].v[l] > RMASK) { bad++; if (bad < 8) printf("lazy transform: output limbs not swept\n"); i = n; break; }
             if (worst == 0) printf("lazy limbs: largest stored %.3f x 2^30, largest before a sweep %.3f x 2^30\n", max_lazy / 1073741824.0, max_presweep / 1073741824.0);
+        }
+    }
+    // The radix-4 units the kernels run (csrc/fr29_ntt.hpp: one unit per thread and pass) on a vector: forward = the radix-2 network
+    // above in every position (bit-identical limbs: the same operations in the same order), inverse (bit-reversed in, natural out,
+    // omega^-j) against the definition; forward then inverse = n times the input.
+    {
+        const int n = 4096, logn = 12;
+        struct VecElems {
+            std::vector<Fr29>* v;
+            Fr29 load(int i) const { return (*v)[i]; }
+            void store(int i, const Fr29& x) const { (*v)[i] = x; }
+        };
+        // omega_8192 and its powers in this form
+        uint32_t e[8];
+        for (int i = 0; i < 8; i++) e[i] = FrParams::MOD[i];
+        e[0] -= 1;
+        for (int s = 0; s < 13; s++) for (int i = 0; i < 8; i++) e[i] = (e[i] >> 1) | (i < 7 ? (e[i + 1] << 31) : 0);
+        Fr g = one<FrParams>(), base = to_mont(small(7));
+        for (int i = 255; i >= 0; i--) { g = sqr(g); if ((e[i >> 5] >> (i & 31)) & 1) g = mul(g, base); }
+        std::vector<Fr> w(8192);
+        w[0] = one<FrParams>();
+        for (int i = 1; i < 8192; i++) w[i] = mul(w[i - 1], g);
+        std::vector<Fr29> w29(8192);
+        for (int i = 0; i < 8192; i++) w29[i] = x_of(w[i]);
+        std::vector<Fr> in(n);
+        for (auto& v : in) v = to_mont(rnd_fr());
+        auto brp = [&](int k) { int q = 0; for (int b = 0; b < logn; b++) q |= ((k >> b) & 1) << (logn - 1 - b); return q; };
+        // forward, radix 4
+        std::vector<Fr29> y(n), z(n);
+        for (int i = 0; i < n; i++) y[i] = z[i] = fr29_from_fr_mont(in[i]);
+        {
+            int log_m = 0;
+            for (int h = 1024; h >= 1; h >>= 2, log_m += 2)
+                for (int u = 0; u < 1024; u++) ntt4096_ct_forward_unit(VecElems{&y}, w29.data(), h, log_m, u);
+        }
+        // forward, radix 2 with the kernels' former layer schedule (lazy, swept, lazy, ...)
+        {
+            int log_m = 0;
+            for (int half = n / 2; half >= 1; half >>= 1, log_m++)
+                for (int q = 0; q < n / 2; q++) {
+                    const int j = q & (half - 1), blk = q / half, i0 = ((q - j) << 1) + j, i1 = i0 + half;
+                    int br = 0;
+                    for (int b = 0; b < log_m; b++) br |= ((blk >> b) & 1) << (log_m - 1 - b);
+                    const Fr29 t = fr29_twiddled(z[i1], w29.data(), br * half * 2);
+                    const Fr29 a = z[i0];
+                    if (log_m & 1) { z[i0] = fr29_add<true>(a, t); z[i1] = fr29_sub2r<true>(a, t); }
+                    else { z[i0] = fr29_add<false>(a, t); z[i1] = fr29_sub2r<false>(a, t); }
+                }
+        }
+        for (int i = 0; i < n; i++) if (!same(y[i], z[i])) { bad++; if (bad < 8) printf("MISMATCH radix-4 forward differs from radix-2 at %d\n", i); }
+        for (int k : {0, 1, 2, 77, 2048, 4095}) {
+            Fr acc = zero<FrParams>();
+            for (int j = 0; j < n; j++) acc = add(acc, mul(in[j], w[(size_t)2 * ((size_t)j * k % n)]));
+            Fr got;
+            fr29_to_words(got.v, canon(fr29_mul(y[brp(k)], fr29_const(r29::ONE_PLAIN))));
+            if (!eq(got, from_mont(acc))) { bad++; if (bad < 8) printf("MISMATCH radix-4 forward output %d\n", k); }
+        }
+        // inverse, radix 4, on the forward transform's output (bit-reversed, as the network wants it): n times the input
+        for (int i = 0; i < n; i++) y[i] = fr29_partial_reduce(y[i]);  // (< 2r again: the kernels never chain two transforms without a product)
+        for (int h = 1; h <= 1024; h <<= 2)
+            for (int u = 0; u < 1024; u++) ntt4096_dit_inverse_unit(VecElems{&y}, w29.data(), h, u);
+        const Fr n_mont = to_mont(small(4096));
+        for (int i = 0; i < n; i++) {
+            Fr got;
+            fr29_to_words(got.v, canon(fr29_mul(y[i], fr29_const(r29::ONE_PLAIN))));
+            if (!eq(got, from_mont(mul(in[i], n_mont)))) { bad++; if (bad < 8) printf("MISMATCH radix-4 inverse(forward(x)) != n x at %d\n", i); }
+        }
+        // and the inverse alone against its definition on a fresh bit-reversed input
+        std::vector<Fr> in2(n);
+        for (auto& v : in2) v = to_mont(rnd_fr());
+        for (int i = 0; i < n; i++) y[i] = fr29_from_fr_mont(in2[i]);  // position i holds x[brp(i)]
+        for (int h = 1; h <= 1024; h <<= 2)
+            for (int u = 0; u < 1024; u++) ntt4096_dit_inverse_unit(VecElems{&y}, w29.data(), h, u);
+        for (int k : {0, 1, 3, 64, 1023, 4095}) {
+            Fr acc = zero<FrParams>();
+            for (int j = 0; j < n; j++) acc = add(acc, mul(in2[brp(j)], w[(size_t)(8192 - 2 * ((size_t)j * k % n)) % 8192]));
+            Fr got;
+            fr29_to_words(got.v, canon(fr29_mul(y[k], fr29_const(r29::ONE_PLAIN))));
+            if (!eq(got, from_mont(acc))) { bad++; if (bad < 8) printf("MISMATCH radix-4 inverse output %d\n", k); }
         }
     }
     printf("%d mismatches\n", bad);
