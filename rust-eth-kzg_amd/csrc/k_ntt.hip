@@ -163,7 +163,7 @@ __global__ __launch_bounds__(1024) void k_coeffs_to_cells(const Fr* __restrict__
 // doubling chain of k_g1circ.hip splits into `segs` independent shorter chains.
 struct SegShifts { Fr29 p[3]; };  // the segment shifts as plain integers times 2^261 (this form), p[seg - 1]
 __global__ __launch_bounds__(256) void k_fk20_scalars(const Fr* __restrict__ coeffs, Fr* __restrict__ scalars,
-                                                      const Fr29* __restrict__ w29, Fr29 scale /* 128^-1 or 1/2, this form */, int n,
+                                                      const Fr29* __restrict__ w29, Fr29 scale /* 32 x (128^-1 or 1/2) as an integer: see the input stage */, int n,
                                                       int segs, SegShifts sh) {
     __shared__ uint32_t s[4][RL][128];
     const int b = blockIdx.x >> 4, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -175,8 +175,11 @@ __global__ __launch_bounds__(256) void k_fk20_scalars(const Fr* __restrict__ coe
         Fr29 lo, hi;
 #pragma unroll
         for (int l = 0; l < RL; l++) lo.v[l] = hi.v[l] = 0;
-        if (lane == 0) lo = fr29_mul(fr29_from_fr_mont(a[N_BLOB - 1 - i]), scale);  // (< 32 r) x (< r) -> < 2r
-        else hi = fr29_mul(fr29_from_fr_mont(a[64 * lane - 1 - i]), scale);
+        // The vectors go through the transform as PLAIN integers (round 5, as in k_blob_to_coeffs): the stored coefficient is the integer
+        // Y = y 2^256, the product with the integer 32 s is Y 32 s / 2^261 = y s, a plain value times a Montgomery-form twiddle stays plain,
+        // and the output needs a reduction below r instead of a Montgomery product by one.
+        if (lane == 0) lo = fr29_mul(fr29_from_plain(a[N_BLOB - 1 - i]), scale);  // (< r) x (< r) -> < 2r
+        else hi = fr29_mul(fr29_from_plain(a[64 * lane - 1 - i]), scale);
 #pragma unroll
         for (int l = 0; l < RL; l++) { sv[l][lane] = lo.v[l]; sv[l][64 + lane] = hi.v[l]; }
     }
@@ -199,9 +202,8 @@ __global__ __launch_bounds__(256) void k_fk20_scalars(const Fr* __restrict__ coe
     }
     // position q holds NTT[brp7(q)].  The scalar leaves already split k = k1 + k2 lambda for the GLV window tables (what the separate
     // k_glv_split pass of round 2 did in place: 0.19 ms of reading and writing 0.5 GB at 2048 blobs)
-    const Fr29 one_plain = fr29_const(r29::ONE_PLAIN);
-    auto emit = [&](size_t at, const Fr29& x_form) {
-        Fr k = fr_words_of(fr29_reduce_once(fr29_mul(x_form, one_plain)));
+    auto emit = [&](size_t at, const Fr29& x) {  // x: the plain value, < 16 r (or < 2r: a segment's product)
+        Fr k = fr_words_of(fr29_reduce_once(fr29_partial_reduce(x)));
         uint32_t h[8];
         glv_split_balanced(k, h);
 #pragma unroll
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void k_fk20_scalars(const Fr* __restrict__ coe
         const int j = __brev((unsigned)q) >> 25;
         emit(((size_t)b * 128 + j) * 64 + i, x);
         for (int sg = 1; sg < segs; sg++)  // (x sh) is this form again
-            emit(((size_t)(sg * n + b) * 128 + j) * 64 + i, fr29_mul(x, sh.p[sg - 1]));
+            emit(((size_t)(sg * n + b) * 128 + j) * 64 + i, fr29_mul(x, sh.p[sg - 1]));  // plain x times the Montgomery form of the shift: plain
     }
 }
 
@@ -277,6 +279,12 @@ static Fr29 fr29_mont_of(const Fr& y_mont) {
     return fr29_from_plain(mul(y_mont, to_mont(c32)));
 }
 static Fr29 fr29_mont_of(const Fr8& y_mont) { return fr29_mont_of(as_fr(y_mont)); }
+// the INTEGER 32 s mod r for a value s given in the saturated Montgomery form: mul(Y, .) = y s for a stored Y = y 2^256 (k_fk20_scalars)
+static Fr29 fr29_int32x_of(const Fr8& s_mont) {
+    Fr c32 = zero<FrParams>();
+    c32.v[0] = 32;
+    return fr29_from_plain(from_mont(mul(as_fr(s_mont), to_mont(c32))));
+}
 static NttConsts ntt_consts(const Fr8& n_inv_mont) {
     NttConsts K;
     K.ninv_to_sat = fr29_mont_of(to_mont(as_fr(n_inv_mont)));     // (n^-1 2^256) 2^261: the Montgomery form of the INTEGER n^-1 2^256 mod r, times 32
@@ -299,7 +307,7 @@ void fk20_scalars(int n, const void* coeffs, void* scalars, const void* w29, con
                   hipStream_t st) {
     SegShifts sh;
     for (int i = 0; i < 3; i++) sh.p[i] = fr29_mont_of(seg_shifts[i]);
-    k_fk20_scalars<<<n * 16, 256, 0, st>>>((const Fr*)coeffs, (Fr*)scalars, (const Fr29*)w29, fr29_mont_of(inv128), n, segs, sh);
+    k_fk20_scalars<<<n * 16, 256, 0, st>>>((const Fr*)coeffs, (Fr*)scalars, (const Fr29*)w29, fr29_int32x_of(inv128), n, segs, sh);
 }
 void test_ntt4096(const uint8_t* in, uint8_t* out, const void* w29, const Fr8& n_inv, int inverse_dit, hipStream_t st) {
     k_test_ntt4096<<<1, 1024, LDS_NTT29, st>>>(in, out, (const Fr29*)w29, ntt_consts(n_inv), inverse_dit);
