@@ -128,6 +128,28 @@ DASContext *eth_kzg_amd_das_context_new_on_device(bool use_precomp, int device_o
  * memory), < 0 = whatever the HBM still holds (242 GB on an idle GPU: eight windows of 16 bits for FK20, nine for commitments). */
 DASContext *eth_kzg_amd_das_context_try_new(bool use_precomp, int device_ordinal, double table_budget_gb, CResult *result);
 
+/* A context over a DEVICE LIST: one engine per listed GPU behind the one pointer, so that a host written against the
+ * reference -- one context, shared by all its threads (bindings/c/src/lib.rs:79-92, bindings/node/src/lib.rs:35,75,
+ * bindings/golang/prover.go) -- uses every GPU of the node through the UNCHANGED sixteen symbols:
+ *   - a single-problem call (eth_kzg_compute_cells_and_kzg_proofs, _verify_cell_kzg_proof_batch, _recover_cells_and_proofs,
+ *     _blob_to_kzg_commitment, the EIP-4844 calls) runs on the device with the least work in flight;
+ *   - a host-pointer batch (eth_kzg_amd_*_batch, _verify_cell_kzg_proof_batch_many) is cut into contiguous slices, slice d =
+ *     [n d / D, n (d + 1) / D) on the d-th listed device, one host thread each, the caller's buffers are the gather target
+ *     (no collective); the call's error is the lowest failing device's;
+ *   - a device-resident call (eth_kzg_amd_*_device) runs on the listed device that owns the caller's buffers (`Err` if none does);
+ *   - the communicator, profiling and table-introspection calls address the FIRST listed device (eth_kzg_amd_table_bytes sums
+ *     the distinct devices, eth_kzg_amd_tables_ready reports the slowest one).
+ * Results are byte-identical to a one-device context's.  eth_kzg_das_context_new reads the list from ETH_KZG_AMD_DEVICES
+ * ("0,1,2,3" or "all"; unset: ETH_KZG_AMD_DEVICE, else GPU 0).  An ordinal may repeat (two engines on one GPU share its window
+ * tables): the form the one-GPU tests use.  Returns NULL and fills *result (as _try_new) when any device fails. */
+DASContext *eth_kzg_amd_das_context_new_on_devices(bool use_precomp, const int32_t *device_ordinals, uint64_t n_devices,
+                                                   double table_budget_gb, CResult *result);
+/* the context's device list: writes up to `capacity` ordinals, returns how many devices the context spans */
+uint64_t eth_kzg_amd_context_devices(const DASContext *ctx, int32_t *out_ordinals, uint64_t capacity);
+/* Version of the eth_kzg_amd_* additions (the sixteen eth_kzg_* symbols never change): 6 = this header.  Bumped whenever a
+ * symbol's meaning changes or one is removed, so that an out-of-tree consumer can check at load time. */
+int eth_kzg_amd_abi_version(void);
+
 /* Host-pointer batches: n blobs; out_cells[b] / out_proofs[b] are arrays of 128 pointers as in the
  * single-blob calls (either may be NULL to skip that output). */
 CResult eth_kzg_amd_compute_cells_and_kzg_proofs_batch(const DASContext *ctx, uint64_t n, const uint8_t *const *blobs,
@@ -227,7 +249,13 @@ CResult eth_kzg_amd_verify_cell_kzg_proof_batch_device(const DASContext *ctx, ui
  * table in use (a GLV table: ceil(128 / w) windows over the two 128-bit halves of each scalar, packed 96-byte entries: 16
  * gathered additions per base at w = 16, 32 at w = 8 -- the start tables, and all there is with use_precomp = false). */
 uint64_t eth_kzg_amd_table_bytes(const DASContext *ctx);
+/* NOMINAL: since ABI version 5 the windows of a table have mixed widths (w = 15: two windows of 15 bits and seven of 14) -- do
+ * not derive the additions per base from it; eth_kzg_amd_window_count gives the windows per 128-bit GLV half directly (gathered
+ * additions per base = 2 x that: 16 on the widest tables, 18 on the default ones, 32 on the start tables). */
 int eth_kzg_amd_window_bits(const DASContext *ctx);
+int eth_kzg_amd_window_count(const DASContext *ctx);
+/* DEPRECATED (kept for consumers linked against the round-4 header): always 1 -- every window table is a GLV table now. */
+int eth_kzg_amd_glv_table(const DASContext *ctx);
 /* 1 once the final window tables are in use, 0 while the context still runs on its start tables (waits up to wait_ms
  * milliseconds for the switch; negative: until it happened), 2 if the wide tables could not be built (memory) and the
  * context stays on what it has.  Results never depend on the table in use. */

@@ -18,7 +18,8 @@ import numpy as np
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libc_eth_kzg.so")
+LIB_PATH = os.path.join(_HERE, "libc_eth_kzg.so")  # the product library: what a maintainer links
+HOOKS_LIB_PATH = os.path.join(_HERE, "libc_eth_kzg_hooks.so")  # the same objects + the stage-level test hooks: what tests/ loads
 
 BYTES_PER_BLOB = 131072
 BYTES_PER_CELL = 2048
@@ -48,7 +49,8 @@ EXPORTED_SYMBOLS = [
     "eth_kzg_compute_kzg_proof", "eth_kzg_compute_blob_kzg_proof", "eth_kzg_verify_kzg_proof",
     "eth_kzg_verify_blob_kzg_proof", "eth_kzg_verify_blob_kzg_proof_batch",
     "eth_kzg_amd_das_context_new_on_device",
-    "eth_kzg_amd_das_context_try_new",
+    "eth_kzg_amd_das_context_try_new", "eth_kzg_amd_das_context_new_on_devices", "eth_kzg_amd_context_devices",
+    "eth_kzg_amd_abi_version", "eth_kzg_amd_window_count", "eth_kzg_amd_glv_table",
     "eth_kzg_amd_compute_cells_and_kzg_proofs_batch", "eth_kzg_amd_blob_to_kzg_commitment_batch",
     "eth_kzg_amd_recover_cells_and_proofs_batch", "eth_kzg_amd_recover_cells_and_proofs_device",
     "eth_kzg_amd_verify_cell_kzg_proof_batch_partial", "eth_kzg_amd_verify_cell_kzg_proof_batch_combine",
@@ -140,11 +142,24 @@ def load_library():
     lib.eth_kzg_amd_set_profiling.argtypes = [P, C.c_int]
     lib.eth_kzg_amd_set_profiling.restype = None
     lib.eth_kzg_amd_get_stage_times.argtypes = [P, P, P, C.c_int]
-    lib.eth_kzg_amd_test_fr_ntt4096.argtypes = [P, U8P, P, C.c_int]
-    lib.eth_kzg_amd_test_g1_fft128.argtypes = [P, U8P, P, C.c_int, C.c_int]
-    lib.eth_kzg_amd_test_fixed_msm.argtypes = [P, U8P, C.c_int, P]
-    lib.eth_kzg_amd_test_g1_decompress.argtypes = [P, U8P, C.c_int, C.c_int, P, P]
-    lib.eth_kzg_amd_test_field_mul.argtypes = [P, U8P, U8P, P, C.c_int, C.c_int]
+    lib.eth_kzg_amd_das_context_new_on_devices.restype = P
+    lib.eth_kzg_amd_das_context_new_on_devices.argtypes = [C.c_bool, P, U64, C.c_double, C.POINTER(CResult)]
+    lib.eth_kzg_amd_context_devices.restype = U64
+    lib.eth_kzg_amd_context_devices.argtypes = [P, P, U64]
+    lib.eth_kzg_amd_abi_version.restype = C.c_int
+    lib.eth_kzg_amd_window_count.argtypes = [P]
+    lib.eth_kzg_amd_glv_table.argtypes = [P]
+    # the stage-level test hooks exist in libc_eth_kzg_hooks.so only (what tests/ loads through ETH_KZG_AMD_LIB); the product
+    # library does not export them
+    for name, args in {
+        "eth_kzg_amd_test_fr_ntt4096": [P, U8P, P, C.c_int],
+        "eth_kzg_amd_test_g1_fft128": [P, U8P, P, C.c_int, C.c_int],
+        "eth_kzg_amd_test_fixed_msm": [P, U8P, C.c_int, P],
+        "eth_kzg_amd_test_g1_decompress": [P, U8P, C.c_int, C.c_int, P, P],
+        "eth_kzg_amd_test_field_mul": [P, U8P, U8P, P, C.c_int, C.c_int],
+    }.items():
+        if hasattr(lib, name):
+            getattr(lib, name).argtypes = args
     _lib = lib
     return lib
 
@@ -218,8 +233,10 @@ class DASContext:
 
     device_index = 0
 
-    def __init__(self, use_precomp=True, device=None, wait_tables=True, table_budget_gb=None):
-        """table_budget_gb: HBM for the two window tables together (None: $ETH_KZG_AMD_TABLE_GB or the library's default of 108 GB;
+    def __init__(self, use_precomp=True, device=None, wait_tables=True, table_budget_gb=None, devices=None):
+        """devices: a device LIST -- one engine per listed GPU behind this one context (eth_kzg_amd_das_context_new_on_devices:
+        single calls go to the least-loaded device, batched calls are cut into contiguous slices); ordinals may repeat.
+        table_budget_gb: HBM for the two window tables together (None: $ETH_KZG_AMD_TABLE_GB or the library's default of 108 GB;
         a negative number: whatever the HBM holds) -- given, the context is made by eth_kzg_amd_das_context_try_new, which reports a
         failure as KzgError instead of aborting the process.
         wait_tables: the C entry point returns as soon as the start tables are up (progressive start); by default this
@@ -227,7 +244,17 @@ class DASContext:
         use the context at once (results are identical on every table)."""
         self.device_index = int(device) if device is not None else int(os.environ.get("ETH_KZG_AMD_DEVICE", "0"))
         self._lib = load_library()
-        if table_budget_gb is not None:
+        if devices is not None:
+            devs = np.array([int(d) for d in devices], dtype=np.int32)
+            self.device_index = int(devs[0]) if len(devs) else 0
+            res = CResult()
+            self._ctx = C.c_void_p(self._lib.eth_kzg_amd_das_context_new_on_devices(
+                bool(use_precomp), _vp(devs) if len(devs) else None, len(devs), float(table_budget_gb or 0.0), C.byref(res)))
+            if not self._ctx.value:
+                msg = C.cast(res.error_msg, C.c_char_p).value.decode() if res.error_msg else "unknown"
+                self._lib.eth_kzg_free_error_message(res.error_msg)
+                raise KzgError(msg)
+        elif table_budget_gb is not None:
             res = CResult()
             self._ctx = C.c_void_p(self._lib.eth_kzg_amd_das_context_try_new(bool(use_precomp), self.device_index, float(table_budget_gb), C.byref(res)))
             if not self._ctx.value:
@@ -242,6 +269,12 @@ class DASContext:
             raise RuntimeError("eth_kzg_das_context_new returned NULL")
         if wait_tables:
             self.tables_ready(-1)
+
+    def devices(self):
+        """The context's device list (eth_kzg_amd_context_devices)."""
+        out = np.zeros(64, dtype=np.int32)
+        n = int(self._lib.eth_kzg_amd_context_devices(self._ctx, _vp(out), 64))
+        return [int(d) for d in out[:n]]
 
     def tables_ready(self, wait_ms=0):
         """1 = final window tables in use, 0 = still on the start tables, 2 = the wide build failed (stays on what it has)."""
@@ -618,6 +651,10 @@ class DASContext:
 
     def window_bits(self):
         return int(self._lib.eth_kzg_amd_window_bits(self._ctx))
+
+    def window_count(self):
+        """Windows per 128-bit GLV half of the FK20 table in use (gathered additions per base = twice that)."""
+        return int(self._lib.eth_kzg_amd_window_count(self._ctx))
 
     def linmap_info(self):
         """(constant multiplications, additions, doublings per blob, launches per call) of the compiled G1 linear map."""

@@ -213,6 +213,7 @@ Engine::Engine(bool use_precomp, int device, const Engine* primary, double table
     // every environment knob is read here, once (knobs.hpp); the auxiliary engines of a context copy their context's values
     knobs_ = primary ? primary->knobs_ : Knobs::from_env();
     if (knobs_.serial_lanes) max_lanes_ = knobs_.serial_lanes;
+    if (knobs_.device_batch_max) device_batch_max_ = ((knobs_.device_batch_max + 63) / 64) * 64;
     if (use_precomp) {
         // default: the widest GLV table inside the budget (108 GB: nine windows, 71 GB, 18 gathered additions per base; the commitment table likewise, 35 GB), see build_final_tables
         if (launch::glv_width_supported(knobs_.glv_window)) want_glv_c_ = knobs_.glv_window;
@@ -227,6 +228,18 @@ Engine::Engine(bool use_precomp, int device, const Engine* primary, double table
     // map in its Karatsuba compilation is flat (5 - 8 blobs: 2.5 - 2.7 ms with the flat MSM) -- round 3's cross-over, against the
     // tuned program, was 8
     circ_max_ = 4;
+    // Everything below can throw (HIPCK, the SRS checks).  A constructor that throws runs no destructor: teardown() frees what
+    // was built so far -- streams, events, device buffers, the published start tables' references -- and the exception goes on to
+    // eth_kzg_amd_das_context_try_new, which promises NULL + a message and never a dead process.
+    try {
+        construct();
+    } catch (...) {
+        teardown();
+        throw;
+    }
+}
+
+void Engine::construct() {
     const bool trace = knobs_.trace;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
@@ -281,6 +294,8 @@ Engine::Engine(bool use_precomp, int device, const Engine* primary, double table
     init_verifier();
     HIPCK(hipStreamSynchronize(stream_));
     lap("verifier (G2 lines, cosets)");
+    if (knobs_.fault && !strcmp(knobs_.fault, "constructor") && !primary_) throw std::runtime_error("injected fault (ETH_KZG_AMD_FAULT=constructor)");
+    start_builder();  // last: nothing after it can throw
 }
 
 // ROCm maps a process's streams onto four hardware queues per priority level, and which streams end up sharing a queue depends
@@ -333,8 +348,12 @@ void Engine::settle_streams() {
     for (hipStream_t r : rejected) hipStreamDestroy(r);
 }
 
-Engine::~Engine() {
-    hipSetDevice(dev_);
+Engine::~Engine() { teardown(); }
+
+// Frees whatever the engine holds; every member it looks at is null / empty until it has been created, so it also serves a
+// constructor that failed half-way.
+void Engine::teardown() noexcept {
+    (void)hipSetDevice(dev_);
     lanes_.clear();
     stop_builder();  // an unfinished build of the wide tables is abandoned (within one 2 GB piece)
     {

@@ -230,10 +230,14 @@ public:
     void table_build_info(double* out4) const;
     void stop_builder();  // abandon an unfinished build of the wide tables and join the helper thread
     size_t table_bytes() const { return table_view(TAB_FK).bytes + table_view(TAB_SRS).bytes; }
-    int window_bits() const { return table_view(TAB_FK).c; }  // of the FK20 table in use
+    int window_bits() const { return table_view(TAB_FK).c; }  // NOMINAL width of the FK20 table in use: its windows are ceil(128 / c) of mixed widths (launch.hpp)
+    int window_count() const { const int c = window_bits(); return c > 0 ? (128 + c - 1) / c : 0; }  // windows per GLV half = gathered additions per base / 2
     const int* linmap_info() const { return slp_info_; }
 
 private:
+    void construct();           // the constructor's body; a throw is followed by teardown()
+    void teardown() noexcept;   // the destructor's body
+    void start_builder();       // progressive start: registers the engine and starts the table builder thread (engine_tables.hip)
     void init_constants();
     void init_linmap(const Fr8* w8192_mont);  // host copy of omega_8192^k
     void init_srs();
@@ -273,7 +277,7 @@ private:
     int recover_batch_to_coeffs(int R, const uint64_t* n_cells, const uint8_t* const* const* cells,
                                 const uint64_t* const* cell_indices, int* st_out);
     void ensure_workspace(int n);  // work_[0]; also makes stream_ wait for the last asynchronous call that used it
-    void ensure_workspace(Work& w, int n);
+    void ensure_workspace(Work& w, int n, bool release = false);
     void ensure_staging(Work& w, int n);
     void run_proofs_from_coeffs(int n, uint8_t* d_proofs, hipStream_t st) { run_proofs_from_coeffs(work_[0], n, d_proofs, st); }
     // msm_cut > 0 (host-pointer path, scalars precomputed): the MSM stage in two launches around the cut -- PROOFS_HEAD issues the
@@ -322,6 +326,7 @@ private:
     bool progressive_build_ = false;  // the wide tables are built next to callers on the start tables: the builder leaves room on the GPU
     hipStream_t build_stream_ = nullptr;
     int wave_slots_ = 2048;  // CUs x 4 SIMDs x 2 waves: what one round of a ~240-VGPR point kernel occupies
+    int device_batch_max_ = 4096;  // a device-resident prover call runs as sub-batches of at most this many blobs (ETH_KZG_AMD_DEVICE_BATCH_MAX)
     int msm_chunks_ = -1;    // -1: pick per launch (launch_msm); otherwise forced by ETH_KZG_AMD_MSM_CHUNKS
     hipStream_t stream_ = nullptr;
     std::recursive_mutex mu_;  // the verification / recovery / EIP-4844 / commitment paths and work_[0]: one call at a time

@@ -22,12 +22,18 @@ extern "C" const unsigned char kzg_srs_end[];
 
 namespace kzg {
 
+// a failed HIP call; `code` lets a caller tell an exhausted HBM (retry with a smaller sub-batch) from a broken device
+struct HipError : std::runtime_error {
+    hipError_t code;
+    HipError(hipError_t c, const std::string& what) : std::runtime_error(what), code(c) {}
+    bool out_of_memory() const { return code == hipErrorOutOfMemory || code == hipErrorMemoryAllocation; }
+};
 #define HIPCK(x)                                                                                              \
     do {                                                                                                      \
         hipError_t e_ = (x);                                                                                  \
         if (e_ != hipSuccess)                                                                                 \
-            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " + __FILE__ + ":" + \
-                                     std::to_string(__LINE__));                                               \
+            throw HipError(e_, std::string("HIP error: ") + hipGetErrorString(e_) + " at " + __FILE__ + ":" + \
+                                   std::to_string(__LINE__));                                                 \
     } while (0)
 
 // batches up to this many lanes (blobs rounded up to 64) use the direct 8 x 16 G1 transforms (k_g1fft.hip)

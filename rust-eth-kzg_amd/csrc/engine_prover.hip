@@ -46,13 +46,17 @@ void Engine::ensure_workspace(int n) {
     ensure_workspace(work_[0], n);
     HIPCK(hipStreamWaitEvent(stream_, work_[0].done, 0));
 }
-void Engine::ensure_workspace(Work& w, int n) {
-    if (n <= w.cap) return;
+void Engine::ensure_workspace(Work& w, int n, bool release) {
+    if (n <= w.cap && !release) return;
     int cap = ((n + 63) / 64) * 64;
     void** ptrs[] = {&w.coeffs, &w.canon, &w.scalars, &w.X, (void**)&w.status};
     for (void** p : ptrs)
         if (*p) { HIPCK(hipFree(*p)); *p = nullptr; }
     w.cap = 0;
+    if (release) {  // give the set's memory back (a sub-batch did not fit: the next attempt is half the size)
+        if (w.slp_arena) { HIPCK(hipFree(w.slp_arena)); w.slp_arena = nullptr; w.slp_arena_bytes = 0; }
+        return;
+    }
     HIPCK(hipMalloc(&w.coeffs, (size_t)cap * N_BLOB * sizeof(Fr)));
     if (&w == &work_[0]) HIPCK(hipMalloc(&w.canon, (size_t)cap * N_BLOB * sizeof(Fr)));  // canonical coefficients: commitment / EIP-4844 paths only
     HIPCK(hipMalloc(&w.scalars, (size_t)cap * 128 * 64 * sizeof(Fr)));
@@ -166,7 +170,7 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         prog = &slp_program(which);
         const size_t need = (size_t)prog->n_slots * bp * launch::SIZEOF_JACQ;
         if (need > w.slp_arena_bytes) {
-            if (w.slp_arena) { HIPCK(hipStreamSynchronize(st)); HIPCK(hipFree(w.slp_arena)); w.slp_arena = nullptr; }
+            if (w.slp_arena) { HIPCK(hipStreamSynchronize(st)); HIPCK(hipFree(w.slp_arena)); w.slp_arena = nullptr; w.slp_arena_bytes = 0; }
             HIPCK(hipMalloc(&w.slp_arena, need));
             w.slp_arena_bytes = need;
         }
@@ -263,8 +267,27 @@ int Engine::compute_cells_and_kzg_proofs_device(int n, const uint8_t* d_blobs, u
             HIPCK(hipEventRecord(w.ev_in, nullptr));
             HIPCK(hipStreamWaitEvent(st, w.ev_in, 0));
         }
-        enqueue_compute(w, n, d_blobs, d_cells, d_proofs, st, nullptr);
-        if (h_status) HIPCK(hipMemcpyAsync(h_status, w.status, n * sizeof(int), hipMemcpyDeviceToHost, st));
+        // A batch larger than the scratch the HBM still holds beside the window tables (0.6 MB per blob: coefficients, MSM scalars, the
+        // linear map's arena) runs as sub-batches on the same stream: at most device_batch_max_ blobs each (4096: twice what fills the
+        // chip), and half of that again whenever an allocation of the work set fails -- down to 64 blobs, below which the failure is the
+        // caller's.  Stages already enqueued for a sub-batch that is then retried smaller are recomputed (same outputs).
+        int sub = std::min(n, device_batch_max_);
+        for (int b0 = 0; b0 < n;) {
+            const int nb = std::min(sub, n - b0);
+            try {
+                enqueue_compute(w, nb, d_blobs + (size_t)b0 * BYTES_PER_BLOB, d_cells ? d_cells + (size_t)b0 * N_CELLS * BYTES_PER_CELL : nullptr,
+                                d_proofs ? d_proofs + (size_t)b0 * N_CELLS * 48 : nullptr, st, nullptr);
+            } catch (const HipError& e) {
+                if (!e.out_of_memory() || sub <= 64) throw;
+                (void)hipGetLastError();
+                HIPCK(hipStreamSynchronize(st));  // kernels of the failed attempt may still read the set's buffers
+                ensure_workspace(w, 0, /*release=*/true);
+                sub = std::max(64, ((sub / 2 + 63) / 64) * 64);
+                continue;
+            }
+            if (h_status) HIPCK(hipMemcpyAsync(h_status + b0, w.status, nb * sizeof(int), hipMemcpyDeviceToHost, st));
+            b0 += nb;
+        }
         HIPCK(hipEventRecord(w.done, st));
         HIPCK(hipGetLastError());
         release_work(w);

@@ -7,7 +7,16 @@ namespace kzg {
 
 static std::mutex g_tables_mu;  // the registry below: held for look-ups and inserts only, never across a build
 static std::map<std::tuple<int, int, int>, std::weak_ptr<Engine::SharedTable>> g_tables;  // (device, kind, width)
-static std::mutex g_build_mu;   // one builder of WIDE tables at a time per process (the helper threads of several contexts queue here)
+// one builder of WIDE tables at a time per GPU (the helper threads of several contexts of one device queue here; the contexts of a
+// device list -- c_api.cpp, ETH_KZG_AMD_DEVICES -- build side by side, one per device)
+static std::mutex& build_mutex_of(int device) {
+    static std::mutex reg;
+    static std::map<int, std::unique_ptr<std::mutex>> mu;
+    std::lock_guard<std::mutex> lk(reg);
+    auto& m = mu[device];
+    if (!m) m.reset(new std::mutex);
+    return *m;
+}
 
 
 // Fill a table the caller has just created: pieces are allocated a chunk of groups ahead of the builder kernels, every
@@ -218,13 +227,19 @@ void Engine::init_fk20() {
         publish(TAB_FK, fk, nullptr);
         publish(TAB_SRS, srs, nullptr);
     }
+    progressive_build_ = true;  // start_builder(), the constructor's LAST step, starts the helper thread
+}
+
+// The helper thread of a progressive start.  Called when everything else of the context stands (a constructor that
+// throws after this point would unwind a joinable std::thread -- std::terminate -- and leave `this` in g_engines).
+void Engine::start_builder() {
+    if (!progressive_build_ || primary_) return;
     {
         std::lock_guard<std::mutex> lk(g_engines_mu);
         static bool registered = false;
         if (!registered) { atexit(stop_all_builders_at_exit); registered = true; }
         g_engines.push_back(this);
     }
-    progressive_build_ = true;
     builder_ = std::thread([this] {
         (void)hipSetDevice(dev_);
         build_final_tables();
@@ -289,7 +304,7 @@ void Engine::build_final_tables() {
         const double p0 = trace_clock_ms();
         launch::preload_code_objects();  // before the first piece is allocated: no caller's first launch of a kernel waits behind a hipMalloc
         if (knobs_.trace) fprintf(stderr, "[context] @%.0f ms: code objects preloaded in %.0f ms\n", trace_clock_ms(), trace_clock_ms() - p0);
-        // Another context of the process may be filling the wide tables right now (its helper thread holds g_build_mu until it is
+        // Another context of the process may be filling the wide tables right now (its helper thread holds the device's build mutex until it is
         // done): this context uses their ready groups meanwhile instead of sitting on its start tables for the other's build.
         auto attach_growing = [&] {
             for (TableSel sel : {TAB_SRS, TAB_FK}) {
@@ -306,7 +321,7 @@ void Engine::build_final_tables() {
                 if (growing && growing->n_groups == cur.main->n_groups) publish(sel, cur.main, growing);
             }
         };
-        std::unique_lock<std::mutex> lk(g_build_mu, std::defer_lock);  // one builder of wide tables at a time per process
+        std::unique_lock<std::mutex> lk(build_mutex_of(dev_), std::defer_lock);  // one builder of wide tables at a time per GPU
         while (!lk.try_lock()) {
             attach_growing();
             if (cancel_build_.load()) throw BuildCancelled{};

@@ -313,4 +313,93 @@ private:
     std::vector<std::shared_ptr<T>> retired_;
 };
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// A context over a DEVICE LIST (c_api.cpp: ETH_KZG_AMD_DEVICES / eth_kzg_amd_das_context_new_on_devices): one engine per GPU behind
+// the reference's unchanged symbols.  The reference's hosts create ONE context and call it from many threads
+// (bindings/node/src/lib.rs:35,75; bindings/c/src/lib.rs:79-92); this is what spreads those calls over the node.
+//   DevicePicker     single calls: the device with the least work in flight (weights = units of the call: blobs, cells), ties broken
+//                    round-robin so that equal loads do not all land on device 0; the ticket gives the weight back when the call ends
+//   fan_out_slices   batched calls: contiguous slices [n d / D, n (d + 1) / D) -- the split of rust-eth-kzg_amd/sharding.py and of
+//                    eth_kzg_amd_compute_cells_and_kzg_proofs_batch_multi --, one thread per non-empty slice (slice 0 on the caller),
+//                    every slice runs to its end whatever the others do, the error of the LOWEST failing device is the call's
+class DevicePicker {
+public:
+    explicit DevicePicker(int n_devices) : load_(n_devices > 0 ? n_devices : 1) {
+        for (auto& l : load_) l.store(0, std::memory_order_relaxed);
+    }
+    class Ticket {
+    public:
+        Ticket(DevicePicker* p, int device, uint64_t weight) : p_(p), device_(device), weight_(weight) {}
+        Ticket(Ticket&& o) noexcept : p_(o.p_), device_(o.device_), weight_(o.weight_) { o.p_ = nullptr; }
+        Ticket(const Ticket&) = delete;
+        Ticket& operator=(const Ticket&) = delete;
+        ~Ticket() { if (p_) p_->load_[device_].fetch_sub(weight_, std::memory_order_acq_rel); }
+        int device() const { return device_; }
+    private:
+        DevicePicker* p_;
+        int device_;
+        uint64_t weight_;
+    };
+    Ticket pick(uint64_t weight = 1) {
+        const int n = (int)load_.size();
+        if (n == 1) { load_[0].fetch_add(weight, std::memory_order_acq_rel); return Ticket(this, 0, weight); }
+        // Two callers may read the same minimum and pick the same device: the loads are a hint, not a reservation -- the engines
+        // serialise or overlap calls themselves (lanes, work sets).  The rotating start spreads callers that see equal loads.
+        const unsigned start = rr_.fetch_add(1, std::memory_order_relaxed);
+        int best = (int)(start % (unsigned)n);
+        uint64_t best_load = load_[best].load(std::memory_order_acquire);
+        for (int k = 1; k < n && best_load != 0; k++) {
+            const int d = (int)((start + (unsigned)k) % (unsigned)n);
+            const uint64_t l = load_[d].load(std::memory_order_acquire);
+            if (l < best_load) { best = d; best_load = l; }
+        }
+        load_[best].fetch_add(weight, std::memory_order_acq_rel);
+        return Ticket(this, best, weight);
+    }
+    uint64_t load(int device) const { return load_[device].load(std::memory_order_acquire); }
+    int devices() const { return (int)load_.size(); }
+
+private:
+    std::vector<std::atomic<uint64_t>> load_;
+    std::atomic<unsigned> rr_{0};
+};
+
+inline uint64_t slice_begin(uint64_t n, int n_devices, int d) { return (uint64_t)((unsigned __int128)n * (unsigned)d / (unsigned)n_devices); }
+
+// run(device, lo, hi) -> "" on success, else the error text.  Returns {-1, ""} or {lowest failing device, its text}.
+// An exception out of run() is that slice's error (never out of a thread).
+template <class F>
+inline std::pair<int, std::string> fan_out_slices(int n_devices, uint64_t n, F run) {
+    if (n_devices < 1) n_devices = 1;
+    std::vector<std::string> why((size_t)n_devices);
+    std::vector<char> failed((size_t)n_devices, 0);
+    auto guarded = [&](int d, uint64_t lo, uint64_t hi) {
+        try {
+            why[d] = run(d, lo, hi);
+        } catch (const std::exception& e) {
+            why[d] = std::string("exception: ") + e.what();
+        } catch (...) {
+            why[d] = "unknown exception";
+        }
+        failed[d] = !why[d].empty();
+    };
+    std::vector<std::thread> th;
+    int first = -1;
+    for (int d = 0; d < n_devices; d++) {
+        const uint64_t lo = slice_begin(n, n_devices, d), hi = slice_begin(n, n_devices, d + 1);
+        if (lo == hi) continue;
+        if (first < 0) { first = d; continue; }  // the caller's own slice: run last, after the helpers have been started
+        try {
+            th.emplace_back(guarded, d, lo, hi);
+        } catch (const std::exception& e) {  // no thread to be had: the slice runs on the caller
+            guarded(d, lo, hi);
+        }
+    }
+    if (first >= 0) guarded(first, slice_begin(n, n_devices, first), slice_begin(n, n_devices, first + 1));
+    for (auto& t : th) t.join();
+    for (int d = 0; d < n_devices; d++)
+        if (failed[d]) return {d, why[d]};
+    return {-1, std::string()};
+}
+
 }  // namespace kzg

@@ -241,6 +241,7 @@ __global__ void k_fk20_gather_bases(const JacQ* __restrict__ X, G1Affine* __rest
     int q = (int)(__brev((unsigned)j) >> 25);
     bases[idx] = to_affine(jac_from_jacq(X[q * 64 + i]));
 }
+#ifdef KZG_TEST_HOOKS  // stage-level test kernels: compiled into libc_eth_kzg_hooks.so only (csrc/Makefile)
 __global__ void k_test_load_points(const uint8_t* in, JacQ* X, int n_lanes, int stride) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 128 * n_lanes) return;
@@ -256,6 +257,7 @@ __global__ void k_test_recompress(const G1Affine* in, uint8_t* out, int n) {
     g1_compress(buf, in[i]);
     for (int k = 0; k < 48; k++) out[(size_t)i * 48 + k] = buf[k];
 }
+#endif
 
 // One wave that stays resident for a fixed wall-clock time: the engine's probe of which streams share a hardware queue.
 __global__ void k_spin(uint64_t ticks) {
@@ -320,9 +322,11 @@ void g1_subgroup2(const void* pts0, int* status0, int n0, const void* pts1, int*
 }
 void fk20_srs_vectors(const void* srs, void* X, hipStream_t st) { k_fk20_srs_vectors<<<128 * 64 / 256, 256, 0, st>>>((const G1Affine*)srs, (JacQ*)X); }
 void fk20_gather_bases(const void* X, void* bases, hipStream_t st) { k_fk20_gather_bases<<<128 * 64 / 256, 256, 0, st>>>((const JacQ*)X, (G1Affine*)bases); }
+#ifdef KZG_TEST_HOOKS
 void test_load_points(const uint8_t* in, void* X, int n_lanes, int stride, hipStream_t st) {
     k_test_load_points<<<(128 * n_lanes + 255) / 256, 256, 0, st>>>(in, (JacQ*)X, n_lanes, stride);
 }
 void test_recompress(const void* pts, uint8_t* out, int n, hipStream_t st) { k_test_recompress<<<(n + 63) / 64, 64, 0, st>>>((const G1Affine*)pts, out, n); }
+#endif
 }  // namespace launch
 }  // namespace kzg

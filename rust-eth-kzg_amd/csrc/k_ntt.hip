@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256) void k_fk20_scalars(const Fr* __restrict__ coe
     }
 }
 
+#ifdef KZG_TEST_HOOKS  // stage-level test kernels: compiled into libc_eth_kzg_hooks.so only (csrc/Makefile)
 __global__ __launch_bounds__(1024) void k_test_ntt4096(const uint8_t* in, uint8_t* out, const Fr29* w29, NttConsts K, int inverse_dit) {
     extern __shared__ uint32_t s[];
     for (int e = threadIdx.x; e < N_BLOB; e += 1024) lds_store(s, e, fr29_from_plain(load_fr_be(in + 32 * e)));  // plain values (see NttConsts)
@@ -256,6 +257,8 @@ __global__ void k_test_field_mul(const uint8_t* a, const uint8_t* b, uint8_t* ou
     }
 }
 
+#endif
+
 namespace launch {
 // the code object of this translation unit is loaded now (HIP loads a code object on the first launch of one of its kernels, and
 // that load is an allocation: it would wait behind a table piece the builder thread is allocating)
@@ -269,7 +272,9 @@ constexpr size_t LDS_NTT29 = (size_t)N_BLOB * RL * 4;  // 144 KiB: one 4096-poin
 void init_attributes() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_blob_to_coeffs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_NTT29);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_coeffs_to_cells), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_NTT29);
+#ifdef KZG_TEST_HOOKS
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_test_ntt4096), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_NTT29);
+#endif
 }
 // host-side constants of the 9 x 29-bit form from the engine's saturated Montgomery values (Y = y 2^256 mod r, canonical)
 // X = y 2^261 mod r = 32 Y mod r: in Fr arithmetic, the Montgomery form of (y * 32) read as a plain integer
@@ -309,6 +314,7 @@ void fk20_scalars(int n, const void* coeffs, void* scalars, const void* w29, con
     for (int i = 0; i < 3; i++) sh.p[i] = fr29_mont_of(seg_shifts[i]);
     k_fk20_scalars<<<n * 16, 256, 0, st>>>((const Fr*)coeffs, (Fr*)scalars, (const Fr29*)w29, fr29_int32x_of(inv128), n, segs, sh);
 }
+#ifdef KZG_TEST_HOOKS
 void test_ntt4096(const uint8_t* in, uint8_t* out, const void* w29, const Fr8& n_inv, int inverse_dit, hipStream_t st) {
     k_test_ntt4096<<<1, 1024, LDS_NTT29, st>>>(in, out, (const Fr29*)w29, ntt_consts(n_inv), inverse_dit);
 }
@@ -319,5 +325,6 @@ void test_field_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, int n, int
     if (is_fp) k_test_field_mul<Fp><<<(n + 63) / 64, 64, 0, st>>>(a, b, out, n);
     else k_test_field_mul<Fr><<<(n + 63) / 64, 64, 0, st>>>(a, b, out, n);
 }
+#endif
 }  // namespace launch
 }  // namespace kzg

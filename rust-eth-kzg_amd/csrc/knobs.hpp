@@ -5,6 +5,8 @@
 //
 //   for the host application
 //   ETH_KZG_AMD_DEVICE=<n>          GPU ordinal of eth_kzg_das_context_new (default 0)
+//   ETH_KZG_AMD_DEVICES=<a,b,..>|all the device LIST of eth_kzg_das_context_new: one engine per listed GPU behind the one context pointer; single
+//                                   calls go to the least-loaded device, batched calls are cut into contiguous slices (c_api.cpp)
 //   ETH_KZG_AMD_TABLE_GB=<gb>|max   HBM for the two window tables together (default 108 = the nine-window GLV tables: 71 GB for FK20,
 //                                   35 GB for commitments; max = whatever the HBM holds: eight windows of 16 bits for FK20, 242 GB in all)
 //   ETH_KZG_AMD_GLV_WINDOW=<w>      exactly this GLV table width for FK20 (16, 15, 14, 12, 8)
@@ -20,16 +22,21 @@
 //   ETH_KZG_AMD_VM_SEARCH=0         many-verification: re-check every problem of a failed pass instead of searching
 //   ETH_KZG_AMD_VM_FOLD=0           many-verification: one pairing per problem instead of one folded check per pass
 //   ETH_KZG_AMD_VERIFY_COMBINE=0    concurrent single verifications are not combined into passes
+//   ETH_KZG_AMD_DEVICE_BATCH_MAX=<n> a device-resident prover call is cut into sub-batches of at most n blobs (default 4096)
+//   ETH_KZG_AMD_FAULT=constructor   the context's constructor throws after its last step but one (tests: try_new returns NULL + a
+//                                   message, nothing leaks, the next context works)
 //   ETH_KZG_AMD_COOP_POINTS=<n>     largest launch that takes the several-lanes-per-point kernels (0: never; process-wide, read
 //                                   once by launch::coop_points_max: launch geometry is decided outside any context)
 #pragma once
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace kzg {
 
 struct Knobs {
     int device = 0;
+    std::vector<int> devices;  // ETH_KZG_AMD_DEVICES: the device list of eth_kzg_das_context_new; {-1} = all GPUs of the node
     double table_budget_gb = 0;  // 0: the engine's default; < 0: what the HBM holds
     int glv_window = 0;
     bool progressive = true;
@@ -38,6 +45,8 @@ struct Knobs {
     bool trace = false;
     int msm_chunks = -1, slp_program = -1, pip_shift_min = 0;
     bool vm_search = true, vm_fold = true, verify_combine = true;
+    const char* fault = nullptr;  // ETH_KZG_AMD_FAULT
+    int device_batch_max = 0;
 
     static Knobs from_env() {
         Knobs k;
@@ -48,6 +57,18 @@ struct Knobs {
             if (const char* s = getenv(name)) out = atoi(s) != 0;
         };
         num("ETH_KZG_AMD_DEVICE", 0, 4095, k.device);
+        if (const char* s = getenv("ETH_KZG_AMD_DEVICES")) {
+            if (!strcmp(s, "all") || !strcmp(s, "ALL")) k.devices.push_back(-1);
+            else
+                for (const char* p = s; *p;) {  // "0,1,2": ordinals, repeats allowed (two engines on one GPU: the one-GPU test of the fan-out)
+                    char* end = nullptr;
+                    const long v = strtol(p, &end, 10);
+                    if (end == p) break;
+                    if (v >= 0 && v <= 4095 && k.devices.size() < 64) k.devices.push_back((int)v);
+                    p = *end == ',' ? end + 1 : end;
+                    if (*end && *end != ',') break;
+                }
+        }
         if (const char* s = getenv("ETH_KZG_AMD_TABLE_GB")) {
             if (!strcmp(s, "max") || !strcmp(s, "MAX")) k.table_budget_gb = -1;
             else if (atof(s) > 0) k.table_budget_gb = atof(s);
@@ -63,6 +84,8 @@ struct Knobs {
         flag("ETH_KZG_AMD_VM_SEARCH", k.vm_search);
         flag("ETH_KZG_AMD_VM_FOLD", k.vm_fold);
         flag("ETH_KZG_AMD_VERIFY_COMBINE", k.verify_combine);
+        k.fault = getenv("ETH_KZG_AMD_FAULT");
+        num("ETH_KZG_AMD_DEVICE_BATCH_MAX", 64, 1 << 20, k.device_batch_max);
         return k;
     }
 };

@@ -6,7 +6,7 @@
 // Reference analogue: the per-blob independence that maybe_rayon's par_iter exploits (crates/eip7594/src/prover.rs,
 // crates/maybe_rayon), stretched over devices.
 #include "../../include/c_eth_kzg.h"
-#include "engine.hpp"
+#include "c_ctx.hpp"
 
 #include <rccl/rccl.h>
 
@@ -19,10 +19,6 @@
 #include <string>
 #include <thread>
 #include <vector>
-
-struct DASContext {
-    kzg::Engine* engine;
-};
 
 namespace {
 
@@ -193,35 +189,27 @@ int eth_kzg_amd_device_count(void) {
 CResult eth_kzg_amd_compute_cells_and_kzg_proofs_batch_multi(const DASContext* const* contexts, uint64_t n_contexts, uint64_t n,
                                                              const uint8_t* const* blobs, uint8_t* const* const* out_cells,
                                                              uint8_t* const* const* out_proofs, int32_t* status) {
-    if (n_contexts == 0 || !contexts) return err("InvalidInput");
+    if (n_contexts == 0 || n_contexts > 64 || !contexts || n > (1u << 24)) return err("InvalidInput");
     for (uint64_t d = 0; d < n_contexts; d++)
         if (!contexts[d] || !contexts[d]->engine) abort();
     if (n == 0) return ok();
-    // contiguous slices, sizes differing by at most one blob (rust-eth-kzg_amd/sharding.py: shard_bounds)
-    std::vector<uint64_t> lo(n_contexts + 1);
-    for (uint64_t d = 0; d <= n_contexts; d++) lo[d] = d * n / n_contexts;
-    std::vector<int> rc(n_contexts, 0);
-    std::vector<std::string> why(n_contexts);
-    std::vector<std::vector<int>> st(n_contexts);
-    std::vector<std::thread> th;
-    for (uint64_t d = 0; d < n_contexts; d++) {
-        const uint64_t b0 = lo[d], nb = lo[d + 1] - lo[d];
-        if (!nb) continue;
-        st[d].assign(nb, 0);
-        th.emplace_back([&, d, b0, nb] {
+    if (!blobs) return err("InvalidInput");
+    try {
+        // contiguous slices, sizes differing by at most one blob (rust-eth-kzg_amd/sharding.py: shard_bounds; host_sync.hpp: the
+        // protocol a context over a device list uses for every batched entry point)
+        std::vector<int> st(n);
+        const auto r = kzg::fan_out_slices((int)n_contexts, n, [&](int d, uint64_t lo, uint64_t hi) -> std::string {
             kzg::Engine* e = contexts[d]->engine;
-            rc[d] = e->compute_cells_and_kzg_proofs_host((int)nb, blobs + b0, out_cells ? out_cells + b0 : nullptr,
-                                                         out_proofs ? out_proofs + b0 : nullptr, st[d].data());
-            if (rc[d]) why[d] = e->last_error();
+            return e->compute_cells_and_kzg_proofs_host((int)(hi - lo), blobs + lo, out_cells ? out_cells + lo : nullptr,
+                                                        out_proofs ? out_proofs + lo : nullptr, st.data() + lo)
+                       ? (e->last_error().empty() ? std::string("unknown failure") : e->last_error()) : std::string();
         });
+        if (r.first >= 0) return err("DeviceError(device " + std::to_string(contexts[r.first]->engine->device()) + ": " + r.second + ")");
+        if (status) for (uint64_t i = 0; i < n; i++) status[i] = st[i];
+        return ok();
+    } catch (const std::exception& ex) {
+        return err(std::string("DeviceError(") + ex.what() + ")");
     }
-    for (auto& t : th) t.join();
-    for (uint64_t d = 0; d < n_contexts; d++)
-        if (rc[d]) return err("DeviceError(device " + std::to_string(contexts[d]->engine->device()) + ": " + why[d] + ")");
-    if (status)
-        for (uint64_t d = 0; d < n_contexts; d++)
-            for (size_t i = 0; i < st[d].size(); i++) status[lo[d] + i] = st[d][i];
-    return ok();
 }
 
 }  // extern "C"

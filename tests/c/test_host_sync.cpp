@@ -7,6 +7,7 @@
 // The contract being defended: one context shared by many threads (bindings/node/src/lib.rs:35,92-299,
 // bindings/java/java_code/src/test/java/ethereum/cryptography/LibEthKZGTest.java:28-37).
 #include "host_sync.hpp"
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -140,6 +141,72 @@ static void builder(FakeContext& c, std::atomic<bool>& stop) {
     for (int spin = 0; spin < 4000 && c.view.reap([](const FakeTable&) { return true; }) > 0; spin++) nap(50);
 }
 
+// The protocol of a context over a device list (c_api.cpp): single calls take a DevicePicker ticket (least load, returned when the
+// call ends), batched calls fan out as contiguous slices with error fan-in -- many threads at once on one picker, fake devices that
+// sleep / fail / throw.  Checked: the loads return to zero, no device is starved or flooded, every index of every batch is served
+// exactly once by the device whose slice holds it, the reported error is the LOWEST failing device's, exceptions stay inside.
+static void device_list_protocol(int threads, int iters) {
+    constexpr int D = 4;
+    DevicePicker picker(D);
+    std::atomic<long> calls[D], in_flight[D], worst[D];
+    for (int d = 0; d < D; d++) { calls[d] = 0; in_flight[d] = 0; worst[d] = 0; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++)
+        th.emplace_back([&, t] {
+            std::mt19937 rng(99 + t);
+            for (int i = 0; i < iters; i++) {
+                if (rng() % 4) {  // a single call
+                    auto ticket = picker.pick(1 + rng() % 128);
+                    const int d = ticket.device();
+                    EXPECT(d >= 0 && d < D, "picker: device out of range");
+                    calls[d]++;
+                    const long now = ++in_flight[d];
+                    long w = worst[d].load();
+                    while (now > w && !worst[d].compare_exchange_weak(w, now)) {}
+                    nap(20 + (int)(rng() % 60));
+                    --in_flight[d];
+                } else {  // a batch of n items over the D devices, device `bad` failing, device `boom` throwing
+                    const uint64_t n = rng() % 23;
+                    const int bad = (int)(rng() % (D + 3)), boom = (int)(rng() % (D + 5));
+                    std::vector<std::atomic<int>> served(n ? n : 1);
+                    for (auto& a : served) a = 0;
+                    auto r = fan_out_slices(D, n, [&](int d, uint64_t lo, uint64_t hi) -> std::string {
+                        if (lo != slice_begin(n, D, d) || hi != slice_begin(n, D, d + 1)) return "wrong slice";
+                        for (uint64_t k = lo; k < hi; k++) served[k] += 1 + 16 * d;
+                        nap(10);
+                        if (d == boom) throw std::runtime_error("device lost");
+                        return d == bad ? "bad " + std::to_string(d) : std::string();
+                    });
+                    int expect = -1;
+                    for (int d = 0; d < D && expect < 0; d++)
+                        if ((d == bad || d == boom) && slice_begin(n, D, d) != slice_begin(n, D, d + 1)) expect = d;
+                    EXPECT(r.first == expect, "fan_out: not the lowest failing device");
+                    EXPECT((r.first < 0) == r.second.empty(), "fan_out: error text and verdict disagree");
+                    if (expect >= 0 && expect == boom) EXPECT(r.second.find("device lost") != std::string::npos, "fan_out: the exception's text is lost");
+                    for (uint64_t k = 0; k < n; k++) {
+                        int owner = 0;
+                        while (slice_begin(n, D, owner + 1) <= k) owner++;
+                        EXPECT(served[k].load() == 1 + 16 * owner, "fan_out: an item served twice, never, or by the wrong device");
+                    }
+                }
+            }
+        });
+    for (auto& t : th) t.join();
+    long total = 0, lo = 1L << 60, hi = 0;
+    for (int d = 0; d < D; d++) {
+        EXPECT(picker.load(d) == 0, "picker: load not returned");
+        total += calls[d].load();
+        lo = std::min(lo, calls[d].load());
+        hi = std::max(hi, calls[d].load());
+    }
+    EXPECT(lo * 2 >= hi, "picker: one device got more than twice the calls of another");
+    printf("device list: %ld single calls over %d devices (%ld .. %ld per device), deepest queue %ld %ld %ld %ld\n", total, D, lo, hi,
+           worst[0].load(), worst[1].load(), worst[2].load(), worst[3].load());
+    DevicePicker one(1);
+    { auto t = one.pick(5); EXPECT(t.device() == 0 && one.load(0) == 5, "picker: one device"); }
+    EXPECT(one.load(0) == 0, "picker: one device, load returned");
+}
+
 int main(int argc, char** argv) {
     const int threads = argc > 1 ? atoi(argv[1]) : 32, iters = argc > 2 ? atoi(argv[2]) : 300;
     {
@@ -196,6 +263,7 @@ int main(int argc, char** argv) {
         printf("passes %ld + %ld (failed %ld + %ld), lanes built %ld + %ld\n", shared[0].passes.load(), shared[1].passes.load(),
                shared[0].failed_passes.load(), shared[1].failed_passes.load(), shared[0].lanes_made.load(), shared[1].lanes_made.load());
     }
+    device_list_protocol(threads, iters);
     EXPECT(FakeTable::alive.load() == 0, "a table outlived its context");
     EXPECT(FakeTable::destroyed_elsewhere.load() == 0, "a table was destroyed on a caller's thread instead of the builder's");
     printf("tables destroyed on the builder thread: %d, elsewhere: %d\n", FakeTable::destroyed_on_builder.load(), FakeTable::destroyed_elsewhere.load());

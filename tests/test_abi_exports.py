@@ -25,10 +25,72 @@ def test_header_and_python_symbol_lists_agree():
     assert not set(kzg.TEST_HOOK_SYMBOLS) & set(_declared_symbols()), "test hooks leaked into the drop-in header"
 
 
-def test_library_exports_every_test_hook():
-    lib = ctypes.CDLL(kzg.LIB_PATH)
+def test_hooks_library_exports_every_test_hook_and_the_product_none():
+    """the stage-level hooks live in libc_eth_kzg_hooks.so (what tests/ loads); the product library -- .so and .a --
+    neither exports nor defines any eth_kzg_amd_test_* symbol, nor the test kernels behind them."""
+    assert os.path.exists(kzg.HOOKS_LIB_PATH), "make -C rust-eth-kzg_amd/csrc builds it next to the product library"
+    hooks = ctypes.CDLL(kzg.HOOKS_LIB_PATH)
     for name in _declared_symbols("c_eth_kzg_test_hooks.h"):
-        assert hasattr(lib, name), name
+        assert hasattr(hooks, name), name
+    for name in _declared_symbols():  # the hooks library is a superset: the whole drop-in ABI too
+        assert hasattr(hooks, name), name
+    for path in (kzg.LIB_PATH, os.path.join(ROOT, "rust-eth-kzg_amd", "libc_eth_kzg.a")):
+        flags = ["--defined-only"] + (["-D"] if path.endswith(".so") else [])
+        out = subprocess.run(["nm"] + flags + [path], capture_output=True, text=True).stdout
+        assert "eth_kzg_amd_test_" not in out and "k_test_" not in out and "test_fixed_msm" not in out, path
+
+
+def test_oversized_counts_are_rejected_not_crashed():
+    """the batched entry points bound their count BEFORE anything else is looked at -- n = 2^32 (which the
+    engine's `int` would have read as 0 and answered Ok with untouched outputs) is Err(InvalidInput).  No GPU needed: the check
+    comes first, so a NULL context is never reached.  The contract: malformed input is Err, never a crash
+    (bindings/c/src/lib.rs:272-280)."""
+    lib = kzg.load_library()
+    n = 1 << 32
+
+    def expect_invalid(res):
+        assert res.status == 1 and res.error_msg
+        msg = ctypes.string_at(res.error_msg).decode()
+        lib.eth_kzg_free_error_message(res.error_msg)
+        assert msg.startswith("InvalidInput"), msg
+
+    expect_invalid(lib.eth_kzg_amd_compute_cells_and_kzg_proofs_batch(None, n, None, None, None, None))
+    expect_invalid(lib.eth_kzg_amd_blob_to_kzg_commitment_batch(None, n, None, None, None))
+    expect_invalid(lib.eth_kzg_amd_recover_cells_and_proofs_batch(None, n, None, None, None, None, None, None, None))
+    expect_invalid(lib.eth_kzg_amd_verify_cell_kzg_proof_batch_many(None, n, None, None, None, None, None, None, None, None, None, None))
+    expect_invalid(lib.eth_kzg_amd_compute_cells_and_kzg_proofs_device(None, n, None, None, None, None, None))
+    expect_invalid(lib.eth_kzg_amd_blob_to_kzg_commitment_device(None, n, None, None, None, None))
+    expect_invalid(lib.eth_kzg_amd_recover_cells_and_proofs_device(None, (1 << 24) + 1, None, None, None, None, None, None))
+    expect_invalid(lib.eth_kzg_amd_compute_cells_and_kzg_proofs_batch_multi(None, 1, n, None, None, None, None))
+    assert lib.eth_kzg_amd_abi_version() == 6
+
+
+def test_device_list_constructor_reports_a_missing_gpu():
+    """eth_kzg_amd_das_context_new_on_devices never aborts: an empty list, an oversized one and a GPU that does not exist are NULL +
+    a message (in a child process, so that a regression that aborts fails the test instead of the run)."""
+    import sys
+    code = (
+        "import ctypes as C, importlib, sys\n"
+        "import numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "kzg = importlib.import_module('rust-eth-kzg_amd')\n"
+        "lib = kzg.load_library()\n"
+        "for devs in ([], [4094, 4095], list(range(65))):\n"
+        "    res = kzg.CResult()\n"
+        "    a = np.array(devs, dtype=np.int32)\n"
+        "    p = lib.eth_kzg_amd_das_context_new_on_devices(True, a.ctypes.data_as(C.c_void_p) if len(devs) else None, len(devs), 8.0, C.byref(res))\n"
+        "    assert not p and res.status == 1 and res.error_msg, devs\n"
+        "    msg = C.cast(res.error_msg, C.c_char_p).value.decode()\n"
+        "    lib.eth_kzg_free_error_message(res.error_msg)\n"
+        "    assert msg.startswith('ContextCreation('), msg\n"
+        "try:\n"
+        "    kzg.DASContext(use_precomp=True, devices=[4094, 4095])\n"
+        "    raise SystemExit('no error from the Python wrapper')\n"
+        "except kzg.KzgError as e:\n"
+        "    assert 'ContextCreation' in str(e)\n"
+        "print('device list ok')\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "device list ok" in out.stdout, out.stdout + out.stderr
 
 
 def _header_prototypes():

@@ -18,6 +18,7 @@ import pytest
 
 import oracle_lib
 import synth
+from conftest import TABLE_BUDGETS, table_budget_ctx
 
 pytestmark = pytest.mark.gpu
 kzg = importlib.import_module("rust-eth-kzg_amd")
@@ -31,12 +32,11 @@ def _torch_first():
     torch.cuda.init()
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=TABLE_BUDGETS, ids=lambda b: f"tables-{b}")
+def ctx(request):
     _torch_first()
-    c = kzg.DASContext(use_precomp=True)
-    yield c
-    c.close()
+    # every full-size test that takes `ctx` runs on the library's DEFAULT tables (108 GB) and on the widest ones (conftest.py)
+    yield from table_budget_ctx(request.param, lambda: kzg.DASContext(use_precomp=True))
 
 
 def _random_blobs(n, seed):

@@ -11,21 +11,21 @@ import pytest
 import oracle_lib
 import synth
 import vectors
+from conftest import TABLE_BUDGETS, table_budget_ctx
 from oracle_lib import OracleError
 
 pytestmark = pytest.mark.gpu
 kzg = importlib.import_module("rust-eth-kzg_amd")
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=TABLE_BUDGETS, ids=lambda b: f"tables-{b}")
+def ctx(request):
     # the torch wheel carries its own HIP runtime: when a test of this module brings torch in, it must have been initialised
     # before the engine's (system) runtime, or it finds no GPU -- same order as bench.py and tests/test_gpu_fullsize.py
     import torch
     torch.cuda.init()
-    c = kzg.DASContext(use_precomp=True)
-    yield c
-    c.close()
+    # every test that takes `ctx` runs on the library's DEFAULT tables (108 GB, mixed 15 / 14-bit windows) and on the widest ones
+    yield from table_budget_ctx(request.param, lambda: kzg.DASContext(use_precomp=True))
 
 
 def _call(fn, *a):

@@ -49,6 +49,20 @@ def _commitments_check(ctx, oracle, seed, sizes=(1, 5, 70, 600)):
             assert comms[b] == oracle.blob_to_kzg_commitment(blobs[b].tobytes()), (n, b)
 
 
+def _windows(w):
+    """(lowest bit, width) of the W = ceil(128 / w) windows of a GLV table of nominal width w (launch.hpp: b = 128 // W bits each, the
+    lowest 128 - W b windows one bit more)."""
+    W = -(-128 // w)
+    b, r = 128 // W, 128 - W * (128 // W)
+    out, lo = [], 0
+    for k in range(W):
+        bits = b + (1 if k < r else 0)
+        out.append((lo, bits))
+        lo += bits
+    assert lo == 128
+    return out
+
+
 def _msm_stage_check(ctx, tag):
     """128 fixed-base MSM_64 per scalar set through the stage hook against oracle_g1_msm (edge scalars included)."""
     lib = kzg.load_library()
@@ -69,7 +83,20 @@ def _msm_stage_check(ctx, tag):
         edge += [(1 << lo), (1 << lo) - 1, (1 << (lo + bits - 1)), (1 << (lo + bits - 1)) + (1 << lo), ((1 << (lo + bits - 1)) - 1) << 0,
                  ((1 << bits) - 1) << lo, (((1 << (lo + bits - 1)) | (1 << lo)) * lam) % synth.R]
         lo += bits
-    assert lo == 128 and len(edge) <= 64 * 3
+    assert lo == 128
+    # HALF-scalars chosen directly: k = k1 + k2 lambda with |k1|, |k2| inside the balanced split's cell
+    # (glv.hpp: magnitudes <= (lambda + 1) / 2 + 1 ~ 2^126.4, so the split returns exactly these halves), whose signed window digits
+    # sit at the recoding's edges in EVERY window at once: the top bit of every window set (each digit becomes negative and carries
+    # into the next window, through every 15 -> 14-bit boundary of a mixed-width table), the largest digits that do not carry, the
+    # smallest that do, and all ones (a carry chain from bit 0 to the top window)
+    cap = (1 << 126) - 1
+    tops = sum(1 << (l + bt - 1) for l, bt in _windows(w)) & cap
+    below = sum(((1 << (bt - 1)) - 1) << l for l, bt in _windows(w)) & cap
+    above = sum(((1 << (bt - 1)) + 1) << l for l, bt in _windows(w)) & cap
+    for h in (tops, below, above, cap):
+        assert h < (lam - 1) // 2
+        edge += [h, h * lam, h + h * lam, -h + h * lam, h - h * lam]
+    assert len(edge) <= 64 * 3
     for k, v in enumerate(edge):
         sc[0][k] = (v % synth.R).to_bytes(32, "big")
     sc[1] = [bytes(32)] * (128 * 64)
@@ -153,6 +180,8 @@ def test_default_budget_is_a_stated_108_gb(oracle, monkeypatch):
             assert c.window_bits() == want_w, (kwargs, c.window_bits())
             if want_w == 15:
                 assert 105e9 < c.table_bytes() <= 108e9, c.table_bytes()
+                assert c.window_count() == 9
+                _msm_stage_check(c, "default budget")  # the mixed 15 / 14-bit windows at stage level, edge half-scalars included
                 _commitments_check(c, oracle, 7820, sizes=(3, 600))
             st, cells, proofs = full._compute_on_device(c, blobs)
             assert st == [0] * 20
