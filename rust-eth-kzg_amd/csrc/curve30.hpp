@@ -73,10 +73,19 @@ struct AffS {  // canonical coordinates, exact centred digits; identity = (0, 0)
 };
 // A GLV window-table entry: both coordinates canonical (Montgomery-390 values in [0, p)) as exact centred digits, packed
 // 12 words each: word i = digit i's low 30 bits | two bits of the top digit (< 2^22) in bits 30-31.  Identity = all zero.
+#ifdef TABS_STRIDE_128
+// EXPERIMENT (tools/exp_variants.sh): one 128-byte line per entry instead of 96 B at 32-B alignment (1.5 lines on
+// average).  Every table grows by a third: only widths <= 15 fit the HBM.
+struct alignas(128) TabS {
+    uint32_t w[24];
+};
+static_assert(sizeof(TabS) == 128, "one line per table entry");
+#else
 struct alignas(16) TabS {
     uint32_t w[24];
 };
 static_assert(sizeof(TabS) == 96, "packed table entries");
+#endif
 // c = a canonical value as non-negative floor digits
 HD void tabs_pack_coord(uint32_t* w, const Fs<1, DU>& c) {
     int32_t d[SL];

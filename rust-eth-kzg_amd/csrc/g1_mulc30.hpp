@@ -54,7 +54,9 @@ __device__ __forceinline__ JacQ mul_by_recoded30(const JacQ& pq, const uint32_t*
             const Fs<1, DC> l2 = sqr(lam);
             A[j].x = mul(ex[j], l2);
             A[j].y = mul(ey[j], mul(l2, lam));
+#ifndef MULC30_NO_BX
             bx[j] = mul(A[j].x, beta);
+#endif
             if (j > 0) lam = mul(lam, dl[j]);
         }
         zc = mul(z0, lam);
@@ -73,9 +75,17 @@ __device__ __forceinline__ JacQ mul_by_recoded30(const JacQ& pq, const uint32_t*
             for (int hf = 0; hf < 2; hf++) {
                 const int d = (int)(int8_t)((hf ? w2 : w1) >> (8 * q));
                 if (d == 0) continue;
+#ifdef MULC30_IDX0_EXPERIMENT  // TIMING ONLY (wrong results): every digit reads entry 0 -- what the table's read traffic costs
+                const int idx = 0;
+#else
                 const int idx = ((d < 0 ? -d : d) - 1) >> 1;
+#endif
                 AffT op = A[idx];
+#ifdef MULC30_NO_BX  // EXPERIMENT: beta x computed per use instead of a second x-table in scratch (a third less table, +351 multiply-adds per k2 digit)
+                if (hf) op.x = mul(op.x, beta);
+#else
                 if (hf) op.x = bx[idx];
+#endif
                 if (!started) {
                     acc.x = relax<4, DC>(op.x);
                     acc.y = cneg(d < 0, op.y);

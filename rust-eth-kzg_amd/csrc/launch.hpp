@@ -67,7 +67,11 @@ void glv_split(void* scalars, size_t n, hipStream_t st);
 void msm_glv(int c, int mode, const void* scalars, const TabBlocks& table, void* out /*JacQ*/, int n_groups, int n_slices, int nb, int out_stride,
              int brp_bits, const Fp12w& beta, hipStream_t st);
 // k_table.hip
+#ifdef TABS_STRIDE_128
+constexpr size_t SIZEOF_TABP = 128;   // EXPERIMENT: a GLV table entry on a line of its own (curve30.hpp)
+#else
 constexpr size_t SIZEOF_TABP = 96;    // a packed GLV table entry
+#endif
 size_t table_glv_entries(int c, int n_groups, int nb);
 size_t table_glv_side_bytes(int c, int n_groups, int nb);
 // scratch: 168 B per entry of the chunk; side: table_glv_side_bytes; false if the width is not built in.

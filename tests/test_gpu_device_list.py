@@ -222,31 +222,6 @@ def test_device_batch_is_cut_into_sub_batches(oracle):
                 os.environ[k] = v
 
 
-def test_six_thousand_blobs_device_resident_on_the_widest_tables(oracle):
-    """6,000 blobs in one device-resident call next to 242 GB of tables: two sub-batches (4096 + 1904), every blob held to the
-    data-in-the-first-half invariant, a sample against the oracle."""
-    full._torch_first()
-    saved = os.environ.get("ETH_KZG_AMD_TABLE_GB")
-    os.environ["ETH_KZG_AMD_TABLE_GB"] = "max"
-    c = kzg.DASContext(use_precomp=True)
-    try:
-        assert c.window_bits() == 16
-        n = 6000
-        blobs = full._random_blobs(n, 670)
-        st, cells, proofs = full._compute_on_device(c, blobs)
-        assert st == [0] * n
-        assert np.array_equal(cells[:, :131072], blobs.reshape(n, 131072)), "cells 0..63 must be the blob itself"
-        full._check_sample_against_oracle(oracle, blobs, cells, proofs, [0, 4095, 4096, 5999])
-        # every proof of the 1024 blobs around the cut between the sub-batches, through the many-verification entry point
-        assert full._verify_every_proof(c, blobs[3584:4608], cells[3584:4608], proofs[3584:4608]) == [True] * 1024
-    finally:
-        c.close()
-        if saved is None:
-            os.environ.pop("ETH_KZG_AMD_TABLE_GB", None)
-        else:
-            os.environ["ETH_KZG_AMD_TABLE_GB"] = saved
-
-
 # ------------------------------------------------------------------------------------------------ ADVICE r5: try_new never kills the host
 def test_constructor_that_throws_late_cleans_up_and_the_next_context_works(oracle):
     """ETH_KZG_AMD_FAULT=constructor makes the engine's constructor throw after its last step but one -- streams, events, constants,
@@ -259,21 +234,23 @@ def test_constructor_that_throws_late_cleans_up_and_the_next_context_works(oracl
         "import torch; torch.cuda.init()\n"
         "import synth\n"
         "kzg = importlib.import_module('rust-eth-kzg_amd')\n"
-        "free0 = torch.cuda.mem_get_info()[0]\n"
         "os.environ['ETH_KZG_AMD_FAULT'] = 'constructor'\n"
-        "for k in range(3):\n"
+        "free0 = None\n"
+        "for k in range(4):\n"
         "    try:\n"
         "        kzg.DASContext(use_precomp=True, table_budget_gb=30)\n"
         "        raise SystemExit('the injected fault did not fire')\n"
         "    except kzg.KzgError as e:\n"
         "        assert 'injected fault' in str(e), str(e)\n"
+        "    if free0 is None:\n"
+        "        free0 = torch.cuda.mem_get_info()[0]  # after the FIRST failure: what the HIP runtime itself keeps (code objects, kernel scratch) is in\n"
         "try:\n"
         "    kzg.DASContext(use_precomp=True, devices=[0, 0], table_budget_gb=30)\n"
         "    raise SystemExit('the injected fault did not fire (device list)')\n"
         "except kzg.KzgError as e:\n"
         "    assert 'injected fault' in str(e), str(e)\n"
         "lost = free0 - torch.cuda.mem_get_info()[0]\n"
-        "assert lost < 1.5e9, 'failed constructors kept %%.1f GB' %% (lost / 1e9)\n"
+        "assert lost < 0.3e9, 'four more failed constructors (one of them over a device list) kept %%.2f GB' %% (lost / 1e9)\n"
         "del os.environ['ETH_KZG_AMD_FAULT']\n"
         "c = kzg.DASContext(use_precomp=True, table_budget_gb=30)\n"
         "assert c.window_bits() == 14\n"

@@ -157,6 +157,20 @@ def test_compute_full_batches_device_resident(ctx, oracle, n):
     assert np.array_equal(proofs2[: n - 1], proofs[: n - 1])
 
 
+def test_six_thousand_blobs_in_one_device_resident_call(ctx, oracle):
+    """a device-resident batch larger than one work set is meant to hold -- 6,000 blobs next to the window tables
+    (242 GB of them under tables-max) -- runs as sub-batches on one stream (4096 + 1904; halved again should an allocation fail)
+    instead of failing on hipMalloc: every blob held to the data-in-the-first-half invariant, a sample on both sides of the cut
+    against the oracle, and every proof of the 1024 blobs around the cut verified."""
+    n = 6000
+    blobs = _random_blobs(n, 670)
+    st, cells, proofs = _compute_on_device(ctx, blobs)
+    assert st == [0] * n
+    assert np.array_equal(cells[:, :131072], blobs.reshape(n, 131072)), "cells 0..63 must be the blob itself"
+    _check_sample_against_oracle(oracle, blobs, cells, proofs, [0, 4095, 4096, 5999])
+    assert _verify_every_proof(ctx, blobs[3584:4608], cells[3584:4608], proofs[3584:4608]) == [True] * 1024
+
+
 def test_compute_512_through_the_host_batch_abi(ctx, oracle):
     """Config 4's 512 blobs through the host-pointer batch entry point (what a C / Go / Java caller uses):
     same bytes as the device-resident form."""
