@@ -712,6 +712,46 @@ def strong_configs(ctx, sharding, torch, dist, dev, world, rank, lib_comm, strea
     return out
 
 
+def device_list_leg(kzg, devices, blobs_h, per_device, steps=3, ref_ctx=None):
+    """ONE context over a device list behind the unchanged ABI (eth_kzg_amd_das_context_new_on_devices; a drop-in host sets
+    ETH_KZG_AMD_DEVICES and keeps calling eth_kzg_das_context_new): a host-pointer batch of per_device x len(devices) blobs through
+    eth_kzg_amd_compute_cells_and_kzg_proofs_batch -- contiguous slices, one host thread per device, the caller's buffers are the
+    gather target, no collective -- timed as a host sees it (PCIe both ways, gather and scatter included).  ref_ctx: a one-device
+    context whose bytes the first blob of every slice must equal.  Runs on the library's current table budget."""
+    import numpy as np
+    n = per_device * len(devices)
+    reps = -(-n // blobs_h.shape[0])
+    blobs = np.ascontiguousarray(np.concatenate([blobs_h] * reps)[:n]) if reps > 1 else np.ascontiguousarray(blobs_h[:n])
+    t0 = time.perf_counter()
+    ctx = kzg.DASContext(use_precomp=True, devices=list(devices))
+    t_ctx = time.perf_counter() - t0
+    try:
+        bufs = ctx.host_batch_buffers(n)
+        st = ctx.compute_cells_and_kzg_proofs_batch_np(blobs, bufs)
+        assert list(st) == [0] * n, "device-list context: a synthetic blob was rejected"
+        checked = None
+        if ref_ctx is not None:
+            checked = True
+            for d in range(len(devices)):
+                b = d * n // len(devices)
+                rc, rp = ref_ctx.compute_cells_and_kzg_proofs(blobs[b].tobytes())
+                checked = checked and bufs["cells"][b].tobytes() == b"".join(rc) and bufs["proofs"][b].tobytes() == b"".join(rp)
+            if not checked:
+                raise SystemExit("bench.py: the device-list context's output differs from the one-device context's")
+        ts = []
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            ctx.compute_cells_and_kzg_proofs_batch_np(blobs, bufs)
+            ts.append(time.perf_counter() - t1)
+        return {"devices": ctx.devices(), "blobs": n, "blobs_per_s": round(n / _median(ts)), "ms_per_call": round(_median(ts) * 1e3, 2),
+                "context_s": round(t_ctx, 2), "window_bits": ctx.window_bits(), "table_GB_all_devices": round(ctx.table_bytes() / 1e9, 1),
+                "first_blob_of_every_slice_checked_against_one_device": checked,
+                "entry": "eth_kzg_amd_compute_cells_and_kzg_proofs_batch on ONE context over the device list (single process, one host "
+                         "thread per device, no collective); host pointers: PCIe both ways, gather and scatter included"}
+    finally:
+        ctx.close()
+
+
 def kernel_sources_hash():
     """SHA-256 over the sources of the dominant kernel (the GLV MSM and the field / curve headers it is made of): the key that
     ties a committed PMC profile to the build it was collected on (tools/pmc_summary.py stores it, bench.py compares it)."""
@@ -847,6 +887,12 @@ def main():
     ap.add_argument("--strong-configs", action="store_true",
                     help="also run the strong-scaling legs (configs 4 and 5 as written) at N = 1; they always run at N > 1")
     ap.add_argument("--launcher-selftest", action="store_true", help="CPU only: check the --gpus N launcher and the rendezvous, then exit")
+    ap.add_argument("--no-device-list-leg", action="store_true",
+                    help="skip the single-process leg: ONE context over the device list (N > 1: all N GPUs from rank 0 after the ranks "
+                         "have freed theirs; N = 1: the list 0,0 on the default tables) beside the process-per-GPU form")
+    ap.add_argument("--table-sharding", choices=["blob"], default="blob",
+                    help="how the FK20 work is cut over GPUs: by blob (every GPU holds every group's table; the only form built -- the "
+                         "group-sharded 19-bit-window design of DESIGN.md section 6 is priced there and not implemented)")
     ap.add_argument("--exchange", choices=["library", "library-required", "torch"], default="library",
                     help="N > 1: the all-gather runs on the library's own RCCL communicator (default; if it cannot be built the run goes "
                          "on over torch.distributed's and SAYS SO in config.exchange and on stderr; library-required: fail instead), "
@@ -1088,6 +1134,39 @@ def main():
         except Exception as e:  # anything else in the side legs must not cost the headline record
             strong = {"error": repr(e)}
 
+    # what the record quotes from the context (read now: at N > 1 the context is freed before the record is written)
+    ctx_window_bits, ctx_table_bytes, ctx_linmap = ctx.window_bits(), ctx.table_bytes(), ctx.linmap_info()
+    device_list = None
+    if world > 1 and not args.no_device_list_leg:
+        # The process-per-GPU form is measured; now the form a drop-in host gets without launching anything: rank 0 alone, ONE context
+        # over all N GPUs.  Every rank first frees its context (its tables would not leave room for a second set on its GPU), the
+        # others wait at the barrier.  On the library's DEFAULT table budget (what such a host gets), per-GPU share = half the
+        # headline's (host memory: 0.4 MB per blob).  A failure here costs this leg, never the record.
+        saved_budget = os.environ.get("ETH_KZG_AMD_TABLE_GB")
+        try:
+            if lib_comm:
+                ctx.comm_destroy()
+            ctx.close()
+            ctx = None
+            hz.barrier()
+            if rank == 0:
+                if rehearsal:
+                    os.environ["ETH_KZG_AMD_TABLE_GB"] = "24"
+                else:
+                    os.environ.pop("ETH_KZG_AMD_TABLE_GB", None)
+                devs = [0] * world if rehearsal else list(range(world))
+                device_list = device_list_leg(kzg, devs, blobs_h, per_device=max(1, min(B, 1024)), steps=3)
+        except SystemExit:
+            raise
+        except Exception as e:  # noqa: BLE001
+            device_list = {"error": repr(e)}
+        finally:
+            if saved_budget is None:
+                os.environ.pop("ETH_KZG_AMD_TABLE_GB", None)
+            else:
+                os.environ["ETH_KZG_AMD_TABLE_GB"] = saved_budget
+            hz.barrier()
+
     if rank == 0:
         total_blobs = B * world * args.steps
         value = total_blobs / dt
@@ -1097,7 +1176,7 @@ def main():
         per_launch_s = dom_ms * 1e-3 / max(1, dom_launches)
         # gathered additions per (scalar, base) of the FK20 table IN USE: 2 ceil(128 / w) for a GLV table of width w (both 128-bit
         # halves over the same windows), ceil(255 / w) for a plain one
-        wbits = ctx.window_bits()
+        wbits = ctx_window_bits
         msm_adds = 2 * -(-128 // wbits)
         # algorithmic bytes per launch of each kernel family (DESIGN.md "kernels"):
         alg_bytes = {
@@ -1113,7 +1192,7 @@ def main():
             "compress": B * 128 * (168 + 48),
             # compiled linear map: ~3.9 k point operations per blob (350 constant multiplications, 3.2 k additions, 0.4 k
             # doubling runs), each reading one or two 168-B points and writing one, over its ~42 launches
-            "g1_linmap": B * (sum(ctx.linmap_info()[:2]) + 400) * 3 * 168 // max(1, ctx.linmap_info()[3]),
+            "g1_linmap": B * (sum(ctx_linmap[:2]) + 400) * 3 * 168 // max(1, ctx_linmap[3]),
         }[dom]
         achieved = alg_bytes / per_launch_s / 1e9
         # HBM traffic of the dominant kernel: NOT measured in this run (PMC passes need rocprofv3) -- taken from the newest
@@ -1130,7 +1209,7 @@ def main():
                 raise RuntimeError("committed PMC profile belongs to another build of the kernel")
             want = {"msm_fixed": ("k_msm_glv_chunked",), "g1_linmap": ("k_slp_mulc",)}.get(dom, ())
             key = next((k for w_ in want for k in pm if w_ in k), None)  # the newest profile names the kernel the default schedule runs
-            if key in pm and B == 2048 and ctx.window_bits() == 16:
+            if key in pm and B == 2048 and ctx_window_bits == 16:
                 # gfx950 correction (MI355X_MICROARCH.md, calibrated for this kernel's 16-B-per-lane gathers in
                 # profiles/r1f_calib_fetch.log): FETCH_SIZE tallies every 128-B line request at 64 B -> double it; WRITE_SIZE is exact
                 traffic = (2.0 * pm[key]["FETCH_SIZE_per_launch_max"] + pm[key]["WRITE_SIZE_per_launch_max"]) * 1024.0
@@ -1147,8 +1226,8 @@ def main():
         stage_ms_per_step = {s: round(stages[s][0] / args.steps, 3) for s in stages}
         # integer-VALU view (the bound that actually binds)
         mac_rate = value * 1.0e9 / 1e9  # reference-algorithm count: ~1.0e9 32x32 MACs per blob
-        li = ctx.linmap_info()
-        mul_eq = fp_mul_eq_per_blob(ctx.window_bits(), li[:3] if li[0] else (642, 14 * 64 * 1.5, 0), args.blobs_per_gpu)
+        li = ctx_linmap
+        mul_eq = fp_mul_eq_per_blob(ctx_window_bits, li[:3] if li[0] else (642, 14 * 64 * 1.5, 0), args.blobs_per_gpu)
         mul_rate = value * mul_eq / 1e9
         out = {
             "metric": "blobs/sec compute_cells_and_kzg_proofs (4096-pt blob)",
@@ -1160,9 +1239,9 @@ def main():
             "config": {"workload": f"compute_cells_and_kzg_proofs on DEVICE-RESIDENT blobs (inputs and outputs stay in HBM; the "
                                    f"host-pointer ABI rate is configs.abi_host_pointer_batch), batch-saturated: {B} synthetic blobs "
                                    f"per GPU per step (config 2's single blob is reported as single_blob_latency_ms)",
-                       "blobs_per_gpu": B, "use_precomp": True, "window_bits": ctx.window_bits(),
+                       "blobs_per_gpu": B, "use_precomp": True, "window_bits": ctx_window_bits,
                        "fk20_table": f"GLV: {msm_adds // 2} windows of {wbits} bits per 128-bit half scalar, packed 96-B entries, {msm_adds} gathered additions per base",
-                       "table_GB": round(ctx.table_bytes() / 1e9, 2),
+                       "table_GB": round(ctx_table_bytes / 1e9, 2),
                        "table_budget": "ETH_KZG_AMD_TABLE_GB=" + os.environ.get("ETH_KZG_AMD_TABLE_GB", "") + " (set by bench.py: the widest tables the HBM holds; "
                                        "the library's default budget is 108 GB = nine-window GLV tables, see configs.blobs_per_s_vs_table_memory)",
                        "g1_transforms": f"compiled linear map: {li[0]} constant multiplications, {li[1]} additions, {li[2]} doublings per blob, {li[3]} launches" if li[0] else "radix-2 network",
@@ -1207,6 +1286,8 @@ def main():
         }
         if strong is not None:
             out["configs_strong"] = strong
+        if device_list is not None:
+            out["single_process_device_list"] = device_list
         if world > 1:
             out["omitted_at_n_gpus_above_1"] = ["cpu_baseline", "configs (single-GPU side figures)", "blobs_per_s_vs_table_memory"]
         extra = None
@@ -1245,6 +1326,28 @@ def main():
                         torch.cuda.synchronize(dev)
                         if it >= 1:
                             ts.append(time.perf_counter() - t0)
+                    if env.get("ETH_KZG_AMD_TABLE_GB") == "108" and not args.no_device_list_leg:
+                        # beside the one-device context on the library's default tables: ONE context over the device list 0,0 (two
+                        # engines on this GPU sharing its tables -- the code path of two GPUs on the one there is) and the same
+                        # host-pointer batch on the one-device context, so that the pair can be compared
+                        try:
+                            _mark("device-list context 0,0 on the default tables")
+                            hb = c2.host_batch_buffers(B)
+                            c2.compute_cells_and_kzg_proofs_batch_np(blobs_h, hb)
+                            th = []
+                            for _ in range(3):
+                                t0 = time.perf_counter()
+                                c2.compute_cells_and_kzg_proofs_batch_np(blobs_h, hb)
+                                th.append(time.perf_counter() - t0)
+                            del hb
+                            leg = device_list_leg(kzg, [local_rank, local_rank], blobs_h, per_device=B // 2, steps=3, ref_ctx=c2)
+                            leg["same_batch_on_the_one_device_context_blobs_per_s"] = round(B / _median(th))
+                            leg["note"] = "two engines on ONE GPU: a check of the device-list path and its cost, not a speed-up (the engines share the GPU)"
+                            out["configs"]["device_list_context_0_0_default_tables"] = leg
+                        except SystemExit:
+                            raise
+                        except Exception as e:  # noqa: BLE001
+                            out["configs"]["device_list_context_0_0_default_tables"] = {"error": repr(e)}
                     w = c2.window_bits()
                     curve.append({"table": label, "table_GB": round(c2.table_bytes() / 1e9, 1),
                                   "gathered_additions_per_base": 2 * -(-128 // w),

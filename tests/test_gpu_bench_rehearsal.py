@@ -37,6 +37,10 @@ def test_two_ranks_on_one_gpu_run_the_sharded_paths():
     for key in ("config4_compute_512_blobs", "config5_recover_256_blobs_half_erased"):
         assert strong[key]["gathered_equals_one_gpu_output"] is True and strong[key]["blobs_per_rank"] * 2 >= strong[key]["total_blobs"]
     assert "cpu_baseline" not in d and "configs" not in d  # rank-0-at-N=1 legs only
+    # beside the process-per-GPU form, rank 0 alone drives ONE context over the device list (here 0,0)
+    leg = d["single_process_device_list"]
+    assert "error" not in leg, leg
+    assert leg["devices"] == [0, 0] and leg["blobs"] == 256 and leg["blobs_per_s"] > 0
 
 
 @pytest.mark.timeout(900)

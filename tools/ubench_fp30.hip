@@ -76,6 +76,83 @@ __global__ __launch_bounds__(256, 2) void k30f(uint32_t* out, uint32_t seed) {
     for (int i = 0; i < SL; i++) h ^= x.v[i] ^ y.v[i] ^ xu.v[i] ^ yu.v[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = h;
 }
+// BIASED column accumulators.  A column starts at BIAS = 1.5 * 2^62 instead of 0 and gets the bias back after
+// every shift (acc = (acc >> 30) + BIAS - (BIAS >> 30): the low 32 bits of both constants are zero, so the quotient digit, the
+// extracted digits and the top digit are untouched): the accumulator never changes sign, its bits 62 and 63 stay 01 for the
+// |column sum| <= 1.17 * 2^62 of a C x C product.  Same results as mul() (checked below), 26 more 64-bit additions per product.
+namespace biased {
+using namespace kzg::q30core;
+constexpr int64_t BIAS = 3LL << 61, REBIAS = BIAS - (BIAS >> 30);
+template <int K>
+__device__ __forceinline__ void lo_col_b(int64_t& acc, const ProdMul& pr, int32_t* m) {
+    pr.template col<K>(acc);
+    run_vp<K, K>(acc, m);
+    m[K] = (int32_t)((uint32_t)acc * q30::N0Q) >> 2;
+    run_vp<1, 0>(acc, m + K);
+    acc = (acc >> 30) + REBIAS;
+}
+template <int K, int OUTF>
+__device__ __forceinline__ void hi_col_b(int64_t& acc, const ProdMul& pr, const int32_t* m, int32_t* r) {
+    constexpr int lo = K - SL + 1, n = SL - lo, J = K - SL;
+    pr.template col<K>(acc);
+    run_vp<n, K - lo>(acc, m + lo);
+    if constexpr (J < SL - 1) { extract<OUTF>(acc, r[J]); acc += REBIAS; }
+    else r[J] = (int32_t)acc;
+}
+template <int OUTF, int... Ks>
+__device__ __forceinline__ void mont_b(const ProdMul& pr, int32_t* r, std::integer_sequence<int, Ks...>) {
+    int32_t m[SL];
+    int64_t acc = BIAS;
+    (lo_col_b<Ks>(acc, pr, m), ...);
+    (hi_col_b<SL + Ks, OUTF>(acc, pr, m, r), ...);
+}
+template <int OUTF = DC, int A, int FA, int B, int FB>
+__device__ __forceinline__ Fs<1, OUTF> mul_b(const Fs<A, FA>& a, const Fs<B, FB>& b) {
+    Fs<1, OUTF> r;
+    mont_b<OUTF>(ProdMul{a.v, b.v}, r.v, Seq{});
+    return r;
+}
+}  // namespace biased
+// OP 0: C x C -> centred, 1: C x U -> floor digits -- the loops of k30<0> / k30<1> on the biased accumulator
+template <int OP>
+__global__ __launch_bounds__(256, 2) void k30b(uint32_t* out, uint32_t seed) {
+    Fs<1, DC> x, y;
+    for (int i = 0; i < SL; i++) { x.v[i] = (int32_t)((threadIdx.x * 2654435761u + seed + i * 977u) & (uint32_t)SMASK) - SHALF; y.v[i] = (x.v[i] ^ 0x1e3779b) % SHALF; }
+    x.v[SL - 1] &= 0xff; y.v[SL - 1] &= 0xff;
+    Fs<1, DU> xu, yu;
+    for (int i = 0; i < SL; i++) { xu.v[i] = x.v[i] & SMASK; yu.v[i] = y.v[i] & SMASK; }
+    xu.v[SL - 1] &= 0xff; yu.v[SL - 1] &= 0xff;
+#pragma unroll 1
+    for (int i = 0; i < ITER; i++) {
+        if (OP == 0) { x = biased::mul_b(x, y); y = biased::mul_b(y, x); }
+        else { xu = biased::mul_b<DU>(x, xu); yu = biased::mul_b<DU>(y, yu); }
+    }
+    uint32_t h = 0;
+    for (int i = 0; i < SL; i++) h ^= x.v[i] ^ y.v[i] ^ xu.v[i] ^ yu.v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = h;
+}
+// every lane: one product both ways on its own operands, digit by digit (the two loops above diverge after the first difference, so a
+// hash of their end states says nothing about WHERE)
+__global__ void k_check_biased(uint32_t* bad, uint32_t seed) {
+    Fs<1, DC> x, y;
+    for (int i = 0; i < SL; i++) { x.v[i] = (int32_t)(((blockIdx.x * 256 + threadIdx.x) * 2654435761u + seed + i * 977u) & (uint32_t)SMASK) - SHALF; y.v[i] = (x.v[i] ^ 0x1e3779b) % SHALF; }
+    x.v[SL - 1] &= 0xff; y.v[SL - 1] &= 0xff;
+    Fs<1, DU> xu;
+    for (int i = 0; i < SL; i++) xu.v[i] = y.v[i] & SMASK;
+    xu.v[SL - 1] &= 0xff;
+    const Fs<1, DC> a = mul(x, y), b = biased::mul_b(x, y);
+    const Fs<1, DU> c = mul<DU>(x, xu), d = biased::mul_b<DU>(x, xu);
+    bool differ = false;
+    for (int i = 0; i < SL; i++) differ |= a.v[i] != b.v[i] || c.v[i] != d.v[i];
+    if (differ) atomicAdd(bad, 1u);
+}
+static unsigned biased_mismatches(uint32_t* out) {
+    CK(hipMemset(out, 0, 4));
+    k_check_biased<<<64, 256>>>(out, 7u);
+    unsigned bad = 0;
+    CK(hipMemcpy(&bad, out, 4, hipMemcpyDeviceToHost));
+    return bad;
+}
 static bool g_sustained = false;  // --sustained: every kernel runs back to back for 1.5 s and the rate of the last second counts --
                                   // the point kernels are POWER-limited on MI355X (1.27 kW, the clock settles near 2.1 of 2.4 GHz), so
                                   // a 2 ms launch measures the issue rate at full clock, not the rate the chip sustains
@@ -121,6 +198,10 @@ int main(int argc, char** argv) {
         const double p29 = run("fp29 mul_add a*b+c*d (588 MACs)", blocks, k29<2>, out);
         const double m30 = run("fp30 mul C x C -> centred (338+13 MACs)", blocks, k30<0>, out);
         const double u30 = run("fp30 mul C x U -> floor digits", blocks, k30<1>, out);
+        const double mb30 = run("fp30 mul C x C, BIASED accumulator", blocks, k30b<0>, out);
+        const double ub30 = run("fp30 mul C x U, BIASED accumulator", blocks, k30b<1>, out);
+        printf("biased / plain at %d waves/SIMD: C x C %.3f  C x U %.3f   (products that differ from mul(): %u of 16384)\n", wps, mb30 / m30, ub30 / u30,
+               biased_mismatches(out));
         const double s30 = run("fp30 sqr -> centred (260 MACs)", blocks, k30<2>, out);
         const double p30 = run("fp30 mul_add, four centred operands (507 MACs)", blocks, k30<3>, out);
         const double q30 = run("fp30 mul_add, wide operands: split columns", blocks, k30<4>, out);
