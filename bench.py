@@ -39,7 +39,7 @@ VALU_INT_PEAK_GOPS = 34000.0     # measured on MI355X with tools/ubench.hip: int
 VALU_MIX_PEAK_TLOPS = 34.4      # measured issue ceiling of the point kernels' 12 : 4 multiply-add mix at 2 waves/SIMD (profiles/r3_ubench_issue.log), T lane-ops/s at 2.4 GHz
 FP_MUL_PEAK_G = 82.2             # measured SUSTAINED rate of the signed 13x30-bit Montgomery multiplication with centred result (338 + 13
                                  # v_mad_i64_i32 as verbatim chains, fp30_mac.hpp) at the 2 waves/SIMD the point kernels hold:
-                                 # tools/ubench_fp30 --sustained, profiles/r5_ubench_fp30_sustained.log (14x29-bit form: 76.2 G/s)
+                                 # tools/ubench_fp30 --sustained, profiles/archive/r5_ubench_fp30_sustained.log (14x29-bit form: 76.2 G/s)
 
 
 def fp_mul_eq_per_blob(window_bits, linmap, batch_lanes=2048):

@@ -570,7 +570,7 @@ const Engine::SlpProgram& Engine::slp_program(int id) {
 // lane group and lasts 1.3 ms with a SIMD to itself, 2.3 ms when two share one (the chip has wave_slots_ / 2 SIMDs), and from
 // two waves per SIMD on the launch is throughput (1.2 us per wave): so the multiplication count M is chosen so that M x groups
 // stays within the SIMDs (<= 2 groups) or the wave slots (<= 5 groups), and within that the program with the shallowest cheap
-// levels wins (tools/linmap_explore.cpp).  Measured per group count on one box (profiles/r4_linmap_programs.log; g1_linmap ms):
+// levels wins (tools/linmap_explore.cpp).  Measured per group count on one box (profiles/archive/r4_linmap_programs.log; g1_linmap ms):
 //   blobs           32    64    128   192   256   320   384   448   512   768   1024  1536
 //   350 (tuned)    2.50  2.55  2.71  3.82  3.87  3.98  5.14  5.19  5.36  7.72  8.98* 13.2*      (* with fused a + b / a - b pairs)
 //   712 Karatsuba  1.70  1.77  3.04  4.29  4.43  5.56  6.91        8.30

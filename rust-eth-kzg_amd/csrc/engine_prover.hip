@@ -187,7 +187,7 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         // link.  The scalars are blob-major, the outputs lane-major with stride bp: a sub-range is a pointer offset on both.
         if (!tv_pre || !linmap_mode || segs != 1 || msm_cut <= 0 || msm_cut >= n || msm_cut % 64) throw std::logic_error("run_proofs_from_coeffs: bad MSM cut");
         // (the head on a stream of its own, next to the later sub-batches' light stages and joined before the linear map, was
-        // measured too: no gain, profiles/r4_early_msm_ab.log)
+        // measured too: no gain, profiles/archive/r4_early_msm_ab.log)
         if (phase == PROOFS_HEAD) {
             launch::g1_set_inf(X, (size_t)128 * bp, st);
             launch_msm(w.scalars, tv, true, X, 128, msm_cut, bp, 0, st);
@@ -463,7 +463,7 @@ int Engine::compute_cells_and_kzg_proofs_host(int n, const uint8_t* const* blobs
             // A batch of several rounds of the chip: the MSMs of the first 256 blobs are launched as soon as THEIR scalars exist,
             // 0.7 ms into the call, and run while the other 235 MB are on the link; the MSMs of the rest follow.  (An MSM launch costs
             // ~1.3 ms beyond its share of the work -- the last waves of a launch -- so the head is as small as will still cover
-            // the uploads: 256 blobs = 6 ms; cut at 512: +1.4 ms, one launch after the last upload: +2.0 ms, profiles/r4_early_msm_ab.log.)
+            // the uploads: 256 blobs = 6 ms; cut at 512: +1.4 ms, one launch after the last upload: +2.0 ms, profiles/archive/r4_early_msm_ab.log.)
             constexpr int early_msm_blobs = 256;
             int msm_cut = 0;
             if (early_scalars && early_msm_blobs > 0 && ns >= 4 * early_msm_blobs)
