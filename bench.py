@@ -141,8 +141,13 @@ def cpu_baseline(blobs, gpu_first=None, extra=None):
         # build container's CPU, -9 % on the GPU boxes' EPYC 9575F), so both are timed on two blobs and the FASTER one is the baseline.
         src = [os.path.join(ROOT, "oracle", f) for f in ("field.c", "g1.c", "pairing.c", "sha256.c", "kzg.c")]
         best = None
+        # a private directory per process (a predictable shared path in /tmp is a pre-creation hazard on a multi-user box,
+        # and concurrent ranks raced writing the file another one was loading)
+        import tempfile
+        native_dir = tempfile.mkdtemp(prefix="kzg_oracle_native_")
+        built = {}
         for tag, flags in (("portable", []), ("adx", ["-DORACLE_ADX"])):
-            so = os.path.join("/tmp", "liboracle_native_%s_%d.so" % (tag, os.getuid()))
+            so = built[tag] = os.path.join(native_dir, "liboracle_native_%s.so" % tag)
             subprocess.check_call(["gcc", "-O3", "-march=native", *flags, "-fopenmp", "-fPIC", "-std=gnu11", "-shared", "-o", so] + src, stderr=subprocess.DEVNULL)
             oracle_lib._SO = so
             o1 = oracle_lib.Oracle(use_precomp=True, threads=1)
@@ -154,10 +159,11 @@ def cpu_baseline(blobs, gpu_first=None, extra=None):
             o1.close()
             if best is None or fp_mul_ab[tag] < fp_mul_ab[best]:
                 best = tag
-        oracle_lib._SO = os.path.join("/tmp", "liboracle_native_%s_%d.so" % (best, os.getuid()))
+        oracle_lib._SO = built[best]
         fp_mul_ab["used"] = best
-    except Exception:
-        pass
+    except Exception as e:  # noqa: BLE001 -- never silent: the record says which build was timed
+        oracle_lib._SO = os.path.join(ROOT, "oracle", "liboracle.so")
+        fp_mul_ab = {"used": "prebuilt generic x86-64 liboracle.so (the native build failed: %s)" % (repr(e)[:200],)}
     from oracle_lib import Oracle
     # --- rayon-like (intra-blob parallel) at all usable cores
     o = Oracle(use_precomp=True, threads=cores)

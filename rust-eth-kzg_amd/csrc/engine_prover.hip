@@ -305,6 +305,15 @@ int Engine::blob_to_kzg_commitment_device(int n, const uint8_t* d_blobs, uint8_t
                                           hipStream_t st, bool sync) {
     if (n <= 0) return OK;
     std::lock_guard<std::recursive_mutex> lk(mu_);
+    if (n > device_batch_max_) {  // sub-batches (0.5 MB of scratch per blob), as compute_cells_and_kzg_proofs_device
+        for (int b0 = 0; b0 < n; b0 += device_batch_max_) {
+            const int nb = std::min(device_batch_max_, n - b0);
+            const int rc = blob_to_kzg_commitment_device(nb, d_blobs + (size_t)b0 * BYTES_PER_BLOB, d_commitments + (size_t)b0 * 48,
+                                                         h_status ? h_status + b0 : nullptr, st, sync);
+            if (rc) return rc;
+        }
+        return OK;
+    }
     try {
         HIPCK(hipSetDevice(dev_));
         if (!st) {  // NULL: the library's stream, ordered behind whatever the caller has queued on the default stream so far

@@ -274,12 +274,17 @@ void Engine::build_final_tables() {
             if (cur.next && cur.next->state.load() == 2) publish(sel, cur.main, nullptr);
         }
         // ~SharedTable (hipFree of every piece) runs inside reap(): outside the lock, on this thread
-        for (int spin = 0; spin < 2000 && pub_[sel].reap([](const SharedTable& r) { return r.state.load() == 2; }) > 0; spin++)
+        int waiting = 0;
+        for (int spin = 0; spin < 2000 && (waiting = pub_[sel].reap([](const SharedTable& r) { return r.state.load() == 2; })) > 0; spin++)
             std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        return waiting == 0;  // false: somebody held a snapshot of an abandoned table for two seconds; its memory is still taken
     };
     auto widen = [&](TableSel sel, int kind, int w, const void* bases, int n_groups) -> std::shared_ptr<SharedTable> {
         if (cancel_build_.load()) throw BuildCancelled{};
-        drop_abandoned(sel);
+        if (!drop_abandoned(sel)) {  // do not allocate a wide table on top of memory an abandoned one still holds
+            why = "an abandoned table is still referenced: its memory is not free yet";
+            return nullptr;
+        }
         bool created = false;
         auto t = find_or_create_table(dev_, kind, w, n_groups, &created);
         const TableView cur = table_view(sel);
@@ -349,6 +354,13 @@ void Engine::build_final_tables() {
             fk = widen(TAB_FK, 2, w, d_fk_bases_, 128);
         }
         if (fk) publish(TAB_FK, fk, nullptr);
+        // The tables this context STARTED on (1.6 + 0.8 GB, complete: state 1) were retired by the two publishes above and are not
+        // counted in the stated budget: they go as soon as no MSM launch's snapshot refers to them -- a snapshot lives for
+        // the microseconds of an enqueue -- here, on the builder thread (hipFree waits for kernels in flight).  A start table that
+        // another context of the device still runs on has other owners and stays.
+        for (TableSel sel : {TAB_SRS, TAB_FK})
+            for (int spin = 0; spin < 200 && pub_[sel].reap([](const SharedTable&) { return true; }) > 0; spin++)
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
     } catch (const BuildCancelled&) {
         state = 2;
         why = "cancelled: the context is being freed";

@@ -577,6 +577,16 @@ int Engine::recover_cells_and_kzg_proofs_device(int R, const uint8_t* d_cells, c
                                                 uint8_t* d_out_proofs, int* status, hipStream_t user_stream) {
     if (R <= 0) return OK;
     std::lock_guard<std::recursive_mutex> lk(mu_);
+    if (R > device_batch_max_) {  // sub-batches on the same streams (the scratch of one pass is 0.9 MB per blob): see compute_cells_and_kzg_proofs_device
+        for (int r0 = 0; r0 < R; r0 += device_batch_max_) {
+            const int nr = std::min(device_batch_max_, R - r0);
+            const int rc = recover_cells_and_kzg_proofs_device(nr, d_cells + (size_t)r0 * N_CELLS * BYTES_PER_CELL, present_masks + 2 * (size_t)r0,
+                                                               d_out_cells ? d_out_cells + (size_t)r0 * N_CELLS * BYTES_PER_CELL : nullptr,
+                                                               d_out_proofs ? d_out_proofs + (size_t)r0 * N_CELLS * 48 : nullptr, status + r0, user_stream);
+            if (rc) return rc;
+        }
+        return OK;
+    }
     try {
         HIPCK(hipSetDevice(dev_));
         ensure_workspace(R);  // also orders stream_ behind the previous asynchronous call that used the workspace

@@ -211,6 +211,33 @@ def test_device_batch_is_cut_into_sub_batches(oracle):
             keep = [i for i in range(300) if i != 129]
             assert np.array_equal(a[1][keep], b[1][keep]) and np.array_equal(a[2][keep], b[2][keep])
             full._check_sample_against_oracle(oracle, blobs, a[1], a[2], [0, 127, 128, 255, 256, 299])
+            # the commitment and the recovery device forms are cut the same way
+            import torch
+            d_blobs = torch.from_numpy(blobs.reshape(-1)).cuda()
+            outs = []
+            for c in (cut, whole):
+                d_comm = torch.zeros(300 * 48, dtype=torch.uint8, device="cuda")
+                st = c.blob_to_kzg_commitment_device(300, d_blobs.data_ptr(), d_comm.data_ptr())
+                torch.cuda.synchronize()
+                outs.append((st, d_comm.cpu().numpy().reshape(300, 48)[keep]))
+            assert outs[0][0] == outs[1][0] and [i for i, s in enumerate(outs[0][0]) if s] == [129] and np.array_equal(outs[0][1], outs[1][1])
+            assert outs[0][1][0].tobytes() == oracle.blob_to_kzg_commitment(blobs[0].tobytes())
+            # recovery: the even cells of every blob (the odd ones overwritten with junk), blob 200 with too few cells
+            ext = torch.from_numpy(np.ascontiguousarray(b[1])).cuda().view(300, 128, 2048).clone()
+            ext[:, 1::2, :] = 0xFF
+            present = [list(range(0, 128, 2))] * 300
+            present[200] = list(range(0, 126, 2))
+            rec = []
+            for c in (cut, whole):
+                d_c = torch.zeros(300 * 128 * 2048, dtype=torch.uint8, device="cuda")
+                d_p = torch.zeros(300 * 128 * 48, dtype=torch.uint8, device="cuda")
+                st = c.recover_cells_and_kzg_proofs_device(300, ext.data_ptr(), present, d_c.data_ptr(), d_p.data_ptr())
+                torch.cuda.synchronize()
+                rec.append((st, d_c.cpu().numpy().reshape(300, -1), d_p.cpu().numpy().reshape(300, -1)))
+            good = [i for i in range(300) if i not in (129, 200)]
+            assert rec[0][0] == rec[1][0] and rec[0][0][200] == 3 and all(rec[0][0][i] == 0 for i in good)
+            assert np.array_equal(rec[0][1][good], b[1][good]) and np.array_equal(rec[0][2][good], b[2][good])
+            assert np.array_equal(rec[1][1][good], b[1][good]) and np.array_equal(rec[1][2][good], b[2][good])
         finally:
             cut.close()
             whole.close()
