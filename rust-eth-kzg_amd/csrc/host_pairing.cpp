@@ -1,6 +1,7 @@
 // See host_pairing.hpp.  Tower Fp2 = Fp[u]/(u^2+1), Fp6 = Fp2[v]/(v^3-(1+u)), Fp12 = Fp6[w]/(w^2-v);
 // M-type twist E'(Fp2): y^2 = x^3 + 4(1+u), untwist (x, y) -> (x / w^2, y / w^3).
 #include "host_pairing.hpp"
+#include <mutex>
 
 namespace kzg {
 namespace pairing {
@@ -156,16 +157,18 @@ static bool is_one12(const Fp12& a) {
 
 // Frobenius: v^p = xi^((p-1)/3) v, w^p = xi^((p-1)/6) w
 static Fp2 G1C, G2C, G4C;  // xi^((p-1)/6), its square, its fourth power
-static bool g_init = false;
-void init() {
-    if (g_init) return;
+static void init_once();
+void init() {  // contexts are created from any thread, and the engines of a device list side by side (c_api.cpp): once, with a fence
+    static std::once_flag once;
+    std::call_once(once, init_once);
+}
+static void init_once() {
     static const uint32_t P16[12] = {0xfffff1c7u, 0x49aa7fffu, 0x72e35555u, 0x051caaaau, 0xd3c82906u, 0xe688231au,
                                      0x7deb831fu, 0xe613e1ebu, 0xb5e1f223u, 0x0c849bf3u, 0x5eeaa66fu, 0x045582fcu};  // (p-1)/6
     Fp2 xi = {fo(), fo()};
     G1C = pow2(xi, P16, 12);
     G2C = sqr2(G1C);
     G4C = sqr2(G2C);
-    g_init = true;
 }
 static inline Fp6 frob6(const Fp6& a) { return {conj(a.c0), conj(a.c1) * G2C, conj(a.c2) * G4C}; }
 static inline Fp12 frob12(const Fp12& a) {

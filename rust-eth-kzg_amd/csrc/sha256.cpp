@@ -103,10 +103,9 @@ static bool self_test_shani() {
     blocks_shani(b, blk, 2);
     return memcmp(a, b, sizeof a) == 0;
 }
-static int g_shani = -1;
-bool sha256_uses_shani() {
-    if (g_shani < 0) g_shani = (detect_shani() && self_test_shani()) ? 1 : 0;
-    return g_shani == 1;
+bool sha256_uses_shani() {  // called from many host threads at once (the transcript hashes of concurrent verifications): a function-local static
+    static const bool shani = detect_shani() && self_test_shani();  // is initialised once, thread-safely
+    return shani;
 }
 static void blocks(uint32_t h[8], const uint8_t* p, size_t n) {
     if (sha256_uses_shani()) blocks_shani(h, p, n);

@@ -2,6 +2,8 @@
 // cyclotomic squaring against the general Fp12 product, and the pairing check itself on points of the trusted setup:
 //   e(a [tau]_1, [1]_2) * e(-a [1]_1, [tau]_2) == 1   and   e(a [1]_1, [1]_2) * e(-a [1]_1, [tau]_2) != 1.
 // Built and run by tests/test_host_units.py with the path of rust-eth-kzg_amd/data/trusted_setup_4096.bin.
+#include <thread>
+#include <vector>
 #include "host_pairing.cpp"
 #include <cstdio>
 #include <cstring>
@@ -35,6 +37,11 @@ static bool eq12(const Fp12& a, const Fp12& b) {
 }
 
 int main(int argc, char** argv) {
+    {   // contexts are created from many threads, and the engines of a device list side by side: init() from eight threads at once
+        std::vector<std::thread> th;
+        for (int t = 0; t < 8; t++) th.emplace_back([] { init(); });
+        for (auto& t : th) t.join();
+    }
     init();
     int bad = 0;
     for (int it = 0; it < 200; it++) {

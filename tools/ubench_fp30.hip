@@ -1,7 +1,8 @@
 // tools/ubench_fp30.hip -- multiplication / squaring / fused-pair rates of the signed 13 x 30-bit field (csrc/fp30.hpp)
 // next to the unsigned 14 x 29-bit field (csrc/fp29.hpp, verbatim chains) in ONE binary on ONE GPU, at 2 and 4 waves per SIMD.
 // VERDICT r4's kill criterion for the 13-digit form: less than +8 % multiplications/s at 2 waves/SIMD -> stop.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DFQ_ASM_MAC -I rust-eth-kzg_amd/csrc tools/ubench_fp30.hip -o tools/ubench_fp30
+//   hipcc -O3 -fwrapv -std=c++17 --offload-arch=gfx950 -DFQ_ASM_MAC -I rust-eth-kzg_amd/csrc tools/ubench_fp30.hip -o tools/ubench_fp30
+//   (-fwrapv: the biased-unsigned variant keeps S + 2^63 in an int64_t)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
@@ -76,33 +77,44 @@ __global__ __launch_bounds__(256, 2) void k30f(uint32_t* out, uint32_t seed) {
     for (int i = 0; i < SL; i++) h ^= x.v[i] ^ y.v[i] ^ xu.v[i] ^ yu.v[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = h;
 }
-// BIASED column accumulators.  A column starts at BIAS = 1.5 * 2^62 instead of 0 and gets the bias back after
-// every shift (acc = (acc >> 30) + BIAS - (BIAS >> 30): the low 32 bits of both constants are zero, so the quotient digit, the
-// extracted digits and the top digit are untouched): the accumulator never changes sign, its bits 62 and 63 stay 01 for the
-// |column sum| <= 1.17 * 2^62 of a C x C product.  Same results as mul() (checked below), 26 more 64-bit additions per product.
+// BIASED-UNSIGNED column accumulators.  The 13 x 30-bit design already uses the signed 64-bit range (a column
+// of a C x C product reaches +-1.17 * 2^62, of a C x W product +-1.92 * 2^62, fp30.hpp), so the only bias there is room for is the
+// unsigned mid-point: a column is kept as U = S + 2^63 in [0, 2^64) (the multiply-add's 64-bit addition is the same instruction
+// either way), shifted LOGICALLY, and given back what the shift took: U' = (U >> 30) + 2^63 - 2^33.  Both constants have zero low
+// 32 bits, so the quotient digit, the extracted digits and the top digit are untouched.  Same results as mul() (checked per lane
+// below), 26 more 64-bit additions per product.  (It cannot keep the upper bits quiet either -- U crosses 2^63 whenever S
+// changes sign -- so what this measures is the price of the idea, with nothing on the other side of the scale.)
 namespace biased {
 using namespace kzg::q30core;
-constexpr int64_t BIAS = 3LL << 61, REBIAS = BIAS - (BIAS >> 30);
+constexpr uint64_t BIAS = 1ull << 63, REBIAS = BIAS - (BIAS >> 30);
+__device__ __forceinline__ void shift_b(int64_t& acc) { acc = (int64_t)(((uint64_t)acc >> 30) + REBIAS); }
 template <int K>
 __device__ __forceinline__ void lo_col_b(int64_t& acc, const ProdMul& pr, int32_t* m) {
     pr.template col<K>(acc);
     run_vp<K, K>(acc, m);
     m[K] = (int32_t)((uint32_t)acc * q30::N0Q) >> 2;
     run_vp<1, 0>(acc, m + K);
-    acc = (acc >> 30) + REBIAS;
+    shift_b(acc);
 }
 template <int K, int OUTF>
 __device__ __forceinline__ void hi_col_b(int64_t& acc, const ProdMul& pr, const int32_t* m, int32_t* r) {
     constexpr int lo = K - SL + 1, n = SL - lo, J = K - SL;
     pr.template col<K>(acc);
     run_vp<n, K - lo>(acc, m + lo);
-    if constexpr (J < SL - 1) { extract<OUTF>(acc, r[J]); acc += REBIAS; }
-    else r[J] = (int32_t)acc;
+    if constexpr (J == SL - 1) r[J] = (int32_t)acc;
+    else if constexpr (OUTF == DC) {
+        acc = (int64_t)((uint64_t)acc + (uint64_t)SHALF);
+        r[J] = ((int32_t)acc & SMASK) - SHALF;
+        shift_b(acc);
+    } else {
+        r[J] = (int32_t)acc & SMASK;
+        shift_b(acc);
+    }
 }
 template <int OUTF, int... Ks>
 __device__ __forceinline__ void mont_b(const ProdMul& pr, int32_t* r, std::integer_sequence<int, Ks...>) {
     int32_t m[SL];
-    int64_t acc = BIAS;
+    int64_t acc = (int64_t)BIAS;
     (lo_col_b<Ks>(acc, pr, m), ...);
     (hi_col_b<SL + Ks, OUTF>(acc, pr, m, r), ...);
 }
