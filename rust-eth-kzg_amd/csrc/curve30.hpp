@@ -198,6 +198,23 @@ HD JacS dbl(const JacS& p) {
 // add-1998-cmo-2 (12M + 4S, no doublings of intermediates): p + q, or p - q when negq.  No exceptional-case test on the way:
 // an identity operand, P + P and P - P all make Z3 = Z1 Z2 H vanish (a fresh product: zero iff its digits are zero).
 HD JacS add_slow(const JacS& p, const JacS& q, bool negq);
+// the common path alone: `degenerate` tells the caller that the result is void and add_slow has to be asked (a caller that can
+// re-read its operands does so then, instead of keeping both points alive across the whole formula: k_g1slp.hip)
+HD JacS add_unchecked(const JacS& p, const JacS& q, bool negq, bool& degenerate) {
+    const Fs<1, DC> z1z1 = sqr(p.z), z2z2 = sqr(q.z);
+    const Fs<1, DU> u1 = mul<DU>(z2z2, p.x);
+    const Fs<1, DU> s1 = mul<DU>(mul(p.y, q.z), z2z2);
+    const auto h = mul_inj<-1, DC>(z1z1, q.x, u1);                                  // U2 - U1: <= 2
+    const auto rr = mul_inj<-1, DC>(mul(cneg(negq, q.y), p.z), z1z1, s1);           // +-S2 - S1: <= 2
+    JacS r;
+    r.z = mul(mul(p.z, q.z), h);
+    degenerate = product_is_zero(r.z);
+    const Fs<1, DC> hh = sqr(h), hhh = mul(h, hh);
+    const Fs<1, DU> v = mul<DU>(hh, u1);
+    r.x = sqr_inj2<-1, -2, DC>(rr, hhh, v);                                         // rr^2 - HHH - 2 V: <= 4
+    r.y = mul_add<DC>(rr, sub(v, r.x), neg(s1), hhh);                               // rr (V - X3) - S1 HHH
+    return r;
+}
 HD JacS add(const JacS& p, const JacS& q, bool negq = false) {
     const Fs<1, DC> z1z1 = sqr(p.z), z2z2 = sqr(q.z);
     const Fs<1, DU> u1 = mul<DU>(z2z2, p.x);
@@ -222,6 +239,52 @@ HD JacS add_slow(const JacS& p, const JacS& q, bool negq) {
     const auto rr = mul_inj<-1, DC>(mul(cneg(negq, q.y), p.z), z1z1, s1);
     if (is_zero_slow(rr)) return dbl(p);
     return jacs_inf();
+}
+// p + q AND p - q (the sum-and-difference pairs of the G1 linear map, k_g1slp.hip) with everything the two share computed once:
+// Z1Z1, Z2Z2, U1, S1, H, HH, HHH, V, Z3 and S2's first product -- 10M + 3S -- then one reduction for +-S2 - S1, one square and one
+// product pair per result (two separate additions: 24M + 8S + two pairs; this: 12M + 5S + two pairs).  In two steps so that the
+// caller can store the first result before the second is computed (six shared values live instead of two whole points).
+// Z3 = Z1 Z2 H is a fresh product: zero iff an operand is the identity or p = +-q -- `degenerate`: the caller takes both results
+// from add_slow (the shared values are then meaningless).
+struct AddSubSharedS {
+    Fs<1, DC> t, z1z1, hhh, z3;  // y2 z1, z1^2, H^3, Z3
+    Fs<1, DU> s1, v;             // S1, V = U1 H^2
+    bool degenerate;
+};
+HD AddSubSharedS add_sub_prepare(const JacS& p, const JacS& q) {
+    AddSubSharedS sh;
+    const Fs<1, DC> z2z2 = sqr(q.z);
+    sh.z1z1 = sqr(p.z);
+    const Fs<1, DU> u1 = mul<DU>(z2z2, p.x);
+    sh.s1 = mul<DU>(mul(p.y, q.z), z2z2);
+    const auto h = mul_inj<-1, DC>(sh.z1z1, q.x, u1);                               // U2 - U1: <= 2
+    sh.t = mul(q.y, p.z);
+    const Fs<1, DC> hh = sqr(h);
+    sh.hhh = mul(h, hh);
+    sh.v = mul<DU>(hh, u1);
+    sh.z3 = mul(mul(p.z, q.z), h);
+    sh.degenerate = product_is_zero(sh.z3);
+    return sh;
+}
+HD JacS add_sub_finish(const AddSubSharedS& sh, bool negq) {  // p + q, or p - q when negq (not for degenerate operands)
+    const auto rr = mul_inj<-1, DC>(cneg(negq, sh.t), sh.z1z1, sh.s1);              // +-S2 - S1: <= 2
+    JacS r;
+    r.x = sqr_inj2<-1, -2, DC>(rr, sh.hhh, sh.v);                                    // <= 4
+    r.y = mul_add<DC>(rr, sub(sh.v, r.x), neg(sh.s1), sh.hhh);                       // rr (V - X3) - S1 HHH
+    r.z = sh.z3;
+    return r;
+}
+// both at once (host tests; sum / diff may alias p or q)
+HD void add_sub(const JacS& p, const JacS& q, JacS& sum, JacS& diff) {
+    const AddSubSharedS sh = add_sub_prepare(p, q);
+    if (sh.degenerate) {
+        const JacS s_ = add_slow(p, q, false), d_ = add_slow(p, q, true);
+        sum = s_;
+        diff = d_;
+        return;
+    }
+    sum = add_sub_finish(sh, false);
+    diff = add_sub_finish(sh, true);
 }
 template <int B>
 HD JacS apply_phi(const JacS& p, const Fs<B, DC>& beta) {

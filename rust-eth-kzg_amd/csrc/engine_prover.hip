@@ -105,34 +105,36 @@ void Engine::launch_msm(const void* scalars, TableSel which, void* out, int n_gr
                         int brp_bits, hipStream_t st) {
     launch_msm(scalars, table_view(which), false, out, n_groups, n_slices, out_stride, brp_bits, st);
 }
+// out_fmt: launch::FMT_JACQ (the default: 14 x 29-bit sums) or FMT_JACS (the signed 13 x 30-bit sums the linear map of a batch of
+// more than one lane group computes in); `out` addresses points of that format
 // tv: ONE snapshot of the table view (the builder thread may publish a wider table at any time); scalars_split: the producer
 // has stored the scalars as balanced GLV halves already (only meaningful for a GLV table).  While a wider table is under
 // construction its leading ready groups run on it and the rest on the complete table: two launches, one MSM stage.
 void Engine::launch_msm(const void* scalars, const TableView& tv, bool scalars_split, void* out, int n_groups, int n_slices,
-                        int out_stride, int brp_bits, hipStream_t st) {
+                        int out_stride, int brp_bits, hipStream_t st, int out_fmt) {
     const SharedTable* main = tv.main.get();
     const SharedTable* next = tv.next.get();
     int ready = 0;
     if (next) ready = std::min(n_groups, next->ready_groups.load(std::memory_order_acquire));
     if (!scalars_split) launch::glv_split(const_cast<void*>(scalars), (size_t)n_groups * n_slices * 64, st);  // in place: they feed nothing else
-    if (ready > 0) launch_msm_range(scalars, *next, 0, ready, out, n_groups, n_slices, out_stride, brp_bits, st);
-    if (ready < n_groups) launch_msm_range(scalars, *main, ready, n_groups - ready, out, n_groups, n_slices, out_stride, brp_bits, st);
+    if (ready > 0) launch_msm_range(scalars, *next, 0, ready, out, n_groups, n_slices, out_stride, brp_bits, st, out_fmt);
+    if (ready < n_groups) launch_msm_range(scalars, *main, ready, n_groups - ready, out, n_groups, n_slices, out_stride, brp_bits, st, out_fmt);
 }
 // groups [g0, g0 + gcnt) of every slice on table t
 void Engine::launch_msm_range(const void* scalars, const SharedTable& t, int g0, int gcnt, void* out, int n_groups, int n_slices,
-                              int out_stride, int brp_bits, hipStream_t st) {
+                              int out_stride, int brp_bits, hipStream_t st, int out_fmt) {
     const launch::TabBlocks tb{(const void* const*)t.d_blocks, g0, gcnt};
     const int c = t.c;
     const long msms = (long)gcnt * n_slices;
     int mode = 1;  // a lane per (MSM, window)
-    if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) mode = 0;  // a handful of blobs: one block per MSM
+    if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0 && out_fmt == launch::FMT_JACQ) mode = 0;  // a handful of blobs: one block per MSM
     else if (msm_chunks_ >= 0) mode = msm_chunks_ == 0 ? 1 : 2;  // tests: 0 = the windowed kernel, anything else = four chunks per MSM
     else if ((msms * 4 + 63) / 64 >= (long)wave_slots_) {
         // The chip is full: four chunks per MSM, 16384 short waves dealt out as slots free up.  (A lane per MSM and a lane per GLV
         // half -- no folds, no barriers, exact rounds of long waves -- were measured 1-2 % SLOWER in rounds 3 and 4 and are gone.)
         mode = 2;
     }
-    launch::msm_glv(c, mode, scalars, tb, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st);
+    launch::msm_glv(c, mode, scalars, tb, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st, out_fmt);
 }
 
 // full FFT_128.  forward: DIF natural -> bit-reversed.  inverse: DIT bit-reversed -> natural (no scaling).
@@ -168,7 +170,7 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         if (slp_force_ < 0 && bp == 64 && n > 32 && launch::coop_points_max() > 0) which = SLP_DEPTH_456;
         mulc_coop_lanes = n <= 32 ? n : (bp == 64 && which == SLP_DEPTH_456) ? n : 0;
         prog = &slp_program(which);
-        const size_t need = (size_t)prog->n_slots * bp * launch::SIZEOF_JACQ;
+        const size_t need = (size_t)prog->n_slots * bp * launch::SIZEOF_JACQ;  // (sized for the larger of the two point formats)
         if (need > w.slp_arena_bytes) {
             if (w.slp_arena) { HIPCK(hipStreamSynchronize(st)); HIPCK(hipFree(w.slp_arena)); w.slp_arena = nullptr; w.slp_arena_bytes = 0; }
             HIPCK(hipMalloc(&w.slp_arena, need));
@@ -176,6 +178,13 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         }
         X = w.slp_arena;
     }
+    // The arena's point format.  More than one lane group (> 64 blobs): every kernel between the scalars and the proofs' bytes --
+    // MSM, constant multiplications, additions, compression -- is a lane-per-blob kernel of the signed 13 x 30-bit field, and the
+    // arena holds its points (JacS, 156 B) as they are: ONE Fp representation under the whole path, no conversions (VERDICT r5
+    // item 5).  One lane group or less: the several-lanes-per-point kernels of g1_coop.hpp (shared with verification) and the
+    // circulant form compute in the 14 x 29-bit field, and the arena holds JacQ.
+    const int fmt = (linmap_mode && bp > 64 && mulc_coop_lanes == 0 && arena_signed_) ? launch::FMT_JACS : launch::FMT_JACQ;
+    const size_t pt = fmt == launch::FMT_JACS ? launch::SIZEOF_JACS : launch::SIZEOF_JACQ;
     const TableView tv = tv_pre ? *tv_pre : table_view(TAB_FK);  // one snapshot for the scalars' form AND the MSM that reads them
     if (!tv_pre) {
         const int mk1 = mark_begin(ST_FK20_SCALARS, st);
@@ -189,26 +198,26 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         // (the head on a stream of its own, next to the later sub-batches' light stages and joined before the linear map, was
         // measured too: no gain, profiles/archive/r4_early_msm_ab.log)
         if (phase == PROOFS_HEAD) {
-            launch::g1_set_inf(X, (size_t)128 * bp, st);
-            launch_msm(w.scalars, tv, true, X, 128, msm_cut, bp, 0, st);
+            launch::g1_set_inf(X, (size_t)128 * bp, st, fmt);
+            launch_msm(w.scalars, tv, true, X, 128, msm_cut, bp, 0, st, fmt);
             return;
         }
-        launch_msm((char*)w.scalars + (size_t)msm_cut * 128 * 64 * sizeof(Fr), tv, true, (char*)X + (size_t)msm_cut * launch::SIZEOF_JACQ, 128, n - msm_cut, bp, 0, st);
+        launch_msm((char*)w.scalars + (size_t)msm_cut * 128 * 64 * sizeof(Fr), tv, true, (char*)X + (size_t)msm_cut * pt, 128, n - msm_cut, bp, 0, st, fmt);
     }
-    if (phase == PROOFS_ALL) launch::g1_set_inf(X, (size_t)128 * bp, st);
+    if (phase == PROOFS_ALL) launch::g1_set_inf(X, (size_t)128 * bp, st, fmt);
     const int mk2 = mark_begin(ST_MSM_FIXED, st);
-    if (phase == PROOFS_ALL) launch_msm(w.scalars, tv, true, X, 128, segs * n, bp, 0, st);
+    if (phase == PROOFS_ALL) launch_msm(w.scalars, tv, true, X, 128, segs * n, bp, 0, st, fmt);
     mark_end(mk2, 1, st);
     if (linmap_mode) {
         const int mk3 = mark_begin(ST_G1_LINMAP, st);
         int n_launches = 0;
         for (auto& L : prog->launches)
             launch::g1_slp_launch(L.kind, w.slp_arena, bp, (const uint32_t*)prog->d_words + (size_t)L.first * 4, L.count, prog->d_naf, beta_, st, 0,
-                                  mulc_coop_lanes);
+                                  mulc_coop_lanes, fmt);
         n_launches = (int)prog->launches.size();
         mark_end(mk3, n_launches, st);
         const int mk4 = mark_begin(ST_COMPRESS, st);
-        launch::g1_compress((const char*)w.slp_arena + (size_t)128 * bp * launch::SIZEOF_JACQ, d_proofs, 128, bp, n, st);
+        launch::g1_compress((const char*)w.slp_arena + (size_t)128 * bp * pt, d_proofs, 128, bp, n, st, fmt);
         mark_end(mk4, 1, st);
         return;
     }

@@ -4,7 +4,8 @@
 // y^2 = x^3 + 4 Z^6) so that every addition of the digit loop is a mixed one -- with the chain written for fp30.hpp:
 //   * doublings in the halved form (curve30.hpp: dbl_half: 2,054 multiply-adds instead of 2,317, no constant multiples),
 //   * mixed additions with the subtractions fused into the reductions (3,497 instead of 3,941),
-//   * the point enters from and leaves to the 14 x 29-bit form (JacQ) the arena holds: six products per multiplication.
+//   * the point is read from and written to the arena as it is when the arena holds the signed form (batches of more than one
+//     lane group); an arena in the 14 x 29-bit form (JacQ) costs six products per multiplication for the way in and out.
 // Reference work being replaced: the blst scalar multiplication behind `b * twiddle` of fft.rs:164-177.
 #pragma once
 #include "kcommon.hpp"
@@ -13,9 +14,8 @@
 
 namespace kzg {
 
-__device__ __forceinline__ JacQ mul_by_recoded30(const JacQ& pq, const uint32_t* __restrict__ row, const Fs<1, DC>& beta) {
+__device__ __forceinline__ JacS mul_by_recoded30(const JacS& p, const uint32_t* __restrict__ row, const Fs<1, DC>& beta) {
     constexpr int NT = 1 << (launch::TWIDDLE_WNAF_W - 2);  // odd multiples P, 3P, .., (2 NT - 1) P
-    const JacS p = jacs_from_jacq(pq);
     AffT A[NT];
     Fs<1, DC> bx[NT];
     Fs<1, DC> zc;
@@ -96,7 +96,11 @@ __device__ __forceinline__ JacQ mul_by_recoded30(const JacQ& pq, const uint32_t*
         }
     }
     acc.z = mul(acc.z, zc);  // back from the isomorphic curve
-    return jacq_from_jacs(acc);
+    return acc;
+}
+// the same on an arena in the 14 x 29-bit form: six products for the way in and out
+__device__ __forceinline__ JacQ mul_by_recoded30(const JacQ& pq, const uint32_t* __restrict__ row, const Fs<1, DC>& beta) {
+    return jacq_from_jacs(mul_by_recoded30(jacs_from_jacq(pq), row, beta));
 }
 
 }  // namespace kzg

@@ -4,6 +4,7 @@
 #include "engine.hpp"
 #include "kcommon.hpp"
 #include "curve29.hpp"
+#include "curve30.hpp"
 #include "g1_subgroup.hpp"
 #include "g1_coop.hpp"
 #include "launch.hpp"
@@ -15,6 +16,19 @@ __global__ void k_g1_set_inf(JacQ* X, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) X[i] = jacq_inf();
 }
+__global__ void k_g1_set_inf_s(JacS* X, size_t n) {  // an array in the signed 13 x 30-bit form (launch::FMT_JACS)
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) X[i] = jacs_inf();
+}
+// a point of either array format as saturated Jacobian coordinates (what the normalisation below computes in)
+__device__ __forceinline__ G1Jac jac_of(const JacQ& p) { return jac_from_jacq(p); }
+__device__ __forceinline__ G1Jac jac_of(const JacS& p) {
+    G1Jac r;
+    r.x = fp_from_fs(p.x);
+    r.y = fp_from_fs(p.y);
+    r.z = fp_from_fs(p.z);  // canonical: the identity arrives as z = 0
+    return r;
+}
 
 // Stage G+I: normalise and compress (lib.rs:56-104, serialization/src/lib.rs:84-86).
 // X[pos * stride + slice] -> out[(slice * n_pos + pos) * 48]
@@ -23,8 +37,8 @@ __global__ void k_g1_set_inf(JacQ* X, size_t n) {
 // an identity (z = 0) takes part as z = 1 and is encoded as the identity afterwards.  The binary-GCD inversion is ~80 % of a
 // one-point normalisation, so this is ~3x fewer instructions per point; n_pos not a multiple of 4: the tail takes part as ones.
 // (NB = 1 for batches that leave the chip part empty: there the kernel lasts as long as one thread's chain.)
-template <int NB>
-__global__ __launch_bounds__(64) void k_g1_compress(const JacQ* __restrict__ X, uint8_t* __restrict__ out, int n_pos,
+template <int NB, class Pt>
+__global__ __launch_bounds__(64) void k_g1_compress(const Pt* __restrict__ X, uint8_t* __restrict__ out, int n_pos,
                                                     int stride, int n_slices) {
     const int pos0 = blockIdx.x * NB, slice = blockIdx.y * 64 + threadIdx.x;
     if (slice >= n_slices) return;
@@ -35,7 +49,7 @@ __global__ __launch_bounds__(64) void k_g1_compress(const JacQ* __restrict__ X, 
     for (int i = 0; i < NB; i++) {
         inf[i] = true;
         if (pos0 + i < n_pos) {
-            P[i] = jac_from_jacq(X[(size_t)(pos0 + i) * stride + slice]);
+            P[i] = jac_of(X[(size_t)(pos0 + i) * stride + slice]);
             inf[i] = is_inf(P[i]);
         }
         const Fp z = inf[i] ? one<FpParams>() : P[i].z;
@@ -280,12 +294,22 @@ void preload_k_g1misc() {
     hipFuncAttributes a;
     (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_g1_set_inf));
 }
-void g1_set_inf(void* X, size_t n, hipStream_t st) { k_g1_set_inf<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((JacQ*)X, n); }
-void g1_compress(const void* X, uint8_t* out, int n_pos, int stride, int n_slices, hipStream_t st) {
+void g1_set_inf(void* X, size_t n, hipStream_t st, int fmt) {
+    if (fmt == FMT_JACS) k_g1_set_inf_s<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((JacS*)X, n);
+    else k_g1_set_inf<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((JacQ*)X, n);
+}
+void g1_compress(const void* X, uint8_t* out, int n_pos, int stride, int n_slices, hipStream_t st, int fmt) {
     // measured (128 positions): 2048 lanes 0.39 -> 0.22 ms with four positions per thread; 512 lanes 0.155 -> 0.21, 64 lanes 0.15 -> 0.21 ms
     // (below two rounds of one-point waves the kernel lasts as long as one thread's chain)
-    if ((long)n_pos * stride >= 128L * 2048) k_g1_compress<4><<<dim3((n_pos + 3) / 4, stride / 64), 64, 0, st>>>((const JacQ*)X, out, n_pos, stride, n_slices);
-    else k_g1_compress<1><<<dim3(n_pos, stride / 64), 64, 0, st>>>((const JacQ*)X, out, n_pos, stride, n_slices);
+    const bool four = (long)n_pos * stride >= 128L * 2048;
+    const dim3 g4((n_pos + 3) / 4, stride / 64), g1(n_pos, stride / 64);
+    if (fmt == FMT_JACS) {  // the arena of a batch of more than one lane group (signed 13 x 30-bit points)
+        if (four) k_g1_compress<4, JacS><<<g4, 64, 0, st>>>((const JacS*)X, out, n_pos, stride, n_slices);
+        else k_g1_compress<1, JacS><<<g1, 64, 0, st>>>((const JacS*)X, out, n_pos, stride, n_slices);
+    } else {
+        if (four) k_g1_compress<4, JacQ><<<g4, 64, 0, st>>>((const JacQ*)X, out, n_pos, stride, n_slices);
+        else k_g1_compress<1, JacQ><<<g1, 64, 0, st>>>((const JacQ*)X, out, n_pos, stride, n_slices);
+    }
 }
 void g1_sum_positions(void* X, int n_pos, int stride, int n_slices, hipStream_t st) {
     if (n_slices > 0) k_g1_sum_positions<<<n_slices, 64, 0, st>>>((JacQ*)X, n_pos, stride, n_slices);

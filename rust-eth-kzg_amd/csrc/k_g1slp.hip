@@ -8,6 +8,7 @@
 // independent and never write a slot that the same launch reads (linmap::make_schedule).
 // words: 4 per operation: dst slot, a slot, b (slot | number of doublings | constant id), flags (1 = subtract, 2 = doubling run, 4 = a + b to dst AND a - b to slot flags >> 16; bits 3-7 of an addition: doublings of operand a first).
 #include "engine.hpp"
+#include <stdexcept>
 #include "g1_mulc.hpp"
 #include "g1_mulc30.hpp"
 #include "g1_coop.hpp"
@@ -23,6 +24,16 @@ __global__ __launch_bounds__(64, 2) void k_slp_mulc(JacQ* __restrict__ A, int st
                    cid = __builtin_amdgcn_readfirstlane(w[2]);
     const int lane = blockIdx.y * 64 + threadIdx.x;
     const JacQ src = A[(size_t)a * stride + lane];
+    A[(size_t)dst * stride + lane] = mul_by_recoded30(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta);
+}
+// ... and on an arena in the signed form itself (launch::FMT_JACS: batches of more than one lane group): nothing is converted
+__global__ __launch_bounds__(64, 2) void k_slp_mulc_s(JacS* __restrict__ A, int stride, const uint32_t* __restrict__ words,
+                                                      const uint32_t* __restrict__ naf, Fs<1, DC> beta) {
+    const uint32_t* w = words + (size_t)blockIdx.x * 4;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
+                   cid = __builtin_amdgcn_readfirstlane(w[2]);
+    const int lane = blockIdx.y * 64 + threadIdx.x;
+    const JacS src = A[(size_t)a * stride + lane];
     A[(size_t)dst * stride + lane] = mul_by_recoded30(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta);
 }
 // the constant multiplications of a batch of <= 16 blobs: four lanes per blob (a wave = 16 blobs x one operation), the quad sharing
@@ -92,6 +103,49 @@ __global__ __launch_bounds__(64, 2) void k_slp_add(JacQ* __restrict__ A, int str
     slp_cheap_op(A, stride, blockIdx.x * 64 + threadIdx.x, dst, a, b, fl);
 }
 
+// The same operations on an arena in the signed 13 x 30-bit form (launch::FMT_JACS; curve30.hpp): add-1998-cmo-2 with the
+// subtractions fused into the reductions, the sum-and-difference pair with its shared part computed once (add_sub), doubling runs
+// in the halved form (dbl_half: (X / 4, Y / 8, Z / 2) is the same point).  Degenerate operands -- an identity, a = +-b -- leave by
+// add_slow inside add / add_sub (Z3 = Z1 Z2 H is a fresh product: zero iff its digits are).
+__global__ __launch_bounds__(64, 2) void k_slp_add_s(JacS* __restrict__ A, int stride, const uint32_t* __restrict__ words) {
+    const uint32_t* w = words + (size_t)blockIdx.y * 4;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
+                   b = __builtin_amdgcn_readfirstlane(w[2]), fl = __builtin_amdgcn_readfirstlane(w[3]);
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    JacS r = A[(size_t)a * stride + lane];
+    const uint32_t runs = (fl & 2u) ? b : (fl >> 3) & 31u;
+#pragma unroll 1
+    for (uint32_t k = 0; k < runs; k++) r = dbl_half(r);
+    bool degenerate = false;
+    if (!(fl & 2u)) {
+        if (fl & 4u) {  // the difference is stored before the sum is computed
+            const AddSubSharedS sh = add_sub_prepare(r, A[(size_t)b * stride + lane]);
+            degenerate = sh.degenerate;  // (an identity, a = +-b: both results are redone below; what is stored here is overwritten)
+            A[(size_t)(fl >> 16) * stride + lane] = add_sub_finish(sh, true);
+            r = add_sub_finish(sh, false);
+        } else {
+            r = add_unchecked(r, A[(size_t)b * stride + lane], (fl & 1u) != 0, degenerate);
+        }
+    }
+    A[(size_t)dst * stride + lane] = r;
+    // the exact slow path comes LAST, when nothing else is live (kept inside the formulas it would hold both operands alive across
+    // them): the operands are read and doubled again.  Rare: all-zero / constant / two-valued / sparse blobs.
+    if (degenerate) {
+        asm volatile("" ::: "memory");
+        JacS p2 = A[(size_t)a * stride + lane];
+#pragma unroll 1
+        for (uint32_t k = 0; k < runs; k++) p2 = dbl_half(p2);
+        const JacS q2 = A[(size_t)b * stride + lane];
+        if (fl & 4u) {
+            const JacS d = add_slow(p2, q2, true);
+            A[(size_t)dst * stride + lane] = add_slow(p2, q2, false);
+            A[(size_t)(fl >> 16) * stride + lane] = d;
+        } else {
+            A[(size_t)dst * stride + lane] = add_slow(p2, q2, (fl & 1u) != 0);
+        }
+    }
+}
+
 // The cheap operations of ONE lane group (<= 64 blobs: BASELINE config 4's and 5's per-GPU shares) with four lanes per blob
 // (g1_coop.hpp): a level is then a few hundred waves on an idle chip, each a single addition -- 16.5 multiplication times for one
 // lane, 5.5 for a quad; a doubling run likewise 3.5 per doubling instead of 6.5.  The sum-and-difference pair is two
@@ -128,9 +182,18 @@ void preload_k_g1slp() {
 }
 // kind: 3 multiplication by a constant, anything else the mixed addition / subtraction / doubling launch (linmap::OpKind)
 void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int count, const void* naf, const Fp12w& beta,
-                   hipStream_t st, int lanes, int coop_lanes) {
+                   hipStream_t st, int lanes, int coop_lanes, int fmt) {
     if (lanes <= 0) lanes = stride;  // (a sub-range of the lanes: arena already points at its first lane, stride stays the arena's)
     const dim3 grid((unsigned)count, (unsigned)(lanes / 64));
+    if (fmt == FMT_JACS) {  // a lane per blob, everything in the signed field (the engine picks this format only for more than one lane group)
+        if (coop_lanes > 0) throw std::logic_error("g1_slp_launch: the several-lanes-per-blob kernels read the 14 x 29-bit arena");
+        if (kind == 3) {
+            Fp b384;
+            for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
+            k_slp_mulc_s<<<grid, 64, 0, st>>>((JacS*)arena, stride, words, (const uint32_t*)naf, fs_from_fp(b384));
+        } else k_slp_add_s<<<dim3((unsigned)(lanes / 64), (unsigned)count), 64, 0, st>>>((JacS*)arena, stride, words);
+        return;
+    }
     if (kind == 3) {
         Fp b384;
         for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];

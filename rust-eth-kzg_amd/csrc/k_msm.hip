@@ -32,7 +32,7 @@ void preload_k_msm() {
 void glv_split(void* scalars, size_t n, hipStream_t st) {
     k_glv_split<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((Fr*)scalars, n);
 }
-#define GLV_DECL(w) void msm_glv_w##w(int, const void*, const TabBlocks&, void*, int, int, int, int, int, const Fp12w&, hipStream_t); void preload_k_msm_glv##w();
+#define GLV_DECL(w) void msm_glv_w##w(int, const void*, const TabBlocks&, void*, int, int, int, int, int, const Fp12w&, hipStream_t, int); void preload_k_msm_glv##w();
 GLV_DECL(8) GLV_DECL(12) GLV_DECL(14) GLV_DECL(15) GLV_DECL(16)
 #undef GLV_DECL
 void preload_k_ntt(); void preload_k_g1fft(); void preload_k_g1circ(); void preload_k_g1misc(); void preload_k_verify();
@@ -48,13 +48,13 @@ bool glv_width_supported(int c) {
     return false;
 }
 void msm_glv(int c, int mode, const void* scalars, const TabBlocks& table, void* out, int n_groups, int n_slices, int nb, int out_stride,
-             int brp_bits, const Fp12w& beta, hipStream_t st) {
+             int brp_bits, const Fp12w& beta, hipStream_t st, int out_fmt) {
     switch (c) {
-        case 8: return msm_glv_w8(mode, scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, beta, st);
-        case 12: return msm_glv_w12(mode, scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, beta, st);
-        case 14: return msm_glv_w14(mode, scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, beta, st);
-        case 15: return msm_glv_w15(mode, scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, beta, st);
-        default: return msm_glv_w16(mode, scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, beta, st);
+        case 8: return msm_glv_w8(mode, scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, beta, st, out_fmt);
+        case 12: return msm_glv_w12(mode, scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, beta, st, out_fmt);
+        case 14: return msm_glv_w14(mode, scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, beta, st, out_fmt);
+        case 15: return msm_glv_w15(mode, scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, beta, st, out_fmt);
+        default: return msm_glv_w16(mode, scalars, table, out, n_groups, n_slices, nb, out_stride, brp_bits, beta, st, out_fmt);
     }
 }
 }  // namespace launch

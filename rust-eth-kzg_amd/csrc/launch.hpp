@@ -64,8 +64,12 @@ constexpr size_t glv_entries_per_base(int c, int w0, int w1) {
 constexpr int GLV_WIDTHS[] = {16, 15, 14, 12, 8};  // widest first: the order the engine tries them in
 bool glv_width_supported(int c);
 void glv_split(void* scalars, size_t n, hipStream_t st);
-void msm_glv(int c, int mode, const void* scalars, const TabBlocks& table, void* out /*JacQ*/, int n_groups, int n_slices, int nb, int out_stride,
-             int brp_bits, const Fp12w& beta, hipStream_t st);
+// Point arrays between the prover's G1 stages come in two formats (FMT_*): the 14 x 29-bit form (JacQ, 168 B: the latency paths of
+// <= 64 blobs, commitments, set-up, verification) and the signed 13 x 30-bit form (JacS, 156 B: the MSM sums, the linear map's arena
+// and the input of the proofs' compression for batches of more than one lane group -- one field under that whole path).
+constexpr int FMT_JACQ = 0, FMT_JACS = 1;
+void msm_glv(int c, int mode, const void* scalars, const TabBlocks& table, void* out /*JacQ or JacS by out_fmt*/, int n_groups, int n_slices, int nb, int out_stride,
+             int brp_bits, const Fp12w& beta, hipStream_t st, int out_fmt = FMT_JACQ);
 // k_table.hip
 #ifdef TABS_STRIDE_128
 constexpr size_t SIZEOF_TABP = 128;   // EXPERIMENT: a GLV table entry on a line of its own (curve30.hpp)
@@ -85,13 +89,14 @@ void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int m
 // k_g1slp.hip: one launch of the straight-line program of the FK20 proofs map (g1_linmap.hpp); kind = linmap::OpKind
 void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int count, const void* naf, const Fp12w& beta,
                    hipStream_t st, int lanes = 0 /* lanes to run (a multiple of 64, from the arena pointer on); 0: all `stride` of them */,
-                   int coop_lanes = 0 /* > 0: the batch has this many blobs (<= 32): the constant multiplications take four (<= 16) or two lanes per blob */);
+                   int coop_lanes = 0 /* > 0: the batch has this many blobs (<= 32): the constant multiplications take four (<= 16) or two lanes per blob */,
+                   int fmt = FMT_JACQ /* the arena's point format; FMT_JACS: the lane-per-blob kernels in the signed field */);
 
 // k_g1misc.hip
-void g1_set_inf(void* X, size_t n, hipStream_t st);
+void g1_set_inf(void* X, size_t n, hipStream_t st, int fmt = FMT_JACQ);
 int coop_points_max();  // largest launch (points) that takes the four-lanes-per-point kernels (k_g1misc.hip)
 void spin(uint64_t wall_clock_ticks, hipStream_t st);  // one wave, resident for that many ticks of the constant-rate device clock
-void g1_compress(const void* X, uint8_t* out, int n_pos, int stride, int n_slices, hipStream_t st);
+void g1_compress(const void* X, uint8_t* out, int n_pos, int stride, int n_slices, hipStream_t st, int fmt = FMT_JACQ);
 void g1_sum_positions(void* X, int n_pos, int stride, int n_slices, hipStream_t st);
 // subgroup_check: 0 none, 1 endomorphism test, 2 definitional [r]P == O
 void g1_decompress(const uint8_t* in, void* out /*G1Affine*/, int* status, int n, int subgroup_check, const Fp12w& beta,
@@ -170,6 +175,7 @@ void vm_fold_ranges(const void* prod, const int* ranges /*[n_ranges][2], device*
 void quotient_by_linear(int n, const void* coeffs, const void* z_mont, void* quotient, void* y_out, hipStream_t st);
 
 constexpr size_t SIZEOF_FR = 32, SIZEOF_G1AFFINE = 96, SIZEOF_G1JAC = 144;
+constexpr size_t SIZEOF_JACS = 156;  // signed 13 x 30-bit Jacobian point (curve30.hpp)
 constexpr size_t SIZEOF_AFFQ = 112, SIZEOF_JACQ = 168;  // unsaturated 14 x 29-bit forms (curve29.hpp): affine points, FFT arrays
 
 }  // namespace launch

@@ -69,6 +69,67 @@ int main() {
         expect(add(jacs_inf(), q, true), neg(Q), "O-Q");
         expect(add(jacs_inf(), jacs_inf()), jac_inf(), "O+O");
         expect(dbl(jacs_inf()), jac_inf(), "2O");
+        // the sum-and-difference pair of the G1 linear map (k_slp_add_s): both results from one shared computation, aliasing the
+        // first operand as the kernel does, and every exit of the slow path; then what the arena of a large batch goes through:
+        // chains of pairs, additions, subtractions and halved doubling runs on points that stay in the signed form throughout
+        {
+            JacS s, d;
+            add_sub(p, q, s, d);
+            expect(s, add(P, Q), "add_sub: sum");
+            expect(d, add(P, neg(Q)), "add_sub: difference");
+            JacS a = p, dd;
+            add_sub(a, q, a, dd);  // sum written over the first operand
+            expect(a, add(P, Q), "add_sub aliased: sum");
+            expect(dd, add(P, neg(Q)), "add_sub aliased: difference");
+            a = p;
+            add_sub(a, p, a, dd);  // P + P and P - P
+            expect(a, dbl(P), "add_sub: P+P");
+            expect(dd, jac_inf(), "add_sub: P-P");
+            a = p;
+            add_sub(a, neg(p), a, dd);  // P - P and P + P
+            expect(a, jac_inf(), "add_sub: P+(-P)");
+            expect(dd, dbl(P), "add_sub: P-(-P)");
+            a = jacs_inf();
+            add_sub(a, q, a, dd);
+            expect(a, Q, "add_sub: O+Q");
+            expect(dd, neg(Q), "add_sub: O-Q");
+            a = p;
+            add_sub(a, jacs_inf(), a, dd);
+            expect(a, P, "add_sub: P+O");
+            expect(dd, P, "add_sub: P-O");
+            {   // the common path alone and its flag (k_slp_add_s re-reads its operands when the flag is up)
+                bool deg = true;
+                expect(add_unchecked(p, q, false, deg), add(P, Q), "add_unchecked");
+                checks++;
+                if (deg) { bad++; printf("add_unchecked flags a generic sum\n"); }
+                expect(add_unchecked(p, q, true, deg), add(P, neg(Q)), "add_unchecked: difference");
+                bool d1 = false, d2 = false, d3 = false, d4 = false;
+                (void)add_unchecked(p, p, false, d1);
+                (void)add_unchecked(p, p, true, d2);
+                (void)add_unchecked(jacs_inf(), q, false, d3);
+                (void)add_unchecked(p, jacs_inf(), true, d4);
+                checks++;
+                if (!(d1 && d2 && d3 && d4)) { bad++; printf("add_unchecked misses a degenerate case\n"); }
+            }
+            JacS x = p, y = q;
+            G1Jac X = P, Y = Q;
+            for (int k = 0; k < 12; k++) {
+                JacS t;
+                add_sub(x, y, x, t);                       // (x, y) <- (x + y, x - y) ...
+                G1Jac T = add(X, neg(Y));
+                X = add(X, Y);
+                y = dbl_half(dbl_half(t));                 // ... the difference doubled twice in the halved form
+                Y = dbl(dbl(T));
+                if (k % 3 == 0) { x = add(x, y, true); X = add(X, neg(Y)); }
+            }
+            expect(x, X, "arena chain: x");
+            expect(y, Y, "arena chain: y");
+            checks++;
+            const Fp zx = fp_from_fs(jacs_inf().z);
+            bool zero = true;
+            for (int i = 0; i < 12; i++) zero = zero && zx.v[i] == 0;
+            if (!zero) { bad++; printf("identity's z is not canonical zero\n"); }
+        }
         // XYZZ accumulator (the MSM's): sums of +-q onto p and the exceptional cases
         {
             XyzzS xa = xyzz30_inf();

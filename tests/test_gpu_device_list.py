@@ -284,7 +284,7 @@ def test_constructor_that_throws_late_cleans_up_and_the_next_context_works(oracl
         "assert (m1 - m2) <= max(m0 - m1, 0) + 0.3e9, 'failed constructors keep memory that completed ones give back'\n"
 
         "c = kzg.DASContext(use_precomp=True, table_budget_gb=30)\n"
-        "assert c.window_bits() == 14\n"
+        "assert c.window_bits() == 12, c.window_bits()  # 30 GB: eleven windows for both tables\n"
         "import hashlib\n"
         "r = c.compute_cells_and_kzg_proofs(synth.seeded_blob(780))\n"
         "print('DIGEST', hashlib.sha256(b''.join(r[0]) + b''.join(r[1])).hexdigest())\n"

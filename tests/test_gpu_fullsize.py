@@ -171,6 +171,48 @@ def test_six_thousand_blobs_in_one_device_resident_call(ctx, oracle):
     assert _verify_every_proof(ctx, blobs[3584:4608], cells[3584:4608], proofs[3584:4608]) == [True] * 1024
 
 
+def test_signed_and_unsigned_arena_give_identical_bytes(ctx, oracle, monkeypatch):
+    """Round 6: for more than one lane group the G1 linear map's arena holds signed 13 x 30-bit points (MSM sums, constant
+    multiplications, additions / pairs / halved doubling runs and the compression's input all in csrc/fp30.hpp: no conversions);
+    ETH_KZG_AMD_ARENA_SIGNED=0 keeps the 14 x 29-bit arena of rounds 2-5.  Same bytes from both, at sizes on both sides of the
+    windowed / chunked MSM schedules and of the fused-pair schedule (>= 1024 lanes), with degenerate blobs inside -- the zero
+    polynomial, a constant, sparse polynomials (identity operands, equal and opposite points meet the exact slow paths of add and
+    add_sub) -- and through recovery."""
+    monkeypatch.setenv("ETH_KZG_AMD_ARENA_SIGNED", "0")
+    old = kzg.DASContext(use_precomp=True)  # shares ctx's tables
+    try:
+        for n in (65, 129, 300, 1100):
+            blobs = _random_blobs(n, 9100 + n)
+            blobs[1] = 0
+            blobs[2] = np.frombuffer((b"\x00" * 31 + b"\x05") * 4096, dtype=np.uint8).reshape(4096, 32)
+            blobs[3] = np.frombuffer(_blob_from_coefficients([0] * 4095 + [11]), dtype=np.uint8).reshape(4096, 32)
+            blobs[64] = np.frombuffer(_blob_from_coefficients([3] + [0] * 63 + [9] + [0] * 4031), dtype=np.uint8).reshape(4096, 32)
+            blobs[n - 1] = np.frombuffer(synth.dummy_blob(), dtype=np.uint8).reshape(4096, 32)
+            a, b = _compute_on_device(ctx, blobs), _compute_on_device(old, blobs)
+            assert a[0] == b[0] == [0] * n
+            assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), n
+            _check_sample_against_oracle(oracle, blobs, a[1], a[2], [0, 1, 2, 3, 64, n - 1])
+        # recovery of 80 half-erased blobs runs the same map from coefficients
+        import torch
+        n = 80
+        blobs = _random_blobs(n, 9200)
+        st, cells, proofs = _compute_on_device(ctx, blobs)
+        ext = torch.from_numpy(np.ascontiguousarray(cells)).cuda().view(n, 128, 2048).clone()
+        ext[:, 1::2, :] = 0xEE
+        outs = []
+        for c in (ctx, old):
+            d_c = torch.zeros(n * 128 * 2048, dtype=torch.uint8, device="cuda")
+            d_p = torch.zeros(n * 128 * 48, dtype=torch.uint8, device="cuda")
+            st = c.recover_cells_and_kzg_proofs_device(n, ext.data_ptr(), [list(range(0, 128, 2))] * n, d_c.data_ptr(), d_p.data_ptr())
+            torch.cuda.synchronize()
+            assert st == [0] * n
+            outs.append((d_c.cpu().numpy().reshape(n, -1), d_p.cpu().numpy().reshape(n, -1)))
+        assert np.array_equal(outs[0][0], cells) and np.array_equal(outs[0][1], proofs)
+        assert np.array_equal(outs[1][0], cells) and np.array_equal(outs[1][1], proofs)
+    finally:
+        old.close()
+
+
 def test_compute_512_through_the_host_batch_abi(ctx, oracle):
     """Config 4's 512 blobs through the host-pointer batch entry point (what a C / Go / Java caller uses):
     same bytes as the device-resident form."""

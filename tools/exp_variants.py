@@ -2,7 +2,7 @@
 clock a build gets depends on what ran just before).  Each run is a fresh process: the 2048-blob device-resident step under the
 per-stage HIP events of the library, stage times printed as one JSON line; package power and shader clock are sampled beside it.
 
-    python tools/exp_variants.py <rounds> <table setting> <name=lib.so> [<name=lib.so> ...] [--check]
+    python tools/exp_variants.py <rounds> <table setting> <name=lib.so[@VAR=value ...]> [<name=lib.so> ...] [--check]
 
 table setting: "max", a budget in GB, or "w15" (ETH_KZG_AMD_GLV_WINDOW=15 with whatever memory that takes).
 --check: blob 0's proofs are compared between the first build and every other one (a timing-only build says `differs`).
@@ -81,7 +81,11 @@ def main():
     results = {n: [] for n, _ in builds}
     for r in range(rounds):
         for name, lib in builds:
+            lib, *sets = lib.split("@")  # name=lib.so@VAR=value@VAR2=value: environment of this build's runs only
             env = dict(env0, ETH_KZG_AMD_LIB=os.path.join(ROOT, lib) if not os.path.isabs(lib) else lib)
+            for kv in sets:
+                k, v = kv.split("=", 1)
+                env[k] = v
             stop, rows = threading.Event(), []
             th = threading.Thread(target=sample_smi, args=(stop, rows))
             th.start()
