@@ -1241,7 +1241,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "ms_per_step_without_stage_events": round(dt_plain / args.steps * 1e3, 3),
             "ms_per_step_per_rank": per_rank_ms, "all_gather_ms_per_step": gather_ms,
-            "vs_baseline": None, "dtype": "u32", "dtype_note": "381-bit Fp as 13 signed 30-bit digits (MSM, constant multiplications), 14x29-bit / 12x32-bit limbs elsewhere, 255-bit Fr as 8x32-bit (stored) and 9x29-bit (inside the transforms) limbs, Montgomery integers; exact arithmetic", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u32", "dtype_note": "381-bit Fp as 13 signed 30-bit digits (everything between the scalars and the proof bytes of this batch: MSM, the G1 linear map's multiplications and additions), 14x29-bit / 12x32-bit limbs in the latency paths, codecs and verification, 255-bit Fr as 8x32-bit (stored) and 9x29-bit (inside the transforms) limbs, Montgomery integers; exact arithmetic", "data": "synthetic",
             "config": {"workload": f"compute_cells_and_kzg_proofs on DEVICE-RESIDENT blobs (inputs and outputs stay in HBM; the "
                                    f"host-pointer ABI rate is configs.abi_host_pointer_batch), batch-saturated: {B} synthetic blobs "
                                    f"per GPU per step (config 2's single blob is reported as single_blob_latency_ms)",
