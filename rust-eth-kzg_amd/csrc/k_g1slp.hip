@@ -15,6 +15,8 @@
 
 namespace kzg {
 
+static_assert(sizeof(JacS) == launch::SIZEOF_JACS && sizeof(JacQ) == launch::SIZEOF_JACQ, "the engine sizes and offsets the arena with these");
+
 // (batches that fill the chip: the multiplication runs in the signed 13 x 30-bit field, g1_mulc30.hpp; the point is read from and
 // written to the arena's 14 x 29-bit form)
 __global__ __launch_bounds__(64, 2) void k_slp_mulc(JacQ* __restrict__ A, int stride, const uint32_t* __restrict__ words,
