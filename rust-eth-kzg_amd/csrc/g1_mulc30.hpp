@@ -10,11 +10,16 @@
 #pragma once
 #include "kcommon.hpp"
 #include "curve30.hpp"
+#include "g1_coop30.hpp"
 #include "launch.hpp"
 
 namespace kzg {
 
-__device__ __forceinline__ JacS mul_by_recoded30(const JacS& p, const uint32_t* __restrict__ row, const Fs<1, DC>& beta) {
+// COOP = 2: the two lanes of a pair hold the same p and share the doublings and mixed additions of the digit loop (g1_coop30.hpp;
+// l0 = this lane is the pair's even lane); the table is built on both lanes.
+template <int COOP = 0>
+__device__ __forceinline__ JacS mul_by_recoded30(const JacS& p, const uint32_t* __restrict__ row, const Fs<1, DC>& beta, bool l0 = false) {
+    static_assert(COOP == 0 || COOP == 2, "one lane or a pair per multiplication");
     constexpr int NT = 1 << (launch::TWIDDLE_WNAF_W - 2);  // odd multiples P, 3P, .., (2 NT - 1) P
     AffT A[NT];
     Fs<1, DC> bx[NT];
@@ -70,7 +75,10 @@ __device__ __forceinline__ JacS mul_by_recoded30(const JacS& p, const uint32_t* 
         if (!started && (w1 | w2) == 0) continue;
 #pragma unroll 1
         for (int q = 3; q >= 0; q--) {
-            if (started) acc = dbl_half(acc);
+            if (started) {
+                if constexpr (COOP == 2) acc = coop2_dbl_half(acc, l0);
+                else acc = dbl_half(acc);
+            }
 #pragma unroll 1
             for (int hf = 0; hf < 2; hf++) {
                 const int d = (int)(int8_t)((hf ? w2 : w1) >> (8 * q));
@@ -91,7 +99,8 @@ __device__ __forceinline__ JacS mul_by_recoded30(const JacS& p, const uint32_t* 
                     acc.y = cneg(d < 0, op.y);
                     acc.z = fs_one();
                     started = true;
-                } else acc = add_mixed(acc, op, d < 0);
+                } else if constexpr (COOP == 2) acc = coop2_add_mixed(acc, op, d < 0, l0);
+                else acc = add_mixed(acc, op, d < 0);
             }
         }
     }
@@ -99,8 +108,9 @@ __device__ __forceinline__ JacS mul_by_recoded30(const JacS& p, const uint32_t* 
     return acc;
 }
 // the same on an arena in the 14 x 29-bit form: six products for the way in and out
-__device__ __forceinline__ JacQ mul_by_recoded30(const JacQ& pq, const uint32_t* __restrict__ row, const Fs<1, DC>& beta) {
-    return jacq_from_jacs(mul_by_recoded30(jacs_from_jacq(pq), row, beta));
+template <int COOP = 0>
+__device__ __forceinline__ JacQ mul_by_recoded30(const JacQ& pq, const uint32_t* __restrict__ row, const Fs<1, DC>& beta, bool l0 = false) {
+    return jacq_from_jacs(mul_by_recoded30<COOP>(jacs_from_jacq(pq), row, beta, l0));
 }
 
 }  // namespace kzg

@@ -52,15 +52,21 @@ __global__ __launch_bounds__(64, 2) void k_slp_mulc_coop(JacQ* __restrict__ A, i
 }
 // ... and of 17 .. 64 blobs (BASELINE config 5's and 4's per-GPU shares): two lanes per blob, a wave = 32 blobs x one operation
 // (from 33 blobs on two waves per operation: the engine then picks a compilation of the map with <= 512 multiplications)
+// Round 6: the pair forms of the signed 13 x 30-bit field (g1_coop30.hpp: 276 k instead of 304 k multiply-adds per chain); the point
+// enters from and leaves to the 14 x 29-bit arena of a single lane group.  SIGNED = false: the 14-digit pair forms (g1_coop.hpp), kept
+// as the cross-check (ETH_KZG_AMD_ARENA_SIGNED=0).
+template <bool SIGNED>
 __global__ __launch_bounds__(64, 2) void k_slp_mulc_coop2(JacQ* __restrict__ A, int stride, const uint32_t* __restrict__ words,
-                                                          const uint32_t* __restrict__ naf, Fq<1> beta, int lanes) {
+                                                          const uint32_t* __restrict__ naf, Fq<1> beta, Fs<1, DC> beta_s, int lanes) {
     const uint32_t* w = words + (size_t)blockIdx.x * 4;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
                    cid = __builtin_amdgcn_readfirstlane(w[2]);
     const int lane = blockIdx.y * 32 + (threadIdx.x >> 1), half = threadIdx.x & 1;
     if (lane >= lanes) return;
     const JacQ src = A[(size_t)a * stride + lane];
-    A[(size_t)dst * stride + lane] = mul_by_recoded<2>(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta, half);
+    const uint32_t* row = naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS);
+    if constexpr (SIGNED) A[(size_t)dst * stride + lane] = mul_by_recoded30<2>(src, row, beta_s, half == 0);
+    else A[(size_t)dst * stride + lane] = mul_by_recoded<2>(src, row, beta, half);
 }
 // one cheap operation of the program on one lane: flags & 2: a run of b doublings; otherwise an addition (flags & 1: subtraction;
 // flags & 4: a + b to dst AND a - b to slot flags >> 16) whose FIRST operand is doubled (flags >> 3) & 31 times in registers
@@ -184,7 +190,7 @@ void preload_k_g1slp() {
 }
 // kind: 3 multiplication by a constant, anything else the mixed addition / subtraction / doubling launch (linmap::OpKind)
 void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int count, const void* naf, const Fp12w& beta,
-                   hipStream_t st, int lanes, int coop_lanes, int fmt) {
+                   hipStream_t st, int lanes, int coop_lanes, int fmt, bool pair_signed) {
     if (lanes <= 0) lanes = stride;  // (a sub-range of the lanes: arena already points at its first lane, stride stays the arena's)
     const dim3 grid((unsigned)count, (unsigned)(lanes / 64));
     if (fmt == FMT_JACS) {  // a lane per blob, everything in the signed field (the engine picks this format only for more than one lane group)
@@ -201,8 +207,11 @@ void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int
         for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
         // coop_lanes: the blobs that are really there when they are few enough for four lanes each (<= 16: one quad wave per operation)
         // or two (<= 32: still one wave per operation)
-        if (coop_lanes > 16 && coop_points_max() > 0)
-            k_slp_mulc_coop2<<<dim3((unsigned)count, (unsigned)((coop_lanes + 31) / 32)), 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fq_from_fp(b384), coop_lanes);
+        if (coop_lanes > 16 && coop_points_max() > 0) {
+            const dim3 g2((unsigned)count, (unsigned)((coop_lanes + 31) / 32));
+            if (pair_signed) k_slp_mulc_coop2<true><<<g2, 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fq_from_fp(b384), fs_from_fp(b384), coop_lanes);
+            else k_slp_mulc_coop2<false><<<g2, 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fq_from_fp(b384), fs_from_fp(b384), coop_lanes);
+        }
         else if (coop_lanes > 0 && coop_points_max() > 0)
             k_slp_mulc_coop<<<dim3((unsigned)count, (unsigned)((coop_lanes + 15) / 16)), 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf,
                                                                                                      fq_from_fp(b384), coop_lanes);

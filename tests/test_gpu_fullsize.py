@@ -179,19 +179,21 @@ def test_signed_and_unsigned_arena_give_identical_bytes(ctx, oracle, monkeypatch
     polynomial, a constant, sparse polynomials (identity operands, equal and opposite points meet the exact slow paths of add and
     add_sub) -- and through recovery."""
     monkeypatch.setenv("ETH_KZG_AMD_ARENA_SIGNED", "0")
-    old = kzg.DASContext(use_precomp=True)  # shares ctx's tables
+    old = kzg.DASContext(use_precomp=True)  # shares ctx's tables; everything of the G1 linear map in the 14-digit field, as in rounds 2-5
     try:
-        for n in (65, 129, 300, 1100):
+        # 20 / 33 / 64 blobs: one lane group -- there the knob switches the constant multiplications between the pair forms of the two
+        # fields (g1_coop30.hpp against g1_coop.hpp; the arena stays in the 14-digit form either way)
+        for n in (20, 33, 64, 65, 129, 300, 1100):
             blobs = _random_blobs(n, 9100 + n)
             blobs[1] = 0
             blobs[2] = np.frombuffer((b"\x00" * 31 + b"\x05") * 4096, dtype=np.uint8).reshape(4096, 32)
             blobs[3] = np.frombuffer(_blob_from_coefficients([0] * 4095 + [11]), dtype=np.uint8).reshape(4096, 32)
-            blobs[64] = np.frombuffer(_blob_from_coefficients([3] + [0] * 63 + [9] + [0] * 4031), dtype=np.uint8).reshape(4096, 32)
+            blobs[n // 2] = np.frombuffer(_blob_from_coefficients([3] + [0] * 63 + [9] + [0] * 4031), dtype=np.uint8).reshape(4096, 32)
             blobs[n - 1] = np.frombuffer(synth.dummy_blob(), dtype=np.uint8).reshape(4096, 32)
             a, b = _compute_on_device(ctx, blobs), _compute_on_device(old, blobs)
             assert a[0] == b[0] == [0] * n
             assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), n
-            _check_sample_against_oracle(oracle, blobs, a[1], a[2], [0, 1, 2, 3, 64, n - 1])
+            _check_sample_against_oracle(oracle, blobs, a[1], a[2], [0, 1, 2, 3, n // 2, n - 1])
         # recovery of 80 half-erased blobs runs the same map from coefficients
         import torch
         n = 80
