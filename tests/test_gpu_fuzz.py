@@ -1,0 +1,222 @@
+"""Differential fuzzing of the reference's error / false / true split through the C ABI: seeded mutations of valid inputs -- wrong
+lengths, indices out of range / unsorted / repeated, field elements >= r, corrupted compression flags, random bytes where a G1 point
+should be, proofs and cells swapped or altered, too few cells, inconsistent cells -- go to the HIP path and to the CPU oracle, and
+both must agree on every case: the same bytes, the same verdict, or an error on both sides
+(`Err` for malformed input, `Ok(false)` for a wrong proof: bindings/c/src/lib.rs:272-280; validation:
+crates/eip7594/src/verifier.rs:123-164, crates/eip7594/src/recovery.rs:90-146, crates/serialization/src/lib.rs:36-99).
+The reference's own vectors hold ~50 such cases; these are a few hundred more, at no cost in oracle time (small inputs).
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import importlib
+import os
+import random
+
+import pytest
+
+import synth
+from oracle_lib import OracleError
+
+pytestmark = pytest.mark.gpu
+kzg = importlib.import_module("rust-eth-kzg_amd")
+R = synth.R
+INF = b"\xc0" + bytes(47)
+
+
+@pytest.fixture(scope="module")
+def small_ctx():
+    """A context on the start tables only (2.4 GB): results never depend on the table, and this module should cost seconds."""
+    import torch
+    torch.cuda.init()
+    saved = os.environ.get("ETH_KZG_AMD_TABLE_GB")
+    os.environ["ETH_KZG_AMD_TABLE_GB"] = "3"
+    try:
+        c = kzg.DASContext(use_precomp=True)
+        yield c
+        c.close()
+    finally:
+        if saved is None:
+            os.environ.pop("ETH_KZG_AMD_TABLE_GB", None)
+        else:
+            os.environ["ETH_KZG_AMD_TABLE_GB"] = saved
+
+
+@pytest.fixture(scope="module")
+def material(small_ctx):
+    """Three blobs with their commitments, cells and proofs (from the GPU; the first one checked against the oracle in the tests)."""
+    blobs = [synth.seeded_blob(4000 + i) for i in range(3)]
+    st, cells, proofs = small_ctx.compute_cells_and_kzg_proofs_batch(blobs)
+    assert st == [0, 0, 0]
+    comms = [small_ctx.blob_to_kzg_commitment(b) for b in blobs]
+    return blobs, comms, cells, proofs
+
+
+def _call(fn, *a):
+    try:
+        return fn(*a)
+    except (kzg.KzgError, OracleError):
+        return "ERR"
+
+
+def _be(x):
+    return int(x).to_bytes(32, "big")
+
+
+def _mutate_verify(rng, comms, cells, proofs):
+    """One verification problem: a random sub-list of (blob, cell) pairs, then one random mutation (or none)."""
+    k = rng.randrange(1, 10)
+    pairs = [(rng.randrange(3), rng.randrange(128)) for _ in range(k)]
+    C_ = [comms[b] for b, _ in pairs]
+    I_ = [c for _, c in pairs]
+    L_ = [cells[b][c] for b, c in pairs]
+    P_ = [proofs[b][c] for b, c in pairs]
+    j = rng.randrange(k)
+    kind = rng.choice(["none", "none", "dup", "cell_byte", "cell_ge_r", "cell_r_minus_1", "proof_swap", "proof_random", "proof_inf",
+                       "proof_flag", "proof_x_ge_p", "comm_random", "comm_flag", "comm_other", "index_big", "index_other",
+                       "len_comm", "len_idx", "len_cells", "len_proofs", "empty", "proof_len47", "cell_len"])
+    if kind == "dup":
+        C_, I_, L_, P_ = C_ + [C_[j]] * 2, I_ + [I_[j]] * 2, L_ + [L_[j]] * 2, P_ + [P_[j]] * 2
+    elif kind == "cell_byte":
+        pos = rng.randrange(2048)
+        L_[j] = L_[j][:pos] + bytes([L_[j][pos] ^ (1 << rng.randrange(8))]) + L_[j][pos + 1:]
+    elif kind == "cell_ge_r":
+        e = rng.randrange(64)
+        L_[j] = L_[j][:32 * e] + _be(R + rng.randrange(3)) + L_[j][32 * e + 32:]
+    elif kind == "cell_r_minus_1":
+        e = rng.randrange(64)
+        L_[j] = L_[j][:32 * e] + _be(R - 1) + L_[j][32 * e + 32:]
+    elif kind == "proof_swap":
+        P_[j] = proofs[(pairs[j][0] + 1) % 3][pairs[j][1]]
+    elif kind == "proof_random":
+        P_[j] = bytes(rng.randrange(256) for _ in range(48))
+    elif kind == "proof_inf":
+        P_[j] = INF
+    elif kind == "proof_flag":
+        P_[j] = bytes([P_[j][0] ^ rng.choice([0x80, 0x40, 0x20])]) + P_[j][1:]
+    elif kind == "proof_x_ge_p":
+        P_[j] = bytes([0x9f]) + b"\xff" * 47
+    elif kind == "comm_random":
+        C_[j] = bytes(rng.randrange(256) for _ in range(48))
+    elif kind == "comm_flag":
+        C_[j] = bytes([C_[j][0] & 0x7f]) + C_[j][1:]
+    elif kind == "comm_other":
+        C_[j] = comms[(pairs[j][0] + 1) % 3]
+    elif kind == "index_big":
+        I_[j] = rng.choice([128, 129, 255, 1 << 20, (1 << 64) - 1])
+    elif kind == "index_other":
+        I_[j] = (I_[j] + 1 + rng.randrange(126)) % 128
+    elif kind == "len_comm":
+        C_ = C_[:-1]
+    elif kind == "len_idx":
+        I_ = I_ + [0]
+    elif kind == "len_cells":
+        L_ = L_[:-1]
+    elif kind == "len_proofs":
+        P_ = P_ + [P_[0]]
+    elif kind == "empty":
+        C_, I_, L_, P_ = [], [], [], []
+    elif kind == "proof_len47":
+        P_[j] = P_[j][:47]
+    elif kind == "cell_len":
+        L_[j] = L_[j] + b"\x00"
+    return kind, (C_, I_, L_, P_)
+
+
+def test_verification_agrees_with_the_oracle_on_mutated_inputs(small_ctx, material, oracle):
+    blobs, comms, cells, proofs = material
+    assert (cells[0], proofs[0]) == tuple(oracle.compute_cells_and_kzg_proofs(blobs[0]))
+    rng = random.Random(20251)
+    seen = {}
+    for case in range(260):
+        kind, args = _mutate_verify(rng, comms, cells, proofs)
+        got, want = _call(small_ctx.verify_cell_kzg_proof_batch, *args), _call(oracle.verify_cell_kzg_proof_batch, *args)
+        assert got == want, (case, kind, got, want)
+        seen.setdefault(kind, set()).add(str(want))
+    # the mutations reach all three outcomes
+    outcomes = set().union(*seen.values())
+    assert outcomes == {"True", "False", "ERR"}, seen
+    assert seen["none"] == {"True"} and seen["dup"] == {"True"} and seen["empty"] == {"True"}
+    assert seen["proof_swap"] == {"False"} and seen["index_big"] == {"ERR"} and seen["cell_ge_r"] == {"ERR"}
+
+
+def test_many_verification_agrees_with_the_oracle_on_the_same_mutations(small_ctx, material, oracle):
+    """The same mutated problems through eth_kzg_amd_verify_cell_kzg_proof_batch_many in passes of 40: per-problem verdict and status
+    as the single form gives them (an error status where it raises), whatever the neighbours are."""
+    _, comms, cells, proofs = material
+    rng = random.Random(20252)
+    problems, kinds = [], []
+    while len(problems) < 120:
+        kind, args = _mutate_verify(rng, comms, cells, proofs)
+        if kind in ("proof_len47", "cell_len"):  # (the Python wrapper of the many-form rejects wrong byte lengths for the whole call)
+            continue
+        problems.append(args)
+        kinds.append(kind)
+    for lo in range(0, len(problems), 40):
+        ver, st = small_ctx.verify_cell_kzg_proof_batch_many(problems[lo:lo + 40])
+        for j, args in enumerate(problems[lo:lo + 40]):
+            want = _call(oracle.verify_cell_kzg_proof_batch, *args)
+            got = "ERR" if st[j] != 0 else bool(ver[j])
+            assert got == want, (lo + j, kinds[lo + j], got, st[j], want)
+
+
+def test_recovery_agrees_with_the_oracle_on_mutated_inputs(small_ctx, material, oracle):
+    blobs, comms, cells, proofs = material
+    rng = random.Random(20253)
+    seen = {}
+    for case in range(48):
+        b = rng.randrange(3)
+        n = rng.choice([64, 64, 65, 80, 100, 127, 128])
+        idx = sorted(rng.sample(range(128), n))
+        cl = [cells[b][i] for i in idx]
+        kind = rng.choice(["none", "none", "none", "too_few", "unsorted", "repeat", "index_big", "cell_ge_r", "cell_wrong", "len_mismatch", "too_many"])
+        if kind == "too_few":
+            idx, cl = idx[:63], cl[:63]
+        elif kind == "unsorted" and n > 1:
+            idx[0], idx[1] = idx[1], idx[0]
+            cl[0], cl[1] = cl[1], cl[0]
+        elif kind == "repeat":
+            idx[1], cl[1] = idx[0], cl[0]
+        elif kind == "index_big":
+            idx[-1] = rng.choice([128, 200, 1 << 40])
+        elif kind == "cell_ge_r":
+            j, e = rng.randrange(len(cl)), rng.randrange(64)
+            cl[j] = cl[j][:32 * e] + _be(R) + cl[j][32 * e + 32:]
+        elif kind == "cell_wrong":  # a cell of another blob: inconsistent when there is redundancy, a different polynomial when there is none
+            j = rng.randrange(len(cl))
+            cl[j] = cells[(b + 1) % 3][idx[j]]
+        elif kind == "len_mismatch":
+            idx = idx[:-1]
+        elif kind == "too_many":
+            idx, cl = idx + [127], cl + [cells[b][127]]
+        got = _call(small_ctx.recover_cells_and_kzg_proofs, idx, cl)
+        want = _call(oracle.recover_cells_and_kzg_proofs, idx, cl)
+        if want != "ERR":
+            want = (want[0], want[1])
+            got = (got[0], got[1]) if got != "ERR" else got
+        assert got == want, (case, kind, n, got == "ERR", want == "ERR")
+        seen.setdefault(kind, set()).add("ERR" if want == "ERR" else "ok")
+    assert seen["none"] == {"ok"} and seen["too_few"] == {"ERR"} and seen["unsorted"] == {"ERR"} and seen["cell_ge_r"] == {"ERR"}
+
+
+def test_prover_and_commitment_agree_with_the_oracle_on_mutated_blobs(small_ctx, oracle):
+    rng = random.Random(20254)
+    for case in range(10):
+        blob = bytearray(synth.seeded_blob(4100 + case))
+        kind = rng.choice(["none", "ge_r", "r_minus_1", "zero_run", "max_u256"])
+        e = rng.randrange(4096)
+        if kind == "ge_r":
+            blob[32 * e:32 * e + 32] = _be(R + rng.randrange(2))
+        elif kind == "r_minus_1":
+            blob[32 * e:32 * e + 32] = _be(R - 1)
+        elif kind == "zero_run":
+            blob[32 * e:] = bytes(len(blob) - 32 * e)
+        elif kind == "max_u256":
+            blob[32 * e:32 * e + 32] = b"\xff" * 32
+        blob = bytes(blob)
+        got, want = _call(small_ctx.compute_cells_and_kzg_proofs, blob), _call(oracle.compute_cells_and_kzg_proofs, blob)
+        assert (got if got == "ERR" else (got[0], got[1])) == (want if want == "ERR" else (want[0], want[1])), (case, kind)
+        assert _call(small_ctx.blob_to_kzg_commitment, blob) == _call(oracle.blob_to_kzg_commitment, blob), (case, kind)
+        assert _call(small_ctx.compute_cells, blob) == (want if want == "ERR" else want[0]), (case, kind)
+    for n in (0, 1, 131071, 131073):  # wrong blob lengths are errors in the reference's bindings before the FFI
+        assert _call(small_ctx.compute_cells_and_kzg_proofs, bytes(n)) == "ERR"
+        assert _call(small_ctx.blob_to_kzg_commitment, bytes(n)) == "ERR"
