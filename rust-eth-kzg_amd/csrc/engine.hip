@@ -295,7 +295,7 @@ void Engine::construct() {
     init_verifier();
     HIPCK(hipStreamSynchronize(stream_));
     lap("verifier (G2 lines, cosets)");
-    if (knobs_.fault && !strcmp(knobs_.fault, "constructor") && !primary_) throw std::runtime_error("injected fault (ETH_KZG_AMD_FAULT=constructor)");
+    if (knobs_.fault == "constructor" && !primary_) throw std::runtime_error("injected fault (ETH_KZG_AMD_FAULT=constructor)");
     start_builder();  // last: nothing after it can throw
 }
 

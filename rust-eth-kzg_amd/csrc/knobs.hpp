@@ -32,6 +32,7 @@
 #pragma once
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 namespace kzg {
@@ -47,7 +48,7 @@ struct Knobs {
     bool trace = false;
     int msm_chunks = -1, slp_program = -1, pip_shift_min = 0;
     bool vm_search = true, vm_fold = true, verify_combine = true, arena_signed = true;
-    const char* fault = nullptr;  // ETH_KZG_AMD_FAULT
+    std::string fault;  // ETH_KZG_AMD_FAULT (a copy: the environment may change under a long-lived context)
     int device_batch_max = 0;
 
     static Knobs from_env() {
@@ -87,7 +88,7 @@ struct Knobs {
         flag("ETH_KZG_AMD_VM_FOLD", k.vm_fold);
         flag("ETH_KZG_AMD_VERIFY_COMBINE", k.verify_combine);
         flag("ETH_KZG_AMD_ARENA_SIGNED", k.arena_signed);
-        k.fault = getenv("ETH_KZG_AMD_FAULT");
+        if (const char* s = getenv("ETH_KZG_AMD_FAULT")) k.fault = s;
         num("ETH_KZG_AMD_DEVICE_BATCH_MAX", 64, 1 << 20, k.device_batch_max);
         return k;
     }

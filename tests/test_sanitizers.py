@@ -44,6 +44,16 @@ def test_host_units_under_asan_and_ubsan(tmp_path, name):
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-4000:]
 
 
+def test_knobs_parsing_under_asan_and_ubsan(tmp_path):
+    """csrc/knobs.hpp (HIP-free): the device list of eth_kzg_das_context_new, the table budget and the other variables -- well-formed,
+    sloppy and garbage values (tests/c/test_knobs.cpp)."""
+    exe = str(tmp_path / "test_knobs")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", *SAN, "-I", CSRC, os.path.join(ROOT, "tests", "c", "test_knobs.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=ENV)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout + out.stderr[-3000:]
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-3000:]
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("san", ["thread", "address,undefined"])
 def test_host_concurrency_protocols_under_sanitizers(tmp_path, san):
