@@ -91,7 +91,12 @@ struct Engine::SharedTable {
         if (block_end > total) block_end = total;
         if (!d_blocks) {
             if (hipMalloc((void**)&d_blocks, (size_t)total * sizeof(void*)) != hipSuccess) { (void)hipGetLastError(); d_blocks = nullptr; why = "hipMalloc of the block pointer array failed"; return false; }
+            // hipMemset on device memory is ASYNCHRONOUS with respect to the host and runs on the NULL stream, which does not order
+            // against this library's non-blocking streams: without the wait the zeroes could land AFTER the first chunk's block
+            // pointers had been uploaded on the build stream -- the builder's kernels then wrote their entries to 0 + offset
+            // (round 6: "write access to a read-only page at 0x500000", seen on a busy GPU only: four contexts under 16 threads)
             (void)hipMemset(d_blocks, 0, (size_t)total * sizeof(void*));
+            (void)hipStreamSynchronize(nullptr);
         }
         while (blocks_allocated < block_end) {
             if (cancel && cancel->load()) { why = "cancelled"; return false; }

@@ -17,6 +17,9 @@ def main():
     blobs[:, :, 0] &= 0x3F
     blobs = [blobs[i].tobytes() for i in range(nb)]
     ctx = kzg.DASContext(True, wait_tables=False)  # the soak starts while the wide tables are still being built
+    # SOAK_CONTEXTS=N: N separate contexts on the GPU instead of one (thread i works on context i mod N)
+    extra = [kzg.DASContext(True, wait_tables=False) for _ in range(int(os.environ.get("SOAK_CONTEXTS", "1")) - 1)]
+    all_ctx = [ctx] + extra
     st, cells, proofs = ctx.compute_cells_and_kzg_proofs_batch(blobs)
     assert st == [0] * nb
     _, comms = ctx.blob_to_kzg_commitment_batch(blobs)
@@ -25,15 +28,17 @@ def main():
     for b in range(8):
         p = list(proofs[b]); p[5] = proofs[(b + 1) % nb][5]
         bad.append(([comms[b]] * 128, list(range(128)), cells[b], p))
+    ops = os.environ.get("SOAK_OPS", "verify,verify,verify_bad,many,compute1,compute64,recover,commit").split(",")  # SOAK_OPS: a sub-list (bisecting)
     stop = time.time() + seconds
     counts, errors, lock = {}, [], threading.Lock()
 
     def worker(seed):
         r = random.Random(seed)
         mine = {}
+        ctx = all_ctx[seed % len(all_ctx)]
         try:
             while time.time() < stop and not errors:
-                op = r.choice(["verify", "verify", "verify_bad", "many", "compute1", "compute64", "recover", "commit"])
+                op = r.choice(ops)
                 b = r.randrange(8)
                 if op == "verify":
                     assert ctx.verify_cell_kzg_proof_batch(*probs[b]) is True
@@ -50,6 +55,10 @@ def main():
                 elif op == "compute64":
                     s2, c2, p2 = ctx.compute_cells_and_kzg_proofs_batch(blobs)
                     assert s2 == [0] * nb and c2[b] == cells[b] and p2[nb - 1] == proofs[nb - 1]
+                elif op.startswith("computeN"):  # computeN<k>: a host-pointer batch of k blobs (bisecting a batch-size regime)
+                    k = int(op[8:])
+                    s2, c2, p2 = ctx.compute_cells_and_kzg_proofs_batch(blobs[:k])
+                    assert s2 == [0] * k and c2[b % k] == cells[b % k] and p2[k - 1] == proofs[k - 1]
                 elif op == "recover":
                     idx = sorted(r.sample(range(128), 64))
                     c, p = ctx.recover_cells_and_kzg_proofs(idx, [cells[b][i] for i in idx])
@@ -74,7 +83,8 @@ def main():
         print("FAILED:", errors[:3])
         sys.exit(1)
     print("soak ok")
-    ctx.close()
+    for c in all_ctx:
+        c.close()
 
 
 if __name__ == "__main__":
