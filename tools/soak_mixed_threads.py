@@ -72,13 +72,30 @@ def main():
             for k, v in mine.items():
                 counts[k] = counts.get(k, 0) + v
 
+    churned = [0]
+
+    def churn():  # SOAK_CHURN=1: contexts created and freed beside the workers (some freed while their wide tables are being built)
+        r = random.Random(7)
+        try:
+            while time.time() < stop and not errors:
+                c = kzg.DASContext(True, wait_tables=r.random() < 0.3)
+                if r.random() < 0.5:
+                    assert c.blob_to_kzg_commitment(blobs[0]) == comms[0]
+                time.sleep(r.random() * 0.5)
+                c.close()
+                churned[0] += 1
+        except BaseException as e:  # noqa: BLE001
+            errors.append("churn: " + repr(e))
+
     ths = [threading.Thread(target=worker, args=(1000 + i,)) for i in range(n_thr)]
+    if os.environ.get("SOAK_CHURN") == "1":
+        ths.append(threading.Thread(target=churn))
     t0 = time.time()
     for t in ths:
         t.start()
     for t in ths:
         t.join()
-    print(f"{n_thr} threads, {time.time() - t0:.1f} s, tables_ready={ctx.tables_ready()}: " + ", ".join(f"{k} {v}" for k, v in sorted(counts.items())))
+    print(f"{n_thr} threads, {time.time() - t0:.1f} s, tables_ready={ctx.tables_ready()}: " + ", ".join(f"{k} {v}" for k, v in sorted(counts.items())) + (f", contexts churned {churned[0]}" if churned[0] else ""))
     if errors:
         print("FAILED:", errors[:3])
         sys.exit(1)
