@@ -28,7 +28,7 @@ def main():
     for b in range(8):
         p = list(proofs[b]); p[5] = proofs[(b + 1) % nb][5]
         bad.append(([comms[b]] * 128, list(range(128)), cells[b], p))
-    ops = os.environ.get("SOAK_OPS", "verify,verify,verify_bad,many,compute1,compute64,recover,commit").split(",")  # SOAK_OPS: a sub-list (bisecting)
+    ops = os.environ.get("SOAK_OPS", "verify,verify,verify_bad,many,compute1,compute64,recover,commit,invalid").split(",")  # SOAK_OPS: a sub-list (bisecting)
     stop = time.time() + seconds
     counts, errors, lock = {}, [], threading.Lock()
 
@@ -59,6 +59,20 @@ def main():
                     k = int(op[8:])
                     s2, c2, p2 = ctx.compute_cells_and_kzg_proofs_batch(blobs[:k])
                     assert s2 == [0] * k and c2[b % k] == cells[b % k] and p2[k - 1] == proofs[k - 1]
+                elif op == "invalid":  # error paths under concurrency: every one of these must raise, and nothing around them may notice
+                    which = r.randrange(4)
+                    try:
+                        if which == 0:
+                            ctx.compute_cells_and_kzg_proofs(b"\xff" * 32 + blobs[b][32:])
+                        elif which == 1:
+                            ctx.recover_cells_and_kzg_proofs(list(range(63)), [cells[b][i] for i in range(63)])
+                        elif which == 2:
+                            ctx.verify_cell_kzg_proof_batch([comms[b]], [128], [cells[b][0]], [proofs[b][0]])
+                        else:
+                            ctx.blob_to_kzg_commitment(blobs[b][:-32] + b"\xff" * 32)
+                        raise AssertionError("an invalid input was accepted")
+                    except kzg.KzgError:
+                        pass
                 elif op == "recover":
                     idx = sorted(r.sample(range(128), 64))
                     c, p = ctx.recover_cells_and_kzg_proofs(idx, [cells[b][i] for i in idx])
