@@ -62,6 +62,13 @@ def test_c_program_reproduces_the_golden_vector(tmp_path):
         assert out[-48:] == expected_commitment[0]
     res = subprocess.run([exe, "verify", str(blob_path)], check=True, capture_output=True, text=True).stdout
     assert "verified=1" in res and "recovered=1" in res
+    # the same unchanged C consumer with ETH_KZG_AMD_DEVICES=0,0: its context spans a device list, same bytes
+    env = dict(os.environ, ETH_KZG_AMD_DEVICES="0,0", ETH_KZG_AMD_TABLE_GB="22")
+    out_list = tmp_path / "out_list.bin"
+    subprocess.check_call([exe, "compute", str(blob_path), str(out_list)], env=env)
+    assert out_list.read_bytes() == out
+    res = subprocess.run([exe, "verify", str(blob_path)], check=True, capture_output=True, text=True, env=env).stdout
+    assert "verified=1" in res and "recovered=1" in res
     # the single-process multi-GPU fan-out (one context per visible GPU; one GPU on the test box) from plain C
     res = subprocess.run([exe, "multi", str(blob_path)], check=True, capture_output=True, text=True).stdout
     assert "multi=1" in res

@@ -33,7 +33,11 @@ def test_addon_builds_and_exports_the_reference_surface():
 
 
 @pytest.mark.gpu
-def test_node_reproduces_the_golden_vector(tmp_path):
+@pytest.mark.parametrize("devices", [None, "0,0"], ids=["one-device", "device-list-0,0"])
+def test_node_reproduces_the_golden_vector(tmp_path, devices):
+    """devices = "0,0": the same UNCHANGED Node host with ETH_KZG_AMD_DEVICES set -- its one DasContextJs then spans a device list (two
+    engines on the test box's GPU; bindings/node/src/lib.rs:35,75 shares one context between all its async calls), and every method
+    still reproduces the vector: how a reference host uses all GPUs of a node without a line of change."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import vectors
     case = vectors.load("compute_cells_and_kzg_proofs")["valid_4aedd1a2a3933c3e"]
@@ -42,7 +46,12 @@ def test_node_reproduces_the_golden_vector(tmp_path):
     blob_path, want_path = tmp_path / "blob.bin", tmp_path / "want.bin"
     blob_path.write_bytes(case["input"]["blob"])
     want_path.write_bytes(b"".join(case["output"][0]) + b"".join(case["output"][1]) + comm)
-    p = subprocess.run([NODE, os.path.join(ROOT, "tests", "node", "spec.js"), str(blob_path), str(want_path)], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ)
+    env.pop("ETH_KZG_AMD_DEVICES", None)
+    if devices:
+        env["ETH_KZG_AMD_DEVICES"] = devices
+        env["ETH_KZG_AMD_TABLE_GB"] = "22"  # (two engines on one GPU share these tables; small so that the module stays quick)
+    p = subprocess.run([NODE, os.path.join(ROOT, "tests", "node", "spec.js"), str(blob_path), str(want_path)], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout + p.stderr
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out and all(out.values()), out
