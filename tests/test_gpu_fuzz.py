@@ -21,6 +21,8 @@ pytestmark = pytest.mark.gpu
 kzg = importlib.import_module("rust-eth-kzg_amd")
 R = synth.R
 INF = b"\xc0" + bytes(47)
+# KZG_FUZZ_ROUNDS=<n>: n times the cases, with other seeds (a one-off hunt on the GPU box; the default keeps the module at seconds)
+ROUNDS = int(os.environ.get("KZG_FUZZ_ROUNDS", "1"))
 
 
 @pytest.fixture(scope="module")
@@ -127,7 +129,7 @@ def test_verification_agrees_with_the_oracle_on_mutated_inputs(small_ctx, materi
     assert (cells[0], proofs[0]) == tuple(oracle.compute_cells_and_kzg_proofs(blobs[0]))
     rng = random.Random(20251)
     seen = {}
-    for case in range(260):
+    for case in range(260 * ROUNDS):
         kind, args = _mutate_verify(rng, comms, cells, proofs)
         got, want = _call(small_ctx.verify_cell_kzg_proof_batch, *args), _call(oracle.verify_cell_kzg_proof_batch, *args)
         assert got == want, (case, kind, got, want)
@@ -145,7 +147,7 @@ def test_many_verification_agrees_with_the_oracle_on_the_same_mutations(small_ct
     _, comms, cells, proofs = material
     rng = random.Random(20252)
     problems, kinds = [], []
-    while len(problems) < 120:
+    while len(problems) < 120 * ROUNDS:
         kind, args = _mutate_verify(rng, comms, cells, proofs)
         if kind in ("proof_len47", "cell_len"):  # (the Python wrapper of the many-form rejects wrong byte lengths for the whole call)
             continue
@@ -163,7 +165,7 @@ def test_recovery_agrees_with_the_oracle_on_mutated_inputs(small_ctx, material, 
     blobs, comms, cells, proofs = material
     rng = random.Random(20253)
     seen = {}
-    for case in range(48):
+    for case in range(48 * ROUNDS):
         b = rng.randrange(3)
         n = rng.choice([64, 64, 65, 80, 100, 127, 128])
         idx = sorted(rng.sample(range(128), n))
@@ -200,7 +202,7 @@ def test_recovery_agrees_with_the_oracle_on_mutated_inputs(small_ctx, material, 
 
 def test_prover_and_commitment_agree_with_the_oracle_on_mutated_blobs(small_ctx, oracle):
     rng = random.Random(20254)
-    for case in range(10):
+    for case in range(10 * ROUNDS):
         blob = bytearray(synth.seeded_blob(4100 + case))
         kind = rng.choice(["none", "ge_r", "r_minus_1", "zero_run", "max_u256"])
         e = rng.randrange(4096)
