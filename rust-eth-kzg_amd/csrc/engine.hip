@@ -224,6 +224,7 @@ Engine::Engine(bool use_precomp, int device, const Engine* primary, double table
     }
     vm_search_ = knobs_.vm_search;
     arena_signed_ = knobs_.arena_signed;
+    msm_split_ = knobs_.msm_split;
     if (knobs_.pip_shift_min >= 1) pip_shift_min_ = knobs_.pip_shift_min;
     // largest batch on the circulant form: its cost grows by 0.3 ms per blob (1 blob 1.48 ms, 4: 2.33, 5: 3.0, 8: 3.5), the compiled
     // map in its Karatsuba compilation is flat (5 - 8 blobs: 2.5 - 2.7 ms with the flat MSM) -- round 3's cross-over, against the

@@ -298,6 +298,7 @@ private:
                     int brp_bits, hipStream_t st, int out_fmt = 0 /* launch::FMT_JACQ */);
     void launch_msm_range(const void* scalars, const SharedTable& t, int g0, int gcnt, void* out, int n_groups, int n_slices, int out_stride,
                           int brp_bits, hipStream_t st, int out_fmt = 0);
+    long msm_waves(long msms, int c) const;  // waves of the MSM launch launch_msm_range would issue (the side-stream decision of enqueue_compute)
     void build_final_tables();  // the wide tables: on the helper thread (progressive start) or inline
     void publish(TableSel which, const std::shared_ptr<SharedTable>& main, const std::shared_ptr<SharedTable>& next);
     void g1_fft128_full(void* X, int stride, int inverse, hipStream_t st);
@@ -328,6 +329,7 @@ private:
     int wave_slots_ = 2048;  // CUs x 4 SIMDs x 2 waves: what one round of a ~240-VGPR point kernel occupies
     int device_batch_max_ = 4096;  // a device-resident prover call runs as sub-batches of at most this many blobs (ETH_KZG_AMD_DEVICE_BATCH_MAX)
     int msm_chunks_ = -1;    // -1: pick per launch (launch_msm); otherwise forced by ETH_KZG_AMD_MSM_CHUNKS
+    bool msm_split_ = true;  // small batches: two lanes per MSM window where they still fit one round of the wave slots (ETH_KZG_AMD_MSM_SPLIT=0: off)
     hipStream_t stream_ = nullptr;
     std::recursive_mutex mu_;  // the verification / recovery / EIP-4844 / commitment paths and work_[0]: one call at a time
     static constexpr int NW = 4;  // work_[0]: the paths under mu_; work_[1..3]: compute_cells(_and_kzg_proofs) calls, concurrently

@@ -120,6 +120,13 @@ void Engine::launch_msm(const void* scalars, const TableView& tv, bool scalars_s
     if (ready > 0) launch_msm_range(scalars, *next, 0, ready, out, n_groups, n_slices, out_stride, brp_bits, st, out_fmt);
     if (ready < n_groups) launch_msm_range(scalars, *main, ready, n_groups - ready, out, n_groups, n_slices, out_stride, brp_bits, st, out_fmt);
 }
+// waves of the MSM launch over `msms` MSMs on a table of nominal width c, as launch_msm_range will schedule it (flat launches aside)
+long Engine::msm_waves(long msms, int c) const {
+    const long W = launch::glv_windows(c);
+    if (msm_chunks_ > 0 || (msm_chunks_ < 0 && (msms * 4 + 63) / 64 >= (long)wave_slots_)) return msms * 4;  // four chunks per MSM: 64 MSMs x 4 waves per block
+    if (msm_chunks_ < 0 && msm_split_ && (msms * 4 * W + 63) / 64 <= (long)wave_slots_ / 2) return (msms * 4 * W + 63) / 64;
+    return (msms * 2 * W + 63) / 64;
+}
 // groups [g0, g0 + gcnt) of every slice on table t
 void Engine::launch_msm_range(const void* scalars, const SharedTable& t, int g0, int gcnt, void* out, int n_groups, int n_slices,
                               int out_stride, int brp_bits, hipStream_t st, int out_fmt) {
@@ -129,6 +136,7 @@ void Engine::launch_msm_range(const void* scalars, const SharedTable& t, int g0,
     int mode = 1;  // a lane per (MSM, window)
     if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0 && out_fmt == launch::FMT_JACQ) mode = 0;  // a handful of blobs: one block per MSM
     else if (msm_chunks_ >= 0) mode = msm_chunks_ == 0 ? 1 : 2;  // tests: 0 = the windowed kernel, anything else = four chunks per MSM
+    else if (msm_split_ && (msms * 4 * launch::glv_windows(c) + 63) / 64 <= (long)wave_slots_ / 2) mode = 3;  // <= 16 blobs on eight windows: two lanes per window while that still leaves a SIMD per wave -- the chain of dependent additions is halved (16 blobs: 0.70 -> 0.49 ms; with two waves per SIMD, 17 .. 32 blobs, it was measured 0.05 ms SLOWER)
     else if ((msms * 4 + 63) / 64 >= (long)wave_slots_) {
         // The chip is full: four chunks per MSM, 16384 short waves dealt out as slots free up.  (A lane per MSM and a lane per GLV
         // half -- no folds, no barriers, exact rounds of long waves -- were measured 1-2 % SLOWER in rounds 3 and 4 and are gone.)
@@ -243,7 +251,14 @@ void Engine::enqueue_compute(Work& w, int n, const uint8_t* d_blobs, uint8_t* d_
     mark_end(mk11, 1, st);
     // a handful of blobs is a chain of latencies: the cells (one 8192-point transform, 0.08 ms) then run on the set's second
     // stream next to the proof stages instead of in front of them
-    const bool side = d_cells && d_proofs && n <= SIDE_CELLS_MAX && w.copy && !profiling_;
+    // ... unless the MSM launch that follows puts a wave on (nearly) every SIMD and no second one: a block of the cells kernel needs a
+    // whole CU (144 KB of LDS, 16 waves) and then neither starts nor lets the map's waves in -- measured: 28 and 32 blobs 2.57 ms with
+    // the side stream against 2.20 ms without, 24 blobs 2.12 against 2.21, 40 blobs 2.72 against 2.82 (tools/sweep_small_batches.sh)
+    bool side = d_cells && d_proofs && n <= SIDE_CELLS_MAX && w.copy && !profiling_;
+    if (side && n > FLAT_MSM_MAX_SLICES) {
+        const long simds = wave_slots_ / 2, waves = msm_waves(128L * n, table_view(TAB_FK).c);
+        if (waves > simds * 4 / 5 && waves <= simds) side = false;
+    }
     if (side) {
         HIPCK(hipEventRecord(w.ev_coeffs, st));
         HIPCK(hipStreamWaitEvent(w.copy, w.ev_coeffs, 0));

@@ -22,6 +22,7 @@
 //   ETH_KZG_AMD_VM_SEARCH=0         many-verification: re-check every problem of a failed pass instead of searching
 //   ETH_KZG_AMD_VM_FOLD=0           many-verification: one pairing per problem instead of one folded check per pass
 //   ETH_KZG_AMD_VERIFY_COMBINE=0    concurrent single verifications are not combined into passes
+//   ETH_KZG_AMD_MSM_SPLIT=0         batches of <= 32 blobs: a lane per MSM window (rounds 2-5) instead of two (A/B runs, the tests' cross-check)
 //   ETH_KZG_AMD_ARENA_SIGNED=0      batches of more than one lane group keep the linear map's arena in the 14 x 29-bit form (rounds 2-5) instead
 //                                   of the signed 13 x 30-bit one: the tests' cross-check of the two forms, A/B runs
 //   ETH_KZG_AMD_DEVICE_BATCH_MAX=<n> a device-resident prover call is cut into sub-batches of at most n blobs (default 4096)
@@ -47,7 +48,7 @@ struct Knobs {
     int serial_lanes = 0;  // 0: the engine's default
     bool trace = false;
     int msm_chunks = -1, slp_program = -1, pip_shift_min = 0;
-    bool vm_search = true, vm_fold = true, verify_combine = true, arena_signed = true;
+    bool vm_search = true, vm_fold = true, verify_combine = true, arena_signed = true, msm_split = true;
     std::string fault;  // ETH_KZG_AMD_FAULT (a copy: the environment may change under a long-lived context)
     int device_batch_max = 0;
 
@@ -88,6 +89,7 @@ struct Knobs {
         flag("ETH_KZG_AMD_VM_FOLD", k.vm_fold);
         flag("ETH_KZG_AMD_VERIFY_COMBINE", k.verify_combine);
         flag("ETH_KZG_AMD_ARENA_SIGNED", k.arena_signed);
+        flag("ETH_KZG_AMD_MSM_SPLIT", k.msm_split);
         if (const char* s = getenv("ETH_KZG_AMD_FAULT")) k.fault = s;
         num("ETH_KZG_AMD_DEVICE_BATCH_MAX", 64, 1 << 20, k.device_batch_max);
         return k;
