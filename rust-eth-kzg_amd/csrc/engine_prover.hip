@@ -221,7 +221,7 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         int n_launches = 0;
         for (auto& L : prog->launches)
             launch::g1_slp_launch(L.kind, w.slp_arena, bp, (const uint32_t*)prog->d_words + (size_t)L.first * 4, L.count, prog->d_naf, beta_, st, 0,
-                                  mulc_coop_lanes, fmt, arena_signed_);
+                                  mulc_coop_lanes, fmt, arena_signed_, n);
         n_launches = (int)prog->launches.size();
         mark_end(mk3, n_launches, st);
         const int mk4 = mark_begin(ST_COMPRESS, st);
