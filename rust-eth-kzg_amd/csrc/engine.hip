@@ -226,10 +226,15 @@ Engine::Engine(bool use_precomp, int device, const Engine* primary, double table
     arena_signed_ = knobs_.arena_signed;
     msm_split_ = knobs_.msm_split;
     if (knobs_.pip_shift_min >= 1) pip_shift_min_ = knobs_.pip_shift_min;
-    // largest batch on the circulant form: its cost grows by 0.3 ms per blob (1 blob 1.48 ms, 4: 2.33, 5: 3.0, 8: 3.5), the compiled
-    // map in its Karatsuba compilation is flat (5 - 8 blobs: 2.5 - 2.7 ms with the flat MSM) -- round 3's cross-over, against the
-    // tuned program, was 8
-    circ_max_ = 4;
+    // largest batch on the circulant form.  Its cost grows with every blob (1 blob 1.11 ms, 2: 1.36, 3: 1.78, 4: 1.87); the compiled
+    // map with four lanes per blob and the flat MSM is flat (3 .. 8 blobs: 1.65 .. 1.86 ms).  Round 3's cross-over was 8 blobs, round
+    // 4's 4; since the round-6 changes below 16 blobs (two lanes per MSM window, the pair forms) it is 2: 3 blobs 1.78 -> 1.65 ms,
+    // 4 blobs 1.87 -> 1.70 ms (tools/ab_circ_max.sh, three alternated rounds on one box, profiles/r6_ab_circ_max.log).
+#ifdef KZG_CIRC_MAX  // (experiment builds of that A/B; <= 4)
+    circ_max_ = KZG_CIRC_MAX;
+#else
+    circ_max_ = 2;
+#endif
     // Everything below can throw (HIPCK, the SRS checks).  A constructor that throws runs no destructor: teardown() frees what
     // was built so far -- streams, events, device buffers, the published start tables' references -- and the exception goes on to
     // eth_kzg_amd_das_context_try_new, which promises NULL + a message and never a dead process.

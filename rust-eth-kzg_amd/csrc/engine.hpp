@@ -408,7 +408,7 @@ private:
     // (k_verify.hip: k_pip_shift): behind the transcript hash for large batches, next to the subgroup tests (second stream) for
     // small ones.  ETH_KZG_AMD_PIP_SHIFT_MIN raises it (tests: the windowed form as the cross-check)
     int pip_shift_min_ = 1;
-    int circ_T_ = 0, circ_per_lane_ = 0, circ_max_ = 8;  // measured cross-over with the compiled linear map (2.8 ms flat up to 64 blobs): 8 blobs 2.5 vs 2.9 ms, 12 blobs 3.2 vs 2.9
+    int circ_T_ = 0, circ_per_lane_ = 0, circ_max_ = 2;  // largest batch on the circulant form: the measured cross-over with the compiled linear map (engine.hip: the constructor)
     Fr8 seg_shift_[3];  // 2^32, 2^64, 2^96 in Montgomery form
     // the two G1 transforms as one compiled linear map (g1_linmap.hpp, k_g1slp.hip).  SEVERAL compilations of the same map:
     // the throughput optimum (fewest point operations: 350 constant multiplications, 8-way Toom-Cook) for batches that fill

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64, 2) void k_slp_mulc(JacQ* __restrict__ A, int st
     const uint32_t* w = words + (size_t)blockIdx.x * 4;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
                    cid = __builtin_amdgcn_readfirstlane(w[2]);
-    const int lane = blockIdx.y * 64 + threadIdx.x;
+    const int lane = (gridDim.y - 1 - blockIdx.y) * 64 + threadIdx.x;  // (the last lane group first: see k_slp_mulc_s)
     if (lane >= n_active) return;
     const JacQ src = A[(size_t)a * stride + lane];
     A[(size_t)dst * stride + lane] = mul_by_recoded30(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta);
@@ -41,7 +41,11 @@ __global__ __launch_bounds__(64, 2) void k_slp_mulc_s(JacS* __restrict__ A, int 
     const uint32_t* w = words + (size_t)blockIdx.x * 4;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
                    cid = __builtin_amdgcn_readfirstlane(w[2]);
-    const int lane = blockIdx.y * 64 + threadIdx.x;
+    // The lane groups are dealt LAST GROUP FIRST: the last one is the one that may be partly filled, and a wave with 16 or fewer
+    // lanes in use runs this kernel about twice as long as a full one (measured, not explained: 2049 .. 2064 blobs spent 14.6 ms
+    // here, 2072 .. 2112 blobs 13.2 ms, tools/sweep_partial_group.sh) -- at the end of the launch that is a tail, at its start it
+    // is hidden under the other 32 groups.
+    const int lane = (gridDim.y - 1 - blockIdx.y) * 64 + threadIdx.x;
     if (lane >= n_active) return;
     const JacS src = A[(size_t)a * stride + lane];
     A[(size_t)dst * stride + lane] = mul_by_recoded30(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta);

@@ -420,7 +420,7 @@ def test_eip4844_round_trip_on_synthetic_blobs(ctx, oracle):
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 8, 9, 16, 17, 32, 33, 64, 65, 128, 129, 192, 193, 200, 256, 257, 320, 321])
 def test_every_batch_size_regime_matches_oracle(ctx, oracle, n):
-    """The engine picks its G1 schedule by batch size (<= 2 / <= 4: flat MSM over 4 / 2 scalar segments + segmented
+    """The engine picks its G1 schedule by batch size (<= 2: flat MSM over 4 scalar segments + segmented
     doubling chains + circulant transforms, above: the compiled linear map (flat MSM up to 8 blobs) -- in the compilation that suits the
     number of 64-blob lane groups: 712 constant multiplications for one group, 456 for two, 606 for three, 456 for four, 372 for
     five, the 350 of the operation-count optimum from six; inside one lane group the map's constant multiplications take four
