@@ -134,7 +134,7 @@ void Engine::launch_msm_range(const void* scalars, const SharedTable& t, int g0,
     const int c = t.c;
     const long msms = (long)gcnt * n_slices;
     int mode = 1;  // a lane per (MSM, window)
-    if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0 && out_fmt == launch::FMT_JACQ) mode = 0;  // a handful of blobs: one block per MSM
+    if (n_slices <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) mode = 0;  // a handful of blobs: one block per MSM
     else if (msm_chunks_ >= 0) mode = msm_chunks_ == 0 ? 1 : 2;  // tests: 0 = the windowed kernel, anything else = four chunks per MSM
     else if (msm_split_ && (msms * 4 * launch::glv_windows(c) + 63) / 64 <= (long)wave_slots_ / 2) mode = 3;  // <= 16 blobs on eight windows: two lanes per window while that still leaves a SIMD per wave -- the chain of dependent additions is halved (16 blobs: 0.70 -> 0.49 ms; with two waves per SIMD, 17 .. 32 blobs, it was measured 0.05 ms SLOWER)
     else if ((msms * 4 + 63) / 64 >= (long)wave_slots_) {
@@ -186,12 +186,12 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         }
         X = w.slp_arena;
     }
-    // The arena's point format.  More than one lane group (> 64 blobs): every kernel between the scalars and the proofs' bytes --
-    // MSM, constant multiplications, additions, compression -- is a lane-per-blob kernel of the signed 13 x 30-bit field, and the
-    // arena holds its points (JacS, 156 B) as they are: ONE Fp representation under the whole path, no conversions (VERDICT r5
-    // item 5).  One lane group or less: the several-lanes-per-point kernels of g1_coop.hpp (shared with verification) and the
-    // circulant form compute in the 14 x 29-bit field, and the arena holds JacQ.
-    const int fmt = (linmap_mode && bp > 64 && mulc_coop_lanes == 0 && arena_signed_) ? launch::FMT_JACS : launch::FMT_JACQ;
+    // The arena's point format: every kernel between the scalars and the proofs' bytes -- MSM, constant multiplications, additions,
+    // compression; a lane, two or four lanes per blob -- is a kernel of the signed 13 x 30-bit field, and the arena holds its points
+    // (JacS, 156 B) as they are: ONE Fp representation under the whole path, no conversions.  What stays in the
+    // 14 x 29-bit field (JacQ) is the circulant form of <= 2 blobs, whose kernels are shared with verification, and the cross-check
+    // ETH_KZG_AMD_ARENA_SIGNED=0.
+    const int fmt = (linmap_mode && arena_signed_) ? launch::FMT_JACS : launch::FMT_JACQ;
     const size_t pt = fmt == launch::FMT_JACS ? launch::SIZEOF_JACS : launch::SIZEOF_JACQ;
     const TableView tv = tv_pre ? *tv_pre : table_view(TAB_FK);  // one snapshot for the scalars' form AND the MSM that reads them
     if (!tv_pre) {
@@ -221,7 +221,7 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
         int n_launches = 0;
         for (auto& L : prog->launches)
             launch::g1_slp_launch(L.kind, w.slp_arena, bp, (const uint32_t*)prog->d_words + (size_t)L.first * 4, L.count, prog->d_naf, beta_, st, 0,
-                                  mulc_coop_lanes, fmt, arena_signed_, n);
+                                  mulc_coop_lanes, fmt, n);
         n_launches = (int)prog->launches.size();
         mark_end(mk3, n_launches, st);
         const int mk4 = mark_begin(ST_COMPRESS, st);

@@ -15,11 +15,11 @@
 
 namespace kzg {
 
-// COOP = 2: the two lanes of a pair hold the same p and share the doublings and mixed additions of the digit loop (g1_coop30.hpp;
-// l0 = this lane is the pair's even lane); the table is built on both lanes.
+// COOP = 2 / 4: the lanes of a pair / quad hold the same p and share the doublings and mixed additions of the digit loop
+// (g1_coop30.hpp; part = this lane's place in its pair / quad); the table is built on every lane.
 template <int COOP = 0>
-__device__ __forceinline__ JacS mul_by_recoded30(const JacS& p, const uint32_t* __restrict__ row, const Fs<1, DC>& beta, bool l0 = false) {
-    static_assert(COOP == 0 || COOP == 2, "one lane or a pair per multiplication");
+__device__ __forceinline__ JacS mul_by_recoded30(const JacS& p, const uint32_t* __restrict__ row, const Fs<1, DC>& beta, int part = 0) {
+    static_assert(COOP == 0 || COOP == 2 || COOP == 4, "one lane, a pair or a quad per multiplication");
     constexpr int NT = 1 << (launch::TWIDDLE_WNAF_W - 2);  // odd multiples P, 3P, .., (2 NT - 1) P
     AffT A[NT];
     Fs<1, DC> bx[NT];
@@ -76,7 +76,8 @@ __device__ __forceinline__ JacS mul_by_recoded30(const JacS& p, const uint32_t* 
 #pragma unroll 1
         for (int q = 3; q >= 0; q--) {
             if (started) {
-                if constexpr (COOP == 2) acc = coop2_dbl_half(acc, l0);
+                if constexpr (COOP == 4) acc = coop4_dbl_half(acc, part);
+                else if constexpr (COOP == 2) acc = coop2_dbl_half(acc, part == 0);
                 else acc = dbl_half(acc);
             }
 #pragma unroll 1
@@ -99,7 +100,8 @@ __device__ __forceinline__ JacS mul_by_recoded30(const JacS& p, const uint32_t* 
                     acc.y = cneg(d < 0, op.y);
                     acc.z = fs_one();
                     started = true;
-                } else if constexpr (COOP == 2) acc = coop2_add_mixed(acc, op, d < 0, l0);
+                } else if constexpr (COOP == 4) acc = coop4_add_mixed(acc, op, d < 0, part);
+                else if constexpr (COOP == 2) acc = coop2_add_mixed(acc, op, d < 0, part == 0);
                 else acc = add_mixed(acc, op, d < 0);
             }
         }
@@ -109,8 +111,8 @@ __device__ __forceinline__ JacS mul_by_recoded30(const JacS& p, const uint32_t* 
 }
 // the same on an arena in the 14 x 29-bit form: six products for the way in and out
 template <int COOP = 0>
-__device__ __forceinline__ JacQ mul_by_recoded30(const JacQ& pq, const uint32_t* __restrict__ row, const Fs<1, DC>& beta, bool l0 = false) {
-    return jacq_from_jacs(mul_by_recoded30<COOP>(jacs_from_jacq(pq), row, beta, l0));
+__device__ __forceinline__ JacQ mul_by_recoded30(const JacQ& pq, const uint32_t* __restrict__ row, const Fs<1, DC>& beta, int part = 0) {
+    return jacq_from_jacs(mul_by_recoded30<COOP>(jacs_from_jacq(pq), row, beta, part));
 }
 
 }  // namespace kzg

@@ -63,22 +63,17 @@ __global__ __launch_bounds__(64, 2) void k_slp_mulc_coop(JacQ* __restrict__ A, i
     A[(size_t)dst * stride + lane] = mul_by_recoded<4>(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta, quad);
 }
 // ... and of 17 .. 64 blobs (BASELINE config 5's and 4's per-GPU shares): two lanes per blob, a wave = 32 blobs x one operation
-// (from 33 blobs on two waves per operation: the engine then picks a compilation of the map with <= 512 multiplications)
-// Round 6: the pair forms of the signed 13 x 30-bit field (g1_coop30.hpp: 276 k instead of 304 k multiply-adds per chain); the point
-// enters from and leaves to the 14 x 29-bit arena of a single lane group.  SIGNED = false: the 14-digit pair forms (g1_coop.hpp), kept
-// as the cross-check (ETH_KZG_AMD_ARENA_SIGNED=0).
-template <bool SIGNED>
+// (from 33 blobs on two waves per operation: the engine then picks a compilation of the map with <= 512 multiplications).
+// These three kernels serve the 14 x 29-bit arena of ETH_KZG_AMD_ARENA_SIGNED=0 (the cross-check of the signed path: k_slp_*_s below).
 __global__ __launch_bounds__(64, 2) void k_slp_mulc_coop2(JacQ* __restrict__ A, int stride, const uint32_t* __restrict__ words,
-                                                          const uint32_t* __restrict__ naf, Fq<1> beta, Fs<1, DC> beta_s, int lanes) {
+                                                          const uint32_t* __restrict__ naf, Fq<1> beta, int lanes) {
     const uint32_t* w = words + (size_t)blockIdx.x * 4;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
                    cid = __builtin_amdgcn_readfirstlane(w[2]);
     const int lane = blockIdx.y * 32 + (threadIdx.x >> 1), half = threadIdx.x & 1;
     if (lane >= lanes) return;
     const JacQ src = A[(size_t)a * stride + lane];
-    const uint32_t* row = naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS);
-    if constexpr (SIGNED) A[(size_t)dst * stride + lane] = mul_by_recoded30<2>(src, row, beta_s, half == 0);
-    else A[(size_t)dst * stride + lane] = mul_by_recoded<2>(src, row, beta, half);
+    A[(size_t)dst * stride + lane] = mul_by_recoded<2>(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta, half);
 }
 // one cheap operation of the program on one lane: flags & 2: a run of b doublings; otherwise an addition (flags & 1: subtraction;
 // flags & 4: a + b to dst AND a - b to slot flags >> 16) whose FIRST operand is doubled (flags >> 3) & 31 times in registers
@@ -195,6 +190,45 @@ __global__ __launch_bounds__(64, 2) void k_slp_add_coop(JacQ* __restrict__ A, in
     A[(size_t)dst * stride + lane] = r;
 }
 
+// ---- one lane group or less on an arena in the signed form (launch::FMT_JACS; round 6): the several-lanes-per-blob kernels of the
+// 13 x 30-bit field (g1_coop30.hpp) -- with them the prover's points are in ONE Fp representation at every batch size above the
+// circulant form's.  COOP = 4: <= 16 blobs, a wave = 16 blobs x one operation; COOP = 2: 17 .. 64 blobs, a wave = 32 blobs.
+template <int COOP>
+__global__ __launch_bounds__(64, 2) void k_slp_mulc_coop_s(JacS* __restrict__ A, int stride, const uint32_t* __restrict__ words,
+                                                           const uint32_t* __restrict__ naf, Fs<1, DC> beta, int lanes) {
+    const uint32_t* w = words + (size_t)blockIdx.x * 4;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
+                   cid = __builtin_amdgcn_readfirstlane(w[2]);
+    const int lane = blockIdx.y * (64 / COOP) + (threadIdx.x / COOP), sub = threadIdx.x % COOP;
+    if (lane >= lanes) return;
+    const JacS src = A[(size_t)a * stride + lane];
+    A[(size_t)dst * stride + lane] = mul_by_recoded30<COOP>(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta, sub);
+}
+// the cheap operations with four lanes per blob (k_slp_add_coop's schedule): a doubling run 3 reductions deep per doubling, an
+// addition 5, the sum-and-difference pair 4 levels + its two fused pairs.  Every lane of a quad stores the same result.
+__global__ __launch_bounds__(64, 2) void k_slp_add_coop_s(JacS* __restrict__ A, int stride, const uint32_t* __restrict__ words, int lanes) {
+    const uint32_t* w = words + (size_t)blockIdx.y * 4;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
+                   b = __builtin_amdgcn_readfirstlane(w[2]), fl = __builtin_amdgcn_readfirstlane(w[3]);
+    const int lane = blockIdx.x * 16 + (threadIdx.x >> 2), quad = threadIdx.x & 3;
+    if (lane >= lanes) return;
+    JacS r = A[(size_t)a * stride + lane];
+    const uint32_t runs = (fl & 2u) ? b : (fl >> 3) & 31u;
+#pragma unroll 1
+    for (uint32_t k = 0; k < runs; k++) r = coop4_dbl_half(r, quad);
+    if (!(fl & 2u)) {
+        const JacS q = A[(size_t)b * stride + lane];
+        if (fl & 4u) {
+            JacS d;
+            coop4_add_sub(r, q, quad, r, d);
+            A[(size_t)(fl >> 16) * stride + lane] = d;
+        } else {
+            r = coop4_add(r, q, (fl & 1u) != 0, quad);
+        }
+    }
+    A[(size_t)dst * stride + lane] = r;
+}
+
 namespace launch {
 // the code object of this translation unit is loaded now (HIP loads a code object on the first launch of one of its kernels, and
 // that load is an allocation: it would wait behind a table piece the builder thread is allocating)
@@ -204,17 +238,29 @@ void preload_k_g1slp() {
 }
 // kind: 3 multiplication by a constant, anything else the mixed addition / subtraction / doubling launch (linmap::OpKind)
 void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int count, const void* naf, const Fp12w& beta,
-                   hipStream_t st, int lanes, int coop_lanes, int fmt, bool pair_signed, int n_active) {
+                   hipStream_t st, int lanes, int coop_lanes, int fmt, int n_active) {
     if (lanes <= 0) lanes = stride;  // (a sub-range of the lanes: arena already points at its first lane, stride stays the arena's)
     if (n_active <= 0 || n_active > lanes) n_active = lanes;
     const dim3 grid((unsigned)count, (unsigned)(lanes / 64));
-    if (fmt == FMT_JACS) {  // a lane per blob, everything in the signed field (the engine picks this format only for more than one lane group)
-        if (coop_lanes > 0) throw std::logic_error("g1_slp_launch: the several-lanes-per-blob kernels read the 14 x 29-bit arena");
+    if (fmt == FMT_JACS) {  // everything in the signed field (the engine's format unless ETH_KZG_AMD_ARENA_SIGNED=0)
+        const bool coop = coop_points_max() > 0;
         if (kind == 3) {
             Fp b384;
             for (int i = 0; i < 12; i++) b384.v[i] = beta.v[i];
-            k_slp_mulc_s<<<grid, 64, 0, st>>>((JacS*)arena, stride, words, (const uint32_t*)naf, fs_from_fp(b384), n_active);
-        } else k_slp_add_s<<<dim3((unsigned)(lanes / 64), (unsigned)count), 64, 0, st>>>((JacS*)arena, stride, words, n_active);
+            const Fs<1, DC> bs = fs_from_fp(b384);
+            // coop_lanes: the blobs that are really there when they are few enough for four lanes each (<= 16: one quad wave per
+            // operation) or two (17 .. 64)
+            if (coop_lanes > 16 && coop)
+                k_slp_mulc_coop_s<2><<<dim3((unsigned)count, (unsigned)((coop_lanes + 31) / 32)), 64, 0, st>>>((JacS*)arena, stride, words, (const uint32_t*)naf, bs, coop_lanes);
+            else if (coop_lanes > 0 && coop)
+                k_slp_mulc_coop_s<4><<<dim3((unsigned)count, (unsigned)((coop_lanes + 15) / 16)), 64, 0, st>>>((JacS*)arena, stride, words, (const uint32_t*)naf, bs, coop_lanes);
+            else k_slp_mulc_s<<<grid, 64, 0, st>>>((JacS*)arena, stride, words, (const uint32_t*)naf, bs, n_active);
+        } else {
+            // one lane group and few enough operations for every quad wave to have a SIMD of its own: four lanes per blob
+            if (lanes == 64 && count * 4 <= 1024 && coop)
+                k_slp_add_coop_s<<<dim3((unsigned)((n_active + 15) / 16), (unsigned)count), 64, 0, st>>>((JacS*)arena, stride, words, n_active);
+            else k_slp_add_s<<<dim3((unsigned)(lanes / 64), (unsigned)count), 64, 0, st>>>((JacS*)arena, stride, words, n_active);
+        }
         return;
     }
     if (kind == 3) {
@@ -224,8 +270,7 @@ void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int
         // or two (<= 32: still one wave per operation)
         if (coop_lanes > 16 && coop_points_max() > 0) {
             const dim3 g2((unsigned)count, (unsigned)((coop_lanes + 31) / 32));
-            if (pair_signed) k_slp_mulc_coop2<true><<<g2, 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fq_from_fp(b384), fs_from_fp(b384), coop_lanes);
-            else k_slp_mulc_coop2<false><<<g2, 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fq_from_fp(b384), fs_from_fp(b384), coop_lanes);
+            k_slp_mulc_coop2<<<g2, 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf, fq_from_fp(b384), coop_lanes);
         }
         else if (coop_lanes > 0 && coop_points_max() > 0)
             k_slp_mulc_coop<<<dim3((unsigned)count, (unsigned)((coop_lanes + 15) / 16)), 64, 0, st>>>((JacQ*)arena, stride, words, (const uint32_t*)naf,

@@ -89,9 +89,8 @@ void g1_fft_layer(void* X, int stride, int half, int tw_step, int inverse, int m
 // k_g1slp.hip: one launch of the straight-line program of the FK20 proofs map (g1_linmap.hpp); kind = linmap::OpKind
 void g1_slp_launch(int kind, void* arena, int stride, const uint32_t* words, int count, const void* naf, const Fp12w& beta,
                    hipStream_t st, int lanes = 0 /* lanes to run (a multiple of 64, from the arena pointer on); 0: all `stride` of them */,
-                   int coop_lanes = 0 /* > 0: the batch has this many blobs (<= 32): the constant multiplications take four (<= 16) or two lanes per blob */,
-                   int fmt = FMT_JACQ /* the arena's point format; FMT_JACS: the lane-per-blob kernels in the signed field */,
-                   bool pair_signed = true /* the two-lanes-per-blob multiplications in the signed field's pair forms (g1_coop30.hpp) */,
+                   int coop_lanes = 0 /* > 0: the batch has this many blobs (<= 64): the constant multiplications take four (<= 16) or two lanes per blob */,
+                   int fmt = FMT_JACQ /* the arena's point format; FMT_JACS: the kernels of the signed field */,
                    int n_active = 0 /* blobs that are really there (0: all `lanes`): the padding lanes behind them are skipped */);
 
 // k_g1misc.hip

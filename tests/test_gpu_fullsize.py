@@ -172,18 +172,18 @@ def test_six_thousand_blobs_in_one_device_resident_call(ctx, oracle):
 
 
 def test_signed_and_unsigned_arena_give_identical_bytes(ctx, oracle, monkeypatch):
-    """Round 6: for more than one lane group the G1 linear map's arena holds signed 13 x 30-bit points (MSM sums, constant
-    multiplications, additions / pairs / halved doubling runs and the compression's input all in csrc/fp30.hpp: no conversions);
-    ETH_KZG_AMD_ARENA_SIGNED=0 keeps the 14 x 29-bit arena of rounds 2-5.  Same bytes from both, at sizes on both sides of the
-    windowed / chunked MSM schedules and of the fused-pair schedule (>= 1024 lanes), with degenerate blobs inside -- the zero
-    polynomial, a constant, sparse polynomials (identity operands, equal and opposite points meet the exact slow paths of add and
-    add_sub) -- and through recovery."""
+    """Round 6: above the circulant form (> 2 blobs) the G1 linear map's arena holds signed 13 x 30-bit points -- MSM sums (one block
+    per MSM with its quad fold, windowed, chunked), constant multiplications (four, two or one lane per blob), additions / pairs /
+    halved doubling runs (four lanes or one) and the compression's input all in csrc/fp30.hpp, g1_coop30.hpp: no conversions;
+    ETH_KZG_AMD_ARENA_SIGNED=0 keeps the 14 x 29-bit arena and kernels of rounds 2-5.  Same bytes from both, at sizes on both sides
+    of every schedule threshold (flat / windowed / chunked MSM, quad / pair / lane multiplications, the fused-pair schedule of
+    >= 1024 lanes), with degenerate blobs inside -- the zero polynomial, a constant, sparse polynomials (identity operands, equal and
+    opposite points meet the exact slow paths of add, add_sub and their quad forms) -- and through recovery."""
     monkeypatch.setenv("ETH_KZG_AMD_ARENA_SIGNED", "0")
     old = kzg.DASContext(use_precomp=True)  # shares ctx's tables; everything of the G1 linear map in the 14-digit field, as in rounds 2-5
     try:
-        # 20 / 33 / 64 blobs: one lane group -- there the knob switches the constant multiplications between the pair forms of the two
-        # fields (g1_coop30.hpp against g1_coop.hpp; the arena stays in the 14-digit form either way)
-        for n in (20, 33, 64, 65, 129, 300, 1100):
+        # up to 64 blobs: one lane group -- the several-lanes-per-blob kernels of the two fields (g1_coop30.hpp against g1_coop.hpp)
+        for n in (6, 9, 16, 17, 20, 33, 64, 65, 129, 300, 1100):
             blobs = _random_blobs(n, 9100 + n)
             blobs[1] = 0
             blobs[2] = np.frombuffer((b"\x00" * 31 + b"\x05") * 4096, dtype=np.uint8).reshape(4096, 32)
