@@ -40,8 +40,10 @@ __device__ __forceinline__ G1Jac jac_of(const JacS& p) {
 template <int NB, class Pt>
 __global__ __launch_bounds__(64) void k_g1_compress(const Pt* __restrict__ X, uint8_t* __restrict__ out, int n_pos,
                                                     int stride, int n_slices) {
-    const int pos0 = blockIdx.x * NB, slice = blockIdx.y * 64 + threadIdx.x;
-    if (slice >= n_slices) return;
+    const int pos0 = blockIdx.x * NB, slice_of_lane = blockIdx.y * 64 + threadIdx.x;
+    // the lanes behind the last blob repeat its work and store nothing (k_g1slp.hip, k_slp_mulc_s: a partly filled wave is the slower one)
+    if ((int)(blockIdx.y * 64) >= n_slices) return;
+    const int slice = slice_of_lane < n_slices ? slice_of_lane : n_slices - 1;
     G1Jac P[NB];
     Fp pre[NB];  // pre[i] = z_0 ... z_i (identities and the tail count as 1)
     bool inf[NB];
@@ -71,8 +73,10 @@ __global__ __launch_bounds__(64) void k_g1_compress(const Pt* __restrict__ X, ui
             g1_compress(buf, a);
             uint32_t* dst = reinterpret_cast<uint32_t*>(out + ((size_t)slice * n_pos + pos0 + i) * 48);
             const uint32_t* src = reinterpret_cast<const uint32_t*>(buf);
+            if (slice_of_lane < n_slices) {
 #pragma unroll
-            for (int k = 0; k < 12; k++) dst[k] = src[k];
+                for (int k = 0; k < 12; k++) dst[k] = src[k];
+            }
         }
     }
 }

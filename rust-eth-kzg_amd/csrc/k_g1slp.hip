@@ -46,9 +46,12 @@ __global__ __launch_bounds__(64, 2) void k_slp_mulc_s(JacS* __restrict__ A, int 
     // here, 2072 .. 2112 blobs 13.2 ms, tools/sweep_partial_group.sh) -- at the end of the launch that is a tail, at its start it
     // is hidden under the other 32 groups.
     const int lane = (gridDim.y - 1 - blockIdx.y) * 64 + threadIdx.x;
-    if (lane >= n_active) return;
-    const JacS src = A[(size_t)a * stride + lane];
-    A[(size_t)dst * stride + lane] = mul_by_recoded30(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta);
+    // A wave with only some of its lanes in use is the SLOWER wave on this part (measured twice: this kernel with <= 16 lanes of the
+    // last group in use lasts about twice as long; k_g1_compress on 12 or 32 of 64 lanes 191 us, on all 64 lanes 150 us), so the
+    // lanes behind the last blob do not leave: they repeat its work and store nothing.
+    const JacS src = A[(size_t)a * stride + (lane < n_active ? lane : n_active - 1)];
+    const JacS r = mul_by_recoded30(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta);
+    if (lane < n_active) A[(size_t)dst * stride + lane] = r;
 }
 // the constant multiplications of a batch of <= 16 blobs: four lanes per blob (a wave = 16 blobs x one operation), the quad sharing
 // the digit loop's doublings and mixed additions
@@ -127,8 +130,9 @@ __global__ __launch_bounds__(64, 2) void k_slp_add_s(JacS* __restrict__ A, int s
     const uint32_t* w = words + (size_t)blockIdx.y * 4;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
                    b = __builtin_amdgcn_readfirstlane(w[2]), fl = __builtin_amdgcn_readfirstlane(w[3]);
-    const int lane = blockIdx.x * 64 + threadIdx.x;
-    if (lane >= n_active) return;
+    const int lane_of_thread = blockIdx.x * 64 + threadIdx.x;
+    const bool keep = lane_of_thread < n_active;  // (padding lanes repeat the last blob's work and store nothing: see k_slp_mulc_s)
+    const int lane = keep ? lane_of_thread : n_active - 1;
     JacS r = A[(size_t)a * stride + lane];
     const uint32_t runs = (fl & 2u) ? b : (fl >> 3) & 31u;
 #pragma unroll 1
@@ -138,16 +142,17 @@ __global__ __launch_bounds__(64, 2) void k_slp_add_s(JacS* __restrict__ A, int s
         if (fl & 4u) {  // the difference is stored before the sum is computed
             const AddSubSharedS sh = add_sub_prepare(r, A[(size_t)b * stride + lane]);
             degenerate = sh.degenerate;  // (an identity, a = +-b: both results are redone below; what is stored here is overwritten)
-            A[(size_t)(fl >> 16) * stride + lane] = add_sub_finish(sh, true);
+            const JacS df = add_sub_finish(sh, true);
+            if (keep) A[(size_t)(fl >> 16) * stride + lane] = df;
             r = add_sub_finish(sh, false);
         } else {
             r = add_unchecked(r, A[(size_t)b * stride + lane], (fl & 1u) != 0, degenerate);
         }
     }
-    A[(size_t)dst * stride + lane] = r;
+    if (keep) A[(size_t)dst * stride + lane] = r;
     // the exact slow path comes LAST, when nothing else is live (kept inside the formulas it would hold both operands alive across
     // them): the operands are read and doubled again.  Rare: all-zero / constant / two-valued / sparse blobs.
-    if (degenerate) {
+    if (degenerate && keep) {
         asm volatile("" ::: "memory");
         JacS p2 = A[(size_t)a * stride + lane];
 #pragma unroll 1
@@ -199,10 +204,12 @@ __global__ __launch_bounds__(64, 2) void k_slp_mulc_coop_s(JacS* __restrict__ A,
     const uint32_t* w = words + (size_t)blockIdx.x * 4;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
                    cid = __builtin_amdgcn_readfirstlane(w[2]);
-    const int lane = blockIdx.y * (64 / COOP) + (threadIdx.x / COOP), sub = threadIdx.x % COOP;
-    if (lane >= lanes) return;
+    const int lane_of_thread = blockIdx.y * (64 / COOP) + (threadIdx.x / COOP), sub = threadIdx.x % COOP;
+    const bool keep = lane_of_thread < lanes;  // (padding lanes repeat the last blob's work and store nothing: see k_slp_mulc_s)
+    const int lane = keep ? lane_of_thread : lanes - 1;
     const JacS src = A[(size_t)a * stride + lane];
-    A[(size_t)dst * stride + lane] = mul_by_recoded30<COOP>(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta, sub);
+    const JacS r = mul_by_recoded30<COOP>(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta, sub);
+    if (keep) A[(size_t)dst * stride + lane] = r;
 }
 // the cheap operations with four lanes per blob (k_slp_add_coop's schedule): a doubling run 3 reductions deep per doubling, an
 // addition 5, the sum-and-difference pair 4 levels + its two fused pairs.  Every lane of a quad stores the same result.
@@ -210,8 +217,9 @@ __global__ __launch_bounds__(64, 2) void k_slp_add_coop_s(JacS* __restrict__ A, 
     const uint32_t* w = words + (size_t)blockIdx.y * 4;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(w[0]), a = __builtin_amdgcn_readfirstlane(w[1]),
                    b = __builtin_amdgcn_readfirstlane(w[2]), fl = __builtin_amdgcn_readfirstlane(w[3]);
-    const int lane = blockIdx.x * 16 + (threadIdx.x >> 2), quad = threadIdx.x & 3;
-    if (lane >= lanes) return;
+    const int lane_of_thread = blockIdx.x * 16 + (threadIdx.x >> 2), quad = threadIdx.x & 3;
+    const bool keep = lane_of_thread < lanes;
+    const int lane = keep ? lane_of_thread : lanes - 1;
     JacS r = A[(size_t)a * stride + lane];
     const uint32_t runs = (fl & 2u) ? b : (fl >> 3) & 31u;
 #pragma unroll 1
@@ -221,12 +229,12 @@ __global__ __launch_bounds__(64, 2) void k_slp_add_coop_s(JacS* __restrict__ A, 
         if (fl & 4u) {
             JacS d;
             coop4_add_sub(r, q, quad, r, d);
-            A[(size_t)(fl >> 16) * stride + lane] = d;
+            if (keep) A[(size_t)(fl >> 16) * stride + lane] = d;
         } else {
             r = coop4_add(r, q, (fl & 1u) != 0, quad);
         }
     }
-    A[(size_t)dst * stride + lane] = r;
+    if (keep) A[(size_t)dst * stride + lane] = r;
 }
 
 namespace launch {
