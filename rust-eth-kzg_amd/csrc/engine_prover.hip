@@ -188,10 +188,9 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
     }
     // The arena's point format: every kernel between the scalars and the proofs' bytes -- MSM, constant multiplications, additions,
     // compression; a lane, two or four lanes per blob -- is a kernel of the signed 13 x 30-bit field, and the arena holds its points
-    // (JacS, 156 B) as they are: ONE Fp representation under the whole path, no conversions.  What stays in the
-    // 14 x 29-bit field (JacQ) is the circulant form of <= 2 blobs, whose kernels are shared with verification, and the cross-check
-    // ETH_KZG_AMD_ARENA_SIGNED=0.
-    const int fmt = (linmap_mode && arena_signed_) ? launch::FMT_JACS : launch::FMT_JACQ;
+    // (JacS, 156 B) as they are: ONE Fp representation under the whole path at every batch size, no conversions.
+    // The 14 x 29-bit field (JacQ) is the cross-check ETH_KZG_AMD_ARENA_SIGNED=0 (and what verification and EIP-4844 compute in).
+    const int fmt = arena_signed_ ? launch::FMT_JACS : launch::FMT_JACQ;
     const size_t pt = fmt == launch::FMT_JACS ? launch::SIZEOF_JACS : launch::SIZEOF_JACQ;
     const TableView tv = tv_pre ? *tv_pre : table_view(TAB_FK);  // one snapshot for the scalars' form AND the MSM that reads them
     if (!tv_pre) {
@@ -232,11 +231,11 @@ void Engine::run_proofs_from_coeffs(Work& w, int n, uint8_t* d_proofs, hipStream
     if (n <= circ_max_) {  // a handful of blobs: the two transforms as one circulant product (k_g1circ.hip)
         if (!w.circ_table) HIPCK(hipMalloc(&w.circ_table, launch::g1_circ_table_bytes(circ_max_, circ_T_)));
         const int mk5 = mark_begin(ST_G1_IFFT, st);
-        launch::g1_circ128(w.X, bp, n, segs, w.circ_table, circ_T_, d_circ_terms_, circ_per_lane_, beta_, st);
+        launch::g1_circ128(w.X, bp, n, segs, w.circ_table, circ_T_, d_circ_terms_, circ_per_lane_, beta_, st, fmt);
         mark_end(mk5, 2, st);
     } else throw std::logic_error("run_proofs_from_coeffs: a batch above the circulant form needs the compiled linear map");
     const int mk10 = mark_begin(ST_COMPRESS, st);
-    launch::g1_compress(w.X, d_proofs, 128, bp, n, st);
+    launch::g1_compress(w.X, d_proofs, 128, bp, n, st, fmt);
     mark_end(mk10, 1, st);
 }
 

@@ -115,6 +115,24 @@ __device__ __forceinline__ JacS coop4_dbl_half(const JacS& p, int quad) {
     return r;
 }
 
+// the same with the product beta X -- the x of phi(p) = (beta X : Y : Z) -- in the lane that the first level leaves idle (the
+// doubling table of the circulant form, k_g1circ.hip, stores p and phi(p) before every doubling)
+__device__ __forceinline__ JacS coop4_dbl_half_phi(const JacS& p, int quad, const Fs<1, DC>& beta, Fs<1, DC>& beta_x) {
+    const bool l0 = quad == 0, l1 = quad == 1, l3 = quad == 3;
+    const Fs<4, DC> y4 = relax<4, DC>(p.y), z4 = relax<4, DC>(p.z);
+    const Fs<1, DC> r1 = mul(select(l0 || l3, p.x, y4), select(l0, p.x, select(l1, y4, select(l3, relax<4, DC>(beta), z4))));
+    const Fs<1, DC> A = quad_bcast<0>(r1), B = quad_bcast<1>(r1), Z3 = quad_bcast<2>(r1);
+    beta_x = quad_bcast<3>(r1);
+    const Fs<2, DC> H = half_of_triple(A);
+    const Fs<1, DC> r2 = mul(select(l0, relax<4, DC>(B), relax<4, DC>(H)), select(l0, p.x, relax<4, DC>(H)));
+    const Fs<1, DC> M = quad_bcast<0>(r2), HH = quad_bcast<1>(r2);
+    JacS r;
+    r.x = relax<4, DC>(sub(HH, mul_small<2>(M)));
+    r.y = mul_add<DC>(H, sub_lazy(M, r.x), neg(B), B);
+    r.z = Z3;
+    return r;
+}
+
 // curve30.hpp: add_mixed(JacS, AffT) by a quad: p + q, or p - q when negq (wave-uniform)
 __device__ __forceinline__ JacS coop4_add_mixed(const JacS& p, const AffT& q, bool negq, int quad) {
     const bool l0 = quad == 0, l1 = quad == 1;

@@ -120,7 +120,7 @@ constexpr int TWIDDLE_WORDS = 33;   // 132 signed digit bytes per 128-bit half
 // k_g1circ.hip
 constexpr int CIRC_LANES = 256;
 size_t g1_circ_table_bytes(int n, int T);
-void g1_circ128(void* X, int stride, int n, int segs, void* D, int T, const void* terms, int per_lane, const Fp12w& beta, hipStream_t st);
+void g1_circ128(void* X, int stride, int n, int segs, void* D, int T, const void* terms, int per_lane, const Fp12w& beta, hipStream_t st, int fmt = FMT_JACQ);
 // k_verify.hip
 void init_attributes_verify();
 // slot_of: destination cell slot per input cell (null = identity); status_of: status word per input cell (null = word 0)

@@ -194,6 +194,17 @@ def test_signed_and_unsigned_arena_give_identical_bytes(ctx, oracle, monkeypatch
             assert a[0] == b[0] == [0] * n
             assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), n
             _check_sample_against_oracle(oracle, blobs, a[1], a[2], [0, 1, 2, 3, n // 2, n - 1])
+        # one and two blobs: the circulant form (k_g1circ.hip) on both point forms, the one-block MSM with its quad fold before it
+        for n in (1, 2):
+            for kind in ("random", "degenerate"):
+                blobs = _random_blobs(n, 9300 + n)
+                if kind == "degenerate":
+                    blobs[0] = np.frombuffer(_blob_from_coefficients([0] * 64 + [1] + [0] * 4031), dtype=np.uint8).reshape(4096, 32)
+                    blobs[n - 1] = 0 if n == 1 else np.frombuffer((b"\x00" * 31 + b"\x05") * 4096, dtype=np.uint8).reshape(4096, 32)
+                a, b = _compute_on_device(ctx, blobs), _compute_on_device(old, blobs)
+                assert a[0] == b[0] == [0] * n
+                assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (n, kind)
+                _check_sample_against_oracle(oracle, blobs, a[1], a[2], list(range(n)))
         # recovery of 80 half-erased blobs runs the same map from coefficients
         import torch
         n = 80
