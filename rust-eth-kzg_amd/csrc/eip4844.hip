@@ -92,10 +92,11 @@ int Engine::open_blobs_at(int n, const uint8_t* const* blobs, const Fr8* z_mont,
     launch::quotient_by_linear(n, d_coeffs_, d_z.p, d_canon_, d_y.p, st);
     if (want_proofs) {
         // proof = g1_lincomb(g1s[..4095], quotient) (kzg_single_open/src/prover.rs:40-43): the commitment MSM path
-        launch::g1_set_inf(d_X_, (size_t)64 * bp, st);
-        launch_msm(d_canon_, TAB_SRS, d_X_, 64, n, bp, 0, st);
-        launch::g1_sum_positions(d_X_, 64, bp, n, st);
-        launch::g1_compress(d_X_, (uint8_t*)d_pr.p, 1, bp, n, st);
+        const int fmt = arena_signed_ ? launch::FMT_JACS : launch::FMT_JACQ;
+        launch::g1_set_inf(d_X_, (size_t)64 * bp, st, fmt);
+        launch_msm(d_canon_, TAB_SRS, d_X_, 64, n, bp, 0, st, fmt);
+        launch::g1_sum_positions(d_X_, 64, bp, n, st, fmt);
+        launch::g1_compress(d_X_, (uint8_t*)d_pr.p, 1, bp, n, st, fmt);
         HIPCK(hipMemcpyAsync(h_proofs, d_pr.p, (size_t)n * 48, hipMemcpyDeviceToHost, st));
     }
     HIPCK(hipMemcpyAsync(h_y_canon, d_y.p, (size_t)n * 32, hipMemcpyDeviceToHost, st));

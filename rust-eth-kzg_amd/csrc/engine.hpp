@@ -293,7 +293,7 @@ private:
     std::condition_variable lease_cv_;
     void set_error(const std::exception& e);
     void launch_msm(const void* scalars, TableSel table, void* out, int n_groups, int n_slices, int out_stride,
-                    int brp_bits, hipStream_t st);
+                    int brp_bits, hipStream_t st, int out_fmt = 0 /* launch::FMT_JACQ */);
     void launch_msm(const void* scalars, const TableView& tv, bool scalars_split, void* out, int n_groups, int n_slices, int out_stride,
                     int brp_bits, hipStream_t st, int out_fmt = 0 /* launch::FMT_JACQ */);
     void launch_msm_range(const void* scalars, const SharedTable& t, int g0, int gcnt, void* out, int n_groups, int n_slices, int out_stride,
@@ -434,7 +434,7 @@ private:
     int pick_slp_program(int lanes) const;        // lanes = blobs rounded up to 64
     int slp_force_ = -1;                          // ETH_KZG_AMD_SLP_PROGRAM: this program at every batch size (tests, A/B runs)
     // a phase = one multiplication launch (level0 < 0) or a run of cheap dependency levels executed by ONE ticket-walking launch
-    bool arena_signed_ = true;  // batches of more than one lane group keep the linear map's arena in the signed 13 x 30-bit form (ETH_KZG_AMD_ARENA_SIGNED=0: the 14 x 29-bit arena of rounds 2-5, for A/B runs and as the tests' cross-check)
+    bool arena_signed_ = true;  // the prover's, the recovery's and the commitments' G1 points live in the signed 13 x 30-bit form from the MSM sums to the compression (ETH_KZG_AMD_ARENA_SIGNED=0: the 14 x 29-bit points and kernels of rounds 2-5, for A/B runs and as the tests' cross-check)
     int slp_fuse_min_ = 1024;  // measured: 512 blobs 5.47 (plain) against 5.55 ms (fused), 2048 blobs 16.13 against 15.93 ms
     int slp_info_[4] = {0, 0, 0, 0};  // constant multiplications, additions, doublings, launches of the tuned program
     Fr8 half_;  // 1/2 in Montgomery form: the scaling folded into the MSM scalars in linear-map mode

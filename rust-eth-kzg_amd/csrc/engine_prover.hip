@@ -102,8 +102,8 @@ void Engine::release_work(Work& w) {
 
 // ---------------------------------------------------------------------------------------------
 void Engine::launch_msm(const void* scalars, TableSel which, void* out, int n_groups, int n_slices, int out_stride,
-                        int brp_bits, hipStream_t st) {
-    launch_msm(scalars, table_view(which), false, out, n_groups, n_slices, out_stride, brp_bits, st);
+                        int brp_bits, hipStream_t st, int out_fmt) {
+    launch_msm(scalars, table_view(which), false, out, n_groups, n_slices, out_stride, brp_bits, st, out_fmt);
 }
 // out_fmt: launch::FMT_JACQ (the default: 14 x 29-bit sums) or FMT_JACS (the signed 13 x 30-bit sums the linear map of a batch of
 // more than one lane group computes in); `out` addresses points of that format
@@ -351,10 +351,11 @@ int Engine::blob_to_kzg_commitment_device(int n, const uint8_t* d_blobs, uint8_t
         // commit = MSM_4096(coeffs, g1_monomial)  (fk20/prover.rs:128-145, commit_key.rs:38-44):
         // 64 groups of 64 bases through the window-table kernel, then a fold over the groups.
         launch::blob_to_coeffs(n, d_blobs, d_coeffs_, d_canon_, d_status_, d_w29_, n_inv4096_, st);
-        launch::g1_set_inf(d_X_, (size_t)64 * bp, st);
-        launch_msm(d_canon_, TAB_SRS, d_X_, 64, n, bp, 0, st);
-        launch::g1_sum_positions(d_X_, 64, bp, n, st);
-        launch::g1_compress(d_X_, d_commitments, 1, bp, n, st);
+        const int fmt = arena_signed_ ? launch::FMT_JACS : launch::FMT_JACQ;  // (the points' form: run_proofs_from_coeffs)
+        launch::g1_set_inf(d_X_, (size_t)64 * bp, st, fmt);
+        launch_msm(d_canon_, TAB_SRS, d_X_, 64, n, bp, 0, st, fmt);
+        launch::g1_sum_positions(d_X_, 64, bp, n, st, fmt);
+        launch::g1_compress(d_X_, d_commitments, 1, bp, n, st, fmt);
         if (h_status) HIPCK(hipMemcpyAsync(h_status, d_status_, n * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCK(hipEventRecord(work_[0].done, st));
         HIPCK(hipGetLastError());

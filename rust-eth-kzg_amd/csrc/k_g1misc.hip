@@ -7,6 +7,7 @@
 #include "curve30.hpp"
 #include "g1_subgroup.hpp"
 #include "g1_coop.hpp"
+#include "g1_coop30.hpp"
 #include "launch.hpp"
 
 namespace kzg {
@@ -86,13 +87,20 @@ __global__ __launch_bounds__(64) void k_g1_compress(const Pt* __restrict__ X, ui
 // dependent additions -- 1.0 ms whatever the batch, two thirds of a single blob's commitment (round 4: 1.59 -> 0.7 ms), and
 // still the longer way at 2048 blobs (32 waves for 1.0 ms against 2048 short ones).  X[slice] (position 0) is read by its own
 // block only, so the sum may land there.
-__global__ __launch_bounds__(64) void k_g1_sum_positions(JacQ* __restrict__ X, int n_pos, int stride, int n_slices) {
-    __shared__ JacQ T[64];
+__device__ __forceinline__ void sum_fold64(JacQ* T, int t) { coop_tree_fold<64>(T, 32, t); }    // four lanes per addition (g1_coop.hpp)
+__device__ __forceinline__ void sum_fold64(JacS* T, int t) { coop4_tree_fold<64>(T, 32, t); }   // ... in the signed field (g1_coop30.hpp)
+__device__ __forceinline__ void set_inf(JacQ& p) { p = jacq_inf(); }
+__device__ __forceinline__ void set_inf(JacS& p) { p = jacs_inf(); }
+template <class Pt>
+__global__ __launch_bounds__(64) void k_g1_sum_positions(Pt* __restrict__ X, int n_pos, int stride, int n_slices) {
+    __shared__ Pt T[64];
     const int slice = blockIdx.x, t = threadIdx.x;
-    JacQ acc = t < n_pos ? X[(size_t)t * stride + slice] : jacq_inf();
+    Pt acc;
+    if (t < n_pos) acc = X[(size_t)t * stride + slice];
+    else set_inf(acc);
     for (int p = t + 64; p < n_pos; p += 64) acc = add(acc, X[(size_t)p * stride + slice]);
     T[t] = acc;
-    coop_tree_fold<64>(T, 32, t);  // four lanes per addition (g1_coop.hpp)
+    sum_fold64(T, t);
     if (t == 0) X[slice] = T[0];
 }
 
@@ -315,8 +323,10 @@ void g1_compress(const void* X, uint8_t* out, int n_pos, int stride, int n_slice
         else k_g1_compress<1, JacQ><<<g1, 64, 0, st>>>((const JacQ*)X, out, n_pos, stride, n_slices);
     }
 }
-void g1_sum_positions(void* X, int n_pos, int stride, int n_slices, hipStream_t st) {
-    if (n_slices > 0) k_g1_sum_positions<<<n_slices, 64, 0, st>>>((JacQ*)X, n_pos, stride, n_slices);
+void g1_sum_positions(void* X, int n_pos, int stride, int n_slices, hipStream_t st, int fmt) {
+    if (n_slices <= 0) return;
+    if (fmt == FMT_JACS) k_g1_sum_positions<JacS><<<n_slices, 64, 0, st>>>((JacS*)X, n_pos, stride, n_slices);
+    else k_g1_sum_positions<JacQ><<<n_slices, 64, 0, st>>>((JacQ*)X, n_pos, stride, n_slices);
 }
 void g1_decompress(const uint8_t* in, void* out, int* status, int n, int subgroup_check, const Fp12w& beta, hipStream_t st) {
     Fp b;

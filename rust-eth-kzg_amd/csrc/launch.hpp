@@ -98,7 +98,7 @@ void g1_set_inf(void* X, size_t n, hipStream_t st, int fmt = FMT_JACQ);
 int coop_points_max();  // largest launch (points) that takes the four-lanes-per-point kernels (k_g1misc.hip)
 void spin(uint64_t wall_clock_ticks, hipStream_t st);  // one wave, resident for that many ticks of the constant-rate device clock
 void g1_compress(const void* X, uint8_t* out, int n_pos, int stride, int n_slices, hipStream_t st, int fmt = FMT_JACQ);
-void g1_sum_positions(void* X, int n_pos, int stride, int n_slices, hipStream_t st);
+void g1_sum_positions(void* X, int n_pos, int stride, int n_slices, hipStream_t st, int fmt = FMT_JACQ);
 // subgroup_check: 0 none, 1 endomorphism test, 2 definitional [r]P == O
 void g1_decompress(const uint8_t* in, void* out /*G1Affine*/, int* status, int n, int subgroup_check, const Fp12w& beta,
                    hipStream_t st);

@@ -205,6 +205,17 @@ def test_signed_and_unsigned_arena_give_identical_bytes(ctx, oracle, monkeypatch
                 assert a[0] == b[0] == [0] * n
                 assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (n, kind)
                 _check_sample_against_oracle(oracle, blobs, a[1], a[2], list(range(n)))
+        # commitments (MSM on the commitment table, fold over the 64 groups, compression) and the EIP-4844 proof, which is the same path
+        for n in (1, 3, 70):
+            cb = [bytes(x.tobytes()) for x in _random_blobs(n, 9400 + n)]
+            cb[0] = bytes(131072)
+            cb[n - 1] = synth.dummy_blob()
+            ca, co = ctx.blob_to_kzg_commitment_batch(cb), old.blob_to_kzg_commitment_batch(cb)
+            assert ca == co and ca[0] == [0] * n, n
+            assert ca[1][n - 1] == oracle.blob_to_kzg_commitment(cb[n - 1]) and (n == 1 or ca[1][0] == b"\xc0" + bytes(47))
+        z = (12345).to_bytes(32, "big")
+        pr = ctx.compute_kzg_proof(cb[1], z)  # (the EIP-4844 vectors pin it; here: the same bytes from both point forms, and it verifies)
+        assert pr == old.compute_kzg_proof(cb[1], z) and ctx.verify_kzg_proof(ca[1][1], z, pr[1], pr[0]) is True
         # recovery of 80 half-erased blobs runs the same map from coefficients
         import torch
         n = 80
