@@ -37,7 +37,12 @@ struct HipError : std::runtime_error {
     } while (0)
 
 // batches up to this many lanes (blobs rounded up to 64) use the direct 8 x 16 G1 transforms (k_g1fft.hip)
-static constexpr int FLAT_MSM_MAX_SLICES = 8;  // measured: 1 blob 0.23 ms (vs 1.0), 16 blobs 1.6 ms (vs 1.06): one block per MSM pays while the chip is not full
+// up to how many blobs the MSM stage runs one block per MSM (k_msm_glv_flat): measured against two lanes per window, one box
+// (tools/ab_flat_msm_max.sh, profiles/r6_ab_flat_msm_max.log): 9 blobs 1.73 -> 1.62 ms per step, 10: 1.73 -> 1.66, 12: 1.74 -> 1.72, 16: 1.78 -> 1.79
+#ifndef KZG_FLAT_MSM_MAX_SLICES  // (experiment builds of that A/B)
+#define KZG_FLAT_MSM_MAX_SLICES 12
+#endif
+static constexpr int FLAT_MSM_MAX_SLICES = KZG_FLAT_MSM_MAX_SLICES;
 static constexpr int SIDE_CELLS_MAX = 256;  // batches up to this size compute their cells on the work set's second stream, next to the proof stages (64 blobs: 0.08 of 3.7 ms)
 static constexpr int N_BLOB = 4096, N_EXT = 8192, N_CELLS = 128, CELL_LEN = 64, BYTES_PER_BLOB = 131072, BYTES_PER_CELL = 2048;
 static_assert(sizeof(Fr) == launch::SIZEOF_FR && sizeof(G1Affine) == launch::SIZEOF_G1AFFINE && sizeof(G1Jac) == launch::SIZEOF_G1JAC, "layout");

@@ -225,9 +225,13 @@ __device__ __forceinline__ void coop4_tree_fold(JacS* red, int first_span, int t
 #pragma unroll 1
         for (int base = 0; base < span; base += NT / 4) {  // a round reads red[a] and red[a + span] and writes red[a]: its own slots only
             const int a = base + slot;
-            if (a < span) {
-                const JacS r = coop4_add(red[a], red[a + span], false, quad);
-                if (quad == 0) red[a] = r;
+            // A wave takes part as a whole or not at all: a wave with few lanes in use is the slow one (k_g1slp.hip: k_slp_mulc_s), and
+            // the last levels have 16, 8 and 4.  The quads behind the last addition repeat it and store nothing; its owner is in their
+            // wave, so they read its operands before it writes.
+            if (base + ((tid & ~63) >> 2) < span) {
+                const int aa = a < span ? a : span - 1;
+                const JacS r = coop4_add(red[aa], red[aa + span], false, quad);
+                if (quad == 0 && a < span) red[a] = r;
             }
         }
         __syncthreads();

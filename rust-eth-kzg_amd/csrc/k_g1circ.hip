@@ -166,23 +166,44 @@ __global__ __launch_bounds__(256) void k_g1_circ_sum_coop(const Pt* __restrict__
     Pt acc = *entry(terms[col0]);
     const int n_terms = 2 * per_lane;  // per logical lane
     const int steps = n_terms - 1 + LEVELS;
+    // the next term's table entry is requested before the current addition starts (a memory latency per step otherwise)
+    Pt nxt;
+    bool nxt_act = false, nxt_minus = false;
+    auto fetch = [&](int i) {
+        const uint32_t w = terms[(size_t)(i >> 1) * CIRC_LANES + col0 + LL * (i & 1)];
+        nxt_act = (w >> 17) & 1;
+        nxt_minus = (w >> 16) & 1;
+        if (nxt_act) nxt = *entry(w);
+    };
+    if (n_terms > 1) fetch(1);
 #pragma unroll 1
     for (int s = 0; s < steps; s++) {
         Pt other;
         bool act, minus = false;
         if (s < n_terms - 1) {
-            const int i = s + 1;
-            const uint32_t w = terms[(size_t)(i >> 1) * CIRC_LANES + col0 + LL * (i & 1)];
-            act = (w >> 17) & 1;
-            minus = (w >> 16) & 1;
-            if (act) other = *entry(w);
+            other = nxt;
+            act = nxt_act;
+            minus = nxt_minus;
+            if (s + 2 < n_terms) fetch(s + 2);
         } else {
+            // the tree: a wave takes part as a whole or not at all (a wave with few lanes in use is the slow one: k_g1slp.hip,
+            // k_slp_mulc_s); the quads behind the last addition of a level repeat it and keep nothing
             const int span = (LL / 2) >> (s - (n_terms - 1));
             if (quad == 0) part[l] = acc;
             __syncthreads();
-            act = l < span;
-            if (act) other = part[l + span];
+            const bool wave_in = (int)((threadIdx.x & ~63u) >> 2) < span, keep = l < span;
+            const int ll = keep ? l : span - 1;
+            Pt mine = acc;
+            if (wave_in) {
+                if (!keep) mine = part[ll];
+                other = part[ll + span];
+            }
             __syncthreads();
+            if (wave_in) {
+                const Pt r = CircOps<Pt>::coop_add4(mine, other, false, quad);
+                if (keep) acc = r;
+            }
+            continue;
         }
         if (act) acc = CircOps<Pt>::coop_add4(acc, other, minus, quad);
     }
