@@ -23,8 +23,8 @@
 //   ETH_KZG_AMD_VM_FOLD=0           many-verification: one pairing per problem instead of one folded check per pass
 //   ETH_KZG_AMD_VERIFY_COMBINE=0    concurrent single verifications are not combined into passes
 //   ETH_KZG_AMD_MSM_SPLIT=0         batches of <= 32 blobs: a lane per MSM window (rounds 2-5) instead of two (A/B runs, the tests' cross-check)
-//   ETH_KZG_AMD_ARENA_SIGNED=0      batches of more than one lane group keep the linear map's arena in the 14 x 29-bit form (rounds 2-5) instead
-//                                   of the signed 13 x 30-bit one: the tests' cross-check of the two forms, A/B runs
+//   ETH_KZG_AMD_ARENA_SIGNED=0      the prover's, recovery's and the commitments' G1 points in the 14 x 29-bit form and kernels of rounds 2-5
+//                                   instead of the signed 13 x 30-bit ones: the tests' cross-check of the two forms, A/B runs
 //   ETH_KZG_AMD_DEVICE_BATCH_MAX=<n> a device-resident prover call is cut into sub-batches of at most n blobs (default 4096)
 //   ETH_KZG_AMD_FAULT=constructor   the context's constructor throws after its last step but one (tests: try_new returns NULL + a
 //                                   message, nothing leaks, the next context works)
