@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64) void k_g1_decompress(const uint8_t* __restrict_
                                                       G1Affine* __restrict__ out1, int* __restrict__ status1, int n1,
                                                       int subgroup_check, Fq<1> beta_q) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n0 + n1) return;
+    if (i >= n0 + n1) i = n0 + n1 - 1;  // (the lanes behind the last point repeat its work -- same values to the same places: a wave with few lanes in use is the slow one, k_g1slp.hip)
     const bool second = i >= n0;
     if (second) i -= n0;
     const uint8_t* in = second ? in1 : in0;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64) void k_g1_decompress_coop(const uint8_t* __rest
                                                            int* __restrict__ status0, int n0, const uint8_t* __restrict__ in1,
                                                            G1Affine* __restrict__ out1, int* __restrict__ status1, int n1, Fq<1> beta_q) {
     int i = blockIdx.x * 16 + (threadIdx.x >> 2);
-    if (i >= n0 + n1) return;
+    if (i >= n0 + n1) i = n0 + n1 - 1;  // (the lanes behind the last point repeat its work -- same values to the same places: a wave with few lanes in use is the slow one, k_g1slp.hip)
     const bool second = i >= n0;
     if (second) i -= n0;
     const uint8_t* in = second ? in1 : in0;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64) void k_g1_decompress_coop(const uint8_t* __rest
 __global__ __launch_bounds__(64) void k_g1_subgroup_coop(const G1Affine* __restrict__ pts0, int* __restrict__ status0, int n0,
                                                          const G1Affine* __restrict__ pts1, int* __restrict__ status1, int n1, Fq<1> beta_q) {
     int i = blockIdx.x * 16 + (threadIdx.x >> 2);
-    if (i >= n0 + n1) return;
+    if (i >= n0 + n1) i = n0 + n1 - 1;
     const bool second = i >= n0;
     if (second) i -= n0;
     int* st = second ? status1 : status0;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64) void k_g1_subgroup_coop(const G1Affine* __restr
 __global__ __launch_bounds__(64) void k_g1_subgroup(const G1Affine* __restrict__ pts0, int* __restrict__ status0, int n0,
                                                     const G1Affine* __restrict__ pts1, int* __restrict__ status1, int n1, Fq<1> beta_q) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n0 + n1) return;
+    if (i >= n0 + n1) i = n0 + n1 - 1;
     const bool second = i >= n0;
     if (second) i -= n0;
     int* st = second ? status1 : status0;

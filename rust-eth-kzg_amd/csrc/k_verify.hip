@@ -398,11 +398,11 @@ __global__ __launch_bounds__(64) void k_pip_shift_subgroup(const G1Affine* __res
                                                            const G1Affine* __restrict__ pts1, int* __restrict__ status1, int n1, Fq<1> beta) {
     if ((int)blockIdx.x < shift_blocks) {
         const int i = blockIdx.x * 64 + threadIdx.x;
-        if (i < n) pip_shift_point(i, in, pts32, jac, pre, n_max, beta);
+        pip_shift_point(i < n ? i : n - 1, in, pts32, jac, pre, n_max, beta);  // (lanes behind the last point repeat it: see the quad form below)
         return;
     }
     int i = ((int)blockIdx.x - shift_blocks) * 64 + threadIdx.x;
-    if (i >= n0 + n1) return;
+    if (i >= n0 + n1) i = n0 + n1 - 1;
     const bool second = i >= n0;
     if (second) i -= n0;
     int* st = second ? status1 : status0;
@@ -419,12 +419,14 @@ __global__ __launch_bounds__(64) void k_pip_shift_subgroup_coop(const G1Affine* 
                                                                 const G1Affine* __restrict__ pts1, int* __restrict__ status1, int n1, Fq<1> beta) {
     const int quad = threadIdx.x & 3;
     if ((int)blockIdx.x < shift_blocks) {
+        // (the quads behind the last point repeat its work -- same values to the same places: a wave with few lanes in use is the
+        // slow one, k_g1slp.hip, and here it would be the launch's longest)
         const int i = blockIdx.x * 16 + (threadIdx.x >> 2);
-        if (i < n) pip_shift_point(i, in, pts32, jac, pre, n_max, beta, quad);
+        pip_shift_point(i < n ? i : n - 1, in, pts32, jac, pre, n_max, beta, quad);
         return;
     }
     int i = ((int)blockIdx.x - shift_blocks) * 16 + (threadIdx.x >> 2);
-    if (i >= n0 + n1) return;
+    if (i >= n0 + n1) i = n0 + n1 - 1;
     const bool second = i >= n0;
     if (second) i -= n0;
     int* st = second ? status1 : status0;
