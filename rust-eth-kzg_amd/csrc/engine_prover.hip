@@ -105,8 +105,8 @@ void Engine::launch_msm(const void* scalars, TableSel which, void* out, int n_gr
                         int brp_bits, hipStream_t st, int out_fmt) {
     launch_msm(scalars, table_view(which), false, out, n_groups, n_slices, out_stride, brp_bits, st, out_fmt);
 }
-// out_fmt: launch::FMT_JACQ (the default: 14 x 29-bit sums) or FMT_JACS (the signed 13 x 30-bit sums the linear map of a batch of
-// more than one lane group computes in); `out` addresses points of that format
+// out_fmt: launch::FMT_JACQ (the default: 14 x 29-bit sums) or FMT_JACS (the signed 13 x 30-bit sums everything after the MSM computes
+// in); `out` addresses points of that format
 // tv: ONE snapshot of the table view (the builder thread may publish a wider table at any time); scalars_split: the producer
 // has stored the scalars as balanced GLV halves already (only meaningful for a GLV table).  While a wider table is under
 // construction its leading ready groups run on it and the rest on the complete table: two launches, one MSM stage.

@@ -315,7 +315,7 @@ void g1_compress(const void* X, uint8_t* out, int n_pos, int stride, int n_slice
     // (below two rounds of one-point waves the kernel lasts as long as one thread's chain)
     const bool four = (long)n_pos * stride >= 128L * 2048;
     const dim3 g4((n_pos + 3) / 4, stride / 64), g1(n_pos, stride / 64);
-    if (fmt == FMT_JACS) {  // the arena of a batch of more than one lane group (signed 13 x 30-bit points)
+    if (fmt == FMT_JACS) {  // signed 13 x 30-bit points: what the prover, recovery and the commitments hand over
         if (four) k_g1_compress<4, JacS><<<g4, 64, 0, st>>>((const JacS*)X, out, n_pos, stride, n_slices);
         else k_g1_compress<1, JacS><<<g1, 64, 0, st>>>((const JacS*)X, out, n_pos, stride, n_slices);
     } else {

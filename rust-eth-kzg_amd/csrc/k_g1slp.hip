@@ -6,9 +6,9 @@
 // one wave = one operation x 64 blobs, so the operation descriptor and, for multiplications, the digits of the public
 // constant are wave-uniform (scalar loads and scalar branches, no divergence).  Operations of one launch are mutually
 // independent and never write a slot that the same launch reads (linmap::make_schedule).
-// Point format of the arena (launch::FMT_*, chosen by the engine): more than one lane group -> signed 13 x 30-bit points (JacS) and the
-// `_s` kernels below: one field from the MSM's sums to the proofs' compression; one lane group or less -> 14 x 29-bit points (JacQ)
-// and the several-lanes-per-blob kernels (whose constant multiplications of 17 .. 64 blobs compute in the signed field all the same).
+// Point format of the arena (launch::FMT_*, chosen by the engine): signed 13 x 30-bit points (JacS) and the `_s` kernels below -- one
+// field from the MSM's sums to the proofs' compression, with one, two or four lanes per blob -- unless ETH_KZG_AMD_ARENA_SIGNED=0 asks
+// for the 14 x 29-bit points (JacQ) and kernels of rounds 2-5 (the cross-check).
 // words: 4 per operation: dst slot, a slot, b (slot | number of doublings | constant id), flags (1 = subtract, 2 = doubling run, 4 = a + b to dst AND a - b to slot flags >> 16; bits 3-7 of an addition: doublings of operand a first).
 #include "engine.hpp"
 #include <stdexcept>
@@ -20,7 +20,7 @@ namespace kzg {
 
 static_assert(sizeof(JacS) == launch::SIZEOF_JACS && sizeof(JacQ) == launch::SIZEOF_JACQ, "the engine sizes and offsets the arena with these");
 
-// (a lane per blob on a 14 x 29-bit arena -- ETH_KZG_AMD_ARENA_SIGNED=0, or 33 .. 64 blobs with the pair kernels switched off: the
+// (a lane per blob on a 14 x 29-bit arena -- ETH_KZG_AMD_ARENA_SIGNED=0: the
 // multiplication runs in the signed 13 x 30-bit field, g1_mulc30.hpp; the point is converted on the way in and out)
 // n_active (every lane-per-blob kernel below): the blobs that are really there.  The lanes behind them (the batch is padded to a
 // multiple of 64) hold the identity, and an identity operand sends its WAVE through the exact slow path of every operation: such
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(64, 2) void k_slp_mulc(JacQ* __restrict__ A, int st
     const JacQ src = A[(size_t)a * stride + lane];
     A[(size_t)dst * stride + lane] = mul_by_recoded30(src, naf + (size_t)cid * (2 * launch::TWIDDLE_WORDS), beta);
 }
-// ... and on an arena in the signed form itself (launch::FMT_JACS: batches of more than one lane group): nothing is converted
+// ... and on an arena in the signed form itself (launch::FMT_JACS: what the engine runs): nothing is converted
 __global__ __launch_bounds__(64, 2) void k_slp_mulc_s(JacS* __restrict__ A, int stride, const uint32_t* __restrict__ words,
                                                       const uint32_t* __restrict__ naf, Fs<1, DC> beta, int n_active) {
     const uint32_t* w = words + (size_t)blockIdx.x * 4;

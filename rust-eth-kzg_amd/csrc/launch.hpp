@@ -64,9 +64,9 @@ constexpr size_t glv_entries_per_base(int c, int w0, int w1) {
 constexpr int GLV_WIDTHS[] = {16, 15, 14, 12, 8};  // widest first: the order the engine tries them in
 bool glv_width_supported(int c);
 void glv_split(void* scalars, size_t n, hipStream_t st);
-// Point arrays between the prover's G1 stages come in two formats (FMT_*): the 14 x 29-bit form (JacQ, 168 B: the latency paths of
-// <= 64 blobs, commitments, set-up, verification) and the signed 13 x 30-bit form (JacS, 156 B: the MSM sums, the linear map's arena
-// and the input of the proofs' compression for batches of more than one lane group -- one field under that whole path).
+// Point arrays between the G1 stages come in two formats (FMT_*): the signed 13 x 30-bit form (JacS, 156 B: the MSM sums, the linear
+// map's arena, the circulant form, the commitment's fold and the input of the compression -- one field under the whole prover, recovery
+// and commitment path) and the 14 x 29-bit form (JacQ, 168 B: set-up, verification, the stage hooks, ETH_KZG_AMD_ARENA_SIGNED=0).
 constexpr int FMT_JACQ = 0, FMT_JACS = 1;
 void msm_glv(int c, int mode, const void* scalars, const TabBlocks& table, void* out /*JacQ or JacS by out_fmt*/, int n_groups, int n_slices, int nb, int out_stride,
              int brp_bits, const Fp12w& beta, hipStream_t st, int out_fmt = FMT_JACQ);
