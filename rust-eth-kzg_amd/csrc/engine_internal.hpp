@@ -37,10 +37,11 @@ struct HipError : std::runtime_error {
     } while (0)
 
 // batches up to this many lanes (blobs rounded up to 64) use the direct 8 x 16 G1 transforms (k_g1fft.hip)
-// up to how many blobs the MSM stage runs one block per MSM (k_msm_glv_flat): measured against two lanes per window, one box
-// (tools/ab_flat_msm_max.sh, profiles/r6_ab_flat_msm_max.log): 9 blobs 1.73 -> 1.62 ms per step, 10: 1.73 -> 1.66, 12: 1.74 -> 1.72, 16: 1.78 -> 1.79
+// up to how many blobs the MSM stage runs one block per MSM (k_msm_glv_flat) instead of two lanes per window: measured on one box
+// (tools/ab_flat_msm_max.sh, profiles/r6_ab_flat_msm_max.log).  With one lane per addition in the windowed kernel's tree the cross-over
+// was 12 blobs; since that tree takes four lanes per addition it is 8 again: 9 blobs 1.61 -> 1.60 ms per step, 10: 1.65 -> 1.60, 12: 1.71 -> 1.61
 #ifndef KZG_FLAT_MSM_MAX_SLICES  // (experiment builds of that A/B)
-#define KZG_FLAT_MSM_MAX_SLICES 12
+#define KZG_FLAT_MSM_MAX_SLICES 8
 #endif
 static constexpr int FLAT_MSM_MAX_SLICES = KZG_FLAT_MSM_MAX_SLICES;
 static constexpr int SIDE_CELLS_MAX = 256;  // batches up to this size compute their cells on the work set's second stream, next to the proof stages (64 blobs: 0.08 of 3.7 ms)

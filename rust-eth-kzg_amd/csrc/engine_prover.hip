@@ -142,6 +142,23 @@ void Engine::launch_msm_range(const void* scalars, const SharedTable& t, int g0,
         // half -- no folds, no barriers, exact rounds of long waves -- were measured 1-2 % SLOWER in rounds 3 and 4 and are gone.)
         mode = 2;
     }
+    if (mode == 1 && msm_chunks_ < 0 && msm_split_) {
+        // A lane per window fills one round of wave slots with 64 blobs on eight windows -- and with 56 on nine (the default tables):
+        // the blobs beyond that used to open a second round of full-length waves on a nearly empty chip (64 blobs on the default
+        // tables: MSM 1.66 ms against 1.13 on eight windows).  An overflow of at most a quarter round runs as its own launch: a block per
+        // MSM for a handful of blobs, two lanes per window (half-length chains) beyond (tools/sweep_default_tables.sh: 64 blobs on the
+        // default tables 3.12 -> 3.03 ms with the second form alone; 65 .. 80 blobs on eight windows 3.9 -> 3.5 ms).
+        const long per_slice = (long)gcnt * 2 * launch::glv_windows(c), slots = (long)wave_slots_ * 64, lanes = per_slice * n_slices;
+        const int n_a = (int)(slots / per_slice);
+        if (lanes > slots && lanes * 4 <= slots * 5 && n_a >= 1 && n_a < n_slices) {
+            const size_t pt = out_fmt == launch::FMT_JACS ? launch::SIZEOF_JACS : launch::SIZEOF_JACQ;
+            launch::msm_glv(c, 1, scalars, tb, out, n_groups, n_a, 64, out_stride, brp_bits, beta_, st, out_fmt);
+            const int n_b = n_slices - n_a;
+            launch::msm_glv(c, (n_b <= FLAT_MSM_MAX_SLICES && circ_max_ > 0) ? 0 : 3, (const char*)scalars + (size_t)n_a * n_groups * 64 * sizeof(Fr), tb,
+                            (char*)out + (size_t)n_a * pt, n_groups, n_b, 64, out_stride, brp_bits, beta_, st, out_fmt);
+            return;
+        }
+    }
     launch::msm_glv(c, mode, scalars, tb, out, n_groups, n_slices, 64, out_stride, brp_bits, beta_, st, out_fmt);
 }
 

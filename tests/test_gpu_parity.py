@@ -421,12 +421,12 @@ def test_eip4844_round_trip_on_synthetic_blobs(ctx, oracle):
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 8, 9, 12, 13, 16, 17, 32, 33, 64, 65, 128, 129, 192, 193, 200, 256, 257, 320, 321])
 def test_every_batch_size_regime_matches_oracle(ctx, oracle, n):
     """The engine picks its G1 schedule by batch size (<= 2: flat MSM over 4 scalar segments + segmented
-    doubling chains + circulant transforms, above: the compiled linear map (flat MSM up to 12 blobs) -- in the compilation that suits the
+    doubling chains + circulant transforms, above: the compiled linear map (flat MSM up to 8 blobs) -- in the compilation that suits the
     number of 64-blob lane groups: 712 constant multiplications for one group, 456 for two, 606 for three, 456 for four, 372 for
     five, the 350 of the operation-count optimum from six; inside one lane group the map's constant multiplications take four
     lanes per blob up to 16 blobs, two from 17 to 64 -- and from 33 the 456-multiplication compilation, two waves each -- and its
     cheap levels four (g1_coop.hpp); one blob takes the four-lanes-per-chain circulant kernels;
-    MSM: flat <= 12, windowed below 256 blobs, chunked above).  Every regime and both sides of every threshold
+    MSM: flat <= 8 (and for a small overflow beyond one round of wave slots), windowed below 256 blobs, chunked above).  Every regime and both sides of every threshold
     must give the oracle's bytes; blobs not checked against the oracle are checked against the single-blob path."""
     import numpy as np
     rng = np.random.RandomState(1000 + n)

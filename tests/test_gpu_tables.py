@@ -133,7 +133,7 @@ def test_every_glv_width_matches_oracle(oracle, monkeypatch, width):
             finally:
                 c2.close()
         monkeypatch.delenv("ETH_KZG_AMD_MSM_CHUNKS", raising=False)
-        # end to end: flat (<= 12 blobs), windowed, four chunks per MSM
+        # end to end: flat (<= 8 blobs), windowed, four chunks per MSM
         for n, seed in ((1, 1), (5, 2), (70, 3), (600, 4)):
             blobs = full._random_blobs(n, 7000 + 10 * width + seed)
             if n > 2:
