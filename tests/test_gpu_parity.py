@@ -418,6 +418,25 @@ def test_eip4844_round_trip_on_synthetic_blobs(ctx, oracle):
     assert ctx.verify_kzg_proof(comms[1], z, y, p) is False
 
 
+@pytest.mark.parametrize("n", [113, 114, 130, 143])
+def test_commitment_batches_around_one_round_of_wave_slots(ctx, oracle, n):
+    """The MSM stage runs an overflow of at most a quarter round of wave slots as its own launch (engine_prover.hip: launch_msm_range);
+    for commitments (64 groups per blob) that is 114 .. 142 blobs on nine windows, 129 .. 160 on eight.  Every commitment of the batch
+    must equal the single call's, and the oracle's for a sample."""
+    import numpy as np
+    rng = np.random.RandomState(2000 + n)
+    a = rng.randint(0, 256, size=(n, 4096, 32), dtype=np.uint8)
+    a[:, :, 0] &= 0x3F
+    blobs = [a[i].tobytes() for i in range(n)]
+    blobs[n - 1] = synth.dummy_blob()
+    st, comms = ctx.blob_to_kzg_commitment_batch(blobs)
+    assert st == [0] * n
+    for b in sorted({0, 1, n // 2, n - 14, n - 2, n - 1}):
+        assert comms[b] == ctx.blob_to_kzg_commitment(blobs[b]), (n, b)
+    for b in (0, n - 1):
+        assert comms[b] == oracle.blob_to_kzg_commitment(blobs[b]), (n, b)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 8, 9, 12, 13, 16, 17, 32, 33, 64, 65, 128, 129, 192, 193, 200, 256, 257, 320, 321])
 def test_every_batch_size_regime_matches_oracle(ctx, oracle, n):
     """The engine picks its G1 schedule by batch size (<= 2: flat MSM over 4 scalar segments + segmented
